@@ -1,0 +1,176 @@
+// Device vocabulary shared by every kernel in aria_amd/csrc (gfx950 / CDNA4 only).
+//
+// Product build (hipcc --offload-arch=gfx950): thin inline wrappers over the gfx950 builtins.
+// Test build (-DARIA_EMU, host clang++): the same names implemented on tests/emu/hip_emu.h so the
+// kernels' index arithmetic and barrier placement can be exercised on a machine without a GPU.
+// The emulated library is test infrastructure; the Python package never loads it.
+#pragma once
+#include <cstdint>
+
+#ifdef ARIA_EMU
+#include "hip_emu.h"
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define ARIA_SMEM_STATIC static
+#define ARIA_DYN_SMEM(name) char* name = emu::g_dyn_smem
+#define ARIA_LAUNCH(kernel, grid, block, shmem, stream, ...) emu::launch(kernel, grid, block, shmem, __VA_ARGS__)
+typedef void* hipStream_t;
+#else
+#include <hip/hip_runtime.h>
+#define ARIA_SMEM_STATIC __shared__
+#define ARIA_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define ARIA_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, static_cast<hipStream_t>(stream), __VA_ARGS__)
+#endif
+
+#ifdef ARIA_EMU
+#include <algorithm>
+#include <cmath>
+inline float __expf(float x) { return std::exp(x); }
+inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+using std::max;
+using std::min;
+#endif
+
+namespace ad {
+
+typedef uint16_t bf16_t;  // storage type: raw bfloat16 bits
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// ---- bf16 <-> f32 (round to nearest even; identical to torch's conversion) ----
+__device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, uint32_t(h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+#ifdef ARIA_EMU
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return bf16_t((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return bf16_t(u >> 16);
+#else
+    return __builtin_bit_cast(bf16_t, static_cast<__bf16>(f));  // v_cvt_pk_bf16_f32 (RNE)
+#endif
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return uint32_t(f2bf(lo)) | (uint32_t(f2bf(hi)) << 16); }
+__device__ __forceinline__ float bflo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+// round an fp32 value through bf16 (mirrors a bf16 tensor op whose result is materialised)
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+// ---- wave (64 lanes) collectives ----
+#ifdef ARIA_EMU
+__device__ __forceinline__ void sync() { emu::syncthreads(); }
+template <class T>
+__device__ __forceinline__ T shfl(T v, int src) { return emu::shfl(v, src); }
+template <class T>
+__device__ __forceinline__ T shfl_xor(T v, int mask) { return emu::shfl(v, emu::lane() ^ mask); }
+__device__ __forceinline__ unsigned long long ballot(bool p) { return emu::ballot(p); }
+__device__ __forceinline__ int lane_id() { return emu::lane(); }
+__device__ __forceinline__ int first_lane(int v) { return emu::shfl(v, __builtin_ctzll(emu::ballot(true))); }
+__device__ __forceinline__ void setprio(int) {}
+template <class T>
+__device__ __forceinline__ T atomic_add(T* p, T v) { T o = *p; *p = o + v; return o; }
+#else
+__device__ __forceinline__ void sync() { __syncthreads(); }
+template <class T>
+__device__ __forceinline__ T shfl(T v, int src) { return __shfl(v, src, 64); }
+template <class T>
+__device__ __forceinline__ T shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void setprio(int) {}
+template <class T>
+__device__ __forceinline__ T atomic_add(T* p, T v) { return atomicAdd(p, v); }
+#endif
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
+    return v;
+}
+
+// ---- MFMA (matrix cores) ----
+// D = A(32x16) * B(16x32) + C, bf16 inputs, f32 accumulate.
+//   A fragment: lane l holds A[l & 31][8 * (l >> 5) + 0..7]
+//   B fragment: lane l holds B[8 * (l >> 5) + 0..7][l & 31]
+//   C/D:        reg r of lane l is C[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][l & 31]
+__device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
+#ifdef ARIA_EMU
+    struct AB { s16x8 a, b; };
+    AB mine{a, b};
+    emu::WaveBuf& w = emu::wbuf();
+    std::memcpy(w.slot[emu::lane()], &mine, sizeof(AB));
+    emu::wave_sync();
+    const int l = emu::lane();
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = 0.f;
+        for (int k = 0; k < 16; ++k) {
+            AB ra, rb;
+            std::memcpy(&ra, w.slot[row + 32 * (k >> 3)], sizeof(AB));
+            std::memcpy(&rb, w.slot[col + 32 * (k >> 3)], sizeof(AB));
+            acc += bf2f(bf16_t(ra.a[k & 7])) * bf2f(bf16_t(rb.b[k & 7]));
+        }
+        d[r] = c[r] + acc;
+    }
+    emu::wave_sync();
+    return d;
+#else
+    typedef __bf16 bfx8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, a), __builtin_bit_cast(bfx8, b), c, 0, 0, 0);
+#endif
+}
+
+// D = A(16x32) * B(32x16) + C.
+//   A fragment: lane l holds A[l & 15][8 * (l >> 4) + 0..7];  B: B[8 * (l >> 4) + 0..7][l & 15]
+//   C/D: reg r of lane l is C[4 * (l >> 4) + r][l & 15]
+__device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) {
+#ifdef ARIA_EMU
+    struct AB { s16x8 a, b; };
+    AB mine{a, b};
+    emu::WaveBuf& w = emu::wbuf();
+    std::memcpy(w.slot[emu::lane()], &mine, sizeof(AB));
+    emu::wave_sync();
+    const int l = emu::lane();
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r, col = l & 15;
+        float acc = 0.f;
+        for (int k = 0; k < 32; ++k) {
+            AB ra, rb;
+            std::memcpy(&ra, w.slot[row + 16 * (k >> 3)], sizeof(AB));
+            std::memcpy(&rb, w.slot[col + 16 * (k >> 3)], sizeof(AB));
+            acc += bf2f(bf16_t(ra.a[k & 7])) * bf2f(bf16_t(rb.b[k & 7]));
+        }
+        d[r] = c[r] + acc;
+    }
+    emu::wave_sync();
+    return d;
+#else
+    typedef __bf16 bfx8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, a), __builtin_bit_cast(bfx8, b), c, 0, 0, 0);
+#endif
+}
+
+// ---- 16-byte global / LDS access helpers ----
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+__device__ __forceinline__ u32x4 zero16() { return u32x4{0u, 0u, 0u, 0u}; }
+
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+
+}  // namespace ad
+

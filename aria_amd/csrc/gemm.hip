@@ -1,0 +1,357 @@
+// bf16 MFMA GEMM family for gfx950 (dense, grouped-by-rows, grouped-by-reduction).
+//
+// Replaces, behind the reference's seams:
+//   * grouped_gemm.ops.gmm / sequential_gemm  -- aria/model/moe_lm.py:398-443,467-484 (fwd) and its
+//     autograd backward (dgrad + per-expert wgrad)
+//   * every nn.Linear GEMM on the path (q/k/v/o, shared expert, router gating, lm_head, ViT linears)
+//     and their dgrad / wgrad.
+//
+// One kernel template, C[M,N] (+)= op(A) * op(B) [+ bias], fp32 accumulation on the matrix cores
+// (v_mfma_f32_32x32x16_bf16), block tile 128x128x64, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles.
+// An operand is either
+//   "rc" reduction-contiguous: element (row, k) at base[row * ld + k]   (activations [M,K]; Linear W [N,K])
+//   "oc" output-contiguous:    element (row, k) at base[k * ld + row]   (expert W[e] [K,N]; x and dy in wgrad)
+// rc tiles sit in LDS as [row][k] (pitch 72: conflict-free ds_read_b128 fragments); oc tiles sit as
+// [k][row] exactly as they stream from HBM (coalesced 16-byte loads), and a lane builds the fragments of
+// TWO adjacent rows from eight ds_read_b32 (rows 2c, 2c+1 of the wave's slice live in the low / high half
+// of one dword): MFMA tile t of the wave then owns rows {2c + t}.  Any permutation of the reduction index
+// is legal as long as A and B use the same one, and any permutation of output rows / columns is undone in
+// the epilogue, so no transposes are ever materialised in HBM or LDS.
+//
+// Modes
+//   0 dense      : one problem.
+//   1 grouped-M  : rows of A and C are grouped by expert (device-side offsets[E+1], no host sync -- the
+//                  reference's GroupedGEMM.forward does tokens_per_expert.cpu(), moe_lm.py:478); block ->
+//                  (expert, row tile) found in-kernel from the offsets; B += expert * strideB.
+//   2 grouped-K  : per-expert wgrad dW[e] = A_e^T * dY_e, reduction over the expert's rows (variable
+//                  length, masked); blockIdx.y = expert.
+#include "aria_device.h"
+#include "aria_hip.h"
+
+namespace {
+using namespace ad;
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int PR = BK + 8;   // rc LDS pitch (elements): 144 B -> 16 rows hit 16 distinct 16-B bank slots
+constexpr int PO = 128;      // oc LDS pitch (elements)
+constexpr int TILE_ELEMS = BM * PR;  // 9216 elements = 18432 B  (>= 64 * 128 for the oc image)
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* B;
+    void* C;
+    const bf16_t* bias;
+    long long lda, ldb, ldc;
+    int M, N, K;
+    int mode;
+    const int* offsets;
+    int E;
+    long long strideB, strideC;
+    int c_f32, accumulate;
+    int ntn;
+};
+
+template <bool OC>
+__device__ __forceinline__ void load_tile(u32x4 (&r)[4], const bf16_t* base, long long ld, int row0, int row_end, int k0,
+                                          int k_end, int t) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (!OC) {
+            const int row = row0 + (t >> 3) + 32 * p, k = k0 + (t & 7) * 8;
+            r[p] = (row < row_end && k < k_end) ? ld16(base + (long long)row * ld + k) : zero16();
+        } else {
+            const int k = k0 + (t >> 4) + 16 * p, row = row0 + (t & 15) * 8;
+            r[p] = (k < k_end && row < row_end) ? ld16(base + (long long)k * ld + row) : zero16();
+        }
+    }
+}
+
+template <bool OC>
+__device__ __forceinline__ void store_tile(const u32x4 (&r)[4], bf16_t* s, int t) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (!OC)
+            st16(s + ((t >> 3) + 32 * p) * PR + (t & 7) * 8, r[p]);
+        else
+            st16(s + ((t >> 4) + 16 * p) * PO + (t & 15) * 8, r[p]);
+    }
+}
+
+// fragments of the wave's two 32-row MFMA tiles for k-substep kk (16 reduction indices)
+template <bool OC>
+__device__ __forceinline__ void load_frags(s16x8 (&f)[2], const bf16_t* s, int wbase, int kk, int l) {
+    if (!OC) {
+#pragma unroll
+        for (int tIdx = 0; tIdx < 2; ++tIdx)
+            f[tIdx] = *reinterpret_cast<const s16x8*>(s + (wbase + tIdx * 32 + (l & 31)) * PR + kk * 16 + (l >> 5) * 8);
+    } else {
+        uint32_t d[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            d[i] = *reinterpret_cast<const uint32_t*>(s + (kk * 16 + (l >> 5) * 8 + i) * PO + wbase + 2 * (l & 31));
+        u32x4 lo, hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lo[j] = (d[2 * j] & 0xffffu) | (d[2 * j + 1] << 16);
+            hi[j] = (d[2 * j] >> 16) | (d[2 * j + 1] & 0xffff0000u);
+        }
+        f[0] = __builtin_bit_cast(s16x8, lo);
+        f[1] = __builtin_bit_cast(s16x8, hi);
+    }
+}
+
+template <bool A_OC, bool B_OC>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
+    ARIA_DYN_SMEM(smem);
+    bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* sB = sA + TILE_ELEMS;
+    const int t = threadIdx.x, l = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+
+    const int tile = blockIdx.x;
+    const int tn = tile % p.ntn;
+    int tmi = tile / p.ntn;
+    const bf16_t* A = p.A;
+    const bf16_t* B = p.B;
+    char* C = static_cast<char*>(p.C);
+    const int csz = p.c_f32 ? 4 : 2;
+    int m0, m_end, k_begin = 0, k_end = p.K;
+    const int n0 = tn * BN;
+    if (p.mode == 0) {
+        m0 = tmi * BM;
+        m_end = p.M;
+    } else if (p.mode == 1) {
+        // block -> (expert, local row tile): walk the (<=64-entry per step) offset table
+        int e_found = -1, start = 0, end = 0, base = 0;
+        for (int e0 = 0; e0 < p.E && e_found < 0; e0 += 64) {
+            const int e = e0 + l;
+            int o0 = 0, o1 = 0;
+            if (e < p.E) {
+                o0 = p.offsets[e];
+                o1 = p.offsets[e + 1];
+            }
+            const int nt = (o1 - o0 + BM - 1) / BM;
+            int incl = nt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = shfl(incl, (l - d) & 63);
+                if (l >= d) incl += v;
+            }
+            const int excl = base + incl - nt;
+            const bool mine = e < p.E && tmi >= excl && tmi < excl + nt;
+            const unsigned long long mask = ballot(mine);
+            if (mask) {
+                const int src = __builtin_ctzll(mask);
+                e_found = e0 + src;
+                start = shfl(o0, src);
+                end = shfl(o1, src);
+                tmi -= shfl(excl, src);
+            }
+            base += shfl(incl, 63);
+        }
+        if (e_found < 0) return;  // uniform across the block
+        m0 = start + tmi * BM;
+        m_end = end;
+        B += (long long)e_found * p.strideB;
+    } else {
+        const int e = blockIdx.y;
+        m0 = tmi * BM;
+        m_end = p.M;
+        k_begin = p.offsets[e];
+        k_end = p.offsets[e + 1];
+        C += (long long)e * p.strideC * csz;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[4], rb[4];
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+    if (nk > 0) {
+        load_tile<A_OC>(ra, A, p.lda, m0, m_end, k_begin, k_end, t);
+        load_tile<B_OC>(rb, B, p.ldb, n0, p.N, k_begin, k_end, t);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tile<A_OC>(ra, sA, t);
+        store_tile<B_OC>(rb, sB, t);
+        sync();
+        if (kt + 1 < nk) {  // next tile's HBM loads fly under this tile's MFMAs
+            const int k0 = k_begin + (kt + 1) * BK;
+            load_tile<A_OC>(ra, A, p.lda, m0, m_end, k0, k_end, t);
+            load_tile<B_OC>(rb, B, p.ldb, n0, p.N, k0, k_end, t);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            s16x8 af[2], bf[2];
+            load_frags<A_OC>(af, sA, wm * 64, kk, l);
+            load_frags<B_OC>(bf, sB, wn * 64, kk, l);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+        }
+        sync();
+    }
+
+    // ---- epilogue: undo the row / column permutations, add bias, (accumulate), round, store
+    const int c = l & 31, h = l >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rt = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = m0 + wm * 64 + (A_OC ? 2 * rt + i : i * 32 + rt);
+            if (m >= m_end) continue;
+            if (B_OC) {
+                const int n = n0 + wn * 64 + 2 * c;  // columns n, n+1 (N % 2 == 0)
+                if (n >= p.N) continue;
+                float v0 = acc[i][0][r], v1 = acc[i][1][r];
+                if (p.bias) {
+                    v0 += bf2f(p.bias[n]);
+                    v1 += bf2f(p.bias[n + 1]);
+                }
+                if (p.c_f32) {
+                    float* dst = reinterpret_cast<float*>(C) + (long long)m * p.ldc + n;
+                    if (p.accumulate) {
+                        v0 += dst[0];
+                        v1 += dst[1];
+                    }
+                    dst[0] = v0;
+                    dst[1] = v1;
+                } else {
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + n);
+                    if (p.accumulate) {
+                        const uint32_t old = *dst;
+                        v0 += bflo(old);
+                        v1 += bfhi(old);
+                    }
+                    *dst = pack2bf(v0, v1);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + wn * 64 + j * 32 + c;
+                    if (n >= p.N) continue;
+                    float v = acc[i][j][r];
+                    if (p.bias) v += bf2f(p.bias[n]);
+                    if (p.c_f32) {
+                        float* dst = reinterpret_cast<float*>(C) + (long long)m * p.ldc + n;
+                        if (p.accumulate) v += *dst;
+                        *dst = v;
+                    } else {
+                        bf16_t* dst = reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + n;
+                        if (p.accumulate) v += bf2f(*dst);
+                        *dst = f2bf(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+int launch_gemm(const GemmParams& p, int a_oc, int b_oc, int grid_x, int grid_y, void* stream) {
+    const size_t shmem = 2 * TILE_ELEMS * sizeof(bf16_t);
+    dim3 grid(grid_x, grid_y), block(NTHREADS);
+    if (grid_x <= 0 || grid_y <= 0) return ARIA_OK;
+    if (!a_oc && !b_oc)
+        ARIA_LAUNCH((gemm_kernel<false, false>), grid, block, shmem, stream, p);
+    else if (!a_oc && b_oc)
+        ARIA_LAUNCH((gemm_kernel<false, true>), grid, block, shmem, stream, p);
+    else if (a_oc && b_oc)
+        ARIA_LAUNCH((gemm_kernel<true, true>), grid, block, shmem, stream, p);
+    else
+        return ARIA_ERR_INVALID;  // (oc, rc) never occurs on this path
+    return aria_check_launch();
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int aria_gemm_bf16(const void* A, const void* B, void* C, const void* bias, int64_t M, int64_t N, int64_t K, int a_oc,
+                   int b_oc, int64_t lda, int64_t ldb, int64_t ldc, int c_f32, int accumulate, void* stream) {
+    if (!A || !B || !C || M < 0 || N < 0 || K < 0) return ARIA_ERR_INVALID;
+    if (M == 0 || N == 0) return ARIA_OK;
+    if (!aligned16(A) || !aligned16(B) || (lda & 7) || (ldb & 7) || (N & 1) || (ldc & 1)) return ARIA_ERR_ALIGN;
+    if ((!a_oc || !b_oc) && (K & 7)) return ARIA_ERR_ALIGN;  // rc operands: 16-byte chunks along K
+    if (a_oc && (M & 7)) return ARIA_ERR_ALIGN;
+    if (b_oc && (N & 7)) return ARIA_ERR_ALIGN;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A);
+    p.B = static_cast<const bf16_t*>(B);
+    p.C = C;
+    p.bias = static_cast<const bf16_t*>(bias);
+    p.lda = lda;
+    p.ldb = ldb;
+    p.ldc = ldc;
+    p.M = int(M);
+    p.N = int(N);
+    p.K = int(K);
+    p.mode = 0;
+    p.c_f32 = c_f32;
+    p.accumulate = accumulate;
+    p.ntn = int((N + BN - 1) / BN);
+    const int ntm = int((M + BM - 1) / BM);
+    return launch_gemm(p, a_oc, b_oc, p.ntn * ntm, 1, stream);
+}
+
+int aria_grouped_gemm_bf16(const void* A, const void* B, void* C, const int32_t* offsets, int64_t E, int64_t M_total,
+                           int64_t N, int64_t K, int b_oc, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldc,
+                           void* stream) {
+    if (!A || !B || !C || !offsets || E <= 0 || M_total < 0) return ARIA_ERR_INVALID;
+    if (M_total == 0 || N == 0) return ARIA_OK;
+    if (!aligned16(A) || !aligned16(B) || (lda & 7) || (ldb & 7) || (K & 7) || (N & 7) || (strideB & 7) || (ldc & 1))
+        return ARIA_ERR_ALIGN;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A);
+    p.B = static_cast<const bf16_t*>(B);
+    p.C = C;
+    p.lda = lda;
+    p.ldb = ldb;
+    p.ldc = ldc;
+    p.M = int(M_total);
+    p.N = int(N);
+    p.K = int(K);
+    p.mode = 1;
+    p.offsets = offsets;
+    p.E = int(E);
+    p.strideB = strideB;
+    p.ntn = int((N + BN - 1) / BN);
+    // every expert adds at most one partial row tile
+    const int max_tm = int(M_total / BM + E);
+    return launch_gemm(p, 0, b_oc, p.ntn * max_tm, 1, stream);
+}
+
+int aria_grouped_gemm_wgrad_bf16(const void* A, const void* dY, void* dW, const int32_t* offsets, int64_t E, int64_t K,
+                                 int64_t N, int64_t lda, int64_t ldy, int c_f32, int accumulate, void* stream) {
+    if (!A || !dY || !dW || !offsets || E <= 0) return ARIA_ERR_INVALID;
+    if (K == 0 || N == 0) return ARIA_OK;
+    if (!aligned16(A) || !aligned16(dY) || (lda & 7) || (ldy & 7) || (K & 7) || (N & 7)) return ARIA_ERR_ALIGN;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A);   // "A operand" = A^T: element (feature i, token k) at A[k * lda + i]
+    p.B = static_cast<const bf16_t*>(dY);  // "B operand": element (token k, n) at dY[k * ldy + n]
+    p.C = dW;
+    p.lda = lda;
+    p.ldb = ldy;
+    p.ldc = N;
+    p.M = int(K);
+    p.N = int(N);
+    p.K = 0;
+    p.mode = 2;
+    p.offsets = offsets;
+    p.E = int(E);
+    p.strideC = K * N;
+    p.c_f32 = c_f32;
+    p.accumulate = accumulate;
+    p.ntn = int((N + BN - 1) / BN);
+    const int ntm = int((K + BM - 1) / BM);
+    return launch_gemm(p, 1, 1, p.ntn * ntm, int(E), stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,486 @@
+// MoE routing / token dispatch kernels (HBM-bound integer + byte work: coalesced 16-byte rows, wave
+// ballots for the stable sort, no host round trips).  Reference: aria/model/moe_lm.py:243-365, 505-507.
+#include "aria_device.h"
+#include "aria_hip.h"
+
+namespace {
+using namespace ad;
+
+constexpr int kMaxPerLane = 4;  // E <= 256
+
+// ------------------------------------------------------------------------------------------- route
+// one wave per token; lane i owns experts i, i+64, ...
+template <bool F32>
+__global__ __launch_bounds__(256) void route_kernel(const void* logits_, void* scores_, int32_t* indices, int32_t* counts,
+                                                    int T, int E, int k) {
+    const int l = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int npl = (E + 63) >> 6;
+    for (int t = wave; t < T; t += nwaves) {
+        float v[kMaxPerLane];
+#pragma unroll
+        for (int i = 0; i < kMaxPerLane; ++i) {
+            const int e = l + 64 * i;
+            v[i] = -INFINITY;
+            if (i < npl && e < E)
+                v[i] = F32 ? static_cast<const float*>(logits_)[(long long)t * E + e]
+                           : bf2f(static_cast<const bf16_t*>(logits_)[(long long)t * E + e]);
+        }
+        float top[8];
+        int topi = -1;  // lane j keeps the j-th selected index
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            top[j] = -INFINITY;
+            if (j < k) {  // wave-uniform
+                float bv = v[0];
+                int bi = l;
+#pragma unroll
+                for (int i = 1; i < kMaxPerLane; ++i)
+                    if (v[i] > bv) {  // strict: lower expert id wins ties
+                        bv = v[i];
+                        bi = l + 64 * i;
+                    }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const float ov = shfl_xor(bv, d);
+                    const int oi = shfl_xor(bi, d);
+                    if (ov > bv || (ov == bv && oi < bi)) {
+                        bv = ov;
+                        bi = oi;
+                    }
+                }
+                top[j] = bv;
+                if (l == j) topi = bi;
+                if ((bi & 63) == l) {
+#pragma unroll
+                    for (int i = 0; i < kMaxPerLane; ++i)
+                        if (i == (bi >> 6)) v[i] = -INFINITY;
+                }
+            }
+        }
+        // softmax over the k selected logits in fp32, cast to the logits dtype (moe_lm.py:262)
+        const float m = top[0];
+        float den = 0.f, mine = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < k) den += expf(top[j] - m);
+            if (j == l) mine = top[j];
+        }
+        if (l < k) {
+            const float s = expf(mine - m) / den;
+            if (F32)
+                static_cast<float*>(scores_)[(long long)t * k + l] = s;
+            else
+                static_cast<bf16_t*>(scores_)[(long long)t * k + l] = f2bf(s);
+            indices[(long long)t * k + l] = topi;
+            atomic_add(&counts[topi], 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- stable sort (E <= 64)
+constexpr int SORT_CHUNK = 2048;
+
+__device__ __forceinline__ unsigned long long match_mask(int key, const unsigned long long (&bal)[6], unsigned long long valid) {
+    unsigned long long m = valid;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) m &= ((key >> b) & 1) ? bal[b] : ~bal[b];
+    return m;
+}
+
+// pass 1: per-chunk histogram (lane e = expert e)
+__global__ __launch_bounds__(64) void sort_count_kernel(const int32_t* idx, int32_t* chunk_counts, int M) {
+    const int l = threadIdx.x, c = blockIdx.x;
+    int cnt = 0;
+    const int begin = c * SORT_CHUNK, end = min(M, begin + SORT_CHUNK);
+    for (int i0 = begin; i0 < end; i0 += 64) {
+        const int i = i0 + l;
+        const bool valid = i < end;
+        const int e = valid ? idx[i] : 0;
+        unsigned long long bal[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) bal[b] = ballot((e >> b) & 1);
+        const unsigned long long vm = ballot(valid);
+        cnt += __builtin_popcountll(match_mask(l, bal, vm));
+    }
+    chunk_counts[c * 64 + l] = cnt;
+}
+
+// pass 2: offsets = exclusive scan of counts; chunk_base[c][e] = offsets[e] + sum_{c' < c} chunk_counts[c'][e]
+__global__ __launch_bounds__(64) void sort_scan_kernel(const int32_t* counts, const int32_t* chunk_counts, int32_t* chunk_base,
+                                                       int32_t* offsets, int E, int nchunks) {
+    const int l = threadIdx.x;
+    const int cnt = l < E ? counts[l] : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = shfl(incl, (l - d) & 63);
+        if (l >= d) incl += v;
+    }
+    int running = incl - cnt;
+    if (l < E) offsets[l] = running;
+    if (l == E - 1) offsets[E] = incl;
+    for (int c = 0; c < nchunks; ++c) {
+        chunk_base[c * 64 + l] = running;
+        running += chunk_counts[c * 64 + l];
+    }
+}
+
+// pass 3: stable positions
+__global__ __launch_bounds__(64) void sort_scatter_kernel(const int32_t* idx, const int32_t* chunk_base, int32_t* sorted_src,
+                                                          int32_t* inv, int M) {
+    const int l = threadIdx.x, c = blockIdx.x;
+    int counter = chunk_base[c * 64 + l];  // lane e: next free position of expert e
+    const int begin = c * SORT_CHUNK, end = min(M, begin + SORT_CHUNK);
+    const unsigned long long below = (1ull << l) - 1ull;
+    for (int i0 = begin; i0 < end; i0 += 64) {
+        const int i = i0 + l;
+        const bool valid = i < end;
+        const int e = valid ? idx[i] : 0;
+        unsigned long long bal[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) bal[b] = ballot((e >> b) & 1);
+        const unsigned long long vm = ballot(valid);
+        const unsigned long long same = match_mask(e, bal, vm);
+        const int base = shfl(counter, e & 63);
+        if (valid) {
+            const int pos = base + __builtin_popcountll(same & below);
+            sorted_src[pos] = i;
+            inv[i] = pos;
+        }
+        counter += __builtin_popcountll(match_mask(l, bal, vm));
+    }
+}
+
+// ------------------------------------------------------------------------------------------- permute (row gather)
+// one wave per destination row, 16-byte chunks, grid-stride
+__global__ __launch_bounds__(256) void permute_kernel(const bf16_t* x, const int32_t* sorted_src, bf16_t* out, int M, int D,
+                                                      int k, long long ldx) {
+    const int l = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nch = D >> 3;
+    for (int p = wave; p < M; p += nwaves) {
+        const int t = sorted_src[p] / k;
+        const bf16_t* src = x + (long long)t * ldx;
+        bf16_t* dst = out + (long long)p * D;
+        for (int c = l; c < nch; c += 64) st16(dst + c * 8, ld16(src + c * 8));
+    }
+}
+
+// ------------------------------------------------------------------------------------------- unpermute (+ shared add)
+template <int K_MAX>
+__global__ __launch_bounds__(256) void unpermute_kernel(const bf16_t* eo, const int32_t* inv, const bf16_t* scores,
+                                                        const bf16_t* add, bf16_t* out, int T, int D, int k) {
+    const int l = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nch = D >> 3;
+    for (int t = wave; t < T; t += nwaves) {
+        int rows[K_MAX];
+        float sc[K_MAX];
+#pragma unroll
+        for (int j = 0; j < K_MAX; ++j) {
+            rows[j] = j < k ? inv[(long long)t * k + j] : 0;
+            sc[j] = (j < k && scores) ? bf2f(scores[(long long)t * k + j]) : 1.f;
+        }
+        for (int c = l; c < nch; c += 64) {
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < K_MAX; ++j) {
+                if (j < k) {
+                    const u32x4 v = ld16(eo + (long long)rows[j] * D + c * 8);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (scores) {  // product materialised in bf16 by the reference (moe_lm.py:362)
+                            acc[2 * q] += rbf(bflo(v[q]) * sc[j]);
+                            acc[2 * q + 1] += rbf(bfhi(v[q]) * sc[j]);
+                        } else {
+                            acc[2 * q] += bflo(v[q]);
+                            acc[2 * q + 1] += bfhi(v[q]);
+                        }
+                    }
+                }
+            }
+            u32x4 o;
+            if (add) {
+                const u32x4 a = ld16(add + (long long)t * D + c * 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = pack2bf(rbf(acc[2 * q]) + bflo(a[q]), rbf(acc[2 * q + 1]) + bfhi(a[q]));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = pack2bf(acc[2 * q], acc[2 * q + 1]);
+            }
+            st16(out + (long long)t * D + c * 8, o);
+        }
+    }
+}
+
+// backward of unpermute: d_eo[inv[t,j]] = bf16(dout[t] * s_j); dscores[t,j] = <eo[inv[t,j]], dout[t]>
+__global__ __launch_bounds__(256) void unpermute_bwd_kernel(const bf16_t* dout, const bf16_t* eo, const int32_t* inv,
+                                                            const bf16_t* scores, bf16_t* d_eo, bf16_t* dscores, int T, int D,
+                                                            int k) {
+    const int l = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nch = D >> 3;
+    for (int t = wave; t < T; t += nwaves) {
+        for (int j = 0; j < k; ++j) {
+            const int row = inv[(long long)t * k + j];
+            const float s = bf2f(scores[(long long)t * k + j]);
+            float dot = 0.f;
+            for (int c = l; c < nch; c += 64) {
+                const u32x4 g = ld16(dout + (long long)t * D + c * 8);
+                const u32x4 v = ld16(eo + (long long)row * D + c * 8);
+                u32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    dot += bflo(g[q]) * bflo(v[q]) + bfhi(g[q]) * bfhi(v[q]);
+                    o[q] = pack2bf(bflo(g[q]) * s, bfhi(g[q]) * s);
+                }
+                st16(d_eo + (long long)row * D + c * 8, o);
+            }
+            dot = wave_sum(dot);
+            if (l == 0) dscores[(long long)t * k + j] = f2bf(dot);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- route backward (+ aux losses)
+__global__ __launch_bounds__(256) void route_bwd_kernel(const bf16_t* logits, const int32_t* indices, const bf16_t* scores,
+                                                        const bf16_t* dscores, const int32_t* counts, bf16_t* dlogits, int T,
+                                                        int E, int k, float z_coeff, float aux_coeff, float aux_scale) {
+    const int l = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const bool aux = (z_coeff != 0.f || aux_coeff != 0.f);
+    for (int t = wave; t < T; t += nwaves) {
+        float x[kMaxPerLane], g[kMaxPerLane], cnt[kMaxPerLane];
+#pragma unroll
+        for (int i = 0; i < kMaxPerLane; ++i) {
+            const int e = l + 64 * i;
+            x[i] = e < E ? bf2f(logits[(long long)t * E + e]) : -INFINITY;
+            cnt[i] = (aux && e < E) ? float(counts[e]) : 0.f;
+            g[i] = 0.f;
+        }
+        // d softmax over the selected k
+        float sdot = 0.f;
+        for (int j = 0; j < k; ++j) sdot += bf2f(scores[(long long)t * k + j]) * bf2f(dscores[(long long)t * k + j]);
+        for (int j = 0; j < k; ++j) {
+            const int e = indices[(long long)t * k + j];
+            const float s = bf2f(scores[(long long)t * k + j]);
+            const float v = s * (bf2f(dscores[(long long)t * k + j]) - sdot);
+#pragma unroll
+            for (int i = 0; i < kMaxPerLane; ++i)
+                if (e == l + 64 * i) g[i] += v;
+        }
+        if (aux) {
+            float m = x[0];
+#pragma unroll
+            for (int i = 1; i < kMaxPerLane; ++i) m = fmaxf(m, x[i]);
+            m = wave_max(m);
+            float se = 0.f;
+#pragma unroll
+            for (int i = 0; i < kMaxPerLane; ++i) se += (l + 64 * i < E) ? expf(x[i] - m) : 0.f;
+            se = wave_sum(se);
+            const float lse = m + logf(se);
+            float pc = 0.f, prob[kMaxPerLane];
+#pragma unroll
+            for (int i = 0; i < kMaxPerLane; ++i) {
+                prob[i] = (l + 64 * i < E) ? expf(x[i] - lse) : 0.f;
+                pc += prob[i] * cnt[i];
+            }
+            pc = wave_sum(pc);
+            const float zc = aux_scale * z_coeff * 2.f * lse / float(T);
+            const float ac = aux_scale * aux_coeff * float(E) / (float(T) * float(k)) / float(T);
+#pragma unroll
+            for (int i = 0; i < kMaxPerLane; ++i) g[i] += zc * prob[i] + ac * prob[i] * (cnt[i] - pc);
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxPerLane; ++i) {
+            const int e = l + 64 * i;
+            if (e < E) dlogits[(long long)t * E + e] = f2bf(g[i]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- swiglu
+__device__ __forceinline__ float silu_f(float a) { return a / (1.f + expf(-a)); }
+
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* h, const bf16_t* h2, bf16_t* act, long long nchunks,
+                                                         int I, long long lda, long long ldb) {
+    const int cpr = I >> 3;  // chunks per row
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (long long)gridDim.x * blockDim.x) {
+        const long long row = c / cpr;
+        const int col = int(c % cpr) * 8;
+        const u32x4 a = ld16(h + row * lda + col);
+        const u32x4 b = ld16(h2 + row * ldb + col);
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            o[q] = pack2bf(rbf(silu_f(bflo(a[q]))) * bflo(b[q]), rbf(silu_f(bfhi(a[q]))) * bfhi(b[q]));
+        st16(act + row * I + col, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* h, const bf16_t* h2, const bf16_t* dact, bf16_t* dh,
+                                                         bf16_t* dh2, long long nchunks, int I, long long lda, long long ldb) {
+    const int cpr = I >> 3;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (long long)gridDim.x * blockDim.x) {
+        const long long row = c / cpr;
+        const int col = int(c % cpr) * 8;
+        const u32x4 a = ld16(h + row * lda + col);
+        const u32x4 b = ld16(h2 + row * ldb + col);
+        const u32x4 g = ld16(dact + row * I + col);
+        u32x4 oa, ob;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float da[2], db[2];
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                const float av = z ? bfhi(a[q]) : bflo(a[q]);
+                const float bv = z ? bfhi(b[q]) : bflo(b[q]);
+                const float gv = z ? bfhi(g[q]) : bflo(g[q]);
+                const float sig = 1.f / (1.f + expf(-av));
+                const float sl = av * sig;
+                db[z] = gv * rbf(sl);
+                da[z] = gv * bv * (sig * (1.f + av * (1.f - sig)));
+            }
+            oa[q] = pack2bf(da[0], da[1]);
+            ob[q] = pack2bf(db[0], db[1]);
+        }
+        st16(dh + row * lda + col, oa);
+        st16(dh2 + row * ldb + col, ob);
+    }
+}
+
+int grid_for_waves(long long n_items, int waves_per_block = 4) {
+    long long g = (n_items + waves_per_block - 1) / waves_per_block;
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;
+    return int(g);
+}
+
+}  // namespace
+
+extern "C" {
+
+int aria_moe_route(const void* logits, int logits_f32, void* scores, int32_t* indices, int32_t* counts, int64_t T, int64_t E,
+                   int64_t k, void* stream) {
+    if (!logits || !scores || !indices || !counts || T < 0 || E <= 0 || k <= 0) return ARIA_ERR_INVALID;
+    if (E > 64 * kMaxPerLane || k > 8 || k > E) return ARIA_ERR_UNSUPPORTED;
+#ifdef ARIA_EMU
+    std::memset(counts, 0, sizeof(int32_t) * E);
+#else
+    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * E, static_cast<hipStream_t>(stream)) != hipSuccess) return ARIA_ERR_LAUNCH;
+#endif
+    if (T == 0) return ARIA_OK;
+    dim3 grid(grid_for_waves(T)), block(256);
+    if (logits_f32)
+        ARIA_LAUNCH((route_kernel<true>), grid, block, 0, stream, logits, scores, indices, counts, int(T), int(E), int(k));
+    else
+        ARIA_LAUNCH((route_kernel<false>), grid, block, 0, stream, logits, scores, indices, counts, int(T), int(E), int(k));
+    return aria_check_launch();
+}
+
+int aria_moe_sort(const int32_t* indices, const int32_t* counts, int32_t* offsets, int32_t* sorted_src, int32_t* inv,
+                  int32_t* workspace, int64_t T, int64_t E, int64_t k, void* stream) {
+    if (!indices || !counts || !offsets || !sorted_src || !inv || !workspace || T < 0 || E <= 0 || k <= 0) return ARIA_ERR_INVALID;
+    if (E > 64) return ARIA_ERR_UNSUPPORTED;
+    const int M = int(T * k);
+    const int nchunks = (M + SORT_CHUNK - 1) / SORT_CHUNK;
+    int32_t* chunk_counts = workspace;
+    int32_t* chunk_base = workspace + (size_t)nchunks * 64;
+    if (nchunks > 0) {
+        ARIA_LAUNCH(sort_count_kernel, dim3(nchunks), dim3(64), 0, stream, indices, chunk_counts, M);
+    }
+    ARIA_LAUNCH(sort_scan_kernel, dim3(1), dim3(64), 0, stream, counts, (const int32_t*)chunk_counts, chunk_base, offsets, int(E),
+                nchunks);
+    if (nchunks > 0) {
+        ARIA_LAUNCH(sort_scatter_kernel, dim3(nchunks), dim3(64), 0, stream, indices, (const int32_t*)chunk_base, sorted_src,
+                    inv, M);
+    }
+    return aria_check_launch();
+}
+
+int aria_moe_permute(const void* x, const int32_t* sorted_src, void* permuted, int64_t M, int64_t D, int64_t k, int64_t ldx,
+                     void* stream) {
+    if (!x || !sorted_src || !permuted || M < 0 || D <= 0 || k <= 0) return ARIA_ERR_INVALID;
+    if ((D & 7) || (ldx & 7)) return ARIA_ERR_ALIGN;
+    if (M == 0) return ARIA_OK;
+    ARIA_LAUNCH(permute_kernel, dim3(grid_for_waves(M)), dim3(256), 0, stream, static_cast<const bf16_t*>(x), sorted_src,
+                static_cast<bf16_t*>(permuted), int(M), int(D), int(k), (long long)ldx);
+    return aria_check_launch();
+}
+
+int aria_moe_unpermute(const void* expert_out, const int32_t* inv, const void* scores, const void* add, void* out, int64_t T,
+                       int64_t D, int64_t k, void* stream) {
+    if (!expert_out || !inv || !out || T < 0 || D <= 0 || k <= 0) return ARIA_ERR_INVALID;
+    if (D & 7) return ARIA_ERR_ALIGN;
+    if (k > 8) return ARIA_ERR_UNSUPPORTED;
+    if (T == 0) return ARIA_OK;
+    ARIA_LAUNCH((unpermute_kernel<8>), dim3(grid_for_waves(T)), dim3(256), 0, stream, static_cast<const bf16_t*>(expert_out), inv,
+                static_cast<const bf16_t*>(scores), static_cast<const bf16_t*>(add), static_cast<bf16_t*>(out), int(T), int(D),
+                int(k));
+    return aria_check_launch();
+}
+
+int aria_moe_unpermute_bwd(const void* dout, const void* expert_out, const int32_t* inv, const void* scores, void* d_expert_out,
+                           void* dscores, int64_t T, int64_t D, int64_t k, void* stream) {
+    if (!dout || !expert_out || !inv || !scores || !d_expert_out || !dscores || T < 0 || D <= 0 || k <= 0) return ARIA_ERR_INVALID;
+    if (D & 7) return ARIA_ERR_ALIGN;
+    if (T == 0) return ARIA_OK;
+    ARIA_LAUNCH(unpermute_bwd_kernel, dim3(grid_for_waves(T)), dim3(256), 0, stream, static_cast<const bf16_t*>(dout),
+                static_cast<const bf16_t*>(expert_out), inv, static_cast<const bf16_t*>(scores),
+                static_cast<bf16_t*>(d_expert_out), static_cast<bf16_t*>(dscores), int(T), int(D), int(k));
+    return aria_check_launch();
+}
+
+int aria_moe_route_bwd(const void* logits, const int32_t* indices, const void* scores, const void* dscores, const int32_t* counts,
+                       void* dlogits, int64_t T, int64_t E, int64_t k, float z_coeff, float aux_coeff, float aux_scale,
+                       void* stream) {
+    if (!logits || !indices || !scores || !dscores || !counts || !dlogits || T < 0 || E <= 0 || k <= 0) return ARIA_ERR_INVALID;
+    if (E > 64 * kMaxPerLane) return ARIA_ERR_UNSUPPORTED;
+    if (T == 0) return ARIA_OK;
+    ARIA_LAUNCH(route_bwd_kernel, dim3(grid_for_waves(T)), dim3(256), 0, stream, static_cast<const bf16_t*>(logits), indices,
+                static_cast<const bf16_t*>(scores), static_cast<const bf16_t*>(dscores), counts, static_cast<bf16_t*>(dlogits),
+                int(T), int(E), int(k), z_coeff, aux_coeff, aux_scale);
+    return aria_check_launch();
+}
+
+int aria_swiglu_fwd(const void* h, const void* h2, void* act, int64_t M, int64_t I, void* stream) {
+    if (!h || !act || M < 0 || I <= 0) return ARIA_ERR_INVALID;
+    if (I & 7) return ARIA_ERR_ALIGN;
+    if (M == 0) return ARIA_OK;
+    const bf16_t* a = static_cast<const bf16_t*>(h);
+    const bf16_t* b = h2 ? static_cast<const bf16_t*>(h2) : a + I;
+    const long long ld = h2 ? I : 2 * I;
+    const long long nchunks = M * (I >> 3);
+    long long g = (nchunks + 255) / 256;
+    if (g > 4096) g = 4096;
+    ARIA_LAUNCH(swiglu_fwd_kernel, dim3(int(g)), dim3(256), 0, stream, a, b, static_cast<bf16_t*>(act), nchunks, int(I), ld, ld);
+    return aria_check_launch();
+}
+
+int aria_swiglu_bwd(const void* h, const void* h2, const void* dact, void* dh, void* dh2, int64_t M, int64_t I, void* stream) {
+    if (!h || !dact || !dh || M < 0 || I <= 0) return ARIA_ERR_INVALID;
+    if (I & 7) return ARIA_ERR_ALIGN;
+    if ((h2 == nullptr) != (dh2 == nullptr)) return ARIA_ERR_INVALID;
+    if (M == 0) return ARIA_OK;
+    const bf16_t* a = static_cast<const bf16_t*>(h);
+    const bf16_t* b = h2 ? static_cast<const bf16_t*>(h2) : a + I;
+    bf16_t* da = static_cast<bf16_t*>(dh);
+    bf16_t* db = dh2 ? static_cast<bf16_t*>(dh2) : da + I;
+    const long long ld = h2 ? I : 2 * I;
+    const long long nchunks = M * (I >> 3);
+    long long g = (nchunks + 255) / 256;
+    if (g > 4096) g = 4096;
+    ARIA_LAUNCH(swiglu_bwd_kernel, dim3(int(g)), dim3(256), 0, stream, a, b, static_cast<const bf16_t*>(dact), da, db, nchunks,
+                int(I), ld, ld);
+    return aria_check_launch();
+}
+
+}  // extern "C"

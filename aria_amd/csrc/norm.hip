@@ -1,0 +1,249 @@
+// RMSNorm (+ fused residual add), RoPE, small elementwise kernels: all HBM-bound, 16-byte accesses,
+// one wave per row.  Reference: transformers/models/llama/modeling_llama.py:62-67, 130-160, 295-325
+// (inherited by aria/model/moe_lm.py:580-602); gptfast/model.py:461-472.
+#include "aria_device.h"
+#include "aria_hip.h"
+
+namespace {
+using namespace ad;
+
+constexpr int MAX_CPL = 5;  // chunks (of 8 elements) per lane: D <= 2560
+
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* x, const bf16_t* res, const bf16_t* w, bf16_t* h_out,
+                                                          bf16_t* y, float* rstd, int T, int D, float eps) {
+    const int l = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nch = D >> 3;
+    for (int t = wave; t < T; t += nwaves) {
+        float v[MAX_CPL][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAX_CPL; ++i) {
+            const int c = l + 64 * i;
+            if (c < nch) {
+                u32x4 a = ld16(x + (long long)t * D + c * 8);
+                if (res) {
+                    const u32x4 b = ld16(res + (long long)t * D + c * 8);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] = pack2bf(bflo(a[q]) + bflo(b[q]), bfhi(a[q]) + bfhi(b[q]));
+                    st16(h_out + (long long)t * D + c * 8, a);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[i][2 * q] = bflo(a[q]);
+                    v[i][2 * q + 1] = bfhi(a[q]);
+                    ss += v[i][2 * q] * v[i][2 * q] + v[i][2 * q + 1] * v[i][2 * q + 1];
+                }
+            }
+        }
+        ss = wave_sum(ss);
+        const float r = rsqrtf(ss / float(D) + eps);
+        if (l == 0 && rstd) rstd[t] = r;
+#pragma unroll
+        for (int i = 0; i < MAX_CPL; ++i) {
+            const int c = l + 64 * i;
+            if (c < nch) {
+                const u32x4 wv = ld16(w + c * 8);
+                u32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    o[q] = pack2bf(bflo(wv[q]) * rbf(v[i][2 * q] * r), bfhi(wv[q]) * rbf(v[i][2 * q + 1] * r));
+                st16(y + (long long)t * D + c * 8, o);
+            }
+        }
+    }
+}
+
+// dx = rstd * (g - hn * mean(g * hn)) (+ dres),  g = dy * w, hn = h * rstd;  dw_partial[block][d] = sum_rows dy * bf16(hn)
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, const bf16_t* h, const bf16_t* w, const float* rstd,
+                                                          const bf16_t* dres, bf16_t* dx, float* dw_partial, int T, int D) {
+    ARIA_DYN_SMEM(smem);
+    float* red = reinterpret_cast<float*>(smem);  // [4][D]
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nch = D >> 3;
+    float dwacc[MAX_CPL][8];
+#pragma unroll
+    for (int i = 0; i < MAX_CPL; ++i)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dwacc[i][q] = 0.f;
+    for (int t = wave; t < T; t += nwaves) {
+        const float r = rstd[t];
+        float g[MAX_CPL][8], hn[MAX_CPL][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAX_CPL; ++i) {
+            const int c = l + 64 * i;
+            if (c < nch) {
+                const u32x4 a = ld16(dy + (long long)t * D + c * 8);
+                const u32x4 b = ld16(h + (long long)t * D + c * 8);
+                const u32x4 ww = ld16(w + c * 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int z = 0; z < 2; ++z) {
+                        const float dyv = z ? bfhi(a[q]) : bflo(a[q]);
+                        const float hv = (z ? bfhi(b[q]) : bflo(b[q])) * r;
+                        const float wvv = z ? bfhi(ww[q]) : bflo(ww[q]);
+                        g[i][2 * q + z] = dyv * wvv;
+                        hn[i][2 * q + z] = hv;
+                        dot += dyv * wvv * hv;
+                        dwacc[i][2 * q + z] += dyv * rbf(hv);
+                    }
+                }
+            }
+        }
+        dot = wave_sum(dot) / float(D);
+#pragma unroll
+        for (int i = 0; i < MAX_CPL; ++i) {
+            const int c = l + 64 * i;
+            if (c < nch) {
+                u32x4 o;
+                u32x4 dr = zero16();
+                if (dres) dr = ld16(dres + (long long)t * D + c * 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float a0 = r * (g[i][2 * q] - hn[i][2 * q] * dot), a1 = r * (g[i][2 * q + 1] - hn[i][2 * q + 1] * dot);
+                    if (dres) {
+                        a0 += bflo(dr[q]);
+                        a1 += bfhi(dr[q]);
+                    }
+                    o[q] = pack2bf(a0, a1);
+                }
+                st16(dx + (long long)t * D + c * 8, o);
+            }
+        }
+    }
+    // block reduce of dw over the 4 waves
+#pragma unroll
+    for (int i = 0; i < MAX_CPL; ++i) {
+        const int c = l + 64 * i;
+        if (c < nch)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) red[wv * D + c * 8 + q] = dwacc[i][q];
+    }
+    sync();
+    for (int d = threadIdx.x; d < D; d += blockDim.x)
+        dw_partial[(long long)blockIdx.x * D + d] = red[d] + red[D + d] + red[2 * D + d] + red[3 * D + d];
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* partial, bf16_t* out, int nrows, int D, int accumulate) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    float s = 0.f;
+    for (int r = 0; r < nrows; ++r) s += partial[(long long)r * D + d];
+    if (accumulate) s += bf2f(out[d]);
+    out[d] = f2bf(s);
+}
+
+// in-place half-split RoPE on n_heads consecutive heads of each row
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* x, const bf16_t* cs, const bf16_t* sn, long long nitems, int S,
+                                                   int n_heads, int hd, long long ld, int inverse) {
+    const int half = hd >> 1, cph = half >> 3;  // 16-byte chunks per half head
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < nitems; it += (long long)gridDim.x * blockDim.x) {
+        const int c = int(it % cph);
+        const long long r = it / cph;
+        const int head = int(r % n_heads);
+        const long long t = r / n_heads;
+        const int pos = int(t % S);
+        bf16_t* p = x + t * ld + (long long)head * hd + c * 8;
+        const u32x4 a = ld16(p), b = ld16(p + half);
+        const u32x4 c1 = ld16(cs + (long long)pos * hd + c * 8), c2 = ld16(cs + (long long)pos * hd + half + c * 8);
+        const u32x4 s1 = ld16(sn + (long long)pos * hd + c * 8), s2 = ld16(sn + (long long)pos * hd + half + c * 8);
+        u32x4 oa, ob;
+        const float sg = inverse ? -1.f : 1.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float ra[2], rb[2];
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                const float av = z ? bfhi(a[q]) : bflo(a[q]), bv = z ? bfhi(b[q]) : bflo(b[q]);
+                const float ca = z ? bfhi(c1[q]) : bflo(c1[q]), cb = z ? bfhi(c2[q]) : bflo(c2[q]);
+                const float sa = sg * (z ? bfhi(s1[q]) : bflo(s1[q])), sb = sg * (z ? bfhi(s2[q]) : bflo(s2[q]));
+                // q*cos + rotate_half(q)*sin ; rotate_half = cat(-x2, x1)
+                ra[z] = rbf(av * ca) + rbf(-bv * sa);
+                rb[z] = rbf(bv * cb) + rbf(av * sb);
+            }
+            oa[q] = pack2bf(ra[0], ra[1]);
+            ob[q] = pack2bf(rb[0], rb[1]);
+        }
+        st16(p, oa);
+        st16(p + half, ob);
+    }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const bf16_t* a, const bf16_t* b, bf16_t* out, long long nchunks) {
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (long long)gridDim.x * blockDim.x) {
+        const u32x4 x = ld16(a + c * 8), y = ld16(b + c * 8);
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = pack2bf(bflo(x[q]) + bflo(y[q]), bfhi(x[q]) + bfhi(y[q]));
+        st16(out + c * 8, o);
+    }
+}
+
+int grid1d(long long n, int per_block, int cap = 4096) {
+    long long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return int(g);
+}
+
+}  // namespace
+
+extern "C" {
+
+int aria_rmsnorm_fwd(const void* x, const void* res, const void* w, void* h_out, void* y, float* rstd, int64_t T, int64_t D,
+                     float eps, void* stream) {
+    if (!x || !w || !y || T < 0 || D <= 0 || (res && !h_out)) return ARIA_ERR_INVALID;
+    if (D & 7) return ARIA_ERR_ALIGN;
+    if (D > 64 * 8 * MAX_CPL) return ARIA_ERR_UNSUPPORTED;
+    if (T == 0) return ARIA_OK;
+    ARIA_LAUNCH(rmsnorm_fwd_kernel, dim3(grid1d(T, 4, 2048)), dim3(256), 0, stream, static_cast<const bf16_t*>(x),
+                static_cast<const bf16_t*>(res), static_cast<const bf16_t*>(w), static_cast<bf16_t*>(h_out),
+                static_cast<bf16_t*>(y), rstd, int(T), int(D), eps);
+    return aria_check_launch();
+}
+
+int aria_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* rstd, const void* dres, void* dx,
+                     float* dw_partial, int64_t nblocks, int64_t T, int64_t D, void* stream) {
+    if (!dy || !h || !w || !rstd || !dx || !dw_partial || nblocks <= 0 || T < 0 || D <= 0) return ARIA_ERR_INVALID;
+    if (D & 7) return ARIA_ERR_ALIGN;
+    if (D > 64 * 8 * MAX_CPL) return ARIA_ERR_UNSUPPORTED;
+    ARIA_LAUNCH(rmsnorm_bwd_kernel, dim3(int(nblocks)), dim3(256), size_t(4 * D * sizeof(float)), stream,
+                static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(h), static_cast<const bf16_t*>(w), rstd,
+                static_cast<const bf16_t*>(dres), static_cast<bf16_t*>(dx), dw_partial, int(T), int(D));
+    return aria_check_launch();
+}
+
+int aria_colsum_f32(const float* partial, void* out, int64_t nrows, int64_t D, int accumulate, void* stream) {
+    if (!partial || !out || nrows < 0 || D <= 0) return ARIA_ERR_INVALID;
+    ARIA_LAUNCH(colsum_kernel, dim3(int((D + 255) / 256)), dim3(256), 0, stream, partial, static_cast<bf16_t*>(out), int(nrows),
+                int(D), accumulate);
+    return aria_check_launch();
+}
+
+int aria_rope_inplace(void* x, const void* cos, const void* sin, int64_t T, int64_t S, int64_t n_heads, int64_t hd, int64_t ld,
+                      int inverse, void* stream) {
+    if (!x || !cos || !sin || T < 0 || S <= 0 || n_heads <= 0 || hd <= 0) return ARIA_ERR_INVALID;
+    if ((hd & 15) || (ld & 7)) return ARIA_ERR_ALIGN;
+    if (T == 0) return ARIA_OK;
+    const long long nitems = T * n_heads * (hd / 16);
+    ARIA_LAUNCH(rope_kernel, dim3(grid1d(nitems, 256)), dim3(256), 0, stream, static_cast<bf16_t*>(x),
+                static_cast<const bf16_t*>(cos), static_cast<const bf16_t*>(sin), nitems, int(S), int(n_heads), int(hd),
+                (long long)ld, inverse);
+    return aria_check_launch();
+}
+
+int aria_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n < 0) return ARIA_ERR_INVALID;
+    if (n & 7) return ARIA_ERR_ALIGN;
+    if (n == 0) return ARIA_OK;
+    ARIA_LAUNCH(add_kernel, dim3(grid1d(n / 8, 256)), dim3(256), 0, stream, static_cast<const bf16_t*>(a),
+                static_cast<const bf16_t*>(b), static_cast<bf16_t*>(out), (long long)(n / 8));
+    return aria_check_launch();
+}
+
+}  // extern "C"

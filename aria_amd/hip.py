@@ -1,0 +1,97 @@
+"""ctypes binding of ``libaria_hip.so`` (the C ABI declared in ``include/aria_hip.h``).
+
+The library is the product: if it is missing, importing an op raises -- there is no
+PyTorch / CPU fallback anywhere in this package (a silent fallback would void every
+parity claim).  Build it with ``make`` or ``python -c "import __graft_entry__ as g; g.build()"``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaria_hip.so")
+
+ERRORS = {
+    1: "ARIA_ERR_INVALID (null pointer / negative size)",
+    2: "ARIA_ERR_ALIGN (pointer or leading dimension not 16-byte aligned)",
+    3: "ARIA_ERR_UNSUPPORTED (shape outside what the kernels implement)",
+    4: "ARIA_ERR_LAUNCH (HIP launch failed)",
+}
+
+P, I64, I32, F32 = c_void_p, c_int64, c_int, c_float
+
+# name -> argtypes (all return int).  Kept in one table so tests can check that the shared
+# library exports every symbol the header declares.
+SIGNATURES = {
+    "aria_abi_version": [],
+    "aria_gemm_bf16": [P, P, P, P, I64, I64, I64, I32, I32, I64, I64, I64, I32, I32, P],
+    "aria_grouped_gemm_bf16": [P, P, P, P, I64, I64, I64, I64, I32, I64, I64, I64, I64, P],
+    "aria_grouped_gemm_wgrad_bf16": [P, P, P, P, I64, I64, I64, I64, I64, I32, I32, P],
+    "aria_moe_route": [P, I32, P, P, P, I64, I64, I64, P],
+    "aria_moe_sort": [P, P, P, P, P, P, I64, I64, I64, P],
+    "aria_moe_permute": [P, P, P, I64, I64, I64, I64, P],
+    "aria_moe_unpermute": [P, P, P, P, P, I64, I64, I64, P],
+    "aria_moe_unpermute_bwd": [P, P, P, P, P, P, I64, I64, I64, P],
+    "aria_moe_route_bwd": [P, P, P, P, P, P, I64, I64, I64, F32, F32, F32, P],
+    "aria_swiglu_fwd": [P, P, P, I64, I64, P],
+    "aria_swiglu_bwd": [P, P, P, P, P, I64, I64, P],
+    "aria_rmsnorm_fwd": [P, P, P, P, P, P, I64, I64, F32, P],
+    "aria_rmsnorm_bwd": [P, P, P, P, P, P, P, I64, I64, I64, P],
+    "aria_colsum_f32": [P, P, I64, I64, I32, P],
+    "aria_rope_inplace": [P, P, P, I64, I64, I64, I64, I64, I32, P],
+    "aria_add_bf16": [P, P, P, I64, P],
+    "aria_attn_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
+    "aria_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
+    "aria_cross_entropy": [P, P, P, P, P, F32, I64, I64, I64, P],
+}
+
+
+class AriaHipError(RuntimeError):
+    pass
+
+
+class HipLibrary:
+    """A loaded C-ABI library; ``call(name, *args)`` raises on a non-zero status."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise AriaHipError(
+                f"{path} not found: the HIP library has not been built (run `make` in the repo root). "
+                "aria_amd has no fallback path."
+            )
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        self.missing = []
+        for name, argtypes in SIGNATURES.items():
+            try:
+                fn = getattr(self.cdll, name)
+            except AttributeError:
+                self.missing.append(name)
+                continue
+            fn.argtypes = argtypes
+            fn.restype = c_int
+
+    def call(self, name: str, *args) -> None:
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            raise AriaHipError(f"{name} failed: {ERRORS.get(rc, rc)}")
+
+
+_LIB: Optional[HipLibrary] = None
+_EMULATED = False  # set only by tests/emu (never by product code)
+
+
+def get_lib() -> HipLibrary:
+    global _LIB
+    if _LIB is None:
+        _LIB = HipLibrary(LIB_PATH)
+        if _LIB.missing:
+            raise AriaHipError(f"{LIB_PATH} lacks symbols {_LIB.missing}: rebuild it")
+    return _LIB
+
+
+def is_emulated() -> bool:
+    return _EMULATED

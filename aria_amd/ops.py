@@ -1,0 +1,303 @@
+"""Functional (non-autograd) wrappers over the C ABI: torch tensors in, raw pointers out.
+
+PyTorch is plumbing here (device memory + the current HIP stream); all arithmetic happens in
+``libaria_hip.so``.  Every function requires CUDA(=HIP) tensors; there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import hip
+
+bf16 = torch.bfloat16
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: torch.Tensor):
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    if not hip.is_emulated():
+        raise hip.AriaHipError("aria_amd ops need tensors on an MI355X (cuda) device; there is no CPU path")
+    return None
+
+
+def _chk(t: torch.Tensor, dtype=bf16, name="tensor"):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _rowmajor_2d(t: torch.Tensor, name="tensor") -> int:
+    """Returns the leading dimension (elements) of a 2-D view whose last dim is contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: need a 2-D view with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+# ----------------------------------------------------------------------------- GEMM
+def gemm(a: torch.Tensor, b: torch.Tensor, *, a_oc: bool = False, b_oc: bool = False, bias: Optional[torch.Tensor] = None,
+         out: Optional[torch.Tensor] = None, out_dtype=bf16, accumulate: bool = False) -> torch.Tensor:
+    """C[M,N] = op(A) op(B) (+bias) (+C).  a: [M,K] (a_oc=False) or [K,M] (a_oc=True);
+    b: [N,K] (b_oc=False, i.e. nn.Linear weight) or [K,N] (b_oc=True)."""
+    _chk(a, name="a"), _chk(b, name="b")
+    lda, ldb = _rowmajor_2d(a, "a"), _rowmajor_2d(b, "b")
+    M, K = (a.shape[1], a.shape[0]) if a_oc else (a.shape[0], a.shape[1])
+    N, Kb = (b.shape[1], b.shape[0]) if b_oc else (b.shape[0], b.shape[1])
+    if K != Kb:
+        raise ValueError(f"gemm: reduction sizes differ ({K} vs {Kb})")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an existing `out`")
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    ldc = _rowmajor_2d(out, "out")
+    if out.shape != (M, N):
+        raise ValueError(f"gemm: out shape {tuple(out.shape)} != {(M, N)}")
+    c_f32 = {bf16: 0, torch.float32: 1}[out.dtype]
+    if bias is not None:
+        _chk(bias, name="bias")
+    hip.get_lib().call("aria_gemm_bf16", _p(a), _p(b), _p(out), _p(bias), M, N, K, int(a_oc), int(b_oc), lda, ldb, ldc,
+                       c_f32, int(accumulate), _stream(a))
+    return out
+
+
+def grouped_gemm(a: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, *, w_is_kn: bool = True,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """experts_gemm with device-side offsets (int32 [E+1]).  w: [E,K,N] (w_is_kn, forward) or [E,N,K]
+    used as W_e^T (dgrad through [E,N,K]-shaped storage, i.e. the forward weight [E, K', N'] with K'=N, N'=K)."""
+    _chk(a, name="a"), _chk(w, name="w"), _chk(offsets, torch.int32, "offsets")
+    if w.dim() != 3 or not w.is_contiguous():
+        raise ValueError("grouped_gemm: w must be a contiguous [E, ., .] tensor")
+    lda = _rowmajor_2d(a, "a")
+    M, K = a.shape
+    E = w.shape[0]
+    if w_is_kn:
+        if w.shape[1] != K:
+            raise ValueError("grouped_gemm: w.shape[1] != K")
+        N = w.shape[2]
+    else:
+        if w.shape[2] != K:
+            raise ValueError("grouped_gemm: w.shape[2] != K")
+        N = w.shape[1]
+    if out is None:
+        out = torch.empty((M, N), dtype=bf16, device=a.device)
+    hip.get_lib().call("aria_grouped_gemm_bf16", _p(a), _p(w), _p(out), _p(offsets), E, M, N, K, int(w_is_kn), lda,
+                       w.shape[2], w.shape[1] * w.shape[2], _rowmajor_2d(out, "out"), _stream(a))
+    return out
+
+
+def grouped_gemm_wgrad(a: torch.Tensor, dy: torch.Tensor, offsets: torch.Tensor, E: int, *,
+                       out: Optional[torch.Tensor] = None, out_dtype=bf16, accumulate: bool = False) -> torch.Tensor:
+    """dW[e] = a[s_e:s_e+n_e]^T @ dy[s_e:s_e+n_e]  -> [E, K, N]."""
+    _chk(a, name="a"), _chk(dy, name="dy"), _chk(offsets, torch.int32, "offsets")
+    K, N = a.shape[1], dy.shape[1]
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an existing `out`")
+        out = torch.empty((E, K, N), dtype=out_dtype, device=a.device)
+    if not out.is_contiguous() or out.shape != (E, K, N):
+        raise ValueError("grouped_gemm_wgrad: out must be contiguous [E,K,N]")
+    c_f32 = {bf16: 0, torch.float32: 1}[out.dtype]
+    if a.shape[0] == 0:  # no rows at all: every expert's gradient is zero
+        return out if accumulate else out.zero_()
+    hip.get_lib().call("aria_grouped_gemm_wgrad_bf16", _p(a), _p(dy), _p(out), _p(offsets), E, K, N, _rowmajor_2d(a, "a"),
+                       _rowmajor_2d(dy, "dy"), c_f32, int(accumulate), _stream(a))
+    return out
+
+
+# ----------------------------------------------------------------------------- MoE routing / dispatch
+def moe_route(logits: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> scores [T,k] (logits dtype), indices int32 [T,k], counts int32 [E]."""
+    if logits.dtype not in (bf16, torch.float32) or not logits.is_contiguous() or logits.dim() != 2:
+        raise ValueError("moe_route: logits must be contiguous [T,E] bf16/fp32")
+    T, E = logits.shape
+    scores = torch.empty((T, k), dtype=logits.dtype, device=logits.device)
+    idx = torch.empty((T, k), dtype=torch.int32, device=logits.device)
+    counts = torch.empty((E,), dtype=torch.int32, device=logits.device)
+    hip.get_lib().call("aria_moe_route", _p(logits), int(logits.dtype == torch.float32), _p(scores), _p(idx), _p(counts), T, E,
+                       k, _stream(logits))
+    return scores, idx, counts
+
+
+def moe_sort(indices: torch.Tensor, counts: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> offsets int32 [E+1], sorted_src int32 [T*k] (== reference sorted_indices), inv int32 [T*k]."""
+    _chk(indices, torch.int32, "indices"), _chk(counts, torch.int32, "counts")
+    T, k = indices.shape
+    E = counts.shape[0]
+    M = T * k
+    dev = indices.device
+    offsets = torch.empty((E + 1,), dtype=torch.int32, device=dev)
+    sorted_src = torch.empty((M,), dtype=torch.int32, device=dev)
+    inv = torch.empty((M,), dtype=torch.int32, device=dev)
+    nchunks = (M + 2047) // 2048
+    ws = torch.empty((max(1, nchunks) * 128 + 64,), dtype=torch.int32, device=dev)
+    hip.get_lib().call("aria_moe_sort", _p(indices), _p(counts), _p(offsets), _p(sorted_src), _p(inv), _p(ws), T, E, k,
+                       _stream(indices))
+    return offsets, sorted_src, inv
+
+
+def moe_permute(x: torch.Tensor, sorted_src: torch.Tensor, k: int) -> torch.Tensor:
+    _chk(x, name="x"), _chk(sorted_src, torch.int32, "sorted_src")
+    ldx = _rowmajor_2d(x, "x")
+    M, D = sorted_src.shape[0], x.shape[1]
+    out = torch.empty((M, D), dtype=bf16, device=x.device)
+    hip.get_lib().call("aria_moe_permute", _p(x), _p(sorted_src), _p(out), M, D, k, ldx, _stream(x))
+    return out
+
+
+def moe_unpermute(expert_out: torch.Tensor, inv: torch.Tensor, scores: Optional[torch.Tensor], k: int,
+                  add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(expert_out, name="expert_out"), _chk(inv, torch.int32, "inv")
+    if not expert_out.is_contiguous():
+        raise ValueError("moe_unpermute: expert_out must be contiguous")
+    M, D = expert_out.shape
+    T = M // k
+    if scores is not None:
+        _chk(scores, name="scores")
+        assert scores.is_contiguous() and scores.shape == (T, k)
+    if add is not None:
+        _chk(add, name="add")
+        assert add.is_contiguous() and add.shape == (T, D)
+    out = torch.empty((T, D), dtype=bf16, device=expert_out.device)
+    hip.get_lib().call("aria_moe_unpermute", _p(expert_out), _p(inv), _p(scores), _p(add), _p(out), T, D, k, _stream(expert_out))
+    return out
+
+
+def moe_unpermute_bwd(dout: torch.Tensor, expert_out: torch.Tensor, inv: torch.Tensor, scores: torch.Tensor, k: int):
+    _chk(dout, name="dout"), _chk(expert_out, name="expert_out"), _chk(scores, name="scores")
+    assert dout.is_contiguous() and expert_out.is_contiguous() and scores.is_contiguous()
+    T, D = dout.shape
+    d_eo = torch.empty_like(expert_out)
+    dscores = torch.empty_like(scores)
+    hip.get_lib().call("aria_moe_unpermute_bwd", _p(dout), _p(expert_out), _p(inv), _p(scores), _p(d_eo), _p(dscores), T, D, k,
+                       _stream(dout))
+    return d_eo, dscores
+
+
+def moe_route_bwd(logits, indices, scores, dscores, counts, z_coeff=0.0, aux_coeff=0.0, aux_scale=1.0) -> torch.Tensor:
+    for t, n in ((logits, "logits"), (scores, "scores"), (dscores, "dscores")):
+        _chk(t, name=n)
+        assert t.is_contiguous()
+    T, E = logits.shape
+    k = indices.shape[1]
+    dlogits = torch.empty_like(logits)
+    hip.get_lib().call("aria_moe_route_bwd", _p(logits), _p(indices), _p(scores), _p(dscores), _p(counts), _p(dlogits), T, E, k,
+                       float(z_coeff), float(aux_coeff), float(aux_scale), _stream(logits))
+    return dlogits
+
+
+def swiglu(h: torch.Tensor, h2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """h [M,2I] -> silu(h[:, :I]) * h[:, I:]   or   (gate [M,I], up [M,I])."""
+    _chk(h, name="h")
+    assert h.is_contiguous() and (h2 is None or (h2.is_contiguous() and h2.shape == h.shape))
+    M = h.shape[0]
+    I = h.shape[1] if h2 is not None else h.shape[1] // 2
+    act = torch.empty((M, I), dtype=bf16, device=h.device)
+    hip.get_lib().call("aria_swiglu_fwd", _p(h), _p(h2), _p(act), M, I, _stream(h))
+    return act
+
+
+def swiglu_bwd(h: torch.Tensor, dact: torch.Tensor, h2: Optional[torch.Tensor] = None):
+    _chk(h, name="h"), _chk(dact, name="dact")
+    assert h.is_contiguous() and dact.is_contiguous()
+    M, I = dact.shape
+    dh = torch.empty_like(h)
+    dh2 = None if h2 is None else torch.empty_like(h2)
+    hip.get_lib().call("aria_swiglu_bwd", _p(h), _p(h2), _p(dact), _p(dh), _p(dh2), M, I, _stream(h))
+    return dh if h2 is None else (dh, dh2)
+
+
+# ----------------------------------------------------------------------------- norm / rope / elementwise
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None, want_rstd: bool = True):
+    """-> (y, h, rstd): h = x (+ residual) is the tensor that was normalised (new residual stream)."""
+    _chk(x, name="x"), _chk(w, name="w")
+    assert x.is_contiguous() and x.dim() == 2
+    T, D = x.shape
+    y = torch.empty_like(x)
+    h = torch.empty_like(x) if residual is not None else x
+    rstd = torch.empty((T,), dtype=torch.float32, device=x.device) if want_rstd else None
+    hip.get_lib().call("aria_rmsnorm_fwd", _p(x), _p(residual), _p(w), _p(h) if residual is not None else None, _p(y), _p(rstd),
+                       T, D, float(eps), _stream(x))
+    return y, h, rstd
+
+
+def rmsnorm_bwd(dy, h, w, rstd, dres: Optional[torch.Tensor] = None, dw_out: Optional[torch.Tensor] = None,
+                accumulate: bool = False):
+    """-> (dx, dw).  dx includes dres (gradient arriving through the residual stream) when given."""
+    T, D = h.shape
+    nblocks = max(1, min(512, (T + 3) // 4))
+    dx = torch.empty_like(h)
+    partial = torch.empty((nblocks, D), dtype=torch.float32, device=h.device)
+    hip.get_lib().call("aria_rmsnorm_bwd", _p(dy), _p(h), _p(w), _p(rstd), _p(dres), _p(dx), _p(partial), nblocks, T, D,
+                       _stream(h))
+    if dw_out is None:
+        dw_out = torch.empty((D,), dtype=bf16, device=h.device)
+        accumulate = False
+    hip.get_lib().call("aria_colsum_f32", _p(partial), _p(dw_out), nblocks, D, int(accumulate), _stream(h))
+    return dx, dw_out
+
+
+def rope_(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, S: int, n_heads: int, hd: int, inverse: bool = False):
+    """In-place half-split RoPE on the first n_heads*hd columns of the 2-D view x [T, >= n_heads*hd]."""
+    _chk(x, name="x"), _chk(cos, name="cos"), _chk(sin, name="sin")
+    ld = _rowmajor_2d(x, "x")
+    assert cos.is_contiguous() and sin.is_contiguous() and cos.shape[1] == hd and cos.shape[0] >= S
+    hip.get_lib().call("aria_rope_inplace", _p(x), _p(cos), _p(sin), x.shape[0], S, n_heads, hd, ld, int(inverse), _stream(x))
+    return x
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _chk(a, name="a"), _chk(b, name="b")
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    out = torch.empty_like(a)
+    hip.get_lib().call("aria_add_bf16", _p(a), _p(b), _p(out), a.numel(), _stream(a))
+    return out
+
+
+# ----------------------------------------------------------------------------- attention
+def attention_fwd(q, k, v, B: int, S: int, H: int, hd: int, scale: float, causal: bool,
+                  kv_len: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """q,k,v: 2-D views [B*S, >= H*hd] (token-major, head h at columns h*hd); -> (o [B*S, H*hd], lse fp32 [B,H,S])."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, name=n)
+    if out is None:
+        out = torch.empty((B * S, H * hd), dtype=bf16, device=q.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+    hip.get_lib().call("aria_attn_fwd", _p(q), _p(k), _p(v), _p(out), _p(lse), _p(kv_len), B, S, H, hd, _rowmajor_2d(q, "q"),
+                       _rowmajor_2d(k, "k"), _rowmajor_2d(v, "v"), _rowmajor_2d(out, "o"), float(scale), int(causal), _stream(q))
+    return out, lse
+
+
+def attention_bwd(q, k, v, o, do, lse, B: int, S: int, H: int, hd: int, scale: float, causal: bool,
+                  kv_len: Optional[torch.Tensor] = None, dq=None, dk=None, dv=None):
+    dev = q.device
+    if dq is None:
+        dq = torch.empty((B * S, H * hd), dtype=bf16, device=dev)
+    if dk is None:
+        dk = torch.empty((B * S, H * hd), dtype=bf16, device=dev)
+    if dv is None:
+        dv = torch.empty((B * S, H * hd), dtype=bf16, device=dev)
+    delta = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+    hip.get_lib().call("aria_attn_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(kv_len),
+                       B, S, H, hd, _rowmajor_2d(q, "q"), _rowmajor_2d(k, "k"), _rowmajor_2d(v, "v"), _rowmajor_2d(o, "o"),
+                       _rowmajor_2d(dq, "dq"), _rowmajor_2d(dk, "dk"), _rowmajor_2d(dv, "dv"), float(scale), int(causal),
+                       _stream(q))
+    return dq, dk, dv
+
+
+# ----------------------------------------------------------------------------- loss
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, grad_scale: Optional[float] = None,
+                  dlogits: Optional[torch.Tensor] = None):
+    """labels int32 [T] already shifted/masked (-100 ignore).  -> (loss_sum fp32[1], count int32[1], dlogits|None).
+    dlogits may alias logits.  grad_scale multiplies (softmax - onehot)."""
+    _chk(logits, name="logits"), _chk(labels, torch.int32, "labels")
+    T, V = logits.shape
+    loss_sum = torch.zeros((1,), dtype=torch.float32, device=logits.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=logits.device)
+    hip.get_lib().call("aria_cross_entropy", _p(logits), _p(labels), _p(loss_sum), _p(count), _p(dlogits),
+                       float(grad_scale if grad_scale is not None else 0.0), T, V, _rowmajor_2d(logits, "logits"), _stream(logits))
+    return loss_sum, count, dlogits

@@ -1,0 +1,163 @@
+/*
+ * aria_hip.h -- C ABI of libaria_hip.so: the MI355X (gfx950) hot path of rhymes-ai/Aria.
+ *
+ * Drop-in boundary.  Every entry point takes raw device pointers, integer
+ * sizes and a hipStream_t (as void*); outputs are caller-allocated; nothing allocates, nothing
+ * synchronises with the host, no global state.  Return value: ARIA_OK or an ARIA_ERR_* code (the
+ * Python host raises on non-zero).  Routing metadata (tokens_per_expert / offsets) stays on the
+ * device -- the reference's GroupedGEMM.forward forces a D2H sync per call (aria/model/moe_lm.py:478).
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to /root/reference;
+ * "transformers/..." = arithmetic the reference inherits from transformers==4.46.3).
+ * All matrices are bfloat16 (raw uint16 bits) unless stated, row-major, leading dimension in ELEMENTS.
+ */
+#ifndef ARIA_HIP_H
+#define ARIA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARIA_OK 0
+#define ARIA_ERR_INVALID 1     /* null pointer / negative size */
+#define ARIA_ERR_ALIGN 2       /* pointer or leading dimension not 16-byte aligned where required */
+#define ARIA_ERR_UNSUPPORTED 3 /* shape outside what the kernels implement (e.g. > 256 experts) */
+#define ARIA_ERR_LAUNCH 4      /* hipGetLastError() != hipSuccess after the launch */
+
+/* Library / ABI version (bumped when a signature changes). */
+int aria_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM family (gemm.hip) -- v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+ * a_oc / b_oc = 0: operand is reduction-contiguous  (A[M,K] row-major;  B given as [N,K] row-major)
+ *             = 1: operand is output-contiguous     (A given as [K,M];  B given as [K,N] row-major)
+ * C[M,N] = A*B (+ bias[N]) (+ C if accumulate); C is bf16, or fp32 when c_f32.
+ * Replaces every nn.Linear / F.linear on the path and its dgrad/wgrad:
+ *   Linear fwd  y = x W^T : (a_oc=0, b_oc=0)   router gating aria/model/moe_lm.py:190-201; q/k/v/o
+ *                                              transformers/models/llama/modeling_llama.py:243-281;
+ *                                              SharedExpertMLP moe_lm.py:368-395; lm_head; ViT linears
+ *   Linear dgrad dx = dy W : (0, 1);  Linear wgrad dW = dy^T x : (1, 1)
+ * ------------------------------------------------------------------------------------------------ */
+int aria_gemm_bf16(const void* A, const void* B, void* C, const void* bias /* bf16[N] or NULL */, int64_t M, int64_t N,
+                   int64_t K, int a_oc, int b_oc, int64_t lda, int64_t ldb, int64_t ldc, int c_f32, int accumulate,
+                   void* stream);
+
+/* experts_gemm(input, weight, tokens_per_expert)  -- seam B1, aria/model/moe_lm.py:431-443 (grouped_gemm.ops.gmm
+ * or sequential_gemm :398-428), called from GroupedGEMM.forward :467-484.
+ *   C[s_e : s_e+n_e, :] = A[s_e : s_e+n_e, :] * B_e       offsets[e] = s_e (device int32[E+1], offsets[E] = M_total)
+ *   b_oc = 1: B_e = B + e*strideB is [K,N] row-major (the reference's weight layout, forward)
+ *   b_oc = 0: B_e is [N,K] row-major, i.e. C = A * W_e^T with W_e [N,K] (dgrad through the same weights) */
+int aria_grouped_gemm_bf16(const void* A, const void* B, void* C, const int32_t* offsets, int64_t E, int64_t M_total,
+                           int64_t N, int64_t K, int b_oc, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldc,
+                           void* stream);
+
+/* autograd backward of experts_gemm w.r.t. weight:  dW[e] (K x N) (+)= A[s_e:s_e+n_e]^T * dY[s_e:s_e+n_e].
+ * Experts with zero rows get zeros (or keep dW when accumulate). */
+int aria_grouped_gemm_wgrad_bf16(const void* A, const void* dY, void* dW, const int32_t* offsets, int64_t E, int64_t K,
+                                 int64_t N, int64_t lda, int64_t ldy, int c_f32, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * MoE routing / dispatch (moe.hip)
+ * ------------------------------------------------------------------------------------------------ */
+/* TopKRouter.routing, aria/model/moe_lm.py:243-273 (eval part): top-k over E logits per token with the
+ * deterministic tie rule "lowest expert id wins" (SURVEY.md section 8a-R), softmax over the k selected logits
+ * in fp32 then cast to the logits dtype (:262), histogram of selected ids (:264-269).
+ *   logits [T,E] bf16 (logits_f32=0) or fp32;  scores [T,k] same dtype as logits;  indices int32 [T,k]
+ *   (descending logit order, like torch.topk);  counts int32[E] (zeroed here, then accumulated). */
+int aria_moe_route(const void* logits, int logits_f32, void* scores, int32_t* indices, int32_t* counts, int64_t T,
+                   int64_t E, int64_t k, void* stream);
+
+/* TokenDispatcher.token_permutation bookkeeping, aria/model/moe_lm.py:326-334: stable sort of the flattened
+ * expert ids.  sorted_src[p] = flat index t*k+j of the p-th row in expert-major order (== the reference's
+ * `sorted_indices`), inv[t*k+j] = p, offsets = exclusive scan of counts.  workspace: int32[(nchunks*2)*64 + 64]
+ * with nchunks = ceil(T*k / 2048). */
+int aria_moe_sort(const int32_t* indices, const int32_t* counts, int32_t* offsets, int32_t* sorted_src, int32_t* inv,
+                  int32_t* workspace, int64_t T, int64_t E, int64_t k, void* stream);
+
+/* permuted[p, :] = x[sorted_src[p] / k, :]   (index_select, moe_lm.py:330). D % 8 == 0. */
+int aria_moe_permute(const void* x, const int32_t* sorted_src, void* permuted, int64_t M, int64_t D, int64_t k,
+                     int64_t ldx, void* stream);
+
+/* TokenDispatcher.token_unpermutation, moe_lm.py:336-365, fused with `output += shared` (:575-576):
+ *   out[t] = bf16( sum_j fp32( bf16(expert_out[inv[t*k+j]] * scores[t,j]) ) ) ; if add: out = bf16(out + add[t]).
+ * scores == NULL -> plain sum (used as the backward of the permute gather). */
+int aria_moe_unpermute(const void* expert_out, const int32_t* inv, const void* scores, const void* add, void* out,
+                       int64_t T, int64_t D, int64_t k, void* stream);
+
+/* backward of token_unpermutation: d_expert_out[inv[t,j]] = bf16(dout[t] * scores[t,j]);
+ * dscores[t,j] = <expert_out[inv[t,j]], dout[t]> (fp32 reduce, stored bf16). */
+int aria_moe_unpermute_bwd(const void* dout, const void* expert_out, const int32_t* inv, const void* scores,
+                           void* d_expert_out, void* dscores, int64_t T, int64_t D, int64_t k, void* stream);
+
+/* backward of TopKRouter.routing incl. the training-only auxiliary losses (moe_lm.py:128-166, 203-241,
+ * MoEAuxLossAutoScaler :84-125): dlogits[T,E] (bf16) from dscores, z-loss and load-balancing loss.
+ * aux_scale = MoEAuxLossAutoScaler.main_loss_backward_scale; coefficients 0 disable a term. */
+int aria_moe_route_bwd(const void* logits, const int32_t* indices, const void* scores, const void* dscores,
+                       const int32_t* counts, void* dlogits, int64_t T, int64_t E, int64_t k, float z_coeff,
+                       float aux_coeff, float aux_scale, void* stream);
+
+/* GroupedMLP.glu, moe_lm.py:505-507 (and LlamaMLP's silu(gate)*up):  act = bf16(bf16(silu(a)) * b).
+ * two_inputs = 0: h is [M, 2I], a = h[:, :I], b = h[:, I:];  two_inputs = 1: a = h, b = h2, each [M, I]. */
+int aria_swiglu_fwd(const void* h, const void* h2, void* act, int64_t M, int64_t I, void* stream);
+/* dh (same layout as h/h2) from dact. */
+int aria_swiglu_bwd(const void* h, const void* h2, const void* dact, void* dh, void* dh2, int64_t M, int64_t I,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Norms / RoPE / elementwise (norm.hip)
+ * ------------------------------------------------------------------------------------------------ */
+/* LlamaRMSNorm.forward, transformers/models/llama/modeling_llama.py:62-67 (== gptfast/model.py:461-472), optionally
+ * fused with the residual add that precedes it in LlamaDecoderLayer.forward (:295-325):
+ *   if res: h = bf16(x + res), written to h_out;  y = bf16(w * bf16(h * rsqrt(mean(h^2) + eps)));  rstd fp32 [T] saved. */
+int aria_rmsnorm_fwd(const void* x, const void* res, const void* w, void* h_out, void* y, float* rstd, int64_t T,
+                     int64_t D, float eps, void* stream);
+/* dx (+= dres if given), partial dw [nblocks, D] fp32 (reduced by aria_colsum_f32). */
+int aria_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* rstd, const void* dres, void* dx,
+                     float* dw_partial, int64_t nblocks, int64_t T, int64_t D, void* stream);
+/* out[D] (bf16, (+)=) = sum over rows of partial[nrows, D] fp32 */
+int aria_colsum_f32(const float* partial, void* out, int64_t nrows, int64_t D, int accumulate, void* stream);
+
+/* apply_rotary_pos_emb, transformers/models/llama/modeling_llama.py:130-160 (half-split rotate), in place on the
+ * q and k column blocks of a [T, ld] activation: x = bf16(bf16(x*cos) + bf16(rot(x)*sin)), cos/sin bf16 [S, hd]
+ * tables built on the host exactly like LlamaRotaryEmbedding (:96-127).  pos = t % S.  inverse != 0 applies the
+ * transposed rotation (backward). */
+int aria_rope_inplace(void* x, const void* cos, const void* sin, int64_t T, int64_t S, int64_t n_heads, int64_t hd,
+                      int64_t ld, int inverse, void* stream);
+
+/* out = bf16(a + b), n elements (n % 8 == 0) */
+int aria_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention (attn.hip)
+ * ------------------------------------------------------------------------------------------------ */
+/* softmax(Q K^T * scale + mask) V, flash style (no S x S tensor), fp32 softmax
+ * (eager_attention_forward transformers/models/llama/modeling_llama.py:192-215; gptfast/model.py:439-442).
+ * q,k,v,o: [B, S, H, hd] views with row strides ld* (elements) between consecutive tokens; head h at column h*hd.
+ * causal != 0: decoder mask.  kv_len int32[B] or NULL: keys >= kv_len[b] are masked (ViT patch padding,
+ * vision_encoder.py:147-152).  lse fp32 [B,H,S] saved for the backward.  hd in {64, 128}. */
+int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* kv_len, int64_t B,
+                  int64_t S, int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
+                  int causal, void* stream);
+int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                  float* delta /* fp32 [B,H,S] scratch */, void* dq, void* dk, void* dv, const int32_t* kv_len, int64_t B,
+                  int64_t S, int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq,
+                  int64_t lddk, int64_t lddv, float scale, int causal, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Loss (loss.hip)
+ * ------------------------------------------------------------------------------------------------ */
+/* shifted, masked mean cross-entropy of aria/model/modeling_aria.py:301-323 on logits [T,V] bf16:
+ * labels int32[T] are ALREADY shifted and masked by the host (-100 = ignore).  loss_sum fp32[1] and
+ * count int32[1] are accumulated (caller zeroes); if dlogits != NULL it receives
+ * (softmax - onehot) * grad_scale for counted rows, 0 for ignored rows (may alias logits). */
+int aria_cross_entropy(const void* logits, const int32_t* labels, float* loss_sum, int32_t* count, void* dlogits,
+                       float grad_scale, int64_t T, int64_t V, int64_t ld, void* stream);
+
+#ifdef __cplusplus
+}
+/* internal helper shared by the translation units */
+int aria_check_launch();
+#endif
+#endif /* ARIA_HIP_H */
