@@ -45,7 +45,8 @@ SIGNATURES = {
     "aria_add_bf16": [P, P, P, I64, P],
     "aria_attn_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
     "aria_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
-    "aria_cross_entropy": [P, P, P, P, P, F32, I64, I64, I64, P],
+    "aria_cross_entropy": [P, P, P, P, P, F32, P, I64, I64, I64, P],
+    "aria_probe_tr16": [P, I32, P],
 }
 
 

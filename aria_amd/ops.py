@@ -291,7 +291,7 @@ def attention_bwd(q, k, v, o, do, lse, B: int, S: int, H: int, hd: int, scale: f
 
 # ----------------------------------------------------------------------------- loss
 def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, grad_scale: Optional[float] = None,
-                  dlogits: Optional[torch.Tensor] = None):
+                  dlogits: Optional[torch.Tensor] = None, count_in: Optional[torch.Tensor] = None):
     """labels int32 [T] already shifted/masked (-100 ignore).  -> (loss_sum fp32[1], count int32[1], dlogits|None).
     dlogits may alias logits.  grad_scale multiplies (softmax - onehot)."""
     _chk(logits, name="logits"), _chk(labels, torch.int32, "labels")
@@ -299,5 +299,5 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, grad_scale: Option
     loss_sum = torch.zeros((1,), dtype=torch.float32, device=logits.device)
     count = torch.zeros((1,), dtype=torch.int32, device=logits.device)
     hip.get_lib().call("aria_cross_entropy", _p(logits), _p(labels), _p(loss_sum), _p(count), _p(dlogits),
-                       float(grad_scale if grad_scale is not None else 0.0), T, V, _rowmajor_2d(logits, "logits"), _stream(logits))
+                       float(grad_scale if grad_scale is not None else 0.0), _p(count_in), T, V, _rowmajor_2d(logits, "logits"), _stream(logits))
     return loss_sum, count, dlogits

@@ -153,7 +153,11 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
  * count int32[1] are accumulated (caller zeroes); if dlogits != NULL it receives
  * (softmax - onehot) * grad_scale for counted rows, 0 for ignored rows (may alias logits). */
 int aria_cross_entropy(const void* logits, const int32_t* labels, float* loss_sum, int32_t* count, void* dlogits,
-                       float grad_scale, int64_t T, int64_t V, int64_t ld, void* stream);
+                       float grad_scale, const int32_t* count_in /* device, or NULL: scale = grad_scale / max(1,*count_in) */,
+                       int64_t T, int64_t V, int64_t ld, void* stream);
+
+/* hardware-semantics probe (ds_read_b64_tr_b16 lane mapping); test-only, see csrc/probe.hip */
+int aria_probe_tr16(void* out /* u16[256] */, int mode, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,310 @@
+"""Kernel parity cases shared by the emulator tests (CPU, tests/test_emu_kernels.py) and the hardware tests
+(MI355X, tests/test_gpu_kernels.py, -m gpu).  Every case feeds the SAME seeded inputs to the C-ABI kernels
+(through aria_amd.ops) and to the CPU oracle (oracle/aria_oracle.py) and compares:
+  * integer / index work (router indices, histogram, sort order, permuted rows): bit-exact;
+  * bf16 elementwise work that mirrors the reference's rounding points: bit-exact under the emulator,
+    <= 1 bf16 ulp on hardware (device expf / rsqrt may differ from the host's libm by one fp32 ulp);
+  * GEMM / attention / reductions: tolerance stated per case (bf16 inputs, fp32 accumulation).
+"""
+import torch
+
+from oracle import aria_oracle as O
+
+bf16 = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(bf16)
+
+
+def close(got, want, rtol=2e-2, atol=2e-2):
+    got, want = got.detach().cpu().float(), want.detach().cpu().float()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.4g} (tol there {tol.flatten()[err.argmax()].item():.3g})"
+
+
+def same(got, want, exact):
+    """bit-exact under the emulator; within one bf16 ulp on hardware."""
+    got, want = got.cpu(), want.cpu()
+    if exact:
+        assert torch.equal(got, want)
+    else:
+        err = (got.float() - want.float()).abs()
+        assert bool((err <= 2 ** -7 * want.float().abs() + 1e-30).all()), err.max().item()
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def case_gemm_layouts(dev, M, N, K, a_oc, b_oc):
+    from aria_amd import ops
+
+    if a_oc and M % 8:
+        M = (M + 7) // 8 * 8
+    A = rnd(M, K, seed=1)
+    B = rnd(K, N, seed=2)  # logical [K,N]
+    a_arg = (A.t().contiguous() if a_oc else A).to(dev)
+    b_arg = (B if b_oc else B.t().contiguous()).to(dev)
+    bias = rnd(N, seed=3)
+    want = A.float() @ B.float()
+    got = ops.gemm(a_arg, b_arg, a_oc=a_oc, b_oc=b_oc)
+    close(got, want.to(bf16), 1e-2, 1e-2 * K ** 0.5)
+    got32 = ops.gemm(a_arg, b_arg, a_oc=a_oc, b_oc=b_oc, out_dtype=torch.float32)
+    close(got32, want, 1e-4, 1e-3)
+    gotb = ops.gemm(a_arg, b_arg, a_oc=a_oc, b_oc=b_oc, bias=bias.to(dev), out_dtype=torch.float32)
+    close(gotb, want + bias.float(), 1e-4, 1e-3)
+    acc = torch.ones(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(a_arg, b_arg, a_oc=a_oc, b_oc=b_oc, out=acc, accumulate=True)
+    close(acc, want + 1.0, 1e-4, 1e-3)
+    accb = torch.ones(M, N, dtype=bf16, device=dev)
+    ops.gemm(a_arg, b_arg, a_oc=a_oc, b_oc=b_oc, out=accb, accumulate=True)
+    close(accb, (want + 1.0).to(bf16), 1e-2, 1e-2 * K ** 0.5)
+
+
+def case_gemm_strided_views(dev):
+    from aria_amd import ops
+
+    T, D = 40, 64
+    x = rnd(T, D, seed=4)
+    w = rnd(D, D, seed=5, scale=0.2)
+    qkv = torch.zeros(T, 3 * D, dtype=bf16, device=dev)
+    ops.gemm(x.to(dev), w.to(dev), out=qkv[:, D:2 * D])
+    ref = (x.float() @ w.float().t()).to(bf16)
+    close(qkv[:, D:2 * D], ref, 1e-2, 5e-2)
+    assert float(qkv[:, :D].abs().max()) == 0 and float(qkv[:, 2 * D:].abs().max()) == 0
+    y = ops.gemm(qkv[:, D:2 * D], w.to(dev))
+    close(y, (qkv[:, D:2 * D].cpu().float() @ w.float().t()).to(bf16), 1e-2, 5e-2)
+
+
+def case_grouped_gemm(dev, counts, K=72, N=136):
+    from aria_amd import ops
+
+    E = len(counts)
+    M = sum(counts)
+    a = rnd(M, K, seed=6)
+    w = rnd(E, K, N, seed=7, scale=0.3)
+    tpe = torch.tensor(counts)
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(tpe, 0)
+    offd = off.to(dev)
+    want = O.sequential_gemm(a.float(), w.float(), tpe)
+    dy = rnd(M, N, seed=8)
+    if M:
+        got = ops.grouped_gemm(a.to(dev), w.to(dev), offd)
+        close(got, want.to(bf16), 1e-2, 1e-2 * K ** 0.5)
+        da = ops.grouped_gemm(dy.to(dev), w.to(dev), offd, w_is_kn=False)
+        want_da = O.sequential_gemm(dy.float(), w.float().transpose(1, 2), tpe)
+        close(da, want_da.to(bf16), 1e-2, 1e-2 * N ** 0.5)
+    dw = ops.grouped_gemm_wgrad(a.to(dev), dy.to(dev), offd, E, out_dtype=torch.float32)
+    want_dw = torch.zeros(E, K, N)
+    s = 0
+    for e, n in enumerate(counts):
+        want_dw[e] = a[s:s + n].float().t() @ dy[s:s + n].float()
+        s += n
+    close(dw, want_dw, 1e-4, 1e-3)
+    dwb = ops.grouped_gemm_wgrad(a.to(dev), dy.to(dev), offd, E)
+    close(dwb, want_dw.to(bf16), 1e-2, 1e-2 * max(1, max(counts)) ** 0.5)
+
+
+# ------------------------------------------------------------------------------------------ routing
+def case_route(dev, T, E, k, dtype, exact):
+    from aria_amd import ops
+
+    g = torch.Generator().manual_seed(T + E)
+    logits = torch.randn(T, E, generator=g) * 0.5
+    logits[:, 3] = logits[:, 1]  # force ties everywhere
+    logits[0] = 0.25              # a fully tied row
+    logits = logits.to(dtype)
+    scores, idx, counts = ops.moe_route(logits.to(dev), k)
+    ws, wi, wc = O.router_routing(logits, k, E)
+    assert torch.equal(idx.cpu().long(), wi)          # router indices bit-exact under the tie protocol
+    assert torch.equal(counts.cpu().long(), wc)
+    if dtype == bf16:
+        same(scores, ws, exact)
+    else:
+        assert torch.allclose(scores.cpu(), ws, atol=1e-6)
+
+
+def case_dispatch(dev, T, E, k, exact, D=72):
+    from aria_amd import ops
+
+    g = torch.Generator().manual_seed(T)
+    logits = torch.randn(T, E, generator=g).to(bf16)
+    scores, idx, counts = ops.moe_route(logits.to(dev), k)
+    off, sorted_src, inv = ops.moe_sort(idx, counts)
+    x = rnd(T, D, seed=9)
+    want_perm, want_sorted = O.token_permutation(x, idx.cpu().long(), k)
+    assert torch.equal(sorted_src.cpu().long(), want_sorted)  # stable order == argsort(stable=True)
+    assert torch.equal(off.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(counts.cpu().long(), 0)]))
+    assert torch.equal(inv.cpu().long()[want_sorted], torch.arange(T * k))
+    perm = ops.moe_permute(x.to(dev), sorted_src, k)
+    assert torch.equal(perm.cpu(), want_perm)
+    eo = rnd(T * k, D, seed=10)
+    shared = rnd(T, D, seed=11)
+    got = ops.moe_unpermute(eo.to(dev), inv, scores, k, add=shared.to(dev))
+    want = O.token_unpermutation(eo, scores.cpu(), want_sorted, k, (T, D)) + shared
+    assert torch.equal(got.cpu(), want)  # only mul/add/round: bit-exact on hardware too
+    gsum = ops.moe_unpermute(eo.to(dev), inv, None, k)
+    close(gsum, torch.zeros(T * k, D).index_copy_(0, want_sorted, eo.float()).view(T, k, D).sum(1).to(bf16), 1e-2, 1e-2)
+
+
+def case_moe_backward_pieces(dev):
+    from aria_amd import ops
+
+    T, E, k, D = 50, 8, 3, 40
+    cfg = O.LMConfig(hidden_size=D, moe_num_experts=E, moe_topk=k, moe_z_loss_coeff=1e-2, moe_aux_loss_coeff=5e-2)
+    logits = rnd(T, E, seed=12)
+    lf = logits.float().requires_grad_(True)
+    O._AuxLossScaler.scale = 0.5
+    try:
+        lz = O._AuxLossScaler.apply(lf, O.z_loss_func(lf, cfg.moe_z_loss_coeff))
+        s, idx, tpe = O.router_routing(lz, k, E)
+        probs = torch.softmax(lz, dim=-1, dtype=torch.float32)
+        s2 = O._AuxLossScaler.apply(s, O.switch_load_balancing_loss_func(probs, tpe, k, cfg.moe_aux_loss_coeff))
+        ds = rnd(T, k, seed=13)
+        s2.backward(ds.float())
+    finally:
+        O._AuxLossScaler.scale = 1.0
+    scores, idx_k, counts = ops.moe_route(logits.to(dev), k)
+    assert torch.equal(idx_k.cpu().long(), idx)
+    dl = ops.moe_route_bwd(logits.to(dev), idx_k, scores, ds.to(dev), counts, cfg.moe_z_loss_coeff, cfg.moe_aux_loss_coeff, 0.5)
+    close(dl, lf.grad, 2e-2, 2e-3)
+
+    off, sorted_src, inv = ops.moe_sort(idx_k, counts)
+    eo = rnd(T * k, D, seed=14)
+    dout = rnd(T, D, seed=15)
+    eof = eo.float().requires_grad_(True)
+    sf = scores.cpu().float().requires_grad_(True)
+    out = O.token_unpermutation(eof, sf, sorted_src.cpu().long(), k, (T, D))
+    out.backward(dout.float())
+    d_eo, dsc = ops.moe_unpermute_bwd(dout.to(dev), eo.to(dev), inv, scores, k)
+    close(d_eo, eof.grad, 1e-2, 1e-2)
+    close(dsc, sf.grad, 2e-2, 5e-2)
+
+
+def case_swiglu(dev, exact):
+    from aria_amd import ops
+
+    M, I = 37, 24
+    h = rnd(M, 2 * I, seed=16)
+    want = O.glu(h)
+    same(ops.swiglu(h.to(dev)), want, exact)
+    gate, up = h[:, :I].contiguous(), h[:, I:].contiguous()
+    same(ops.swiglu(gate.to(dev), up.to(dev)), want, exact)
+    hf = h.float().requires_grad_(True)
+    dact = rnd(M, I, seed=17)
+    O.glu(hf).backward(dact.float())
+    close(ops.swiglu_bwd(h.to(dev), dact.to(dev)), hf.grad, 2e-2, 2e-2)
+    dg, du = ops.swiglu_bwd(gate.to(dev), dact.to(dev), up.to(dev))
+    close(torch.cat([dg, du], 1), hf.grad, 2e-2, 2e-2)
+
+
+# ------------------------------------------------------------------------------------------ norm / rope
+def case_rmsnorm(dev, T, D, exact):
+    from aria_amd import ops
+
+    x, res, w = rnd(T, D, seed=18), rnd(T, D, seed=19), (1 + 0.1 * torch.randn(D, generator=torch.Generator().manual_seed(1))).to(bf16)
+    y, h, rstd = ops.rmsnorm(x.to(dev), w.to(dev), 1e-6)
+    same(y, O.rms_norm(x, w, 1e-6), exact)
+    y2, h2, rstd2 = ops.rmsnorm(x.to(dev), w.to(dev), 1e-6, residual=res.to(dev))
+    assert torch.equal(h2.cpu(), x + res)
+    same(y2, O.rms_norm(x + res, w, 1e-6), exact)
+    hf = (x + res).float().requires_grad_(True)
+    wf = w.float().requires_grad_(True)
+    dy, dres = rnd(T, D, seed=20), rnd(T, D, seed=21)
+    yf = O.rms_norm(hf, wf, 1e-6)
+    (yf * dy.float()).sum().backward()
+    dx, dw = ops.rmsnorm_bwd(dy.to(dev), h2, w.to(dev), rstd2, dres=dres.to(dev))
+    close(dx, hf.grad + dres.float(), 2e-2, 2e-2)
+    close(dw, wf.grad, 2e-2, 2e-2 * T ** 0.5)
+
+
+def case_rope(dev):
+    from aria_amd import ops
+
+    B, S, H, hd = 2, 7, 3, 32
+    D = H * hd
+    qkv = rnd(B * S, 3 * D, seed=22)
+    pos = torch.arange(S)[None].expand(B, S)
+    cos, sin = O.rope_cos_sin(pos[:1], hd, 5e6, bf16)
+    cos, sin = cos[0].contiguous(), sin[0].contiguous()
+    q = qkv[:, :D].view(B, S, H, hd).transpose(1, 2)
+    k = qkv[:, D:2 * D].view(B, S, H, hd).transpose(1, 2)
+    cb, sb = O.rope_cos_sin(pos, hd, 5e6, bf16)
+    wq, wk = O.apply_rope_half(q, k, cb, sb)
+    work = qkv.clone().to(dev)
+    ops.rope_(work[:, :2 * D], cos.to(dev), sin.to(dev), S, 2 * H, hd)
+    wc = work.cpu()
+    assert torch.equal(wc[:, :D].view(B, S, H, hd).transpose(1, 2), wq)  # mul/add/round only: exact everywhere
+    assert torch.equal(wc[:, D:2 * D].view(B, S, H, hd).transpose(1, 2), wk)
+    assert torch.equal(wc[:, 2 * D:], qkv[:, 2 * D:])
+    ops.rope_(work[:, :2 * D], cos.to(dev), sin.to(dev), S, 2 * H, hd, inverse=True)
+    close(work, qkv, 2e-2, 2e-2)
+
+
+def case_add(dev):
+    from aria_amd import ops
+
+    a, b = rnd(5, 16, seed=23), rnd(5, 16, seed=24)
+    assert torch.equal(ops.add(a.to(dev), b.to(dev)).cpu(), a + b)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_ref(q, k, v, B, S, H, hd, scale, causal, kv_len=None):
+    """fp32 oracle on bf16 inputs: O.attention_eager with key padding from kv_len."""
+    qh = q.float().view(B, S, H, hd).transpose(1, 2)
+    kh = k.float().view(B, S, H, hd).transpose(1, 2)
+    vh = v.float().view(B, S, H, hd).transpose(1, 2)
+    pad = None
+    if kv_len is not None:
+        pad = torch.arange(S)[None, :] >= kv_len[:, None]
+    o = O.attention_eager(qh, kh, vh, scale, causal, key_padding=pad)
+    return o.transpose(1, 2).reshape(B * S, H * hd)
+
+
+def case_attention(dev, B, S, H, hd, causal, use_len, bwd=True):
+    from aria_amd import ops
+
+    D = H * hd
+    qkv = rnd(B * S, 3 * D, seed=30, scale=1.0)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    kv_len = None
+    if use_len:
+        kv_len = torch.tensor([max(1, S - 3 - 5 * b) for b in range(B)], dtype=torch.int32)
+    scale = hd ** -0.5
+    qd = qkv.to(dev)
+    o, lse = ops.attention_fwd(qd[:, :D], qd[:, D:2 * D], qd[:, 2 * D:], B, S, H, hd, scale, causal,
+                               None if kv_len is None else kv_len.to(dev))
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    want = attn_ref(qf, kf, vf, B, S, H, hd, scale, causal, kv_len)
+    close(o, want, 2e-2, 2e-2)
+    if not bwd:
+        return
+    do = rnd(B * S, D, seed=31)
+    want.backward(do.float())
+    dq, dk, dv = ops.attention_bwd(qd[:, :D], qd[:, D:2 * D], qd[:, 2 * D:], o, do.to(dev), lse, B, S, H, hd, scale, causal,
+                                   None if kv_len is None else kv_len.to(dev))
+    close(dq, qf.grad, 3e-2, 3e-2)
+    close(dk, kf.grad, 3e-2, 3e-2)
+    close(dv, vf.grad, 3e-2, 3e-2)
+
+
+# ------------------------------------------------------------------------------------------ loss
+def case_cross_entropy(dev, T, V):
+    from aria_amd import ops
+
+    logits = rnd(T, V, seed=40, scale=2.0)
+    g = torch.Generator().manual_seed(41)
+    labels = torch.randint(0, V, (T,), generator=g)
+    labels[::5] = -100
+    lf = logits.float().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(lf, labels, ignore_index=-100)
+    want.backward()
+    n = int((labels != -100).sum())
+    ld = logits.to(dev)
+    dl = torch.empty_like(ld)
+    loss_sum, count, _ = ops.cross_entropy(ld, labels.to(torch.int32).to(dev), grad_scale=1.0 / n, dlogits=dl)
+    assert int(count.cpu()) == n
+    close(loss_sum.cpu() / n, want.detach().reshape(1), 1e-4, 1e-4)
+    close(dl, lf.grad, 2e-2, 1e-4)
