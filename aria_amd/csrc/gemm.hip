@@ -111,10 +111,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
     const int tn = tile % p.ntn;
     int tmi = tile / p.ntn;
     const bf16_t* A = p.A;
-    const bf16_t* B = p.B;
-    char* C = static_cast<char*>(p.C);
     const int csz = p.c_f32 ? 4 : 2;
-    int m0, m_end, k_begin = 0, k_end = p.K;
+    // NOTE: expert offsets are carried as integers and applied once below; a pointer that is only modified on
+    // one mode's path was left undefined on another path by hipcc (ROCm 7.2) -- found in the ISA, see DESIGN.md.
+    long long b_off = 0, c_off = 0;
+    int m0 = 0, m_end = 0, k_begin = 0, k_end = p.K;
     const int n0 = tn * BN;
     if (p.mode == 0) {
         m0 = tmi * BM;
@@ -151,15 +152,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
         if (e_found < 0) return;  // uniform across the block
         m0 = start + tmi * BM;
         m_end = end;
-        B += (long long)e_found * p.strideB;
+        b_off = (long long)e_found * p.strideB;
     } else {
         const int e = blockIdx.y;
         m0 = tmi * BM;
         m_end = p.M;
         k_begin = p.offsets[e];
         k_end = p.offsets[e + 1];
-        C += (long long)e * p.strideC * csz;
+        c_off = (long long)e * p.strideC;
     }
+    const bf16_t* B = p.B + b_off;
+    char* C = static_cast<char*>(p.C) + c_off * csz;
 
     f32x16 acc[2][2];
 #pragma unroll

@@ -27,13 +27,14 @@ def close(got, want, rtol=2e-2, atol=2e-2):
 
 
 def same(got, want, exact):
-    """bit-exact under the emulator; within one bf16 ulp on hardware."""
+    """bit-exact under the emulator; within two bf16 ulps on hardware (device rsqrt/exp differ from the host libm
+    by an fp32 ulp, which can flip one bf16 rounding; a second rounding point can double it)."""
     got, want = got.cpu(), want.cpu()
     if exact:
         assert torch.equal(got, want)
     else:
         err = (got.float() - want.float()).abs()
-        assert bool((err <= 2 ** -7 * want.float().abs() + 1e-30).all()), err.max().item()
+        assert bool((err <= 2 ** -6 * want.float().abs() + 1e-30).all()), err.max().item()
 
 
 # ------------------------------------------------------------------------------------------ GEMM
