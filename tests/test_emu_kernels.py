@@ -69,3 +69,9 @@ def test_add():
 @pytest.mark.parametrize("T,V", [(7, 128), (19, 1000)])
 def test_cross_entropy(T, V):
     C.case_cross_entropy(DEV, T, V)
+
+
+@pytest.mark.parametrize("B,S,H,hd,causal,use_len", [(2, 70, 2, 64, True, False), (1, 200, 1, 64, False, True),
+                                                     (1, 130, 1, 128, True, False), (2, 64, 1, 64, False, False)])
+def test_attention_fwd_bwd(B, S, H, hd, causal, use_len):
+    C.case_attention(DEV, B, S, H, hd, causal, use_len)
