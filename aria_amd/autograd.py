@@ -1,0 +1,205 @@
+"""``torch.autograd.Function`` wrappers that make the hand-written forward/backward blocks of
+``aria_amd.functional`` differentiable drop-ins (seams B1-B3 of SURVEY.md section 8b)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import functional as Fn
+from . import ops
+
+bf16 = torch.bfloat16
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) on 2-D x."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return ops.gemm(x, w, bias=bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dx = ops.gemm(dy, w, b_oc=True) if ctx.needs_input_grad[0] else None
+        dw = ops.gemm(dy, x, a_oc=True, b_oc=True) if ctx.needs_input_grad[1] else None
+        db = dy.sum(0).to(bf16) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    shp = x.shape
+    y = LinearFn.apply(_c(x.reshape(-1, shp[-1])), w, bias)
+    return y.view(*shp[:-1], w.shape[0])
+
+
+class RMSNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        y, _, rstd = ops.rmsnorm(x, w, eps)
+        ctx.save_for_backward(x, w, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, rstd = ctx.saved_tensors
+        dx, dw = ops.rmsnorm_bwd(_c(dy), x, w, rstd)
+        return dx, dw, None
+
+
+def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    shp = x.shape
+    return RMSNormFn.apply(_c(x.reshape(-1, shp[-1])), w, eps).view(shp)
+
+
+class ExpertsGemmFn(torch.autograd.Function):
+    """experts_gemm(input, weight, tokens_per_expert) -- seam B1 (aria/model/moe_lm.py:431-443), differentiable in
+    input and weight like grouped_gemm.ops.gmm."""
+
+    @staticmethod
+    def forward(ctx, inp, weight, offsets):
+        ctx.save_for_backward(inp, weight, offsets)
+        return ops.grouped_gemm(inp, weight, offsets)
+
+    @staticmethod
+    def backward(ctx, dy):
+        inp, weight, offsets = ctx.saved_tensors
+        dy = _c(dy)
+        dx = ops.grouped_gemm(dy, weight, offsets, w_is_kn=False) if ctx.needs_input_grad[0] else None
+        dw = ops.grouped_gemm_wgrad(inp, dy, offsets, weight.shape[0]) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+def offsets_from_tokens_per_expert(tpe: torch.Tensor, device) -> torch.Tensor:
+    """int32 [E+1] device offsets from a tokens_per_expert tensor (CPU int64 in the reference, moe_lm.py:478)."""
+    off = torch.zeros(tpe.numel() + 1, dtype=torch.int32, device=tpe.device)
+    off[1:] = torch.cumsum(tpe.to(torch.int32), 0)
+    return off.to(device, non_blocking=True)
+
+
+def experts_gemm(inp: torch.Tensor, weight: torch.Tensor, tokens_per_expert: torch.Tensor) -> torch.Tensor:
+    return ExpertsGemmFn.apply(_c(inp), weight, offsets_from_tokens_per_expert(tokens_per_expert, inp.device))
+
+
+class SwiGLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h):
+        ctx.save_for_backward(h)
+        return ops.swiglu(h)
+
+    @staticmethod
+    def backward(ctx, dact):
+        (h,) = ctx.saved_tensors
+        return ops.swiglu_bwd(h, _c(dact))
+
+
+class MoELayerFn(torch.autograd.Function):
+    """MoELayer.forward (moe_lm.py:548-577) as one node: router -> permute -> experts -> unpermute + shared."""
+
+    @staticmethod
+    def forward(ctx, x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg):
+        out, c = Fn.moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg, save=True)
+        ctx.c = c
+        ctx.save_for_backward(router_w, fc1, fc2, gate_w, up_w, down_w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        router_w, fc1, fc2, gate_w, up_w, down_w = ctx.saved_tensors
+        dx, g = Fn.moe_bwd(_c(dout), ctx.c, router_w, fc1, fc2, gate_w, up_w, down_w)
+        ctx.c = None
+        return dx, g["router"], g["fc1"], g["fc2"], g["gate"], g["up"], g["down"], None
+
+
+class AttnBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, wo, cos, sin, B, S, cfg, kv_len):
+        out, c = Fn.attn_block_fwd(x, wq, wk, wv, wo, cos, sin, B, S, cfg, kv_len, save=True)
+        ctx.c = c
+        ctx.save_for_backward(wq, wk, wv, wo, cos, sin)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        wq, wk, wv, wo, cos, sin = ctx.saved_tensors
+        dx, g = Fn.attn_block_bwd(_c(dout), ctx.c, wq, wk, wv, wo, cos, sin)
+        ctx.c = None
+        return dx, g["q"], g["k"], g["v"], g["o"], None, None, None, None, None, None
+
+
+_LAYER_KEYS = ("ln1", "wq", "wk", "wv", "wo", "ln2", "router", "fc1", "fc2", "gate", "up", "down")
+
+
+class DecoderLayerFn(torch.autograd.Function):
+    """One MoEDecoderLayer (moe_lm.py:580-602) as a single autograd node with a hand-written backward.
+    With ``recompute`` the forward keeps only the layer input and re-runs itself inside backward
+    (= the reference recipe's gradient_checkpointing, recipes/config_full.yaml:17)."""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin, B, S, acfg, mcfg, eps, kv_len, recompute, *params):
+        p = dict(zip(_LAYER_KEYS, params))
+        out, c = Fn.decoder_layer_fwd(x, p, cos, sin, B, S, acfg, mcfg, eps, kv_len, save=not recompute)
+        ctx.c = c
+        ctx.meta = (B, S, acfg, mcfg, eps, kv_len, recompute)
+        ctx.save_for_backward(x, cos, sin, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, cos, sin, *params = ctx.saved_tensors
+        B, S, acfg, mcfg, eps, kv_len, recompute = ctx.meta
+        p = dict(zip(_LAYER_KEYS, params))
+        c = ctx.c
+        if recompute:
+            _, c = Fn.decoder_layer_fwd(x, p, cos, sin, B, S, acfg, mcfg, eps, kv_len, save=True)
+        dx, g = Fn.decoder_layer_bwd(_c(dout), c, p, cos, sin)
+        ctx.c = None
+        return (dx, None, None, None, None, None, None, None, None, None) + tuple(g[k] for k in _LAYER_KEYS)
+
+
+class LMHeadLossFn(torch.autograd.Function):
+    """final-norm output -> lm_head -> shifted masked CE (modeling_aria.py:301-323); gradients are produced during
+    the forward (the logits buffer is overwritten with dlogits), backward just scales them."""
+
+    @staticmethod
+    def forward(ctx, hn, lm_w, labels_shifted):
+        need = hn.requires_grad or lm_w.requires_grad
+        loss, d_hn, g_w = Fn.lm_head_loss_fwd_bwd(hn, lm_w, labels_shifted, need_grads=need)
+        ctx.d_hn, ctx.g_w = d_hn, g_w
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        d_hn, g_w = ctx.d_hn, ctx.g_w
+        ctx.d_hn = ctx.g_w = None
+        # dloss is a device scalar (ones for a plain loss.backward()): scale in place, no host sync
+        if d_hn is not None:
+            d_hn.mul_(dloss)
+        if g_w is not None:
+            g_w.mul_(dloss)
+        return d_hn, g_w, None
+
+
+class EmbeddingFn(torch.autograd.Function):
+    """embed_tokens lookup (modeling_aria.py:250) as a row gather; backward = row scatter-add."""
+
+    @staticmethod
+    def forward(ctx, ids32, weight):
+        ctx.save_for_backward(ids32)
+        ctx.shape = weight.shape
+        return ops.moe_permute(weight, ids32, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids32,) = ctx.saved_tensors
+        dw = torch.zeros(ctx.shape, dtype=bf16, device=dy.device)
+        ops.embedding_bwd(_c(dy), ids32, dw)
+        return None, dw

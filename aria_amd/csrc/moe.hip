@@ -357,6 +357,33 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* h, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------- embedding backward
+// dW[ids[t], :] += dy[t, :]  (bf16 pairs updated with a 32-bit CAS loop: order-independent up to bf16 rounding)
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const bf16_t* dy, const int32_t* ids, bf16_t* dw, int T, int D) {
+    const int l = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nw = D >> 1;
+    for (int t = wave; t < T; t += nwaves) {
+        const int row = ids[t];
+        if (row < 0) continue;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(dy + (long long)t * D);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(dw + (long long)row * D);
+        for (int c = l; c < nw; c += 64) {
+            const uint32_t g = src[c];
+#ifdef ARIA_EMU
+            dst[c] = pack2bf(bflo(dst[c]) + bflo(g), bfhi(dst[c]) + bfhi(g));
+#else
+            uint32_t old = dst[c], assumed;
+            do {
+                assumed = old;
+                old = atomicCAS(dst + c, assumed, pack2bf(bflo(assumed) + bflo(g), bfhi(assumed) + bfhi(g)));
+            } while (old != assumed);
+#endif
+        }
+    }
+}
+
 int grid_for_waves(long long n_items, int waves_per_block = 4) {
     long long g = (n_items + waves_per_block - 1) / waves_per_block;
     if (g < 1) g = 1;
@@ -480,6 +507,15 @@ int aria_swiglu_bwd(const void* h, const void* h2, const void* dact, void* dh, v
     if (g > 4096) g = 4096;
     ARIA_LAUNCH(swiglu_bwd_kernel, dim3(int(g)), dim3(256), 0, stream, a, b, static_cast<const bf16_t*>(dact), da, db, nchunks,
                 int(I), ld, ld);
+    return aria_check_launch();
+}
+
+int aria_embedding_bwd(const void* dy, const int32_t* ids, void* dw, int64_t T, int64_t D, void* stream) {
+    if (!dy || !ids || !dw || T < 0 || D <= 0) return ARIA_ERR_INVALID;
+    if (D & 1) return ARIA_ERR_ALIGN;
+    if (T == 0) return ARIA_OK;
+    ARIA_LAUNCH(embedding_bwd_kernel, dim3(grid_for_waves(T)), dim3(256), 0, stream, static_cast<const bf16_t*>(dy), ids,
+                static_cast<bf16_t*>(dw), int(T), int(D));
     return aria_check_launch();
 }
 

@@ -1,0 +1,257 @@
+"""Hand-written forward/backward of the Aria decoder blocks on top of the C-ABI kernels.
+
+Each ``*_fwd`` returns ``(output, ctx)`` and each ``*_bwd`` consumes ``ctx``; ``aria_amd.autograd`` wraps them
+in ``torch.autograd.Function``s so the modules in ``aria_amd.moe_lm`` are differentiable drop-ins.  Everything is
+2-D token-major ([T, features], bf16) -- batch/sequence only matter to RoPE and attention.
+
+Reference semantics (file:line relative to /root/reference):
+  MoE block       aria/model/moe_lm.py:548-577 (router :243-293, dispatcher :313-365, experts :505-525, shared :368-395)
+  attention block transformers/models/llama/modeling_llama.py:243-281 (inherited through moe_lm.py:594)
+  decoder layer   transformers/models/llama/modeling_llama.py:295-325 (MoEDecoderLayer moe_lm.py:580-602)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import ops
+
+bf16 = torch.bfloat16
+
+
+# ----------------------------------------------------------------------------------------------- linear
+def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    return ops.gemm(x, w, bias=bias, out=out)
+
+
+def linear_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, need_dx: bool = True, dx_out: Optional[torch.Tensor] = None,
+               accumulate_dx: bool = False, need_dw: bool = True):
+    """dx = dy @ W  ([T,N] x [N,K]),  dW = dy^T @ x ([N,K])."""
+    dx = None
+    if need_dx:
+        dx = ops.gemm(dy, w, b_oc=True, out=dx_out, accumulate=accumulate_dx)
+    dw = ops.gemm(dy, x, a_oc=True, b_oc=True) if need_dw else None
+    return dx, dw
+
+
+# ----------------------------------------------------------------------------------------------- MoE block
+@dataclass
+class MoEConfig:
+    topk: int
+    num_experts: int
+    z_loss_coeff: float = 0.0
+    aux_loss_coeff: float = 0.0
+    aux_scale: float = 1.0  # MoEAuxLossAutoScaler.main_loss_backward_scale (train.py:229)
+
+
+def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save: bool = True):
+    """MoELayer.forward on x [T,D] -> (out [T,D], ctx)."""
+    k = cfg.topk
+    logits = ops.gemm(x, router_w)                                   # TopKRouter.gating  moe_lm.py:190-201
+    scores, idx, counts = ops.moe_route(logits, k)                   # routing :261-269 (device-side histogram)
+    offsets, sorted_src, inv = ops.moe_sort(idx, counts)             # token_permutation :326-334 (stable)
+    perm = ops.moe_permute(x, sorted_src, k)
+    h1 = ops.grouped_gemm(perm, fc1, offsets)                        # experts.fc1 :522 (no D2H sync)
+    act = ops.swiglu(h1)                                             # glu :505-507
+    eo = ops.grouped_gemm(act, fc2, offsets)                         # experts.fc2 :524
+    T = x.shape[0]
+    I2 = gate_w.shape[0]
+    gu = torch.empty((T, 2 * I2), dtype=bf16, device=x.device)       # SharedExpertMLP :368-395
+    ops.gemm(x, gate_w, out=gu[:, :I2])
+    ops.gemm(x, up_w, out=gu[:, I2:])
+    sact = ops.swiglu(gu)
+    sh = ops.gemm(sact, down_w)
+    out = ops.moe_unpermute(eo, inv, scores, k, add=sh)              # token_unpermutation :336-365 + `output += shared` :576
+    ctx = None
+    if save:
+        ctx = dict(x=x, logits=logits, scores=scores, idx=idx, counts=counts, offsets=offsets, inv=inv, perm=perm, h1=h1,
+                   act=act, eo=eo, gu=gu, sact=sact, cfg=cfg)
+    return out, ctx
+
+
+def moe_bwd(dout, ctx, router_w, fc1, fc2, gate_w, up_w, down_w):
+    """-> dx, dict(grads)."""
+    cfg: MoEConfig = ctx["cfg"]
+    k, E = cfg.topk, cfg.num_experts
+    x, inv, offsets = ctx["x"], ctx["inv"], ctx["offsets"]
+    I2 = gate_w.shape[0]
+    # routed experts
+    d_eo, dscores = ops.moe_unpermute_bwd(dout, ctx["eo"], inv, ctx["scores"], k)
+    d_act = ops.grouped_gemm(d_eo, fc2, offsets, w_is_kn=False)
+    g_fc2 = ops.grouped_gemm_wgrad(ctx["act"], d_eo, offsets, E)
+    d_h1 = ops.swiglu_bwd(ctx["h1"], d_act)
+    d_perm = ops.grouped_gemm(d_h1, fc1, offsets, w_is_kn=False)
+    g_fc1 = ops.grouped_gemm_wgrad(ctx["perm"], d_h1, offsets, E)
+    dx = ops.moe_unpermute(d_perm, inv, None, k)                     # backward of the row gather
+    # shared expert
+    d_sact = ops.gemm(dout, down_w, b_oc=True)
+    g_down = ops.gemm(dout, ctx["sact"], a_oc=True, b_oc=True)
+    d_gu = ops.swiglu_bwd(ctx["gu"], d_sact)
+    ops.gemm(d_gu[:, :I2], gate_w, b_oc=True, out=dx, accumulate=True)
+    ops.gemm(d_gu[:, I2:], up_w, b_oc=True, out=dx, accumulate=True)
+    g_gate = ops.gemm(d_gu[:, :I2], x, a_oc=True, b_oc=True)
+    g_up = ops.gemm(d_gu[:, I2:], x, a_oc=True, b_oc=True)
+    # router (top-k softmax + z-loss + load-balancing loss gradients)
+    dlogits = ops.moe_route_bwd(ctx["logits"], ctx["idx"], ctx["scores"], dscores, ctx["counts"], cfg.z_loss_coeff,
+                                cfg.aux_loss_coeff, cfg.aux_scale)
+    ops.gemm(dlogits, router_w, b_oc=True, out=dx, accumulate=True)
+    g_router = ops.gemm(dlogits, x, a_oc=True, b_oc=True)
+    return dx, dict(router=g_router, fc1=g_fc1, fc2=g_fc2, gate=g_gate, up=g_up, down=g_down)
+
+
+# ----------------------------------------------------------------------------------------------- attention block
+@dataclass
+class AttnConfig:
+    num_heads: int
+    num_kv_heads: int
+    head_dim: int
+    causal: bool = True
+
+
+_SUPPORTED_HD = (64, 128)
+
+
+def _pad_hd(hd: int) -> int:
+    for s in _SUPPORTED_HD:
+        if hd <= s:
+            return s
+    raise ValueError(f"head_dim {hd} > 128 is not supported")
+
+
+def _pad_heads(t: torch.Tensor, H: int, hd: int, hdp: int) -> torch.Tensor:
+    """[T, H*hd] -> zero-padded [T, H*hdp] (only for head dims the kernels do not implement natively)."""
+    T = t.shape[0]
+    out = torch.zeros((T, H, hdp), dtype=t.dtype, device=t.device)
+    out[:, :, :hd] = t.reshape(T, H, hd)
+    return out.view(T, H * hdp)
+
+
+def _unpad_heads(t: torch.Tensor, H: int, hd: int, hdp: int) -> torch.Tensor:
+    return t.view(t.shape[0], H, hdp)[:, :, :hd].reshape(t.shape[0], H * hd)
+
+
+def sdpa_fwd(q, k, v, B, S, H, hd, scale, causal, kv_len=None):
+    """q,k,v [B*S, H*hd] views -> (o [B*S, H*hd], ctx).  Pads the head dim to 64/128 when needed."""
+    hdp = _pad_hd(hd)
+    if hdp != hd:
+        qp, kp, vp = (_pad_heads(t, H, hd, hdp) for t in (q, k, v))
+        o, lse = ops.attention_fwd(qp, kp, vp, B, S, H, hdp, scale, causal, kv_len)
+        return _unpad_heads(o, H, hd, hdp), dict(q=qp, k=kp, v=vp, o=o, lse=lse, hdp=hdp)
+    o, lse = ops.attention_fwd(q, k, v, B, S, H, hd, scale, causal, kv_len)
+    return o, dict(q=q, k=k, v=v, o=o, lse=lse, hdp=hd)
+
+
+def sdpa_bwd(do, ctx, B, S, H, hd, scale, causal, kv_len=None, dq=None, dk=None, dv=None):
+    hdp = ctx["hdp"]
+    if hdp != hd:
+        dop = _pad_heads(do, H, hd, hdp)
+        gq, gk, gv = ops.attention_bwd(ctx["q"], ctx["k"], ctx["v"], ctx["o"], dop, ctx["lse"], B, S, H, hdp, scale, causal, kv_len)
+        outs = [_unpad_heads(t, H, hd, hdp) for t in (gq, gk, gv)]
+        for dst, src in zip((dq, dk, dv), outs):
+            if dst is not None:
+                dst.copy_(src)
+        return tuple(d if d is not None else s for d, s in zip((dq, dk, dv), outs))
+    return ops.attention_bwd(ctx["q"], ctx["k"], ctx["v"], ctx["o"], do, ctx["lse"], B, S, H, hd, scale, causal, kv_len,
+                             dq=dq, dk=dk, dv=dv)
+
+
+def attn_block_fwd(x, wq, wk, wv, wo, cos, sin, B: int, S: int, cfg: AttnConfig, kv_len=None, save: bool = True):
+    """LlamaAttention.forward on normalised x [B*S, D]: q/k/v proj, half-split RoPE, causal flash attention, o proj."""
+    H, Hkv, hd = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
+    if Hkv != H:
+        raise NotImplementedError("GQA (num_key_value_heads != num_attention_heads): Aria is MHA (gptfast/model.py:56-58)")
+    T = x.shape[0]
+    Dq = H * hd
+    qkv = torch.empty((T, 3 * Dq), dtype=bf16, device=x.device)
+    ops.gemm(x, wq, out=qkv[:, :Dq])
+    ops.gemm(x, wk, out=qkv[:, Dq:2 * Dq])
+    ops.gemm(x, wv, out=qkv[:, 2 * Dq:])
+    ops.rope_(qkv[:, :2 * Dq], cos, sin, S, 2 * H, hd)
+    o, actx = sdpa_fwd(qkv[:, :Dq], qkv[:, Dq:2 * Dq], qkv[:, 2 * Dq:], B, S, H, hd, hd ** -0.5, cfg.causal, kv_len)
+    out = ops.gemm(o if o.is_contiguous() else o.contiguous(), wo)
+    ctx = dict(x=x, o=o, actx=actx, B=B, S=S, cfg=cfg, kv_len=kv_len) if save else None
+    return out, ctx
+
+
+def attn_block_bwd(dout, ctx, wq, wk, wv, wo, cos, sin):
+    cfg: AttnConfig = ctx["cfg"]
+    H, hd = cfg.num_heads, cfg.head_dim
+    B, S, x, o = ctx["B"], ctx["S"], ctx["x"], ctx["o"]
+    T, Dq = x.shape[0], H * hd
+    d_o = ops.gemm(dout, wo, b_oc=True)
+    g_wo = ops.gemm(dout, o if o.is_contiguous() else o.contiguous(), a_oc=True, b_oc=True)
+    dqkv = torch.empty((T, 3 * Dq), dtype=bf16, device=x.device)
+    sdpa_bwd(d_o, ctx["actx"], B, S, H, hd, hd ** -0.5, cfg.causal, ctx["kv_len"], dq=dqkv[:, :Dq], dk=dqkv[:, Dq:2 * Dq],
+             dv=dqkv[:, 2 * Dq:])
+    ops.rope_(dqkv[:, :2 * Dq], cos, sin, S, 2 * H, hd, inverse=True)
+    dx = ops.gemm(dqkv[:, :Dq], wq, b_oc=True)
+    ops.gemm(dqkv[:, Dq:2 * Dq], wk, b_oc=True, out=dx, accumulate=True)
+    ops.gemm(dqkv[:, 2 * Dq:], wv, b_oc=True, out=dx, accumulate=True)
+    g_wq = ops.gemm(dqkv[:, :Dq], x, a_oc=True, b_oc=True)
+    g_wk = ops.gemm(dqkv[:, Dq:2 * Dq], x, a_oc=True, b_oc=True)
+    g_wv = ops.gemm(dqkv[:, 2 * Dq:], x, a_oc=True, b_oc=True)
+    return dx, dict(q=g_wq, k=g_wk, v=g_wv, o=g_wo)
+
+
+# ----------------------------------------------------------------------------------------------- decoder layer
+def decoder_layer_fwd(x, p: dict, cos, sin, B: int, S: int, acfg: AttnConfig, mcfg: MoEConfig, eps: float, kv_len=None,
+                      save: bool = True):
+    """h = x + Attn(RMSNorm(x)); out = h + MoE(RMSNorm(h)).  p: dict of the layer's parameter tensors."""
+    xn, _, rstd1 = ops.rmsnorm(x, p["ln1"], eps, want_rstd=save)
+    a, actx = attn_block_fwd(xn, p["wq"], p["wk"], p["wv"], p["wo"], cos, sin, B, S, acfg, kv_len, save)
+    hn, h, rstd2 = ops.rmsnorm(a, p["ln2"], eps, residual=x, want_rstd=save)   # fused residual add
+    mo, mctx = moe_fwd(hn, p["router"], p["fc1"], p["fc2"], p["gate"], p["up"], p["down"], mcfg, save)
+    out = ops.add(h, mo)
+    ctx = dict(x=x, h=h, rstd1=rstd1, rstd2=rstd2, actx=actx, mctx=mctx, eps=eps) if save else None
+    return out, ctx
+
+
+def decoder_layer_bwd(dout, ctx, p: dict, cos, sin):
+    dhn, gm = moe_bwd(dout, ctx["mctx"], p["router"], p["fc1"], p["fc2"], p["gate"], p["up"], p["down"])
+    dh, g_ln2 = ops.rmsnorm_bwd(dhn, ctx["h"], p["ln2"], ctx["rstd2"], dres=dout)       # + gradient of the residual stream
+    dxn, ga = attn_block_bwd(dh, ctx["actx"], p["wq"], p["wk"], p["wv"], p["wo"], cos, sin)
+    dx, g_ln1 = ops.rmsnorm_bwd(dxn, ctx["x"], p["ln1"], ctx["rstd1"], dres=dh)
+    grads = dict(ln1=g_ln1, ln2=g_ln2, wq=ga["q"], wk=ga["k"], wv=ga["v"], wo=ga["o"], router=gm["router"], fc1=gm["fc1"],
+                 fc2=gm["fc2"], gate=gm["gate"], up=gm["up"], down=gm["down"])
+    return dx, grads
+
+
+# ----------------------------------------------------------------------------------------------- RoPE tables (host)
+def rope_tables(S: int, head_dim: int, theta: float, device) -> tuple:
+    """bf16 cos/sin [S, head_dim] built exactly like LlamaRotaryEmbedding (transformers/.../modeling_llama.py:96-127):
+    fp32 angles on the host, emb = cat(freqs, freqs), cast to the activation dtype."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    freqs = torch.arange(S, dtype=torch.float32)[:, None] * inv_freq[None, :]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(bf16).to(device).contiguous(), emb.sin().to(bf16).to(device).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------- LM head + loss
+def lm_head_loss_fwd_bwd(hn, lm_w, labels_shifted, need_grads: bool = True):
+    """logits = hn @ lm_w^T; masked-mean CE (labels already shifted, -100 = ignore).  The CE kernel overwrites the logits
+    with d(loss)/d(logits) (scaled by 1/n_valid on the device: no host sync), so the backward GEMMs can run immediately.
+    -> (loss fp32 scalar tensor, d_hn | None, g_lm_w | None)"""
+    logits = ops.gemm(hn, lm_w)
+    count_in = (labels_shifted >= 0).sum(dtype=torch.int32).reshape(1)
+    loss_sum, count, _ = ops.cross_entropy(logits, labels_shifted, grad_scale=1.0, dlogits=logits if need_grads else None,
+                                           count_in=count_in)
+    loss = (loss_sum / count_in.clamp(min=1).to(torch.float32)).reshape(())
+    if not need_grads:
+        return loss, None, None
+    d_hn = ops.gemm(logits, lm_w, b_oc=True)
+    g_w = ops.gemm(logits, hn, a_oc=True, b_oc=True)
+    return loss, d_hn, g_w
+
+
+def shift_labels(labels: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """aria/model/modeling_aria.py:301-316 as a per-position label vector: position t is scored against labels[t+1]
+    iff attention_mask[t+1] != 0; the last position of every sequence is ignored.  [B,S] -> int32 [B*S]."""
+    B, S = labels.shape
+    out = torch.full((B, S), -100, dtype=torch.int32, device=labels.device)
+    nxt = labels[:, 1:].to(torch.int32)
+    if attention_mask is not None:
+        nxt = torch.where(attention_mask[:, 1:] != 0, nxt, torch.full_like(nxt, -100))
+    out[:, :-1] = nxt
+    return out.reshape(-1)

@@ -36,6 +36,7 @@ SIGNATURES = {
     "aria_moe_unpermute": [P, P, P, P, P, I64, I64, I64, P],
     "aria_moe_unpermute_bwd": [P, P, P, P, P, P, I64, I64, I64, P],
     "aria_moe_route_bwd": [P, P, P, P, P, P, I64, I64, I64, F32, F32, F32, P],
+    "aria_embedding_bwd": [P, P, P, I64, I64, P],
     "aria_swiglu_fwd": [P, P, P, I64, I64, P],
     "aria_swiglu_bwd": [P, P, P, P, P, I64, I64, P],
     "aria_rmsnorm_fwd": [P, P, P, P, P, P, I64, I64, F32, P],

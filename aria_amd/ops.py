@@ -190,6 +190,14 @@ def moe_route_bwd(logits, indices, scores, dscores, counts, z_coeff=0.0, aux_coe
     return dlogits
 
 
+def embedding_bwd(dy: torch.Tensor, ids: torch.Tensor, dw: torch.Tensor) -> torch.Tensor:
+    """dw[ids[t]] += dy[t] (dw bf16 [V,D], zero-initialised by the caller)."""
+    _chk(dy, name="dy"), _chk(ids, torch.int32, "ids"), _chk(dw, name="dw")
+    assert dy.is_contiguous() and dw.is_contiguous() and ids.is_contiguous()
+    hip.get_lib().call("aria_embedding_bwd", _p(dy), _p(ids), _p(dw), dy.shape[0], dy.shape[1], _stream(dy))
+    return dw
+
+
 def swiglu(h: torch.Tensor, h2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """h [M,2I] -> silu(h[:, :I]) * h[:, I:]   or   (gate [M,I], up [M,I])."""
     _chk(h, name="h")

@@ -105,6 +105,10 @@ int aria_swiglu_fwd(const void* h, const void* h2, void* act, int64_t M, int64_t
 int aria_swiglu_bwd(const void* h, const void* h2, const void* dact, void* dh, void* dh2, int64_t M, int64_t I,
                     void* stream);
 
+/* backward of the embed_tokens lookup (aria/model/modeling_aria.py:250): dW[ids[t], :] += dy[t, :] (dW bf16, caller
+ * zero-initialises; ids < 0 are skipped).  The forward lookup is aria_moe_permute with k = 1. */
+int aria_embedding_bwd(const void* dy, const int32_t* ids, void* dw, int64_t T, int64_t D, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Norms / RoPE / elementwise (norm.hip)
  * ------------------------------------------------------------------------------------------------ */

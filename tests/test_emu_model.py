@@ -1,0 +1,27 @@
+"""Module-level parity through the SIMT emulator (CPU): aria_amd modules vs the oracle on the golden fixtures."""
+import pytest
+
+from tests import model_cases as M
+
+DEV = "cpu"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emu():
+    from tests.emu import emu_lib
+
+    emu_lib.install()
+    yield
+    emu_lib.uninstall()
+
+
+def test_moe_layer_golden(golden):
+    M.case_moe_layer_golden(DEV, golden)
+
+
+def test_moe_layer_train_golden(golden):
+    M.case_moe_layer_train_golden(DEV, golden)
+
+
+def test_lm_golden(golden):
+    M.case_lm_golden(DEV, golden)

@@ -1,0 +1,23 @@
+"""Module-level parity on hardware (-m gpu): aria_amd modules (HIP kernels) vs the oracle on the golden fixtures."""
+import pytest
+
+from tests import model_cases as M
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_moe_layer_golden(golden):
+    M.case_moe_layer_golden(DEV, golden)
+
+
+def test_moe_layer_train_golden(golden):
+    M.case_moe_layer_train_golden(DEV, golden)
+
+
+def test_lm_golden(golden):
+    M.case_lm_golden(DEV, golden)
+
+
+def test_lm_golden_with_recompute(golden):
+    M.case_lm_golden(DEV, golden, recompute=True)
