@@ -1,0 +1,40 @@
+"""Pin the oracle against the LIVE reference on fresh random inputs (only where /root/reference exists: the build
+container).  On the GPU box the committed fixtures (tests/test_oracle_golden.py) play this role."""
+import pytest
+import torch
+
+from oracle import aria_oracle as O
+from oracle.ref_shims import load_reference, reference_available
+
+pytestmark = pytest.mark.skipif(not reference_available(), reason="reference checkout not present")
+
+TEXT = dict(hidden_size=48, num_attention_heads=3, num_key_value_heads=3, num_hidden_layers=1, vocab_size=64,
+            intermediate_size=48, moe_intermediate_size=16, moe_num_experts=6, moe_topk=2, moe_num_shared_experts=2,
+            rms_norm_eps=1e-6, rope_theta=5_000_000.0, max_position_embeddings=128, pad_token_id=0)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_moe_layer_and_lm_match_live_reference(seed):
+    ns = load_reference()
+    torch.manual_seed(seed)
+    cfg = ns.moe.AriaMoELMConfig(**TEXT, attn_implementation="eager")
+    lm = ns.moe.AriaMoELMForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for p in lm.parameters():
+            p.normal_(0, 0.08)
+    ids = torch.randint(1, 64, (2, 13))
+    w = {k: v.detach() for k, v in lm.state_dict().items()}
+    ocfg = O.LMConfig(**{k: v for k, v in TEXT.items() if k in O.LMConfig.__dataclass_fields__})
+    with torch.no_grad():
+        want = lm(input_ids=ids).logits
+        got = O.lm_forward(w["model.embed_tokens.weight"][ids], w, ocfg)
+    assert torch.allclose(got, want, atol=2e-5, rtol=1e-4)
+    layer = lm.model.layers[0].mlp
+    x = torch.randn(2, 9, 48)
+    with torch.no_grad():
+        s, i, t = layer.router(x.view(-1, 48))
+        o = layer(x)
+    wl = {k[len("model.layers.0.mlp."):]: v for k, v in w.items() if k.startswith("model.layers.0.mlp.")}
+    out, im = O.moe_layer(x, wl, "", ocfg, return_intermediates=True)
+    assert torch.equal(im["indices"], i) and torch.equal(im["tokens_per_expert"], t)
+    assert torch.allclose(out, o, atol=2e-5)
