@@ -31,7 +31,7 @@ class LinearFn(torch.autograd.Function):
         dy = _c(dy)
         dx = ops.gemm(dy, w, b_oc=True) if ctx.needs_input_grad[0] else None
         dw = ops.gemm(dy, x, a_oc=True, b_oc=True) if ctx.needs_input_grad[1] else None
-        db = dy.sum(0).to(bf16) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = ops.colsum(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
 

@@ -102,18 +102,21 @@ __device__ __forceinline__ f32x16 zero_acc() {
 // grid (ceil(S/128), H, B); wave w owns queries q0 + 32w + (l&31)
 template <int HD>
 __global__ __launch_bounds__(NT) void attn_fwd_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE,
-                                                      const int32_t* kv_len, int S, int H, long long ldq, long long ldk,
-                                                      long long ldv, long long ldo, float scale, int causal) {
+                                                      const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
+                                                      long long ldq, long long ldk, long long ldv, long long ldo, float scale,
+                                                      int causal) {
     using C = Cfg<HD>;
     ARIA_DYN_SMEM(smem);
     bf16_t* sK = reinterpret_cast<bf16_t*>(smem);
     bf16_t* sV = sK + 64 * C::PITCH;
+    uint8_t* sM = reinterpret_cast<uint8_t*>(sV + 64 * C::PITCH);
     const int t = threadIdx.x, l = t & 63, w = t >> 6, h2 = l >> 5;
     const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
-    const long long tok0 = (long long)b * S;
-    const bf16_t* Qb = Q + tok0 * ldq + head * HD;
+    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
+    const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
     const bf16_t* Kb = K + tok0 * ldk + head * HD;
     const bf16_t* Vb = V + tok0 * ldv + head * HD;
+    const uint8_t* kmb = key_mask ? key_mask + tok0 : nullptr;
     const int q_abs = q0 + 32 * w + (l & 31);
     const int klen = kv_len ? min(S, kv_len[b]) : S;
 
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const bf16_t* Q, const bf1
 #pragma unroll
     for (int kk = 0; kk < C::KS; ++kk) {
         u32x4 v = zero16();
-        if (q_abs < S) v = ld16(Qb + (long long)q_abs * ldq + kk * 16 + h2 * 8);
+        if (q_abs < Sq) v = ld16(Qb + (long long)q_abs * ldq + kk * 16 + h2 * 8);
         qf[kk] = __builtin_bit_cast(s16x8, v);
     }
     f32x16 o[2 * C::DB];
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const bf16_t* Q, const bf1
         const int kv0 = it * 64;
         tile_store<HD>(rk, sK, t);
         tile_store<HD>(rv, sV, t);
+        if (kmb && t < 64) sM[t] = (kv0 + t < S) ? kmb[kv0 + t] : 0;
         sync();
         if (it + 1 < ntiles) {
             tile_load<HD>(rk, Kb, ldk, kv0 + 64, S, t);
@@ -161,9 +165,10 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const bf16_t* Q, const bf1
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kv = kv0 + i * 32 + acc_row(r, l);
+                const int kvl = i * 32 + acc_row(r, l);
+                const int kv = kv0 + kvl;
                 float v = st[i][r] * scale;
-                if (kv >= klen || (causal && kv > q_abs)) v = -INFINITY;
+                if (kv >= klen || (causal && kv > q_abs) || (kmb && !sM[kvl])) v = -INFINITY;
                 st[i][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -204,9 +209,9 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const bf16_t* Q, const bf1
     }
     const float ltot = lsum + shfl_xor(lsum, 32);
     const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
-    if (q_abs < S) {
-        if (h2 == 0 && LSE) LSE[((long long)b * H + head) * S + q_abs] = (ltot > 0.f) ? m + logf(ltot) : -INFINITY;
-        bf16_t* orow = O + (tok0 + q_abs) * ldo + head * HD;
+    if (q_abs < Sq) {
+        if (h2 == 0 && LSE) LSE[((long long)b * H + head) * Sq + q_abs] = (ltot > 0.f) ? m + logf(ltot) : -INFINITY;
+        bf16_t* orow = O + (tokq0 + q_abs) * ldo + head * HD;
 #pragma unroll
         for (int db = 0; db < C::DB; ++db)
 #pragma unroll
@@ -249,9 +254,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* O, const 
 template <int HD>
 __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
                                                            const float* LSE, const float* DELTA, bf16_t* dK, bf16_t* dV,
-                                                           const int32_t* kv_len, int S, int H, long long ldq, long long ldk,
-                                                           long long ldv, long long lddo, long long lddk, long long lddv,
-                                                           float scale, int causal) {
+                                                           const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
+                                                           long long ldq, long long ldk, long long ldv, long long lddo,
+                                                           long long lddk, long long lddv, float scale, int causal) {
     using C = Cfg<HD>;
     ARIA_DYN_SMEM(smem);
     bf16_t* sQ = reinterpret_cast<bf16_t*>(smem);
@@ -260,15 +265,16 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(const bf16_t* Q, cons
     float* sDel = sLse + 64;
     const int t = threadIdx.x, l = t & 63, w = t >> 6, h2 = l >> 5;
     const int b = blockIdx.z, head = blockIdx.y, kv0 = blockIdx.x * 128;
-    const long long tok0 = (long long)b * S;
-    const bf16_t* Qb = Q + tok0 * ldq + head * HD;
+    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
+    const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
     const bf16_t* Kb = K + tok0 * ldk + head * HD;
     const bf16_t* Vb = V + tok0 * ldv + head * HD;
-    const bf16_t* dOb = dO + tok0 * lddo + head * HD;
-    const float* lseb = LSE + ((long long)b * H + head) * S;
-    const float* delb = DELTA + ((long long)b * H + head) * S;
+    const bf16_t* dOb = dO + tokq0 * lddo + head * HD;
+    const float* lseb = LSE + ((long long)b * H + head) * Sq;
+    const float* delb = DELTA + ((long long)b * H + head) * Sq;
     const int kv_abs = kv0 + 32 * w + (l & 31);
     const int klen = kv_len ? min(S, kv_len[b]) : S;
+    const bool key_ok = kv_abs < klen && (!key_mask || key_mask[tok0 + kv_abs] != 0);
 
     // K and V fragments of this lane's key (B operands of S = Q K^T and dP = dO V^T)
     s16x8 kf[C::KS], vf[C::KS];
@@ -290,11 +296,11 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(const bf16_t* Q, cons
     }
     // queries that can see any of this block's keys
     const int q_begin = causal ? (kv0 / 64) * 64 : 0;
-    const int ntiles = kv0 < klen ? (S - q_begin + 63) / 64 : 0;
+    const int ntiles = kv0 < klen ? (Sq - q_begin + 63) / 64 : 0;
     u32x4 rq[C::NCH64], rdo[C::NCH64];
     if (ntiles > 0) {
-        tile_load<HD>(rq, Qb, ldq, q_begin, S, t);
-        tile_load<HD>(rdo, dOb, lddo, q_begin, S, t);
+        tile_load<HD>(rq, Qb, ldq, q_begin, Sq, t);
+        tile_load<HD>(rdo, dOb, lddo, q_begin, Sq, t);
     }
     for (int it = 0; it < ntiles; ++it) {
         const int qt0 = q_begin + it * 64;
@@ -302,13 +308,13 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(const bf16_t* Q, cons
         tile_store<HD>(rdo, sdO, t);
         if (t < 64) {
             const int q = qt0 + t;
-            sLse[t] = q < S ? lseb[q] : 0.f;
-            sDel[t] = q < S ? delb[q] : 0.f;
+            sLse[t] = q < Sq ? lseb[q] : 0.f;
+            sDel[t] = q < Sq ? delb[q] : 0.f;
         }
         sync();
         if (it + 1 < ntiles) {
-            tile_load<HD>(rq, Qb, ldq, qt0 + 64, S, t);
-            tile_load<HD>(rdo, dOb, lddo, qt0 + 64, S, t);
+            tile_load<HD>(rq, Qb, ldq, qt0 + 64, Sq, t);
+            tile_load<HD>(rdo, dOb, lddo, qt0 + 64, Sq, t);
         }
         // S and dP tiles: rows = queries (2 x 32), cols = this wave's 32 keys
         f32x16 s[2], dp[2];
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(const bf16_t* Q, cons
                 const int ql = i * 32 + acc_row(r, l);
                 const int q = qt0 + ql;
                 float p = 0.f;
-                if (q < S && kv_abs < klen && !(causal && kv_abs > q)) p = __expf(s[i][r] * scale - sLse[ql]);
+                if (q < Sq && key_ok && !(causal && kv_abs > q)) p = __expf(s[i][r] * scale - sLse[ql]);
                 s[i][r] = p;                                       // P
                 dp[i][r] = p * (dp[i][r] - sDel[ql]) * scale;      // dS * scale
             }
@@ -373,26 +379,29 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(const bf16_t* Q, cons
 template <int HD>
 __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
                                                          const float* LSE, const float* DELTA, bf16_t* dQ, const int32_t* kv_len,
-                                                         int S, int H, long long ldq, long long ldk, long long ldv, long long lddo,
-                                                         long long lddq, float scale, int causal) {
+                                                         const uint8_t* key_mask, int Sq, int S, int H, long long ldq,
+                                                         long long ldk, long long ldv, long long lddo, long long lddq,
+                                                         float scale, int causal) {
     using C = Cfg<HD>;
     ARIA_DYN_SMEM(smem);
     bf16_t* sK = reinterpret_cast<bf16_t*>(smem);
     bf16_t* sV = sK + 64 * C::PITCH;
+    uint8_t* sM = reinterpret_cast<uint8_t*>(sV + 64 * C::PITCH);
     const int t = threadIdx.x, l = t & 63, w = t >> 6, h2 = l >> 5;
     const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
-    const long long tok0 = (long long)b * S;
-    const bf16_t* Qb = Q + tok0 * ldq + head * HD;
+    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
+    const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
     const bf16_t* Kb = K + tok0 * ldk + head * HD;
     const bf16_t* Vb = V + tok0 * ldv + head * HD;
-    const bf16_t* dOb = dO + tok0 * lddo + head * HD;
+    const bf16_t* dOb = dO + tokq0 * lddo + head * HD;
+    const uint8_t* kmb = key_mask ? key_mask + tok0 : nullptr;
     const int q_abs = q0 + 32 * w + (l & 31);
     const int klen = kv_len ? min(S, kv_len[b]) : S;
     s16x8 qf[C::KS], dof[C::KS];
 #pragma unroll
     for (int kk = 0; kk < C::KS; ++kk) {
         u32x4 a = zero16(), c = zero16();
-        if (q_abs < S) {
+        if (q_abs < Sq) {
             a = ld16(Qb + (long long)q_abs * ldq + kk * 16 + h2 * 8);
             c = ld16(dOb + (long long)q_abs * lddo + kk * 16 + h2 * 8);
         }
@@ -400,9 +409,9 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const bf16_t* Q, const 
         dof[kk] = __builtin_bit_cast(s16x8, c);
     }
     float lse = 0.f, del = 0.f;
-    if (q_abs < S) {
-        lse = LSE[((long long)b * H + head) * S + q_abs];
-        del = DELTA[((long long)b * H + head) * S + q_abs];
+    if (q_abs < Sq) {
+        lse = LSE[((long long)b * H + head) * Sq + q_abs];
+        del = DELTA[((long long)b * H + head) * Sq + q_abs];
     }
     f32x16 dq[2 * C::DB];
 #pragma unroll
@@ -419,6 +428,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const bf16_t* Q, const 
         const int kv0 = it * 64;
         tile_store<HD>(rk, sK, t);
         tile_store<HD>(rv, sV, t);
+        if (kmb && t < 64) sM[t] = (kv0 + t < S) ? kmb[kv0 + t] : 0;
         sync();
         if (it + 1 < ntiles) {
             tile_load<HD>(rk, Kb, ldk, kv0 + 64, S, t);
@@ -441,9 +451,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const bf16_t* Q, const 
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kv = kv0 + i * 32 + acc_row(r, l);
+                const int kvl = i * 32 + acc_row(r, l);
+                const int kv = kv0 + kvl;
                 float p = 0.f;
-                if (q_abs < S && kv < klen && !(causal && kv > q_abs)) p = __expf(st[i][r] * scale - lse);
+                if (q_abs < Sq && kv < klen && !(causal && kv > q_abs) && !(kmb && !sM[kvl])) p = __expf(st[i][r] * scale - lse);
                 dpt[i][r] = p * (dpt[i][r] - del) * scale;  // dS^T * scale
             }
         // dQ^T += K^T dS^T
@@ -462,8 +473,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const bf16_t* Q, const 
             }
         sync();
     }
-    if (q_abs < S) {
-        bf16_t* row = dQ + (tok0 + q_abs) * lddq + head * HD;
+    if (q_abs < Sq) {
+        bf16_t* row = dQ + (tokq0 + q_abs) * lddq + head * HD;
 #pragma unroll
         for (int db = 0; db < C::DB; ++db)
 #pragma unroll
@@ -480,63 +491,69 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" {
 
-int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* kv_len, int64_t B, int64_t S,
-                  int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal,
-                  void* stream) {
-    if (!q || !k || !v || !o || B < 0 || S < 0 || H <= 0) return ARIA_ERR_INVALID;
+int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* kv_len, const uint8_t* key_mask,
+                  int64_t B, int64_t Sq, int64_t Skv, int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                  float scale, int causal, void* stream) {
+    if (!q || !k || !v || !o || B < 0 || Sq < 0 || Skv < 0 || H <= 0) return ARIA_ERR_INVALID;
     if (hd != 64 && hd != 128) return ARIA_ERR_UNSUPPORTED;
+    if (causal && Sq != Skv) return ARIA_ERR_UNSUPPORTED;
     if (!al16(q) || !al16(k) || !al16(v) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 1) || (reinterpret_cast<uintptr_t>(o) & 3))
         return ARIA_ERR_ALIGN;
-    if (B == 0 || S == 0) return ARIA_OK;
-    dim3 grid(unsigned((S + 127) / 128), unsigned(H), unsigned(B)), block(NT);
+    if (B == 0 || Sq == 0) return ARIA_OK;
+    dim3 grid(unsigned((Sq + 127) / 128), unsigned(H), unsigned(B)), block(NT);
     const bf16_t *Q = static_cast<const bf16_t*>(q), *K = static_cast<const bf16_t*>(k), *V = static_cast<const bf16_t*>(v);
     if (hd == 128) {
-        const size_t sh = 2 * 64 * Cfg<128>::PITCH * sizeof(bf16_t);
-        ARIA_LAUNCH((attn_fwd_kernel<128>), grid, block, sh, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len, int(S), int(H),
-                    (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal);
+        const size_t sh = 2 * 64 * Cfg<128>::PITCH * sizeof(bf16_t) + 64;
+        ARIA_LAUNCH((attn_fwd_kernel<128>), grid, block, sh, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq),
+                    int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal);
     } else {
-        const size_t sh = 2 * 64 * Cfg<64>::PITCH * sizeof(bf16_t);
-        ARIA_LAUNCH((attn_fwd_kernel<64>), grid, block, sh, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len, int(S), int(H),
-                    (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal);
+        const size_t sh = 2 * 64 * Cfg<64>::PITCH * sizeof(bf16_t) + 64;
+        ARIA_LAUNCH((attn_fwd_kernel<64>), grid, block, sh, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq),
+                    int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal);
     }
     return aria_check_launch();
 }
 
 int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
-                  void* dq, void* dk, void* dv, const int32_t* kv_len, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t ldq,
-                  int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal,
-                  void* stream) {
-    if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv || B < 0 || S < 0 || H <= 0) return ARIA_ERR_INVALID;
+                  void* dq, void* dk, void* dv, const int32_t* kv_len, const uint8_t* key_mask, int64_t B, int64_t Sq, int64_t Skv,
+                  int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
+                  float scale, int causal, void* stream) {
+    if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv || B < 0 || Sq < 0 || Skv < 0 || H <= 0)
+        return ARIA_ERR_INVALID;
     if (hd != 64 && hd != 128) return ARIA_ERR_UNSUPPORTED;
+    if (causal && Sq != Skv) return ARIA_ERR_UNSUPPORTED;
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(d_o) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) ||
         (lddq & 1) || (lddk & 1) || (lddv & 1))
         return ARIA_ERR_ALIGN;
-    if (B == 0 || S == 0) return ARIA_OK;
+    if (B == 0 || Sq == 0 || Skv == 0) return ARIA_OK;
     const bf16_t *Q = static_cast<const bf16_t*>(q), *K = static_cast<const bf16_t*>(k), *V = static_cast<const bf16_t*>(v);
     const bf16_t *Op = static_cast<const bf16_t*>(o), *dO = static_cast<const bf16_t*>(d_o);
     // dO is laid out like O (same leading dimension)
-    const long long nrows = B * S * H;
+    const long long nrows = B * Sq * H;
     long long g = (nrows + 15) / 16;
     if (g > 8192) g = 8192;
-    ARIA_LAUNCH(attn_delta_kernel, dim3(unsigned(g)), dim3(256), 0, stream, Op, dO, delta, int(S), int(H), int(hd), (long long)ldo,
+    ARIA_LAUNCH(attn_delta_kernel, dim3(unsigned(g)), dim3(256), 0, stream, Op, dO, delta, int(Sq), int(H), int(hd), (long long)ldo,
                 (long long)ldo, nrows);
-    dim3 grid(unsigned((S + 127) / 128), unsigned(H), unsigned(B)), block(NT);
+    dim3 gridk(unsigned((Skv + 127) / 128), unsigned(H), unsigned(B)), gridq(unsigned((Sq + 127) / 128), unsigned(H), unsigned(B));
+    dim3 block(NT);
     if (hd == 128) {
         using C = Cfg<128>;
-        ARIA_LAUNCH((attn_bwd_dkdv_kernel<128>), grid, block, size_t(2 * 64 * C::PITCH * 2 + 128 * 4), stream, Q, K, V, dO, lse,
-                    (const float*)delta, static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), kv_len, int(S), int(H), (long long)ldq,
-                    (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddk, (long long)lddv, scale, causal);
-        ARIA_LAUNCH((attn_bwd_dq_kernel<128>), grid, block, size_t(2 * 64 * C::PITCH * 2), stream, Q, K, V, dO, lse,
-                    (const float*)delta, static_cast<bf16_t*>(dq), kv_len, int(S), int(H), (long long)ldq, (long long)ldk,
-                    (long long)ldv, (long long)ldo, (long long)lddq, scale, causal);
+        ARIA_LAUNCH((attn_bwd_dkdv_kernel<128>), gridk, block, size_t(2 * 64 * C::PITCH * 2 + 128 * 4), stream, Q, K, V, dO, lse,
+                    (const float*)delta, static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), kv_len, key_mask, int(Sq), int(Skv),
+                    int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddk, (long long)lddv, scale,
+                    causal);
+        ARIA_LAUNCH((attn_bwd_dq_kernel<128>), gridq, block, size_t(2 * 64 * C::PITCH * 2 + 64), stream, Q, K, V, dO, lse,
+                    (const float*)delta, static_cast<bf16_t*>(dq), kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq,
+                    (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddq, scale, causal);
     } else {
         using C = Cfg<64>;
-        ARIA_LAUNCH((attn_bwd_dkdv_kernel<64>), grid, block, size_t(2 * 64 * C::PITCH * 2 + 128 * 4), stream, Q, K, V, dO, lse,
-                    (const float*)delta, static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), kv_len, int(S), int(H), (long long)ldq,
-                    (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddk, (long long)lddv, scale, causal);
-        ARIA_LAUNCH((attn_bwd_dq_kernel<64>), grid, block, size_t(2 * 64 * C::PITCH * 2), stream, Q, K, V, dO, lse,
-                    (const float*)delta, static_cast<bf16_t*>(dq), kv_len, int(S), int(H), (long long)ldq, (long long)ldk,
-                    (long long)ldv, (long long)ldo, (long long)lddq, scale, causal);
+        ARIA_LAUNCH((attn_bwd_dkdv_kernel<64>), gridk, block, size_t(2 * 64 * C::PITCH * 2 + 128 * 4), stream, Q, K, V, dO, lse,
+                    (const float*)delta, static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), kv_len, key_mask, int(Sq), int(Skv),
+                    int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddk, (long long)lddv, scale,
+                    causal);
+        ARIA_LAUNCH((attn_bwd_dq_kernel<64>), gridq, block, size_t(2 * 64 * C::PITCH * 2 + 64), stream, Q, K, V, dO, lse,
+                    (const float*)delta, static_cast<bf16_t*>(dq), kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq,
+                    (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddq, scale, causal);
     }
     return aria_check_launch();
 }

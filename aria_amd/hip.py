@@ -44,8 +44,17 @@ SIGNATURES = {
     "aria_colsum_f32": [P, P, I64, I64, I32, P],
     "aria_rope_inplace": [P, P, P, I64, I64, I64, I64, I64, I32, P],
     "aria_add_bf16": [P, P, P, I64, P],
-    "aria_attn_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
-    "aria_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
+    "aria_attn_fwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
+    "aria_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
+    "aria_layernorm_fwd": [P, P, P, P, P, P, I64, I64, F32, P],
+    "aria_layernorm_bwd": [P, P, P, P, P, P, P, P, I64, I64, I64, P],
+    "aria_gelu_tanh_fwd": [P, P, I64, P],
+    "aria_gelu_tanh_bwd": [P, P, P, I64, P],
+    "aria_vit_patch_mask": [P, P, I64, I64, I64, P],
+    "aria_vit_pos_ids": [P, P, P, I64, I64, I64, I64, P],
+    "aria_vit_im2col": [P, I32, P, I64, I64, I64, I64, I64, P],
+    "aria_gather_add_rows": [P, P, P, I64, I64, P],
+    "aria_colsum_bf16": [P, P, I64, I64, I64, I64, P],
     "aria_cross_entropy": [P, P, P, P, P, F32, P, I64, I64, I64, P],
     "aria_probe_tr16": [P, I32, P],
 }

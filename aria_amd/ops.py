@@ -266,34 +266,131 @@ def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ----------------------------------------------------------------------------- ViT / projector support
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, want_stats: bool = True):
+    _chk(x, name="x"), _chk(w, name="w"), _chk(b, name="b")
+    assert x.is_contiguous() and x.dim() == 2
+    T, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty((T,), dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty((T,), dtype=torch.float32, device=x.device) if want_stats else None
+    hip.get_lib().call("aria_layernorm_fwd", _p(x), _p(w), _p(b), _p(y), _p(mean), _p(rstd), T, D, float(eps), _stream(x))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd):
+    """-> (dx, dw bf16 [D], db bf16 [D])"""
+    T, D = x.shape
+    nblocks = max(1, min(512, (T + 3) // 4))
+    dx = torch.empty_like(x)
+    pw = torch.empty((nblocks, D), dtype=torch.float32, device=x.device)
+    pb = torch.empty((nblocks, D), dtype=torch.float32, device=x.device)
+    hip.get_lib().call("aria_layernorm_bwd", _p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(pw), _p(pb), nblocks, T, D,
+                       _stream(x))
+    dw = torch.empty((D,), dtype=bf16, device=x.device)
+    db = torch.empty((D,), dtype=bf16, device=x.device)
+    hip.get_lib().call("aria_colsum_f32", _p(pw), _p(dw), nblocks, D, 0, _stream(x))
+    hip.get_lib().call("aria_colsum_f32", _p(pb), _p(db), nblocks, D, 0, _stream(x))
+    return dx, dw, db
+
+
+def gelu_tanh(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, name="x")
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    hip.get_lib().call("aria_gelu_tanh_fwd", _p(x), _p(y), x.numel(), _stream(x))
+    return y
+
+
+def gelu_tanh_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    assert x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x)
+    hip.get_lib().call("aria_gelu_tanh_bwd", _p(x), _p(dy), _p(dx), x.numel(), _stream(x))
+    return dx
+
+
+def vit_patch_mask(pixel_mask: torch.Tensor, patch: int) -> torch.Tensor:
+    """pixel_mask bool/uint8 [N,R,R] -> uint8 [N, R/patch, R/patch]"""
+    pm = pixel_mask.to(torch.uint8).contiguous()
+    N, R, _ = pm.shape
+    out = torch.empty((N, R // patch, R // patch), dtype=torch.uint8, device=pm.device)
+    hip.get_lib().call("aria_vit_patch_mask", _p(pm), _p(out), N, R, patch, _stream(pm))
+    return out
+
+
+def vit_pos_ids(patch_mask: torch.Tensor, boundaries: torch.Tensor, n_side: int) -> torch.Tensor:
+    _chk(patch_mask, torch.uint8, "patch_mask"), _chk(boundaries, torch.float32, "boundaries")
+    N, Hp, Wp = patch_mask.shape
+    ids = torch.empty((N, Hp * Wp), dtype=torch.int32, device=patch_mask.device)
+    hip.get_lib().call("aria_vit_pos_ids", _p(patch_mask), _p(boundaries), _p(ids), N, Hp, Wp, n_side, _stream(patch_mask))
+    return ids
+
+
+def vit_im2col(pixels: torch.Tensor, patch: int, KP: int) -> torch.Tensor:
+    assert pixels.is_contiguous() and pixels.dtype in (bf16, torch.float32)
+    N, C, R, _ = pixels.shape
+    Hp = R // patch
+    out = torch.empty((N * Hp * Hp, KP), dtype=bf16, device=pixels.device)
+    hip.get_lib().call("aria_vit_im2col", _p(pixels), int(pixels.dtype == torch.float32), _p(out), N, C, R, patch, KP, _stream(pixels))
+    return out
+
+
+def gather_add_rows_(x: torch.Tensor, table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    _chk(x, name="x"), _chk(table, name="table"), _chk(ids, torch.int32, "ids")
+    assert x.is_contiguous() and table.is_contiguous() and ids.is_contiguous()
+    hip.get_lib().call("aria_gather_add_rows", _p(x), _p(table), _p(ids), x.shape[0], x.shape[1], _stream(x))
+    return x
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """bf16 [T,D] -> bf16 [D] column sums (bias gradient), fp32 accumulation."""
+    _chk(x, name="x")
+    T, D = x.shape
+    nparts = max(1, min(64, T // 64))
+    partial = torch.empty((nparts, D), dtype=torch.float32, device=x.device)
+    hip.get_lib().call("aria_colsum_bf16", _p(x), _p(partial), nparts, T, D, _rowmajor_2d(x, "x"), _stream(x))
+    out = torch.empty((D,), dtype=bf16, device=x.device)
+    hip.get_lib().call("aria_colsum_f32", _p(partial), _p(out), nparts, D, 0, _stream(x))
+    return out
+
+
 # ----------------------------------------------------------------------------- attention
 def attention_fwd(q, k, v, B: int, S: int, H: int, hd: int, scale: float, causal: bool,
-                  kv_len: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
-    """q,k,v: 2-D views [B*S, >= H*hd] (token-major, head h at columns h*hd); -> (o [B*S, H*hd], lse fp32 [B,H,S])."""
+                  kv_len: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                  key_mask: Optional[torch.Tensor] = None, Skv: Optional[int] = None):
+    """q: [B*S, >= H*hd], k,v: [B*Skv, >= H*hd] token-major views (head h at columns h*hd);
+    key_mask uint8 [B, Skv] (1 = attend).  -> (o [B*S, H*hd], lse fp32 [B,H,S])."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk(t, name=n)
+    Skv = S if Skv is None else Skv
+    if key_mask is not None:
+        _chk(key_mask, torch.uint8, "key_mask")
+        assert key_mask.is_contiguous() and key_mask.numel() == B * Skv
     if out is None:
         out = torch.empty((B * S, H * hd), dtype=bf16, device=q.device)
     lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
-    hip.get_lib().call("aria_attn_fwd", _p(q), _p(k), _p(v), _p(out), _p(lse), _p(kv_len), B, S, H, hd, _rowmajor_2d(q, "q"),
-                       _rowmajor_2d(k, "k"), _rowmajor_2d(v, "v"), _rowmajor_2d(out, "o"), float(scale), int(causal), _stream(q))
+    hip.get_lib().call("aria_attn_fwd", _p(q), _p(k), _p(v), _p(out), _p(lse), _p(kv_len), _p(key_mask), B, S, Skv, H, hd,
+                       _rowmajor_2d(q, "q"), _rowmajor_2d(k, "k"), _rowmajor_2d(v, "v"), _rowmajor_2d(out, "o"), float(scale),
+                       int(causal), _stream(q))
     return out, lse
 
 
 def attention_bwd(q, k, v, o, do, lse, B: int, S: int, H: int, hd: int, scale: float, causal: bool,
-                  kv_len: Optional[torch.Tensor] = None, dq=None, dk=None, dv=None):
+                  kv_len: Optional[torch.Tensor] = None, dq=None, dk=None, dv=None, key_mask: Optional[torch.Tensor] = None,
+                  Skv: Optional[int] = None):
     dev = q.device
+    Skv = S if Skv is None else Skv
     if dq is None:
         dq = torch.empty((B * S, H * hd), dtype=bf16, device=dev)
     if dk is None:
-        dk = torch.empty((B * S, H * hd), dtype=bf16, device=dev)
+        dk = torch.empty((B * Skv, H * hd), dtype=bf16, device=dev)
     if dv is None:
-        dv = torch.empty((B * S, H * hd), dtype=bf16, device=dev)
+        dv = torch.empty((B * Skv, H * hd), dtype=bf16, device=dev)
     delta = torch.empty((B, H, S), dtype=torch.float32, device=dev)
     hip.get_lib().call("aria_attn_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(kv_len),
-                       B, S, H, hd, _rowmajor_2d(q, "q"), _rowmajor_2d(k, "k"), _rowmajor_2d(v, "v"), _rowmajor_2d(o, "o"),
-                       _rowmajor_2d(dq, "dq"), _rowmajor_2d(dk, "dk"), _rowmajor_2d(dv, "dv"), float(scale), int(causal),
-                       _stream(q))
+                       _p(key_mask), B, S, Skv, H, hd, _rowmajor_2d(q, "q"), _rowmajor_2d(k, "k"), _rowmajor_2d(v, "v"),
+                       _rowmajor_2d(o, "o"), _rowmajor_2d(dq, "dq"), _rowmajor_2d(dk, "dk"), _rowmajor_2d(dv, "dv"), float(scale),
+                       int(causal), _stream(q))
     return dq, dk, dv
 
 

@@ -136,18 +136,49 @@ int aria_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stre
 /* ------------------------------------------------------------------------------------------------
  * Attention (attn.hip)
  * ------------------------------------------------------------------------------------------------ */
-/* softmax(Q K^T * scale + mask) V, flash style (no S x S tensor), fp32 softmax
- * (eager_attention_forward transformers/models/llama/modeling_llama.py:192-215; gptfast/model.py:439-442).
- * q,k,v,o: [B, S, H, hd] views with row strides ld* (elements) between consecutive tokens; head h at column h*hd.
- * causal != 0: decoder mask.  kv_len int32[B] or NULL: keys >= kv_len[b] are masked (ViT patch padding,
- * vision_encoder.py:147-152).  lse fp32 [B,H,S] saved for the backward.  hd in {64, 128}. */
-int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* kv_len, int64_t B,
-                  int64_t S, int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
-                  int causal, void* stream);
+/* softmax(Q K^T * scale + mask) V, flash style (no Sq x Skv tensor), fp32 softmax
+ * (eager_attention_forward transformers/models/llama/modeling_llama.py:192-215; gptfast/model.py:439-442;
+ * nn.MultiheadAttention of the projector, aria/model/projector.py:73-102).
+ * q,o: [B, Sq, H, hd] and k,v: [B, Skv, H, hd] views of token-major activations with row strides ld* (elements); head h at
+ * column h*hd.  causal != 0: decoder mask (needs Sq == Skv).  kv_len int32[B] or NULL: keys >= kv_len[b] are masked (right
+ * padding).  key_mask uint8 [B, Skv] or NULL: keys with 0 are masked (ViT patch padding, vision_encoder.py:132-152).
+ * lse fp32 [B,H,Sq] saved for the backward.  hd in {64, 128} (the host zero-pads other head dims). */
+int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* kv_len, const uint8_t* key_mask,
+                  int64_t B, int64_t Sq, int64_t Skv, int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                  float scale, int causal, void* stream);
 int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
-                  float* delta /* fp32 [B,H,S] scratch */, void* dq, void* dk, void* dv, const int32_t* kv_len, int64_t B,
-                  int64_t S, int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq,
-                  int64_t lddk, int64_t lddv, float scale, int causal, void* stream);
+                  float* delta /* fp32 [B,H,Sq] scratch */, void* dq, void* dk, void* dv, const int32_t* kv_len,
+                  const uint8_t* key_mask, int64_t B, int64_t Sq, int64_t Skv, int64_t H, int64_t hd, int64_t ldq, int64_t ldk,
+                  int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ViT / projector support (vit.hip)
+ * ------------------------------------------------------------------------------------------------ */
+/* nn.LayerNorm (ViT layer_norm1/2, transformers/models/idefics2/modeling_idefics2.py:330-363; projector layer_norm / ln_kv /
+ * ln_ffn, aria/model/projector.py:66-67,152): y = bf16((x - mean) * rstd * w + b), fp32 statistics saved for the backward. */
+int aria_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t T, int64_t D,
+                       float eps, void* stream);
+/* dx and per-block partial dw/db [nblocks, D] fp32 (reduce with aria_colsum_f32). */
+int aria_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, void* dx,
+                       float* dw_partial, float* db_partial, int64_t nblocks, int64_t T, int64_t D, void* stream);
+/* tanh-form GELU: ACT2FN["gelu_pytorch_tanh"] (ViT MLP) == ACT2FN["gelu_new"] (projector FFN, projector.py:40). n % 8 == 0. */
+int aria_gelu_tanh_fwd(const void* x, void* y, int64_t n, void* stream);
+int aria_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
+/* AriaVisionModel._create_patch_attention_mask, aria/model/vision_encoder.py:132-145: pixel_mask uint8 [N,R,R] ->
+ * patch_mask uint8 [N, R/patch, R/patch] (1 = patch contains at least one valid pixel). */
+int aria_vit_patch_mask(const uint8_t* pixel_mask, uint8_t* patch_mask, int64_t N, int64_t R, int64_t patch, void* stream);
+/* Idefics2VisionEmbeddings position ids (modeling_idefics2.py:141-170), fp32 exactly as the reference computes them on CPU;
+ * boundaries = fp32 torch.arange(1/n_side, 1.0, 1/n_side) built on the host.  ids int32 [N, Hp*Wp], 0 on padded patches. */
+int aria_vit_pos_ids(const uint8_t* patch_mask, const float* boundaries, int32_t* ids, int64_t N, int64_t Hp, int64_t Wp,
+                     int64_t n_side, void* stream);
+/* A operand of the patch-embed GEMM (Conv2d(3 -> hidden, k = s = patch), modeling_idefics2.py:117-133):
+ * patches [N*Hp*Hp, KP] bf16 with KP >= C*patch*patch, KP % 8 == 0, zero padded.  pixels [N,C,R,R] bf16 or fp32. */
+int aria_vit_im2col(const void* pixels, int pixels_f32, void* patches, int64_t N, int64_t C, int64_t R, int64_t patch, int64_t KP,
+                    void* stream);
+/* x[t,:] = bf16(x[t,:] + table[ids[t],:])  -- `embeddings + position_embedding(position_ids)` modeling_idefics2.py:172 */
+int aria_gather_add_rows(void* x, const void* table, const int32_t* ids, int64_t T, int64_t D, void* stream);
+/* partial[p, d] = sum over the p-th slice of rows of x[t, d] (bias gradients; reduce with aria_colsum_f32) */
+int aria_colsum_bf16(const void* x, float* partial, int64_t nparts, int64_t T, int64_t D, int64_t ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Loss (loss.hip)

@@ -309,3 +309,33 @@ def case_cross_entropy(dev, T, V):
     assert int(count.cpu()) == n
     close(loss_sum.cpu() / n, want.detach().reshape(1), 1e-4, 1e-4)
     close(dl, lf.grad, 2e-2, 1e-4)
+
+
+def case_attention_cross_masked(dev, B, Sq, Skv, H, hd):
+    """Sq != Skv with an arbitrary (non-prefix) key mask: the projector's cross-attention and the ViT's patch padding."""
+    from aria_amd import ops
+
+    D = H * hd
+    q = rnd(B * Sq, D, seed=50)
+    kv = rnd(B * Skv, 2 * D, seed=51)
+    g = torch.Generator().manual_seed(52)
+    km = (torch.rand(B, Skv, generator=g) > 0.3).to(torch.uint8)
+    km[:, 0] = 1
+    scale = hd ** -0.5
+    qd, kvd = q.to(dev), kv.to(dev)
+    o, lse = ops.attention_fwd(qd, kvd[:, :D], kvd[:, D:], B, Sq, H, hd, scale, False, key_mask=km.to(dev), Skv=Skv)
+    qf = q.float().clone().requires_grad_(True)
+    kf = kv[:, :D].float().clone().requires_grad_(True)
+    vf = kv[:, D:].float().clone().requires_grad_(True)
+    qh = qf.view(B, Sq, H, hd).transpose(1, 2)
+    kh = kf.view(B, Skv, H, hd).transpose(1, 2)
+    vh = vf.view(B, Skv, H, hd).transpose(1, 2)
+    want = O.attention_eager(qh, kh, vh, scale, False, key_padding=(km == 0)).transpose(1, 2).reshape(B * Sq, D)
+    close(o, want, 2e-2, 2e-2)
+    do = rnd(B * Sq, D, seed=53)
+    want.backward(do.float())
+    dq, dk, dv = ops.attention_bwd(qd, kvd[:, :D], kvd[:, D:], o, do.to(dev), lse, B, Sq, H, hd, scale, False,
+                                   key_mask=km.to(dev), Skv=Skv)
+    close(dq, qf.grad, 3e-2, 3e-2)
+    close(dk, kf.grad, 3e-2, 3e-2)
+    close(dv, vf.grad, 3e-2, 3e-2)

@@ -25,3 +25,11 @@ def test_moe_layer_train_golden(golden):
 
 def test_lm_golden(golden):
     M.case_lm_golden(DEV, golden)
+
+
+def test_vit_projector_golden(golden):
+    M.case_vit_projector_golden(DEV, golden)
+
+
+def test_aria_full_golden(golden):
+    M.case_aria_full_golden(DEV, golden)

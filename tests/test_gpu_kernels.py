@@ -83,3 +83,8 @@ def test_cross_entropy(T, V):
                                                      (2, 1024, 3, 128, True, False), (3, 1225, 2, 128, False, True)])
 def test_attention_fwd_bwd(B, S, H, hd, causal, use_len):
     C.case_attention(DEV, B, S, H, hd, causal, use_len)
+
+
+@pytest.mark.parametrize("B,Sq,Skv,H,hd", [(2, 40, 150, 2, 64), (1, 130, 70, 1, 128), (3, 256, 4900, 2, 128)])
+def test_attention_cross_masked(B, Sq, Skv, H, hd):
+    C.case_attention_cross_masked(DEV, B, Sq, Skv, H, hd)

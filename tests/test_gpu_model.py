@@ -21,3 +21,11 @@ def test_lm_golden(golden):
 
 def test_lm_golden_with_recompute(golden):
     M.case_lm_golden(DEV, golden, recompute=True)
+
+
+def test_vit_projector_golden(golden):
+    M.case_vit_projector_golden(DEV, golden)
+
+
+def test_aria_full_golden(golden):
+    M.case_aria_full_golden(DEV, golden)
