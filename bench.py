@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--recompute", action="store_true", help="gradient checkpointing per layer (reference recipe); "
                     "off by default: 288 GB HBM holds all activations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--images", type=int, default=2, help="980px images per sample (NLVR2-style: 2); 0 = text only")
+    ap.add_argument("--vit-layers", type=int, default=27, help="debug only")
     ap.add_argument("--no-overlap", action="store_true", help="exchange gradients after backward instead of under it")
     return ap.parse_args()
 
@@ -119,23 +121,37 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from aria_amd import ops
-    from aria_amd.moe_lm import AriaMoELMConfig, AriaMoELMForCausalLM
+    from aria_amd.modeling_aria import AriaConfig, AriaForConditionalGeneration
+    from aria_amd.moe_lm import AriaMoELMConfig
     from aria_amd.parallel import GradSync
+    from aria_amd.vision import AriaVisionConfig
 
     cfg_kwargs = dict(hidden_size=2560, num_hidden_layers=args.layers, num_attention_heads=20, vocab_size=100352,
                       moe_intermediate_size=1664, moe_num_experts=64, moe_topk=6, moe_num_shared_experts=2,
                       rms_norm_eps=1e-6, rope_theta=5_000_000.0, moe_z_loss_coeff=1e-5, moe_aux_loss_coeff=1e-4)
     cfg = AriaMoELMConfig(**cfg_kwargs, gradient_checkpointing=args.recompute)
+    IMG_TOKEN, QTOK = 9, 256                       # gptfast/model.py:54; 980px image -> 4900 patches -> 256 query tokens
+    acfg = AriaConfig(vision_config=AriaVisionConfig(num_hidden_layers=args.vit_layers), text_config=cfg,
+                      projector_patch_to_query_dict={1225: 128, 4900: 256}, image_token_index=IMG_TOKEN)
     torch.set_default_device(dev)
-    model = AriaMoELMForCausalLM(cfg)
+    model = AriaForConditionalGeneration(acfg)
     torch.set_default_device("cpu")
     init_params(model, seed=0)  # same weights on every rank (DP replicas)
     model.train()
+    model.freeze_vit()          # recipes/config_full.yaml:39-42: ViT frozen, projector + LLM trainable
     sync = GradSync(model, overlap=not args.no_overlap) if world > 1 else None
 
     B, S, V = args.batch, args.seq, cfg.vocab_size
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
     ids = torch.randint(10, V, (B, S), generator=g, device=dev)
+    pixel_values = pixel_mask = None
+    n_img = args.images
+    if n_img > 0:
+        for j in range(n_img):                      # contiguous runs of 256 image placeholders per image
+            ids[:, 16 + j * (QTOK + 28): 16 + j * (QTOK + 28) + QTOK] = IMG_TOKEN
+        pixel_values = torch.randn((B * n_img, 3, 980, 980), generator=g, device=dev).clamp_(-1, 1).to(bf16)
+        pixel_mask = torch.ones((B * n_img, 980, 980), dtype=torch.bool, device=dev)
+        pixel_mask[0, 735:, :] = False              # one image with its bottom 25 % rows padded (mask path exercised)
     labels = ids.clone()
     labels[:, : int(0.75 * S)] = -100  # prompt masked like an SFT sample
 
@@ -158,7 +174,8 @@ def main():
 
     def step():
         model.zero_grad(set_to_none=True)
-        out = model(input_ids=ids, labels=labels, return_logits=False)
+        out = model(input_ids=ids, pixel_values=pixel_values, pixel_mask=pixel_mask, labels=labels, return_logits=False,
+                    validate_image_tokens=False)
         out.loss.backward()
         if sync is not None:
             sync.finish()
@@ -199,10 +216,11 @@ def main():
             "metric": "tokens/sec (fwd+bwd) Aria-25.3B bf16", "value": round(tokens / dt, 2), "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "config#3 per-GPU shape: Aria-25.3B MoE decoder (28 layers x 64 experts top-6, D=2560, V=100352, "
-                                   "random-init) fwd+bwd incl. lm_head+CE and router aux-loss grads; image tokens enter as ordinary "
-                                   "embeddings (frozen ViT+projector forward not yet in the timed region)",
-                       "layers": args.layers, "global_batch": world * B, "seq_len": S,
+            "config": {"workload": "config#3 per-GPU shape (recipes/config_full.yaml): Aria-25.3B random-init, per GPU 8 samples x "
+                                   f"({n_img} x 980px images + text) padded to S=2048; frozen 27-layer ViT fwd (4900 patches/img) -> "
+                                   "trainable projector (256 tok/img) -> 28-layer MoE decoder (64 experts top-6, D=2560, V=100352) "
+                                   "fwd+bwd incl. lm_head+CE and router aux-loss grads",
+                       "layers": args.layers, "vit_layers": args.vit_layers, "images_per_sample": n_img, "global_batch": world * B, "seq_len": S,
                        "parallelism": f"dp{world}" if world > 1 else "single", "grad_checkpointing": bool(args.recompute),
                        "optimizer_in_step": False, "loss": round(float(loss), 4)},
             "roofline": {"kernel": "gemm_kernel<rc,oc> grouped-M (experts.fc1 forward)", "bound": "mfma",
@@ -211,8 +229,8 @@ def main():
                          "launches_timed": len(durs), "avg_launch_ms": round(avg * 1e3, 4),
                          "algorithmic_flops_per_launch": flops_launch},
         }
-        if args.layers != 28:
-            res["config"]["INVALID"] = "reduced depth (debug run)"
+        if args.layers != 28 or args.vit_layers != 27 or n_img != 2:
+            res["config"]["INVALID"] = "reduced depth / no images (debug run)"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(cfg_kwargs)
