@@ -172,5 +172,38 @@ __device__ __forceinline__ u32x4 zero16() { return u32x4{0u, 0u, 0u, 0u}; }
 
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
+// 2^x straight on v_exp_f32 (no denormal range fix-up: results below 2^-126 flush to 0, which is what softmax wants)
+__device__ __forceinline__ float exp2_fast(float x) {
+#ifdef ARIA_EMU
+    return std::exp2(x);
+#else
+    return __builtin_amdgcn_exp2f(x);
+#endif
+}
+
+// ds_read_b64_tr_b16: every lane passes the LDS address of 4 consecutive bf16 (8-byte aligned); within each 16-lane group
+// lane q receives element (q & 3) of the four lanes 4j + (q >> 2), j = 0..3 (semantics verified on hardware by
+// tests/test_gpu_probes.py).  Used to read row-major [k][n] tiles as k-contiguous MFMA fragments.
+__device__ __forceinline__ s16x4 ds_read_tr16(const bf16_t* p) {
+#ifdef ARIA_EMU
+    emu::WaveBuf& w = emu::wbuf();
+    const int l = emu::lane();
+    std::memcpy(w.slot[l], &p, sizeof(p));
+    emu::wave_sync();
+    s16x4 r;
+    const int base = l & ~15, q = l & 15;
+    for (int j = 0; j < 4; ++j) {
+        const bf16_t* src;
+        std::memcpy(&src, w.slot[base + 4 * j + (q >> 2)], sizeof(src));
+        r[j] = short(src[q & 3]);
+    }
+    emu::wave_sync();
+    return r;
+#else
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+#endif
+}
+
 }  // namespace ad
 

@@ -222,6 +222,219 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const bf16_t* Q, const bf1
     }
 }
 
+// =========================================================================================== forward v2
+// 8 waves / 256 queries per block, K/V double-buffered in LDS (ONE barrier per 64-key tile), V fragments through
+// ds_read_b64_tr_b16 (row-major [key][d] tile read as key-contiguous fragments: half the LDS cycles of the dword-pair
+// read and no VALU repacking), softmax in the log2 domain on v_exp_f32 with the scale folded in, lazy (wave-uniform)
+// rescale, mask arithmetic only on edge / diagonal / padded tiles, native head dims 64 / 72 / 128 (72 = ViT and
+// projector: reduction padded to 80, output tiles 32+32+8).
+template <int HD>
+struct Cfg2 {
+    static constexpr int NT2 = 512;
+    static constexpr int KS = (HD + 15) / 16;
+    static constexpr int HDK = KS * 16;
+    static constexpr int DT = (HD + 31) / 32;
+    static constexpr int CPR = HD / 8;
+    static constexpr int KP = HDK + 8;                 // K tile pitch (elements): conflict-free ds_read_b128 fragments
+    static constexpr int VP = HD == 128 ? 160 : 96;    // V tile pitch: 16 (mod 64) dwords apart rows -> conflict-free tr reads
+    static constexpr int NCH = (64 * CPR + NT2 - 1) / NT2;
+    static constexpr size_t SMEM = size_t(2) * 64 * (KP + VP) * 2 + 2 * 64 + 16;
+};
+
+template <int HD>
+__device__ __forceinline__ void tile2_load(u32x4 (&r)[Cfg2<HD>::NCH], const bf16_t* base, long long ld, int row0, int row_end,
+                                           int t) {
+    using C = Cfg2<HD>;
+#pragma unroll
+    for (int p = 0; p < C::NCH; ++p) {
+        const int c = t + C::NT2 * p;
+        const int row = row0 + c / C::CPR, col = (c % C::CPR) * 8;
+        r[p] = (c < 64 * C::CPR && row < row_end) ? ld16(base + (long long)row * ld + col) : zero16();
+    }
+}
+template <int HD, int PITCH>
+__device__ __forceinline__ void tile2_store(const u32x4 (&r)[Cfg2<HD>::NCH], bf16_t* s, int t) {
+    using C = Cfg2<HD>;
+#pragma unroll
+    for (int p = 0; p < C::NCH; ++p) {
+        const int c = t + C::NT2 * p;
+        if (c < 64 * C::CPR) st16(s + (c / C::CPR) * PITCH + (c % C::CPR) * 8, r[p]);
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE,
+                                                        const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
+                                                        long long ldq, long long ldk, long long ldv, long long ldo, float scale,
+                                                        int causal) {
+    using C = Cfg2<HD>;
+    ARIA_DYN_SMEM(smem);
+    bf16_t* sK = reinterpret_cast<bf16_t*>(smem);          // [2][64][KP]
+    bf16_t* sV = sK + 2 * 64 * C::KP;                      // [2][64][VP]
+    uint8_t* sM = reinterpret_cast<uint8_t*>(sV + 2 * 64 * C::VP);  // [2][64]
+    int* sFlag = reinterpret_cast<int*>(sM + 128);         // [2]
+    const int t = threadIdx.x, l = t & 63, w = t >> 6, h2 = l >> 5;
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 256;
+    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
+    const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
+    const bf16_t* Kb = K + tok0 * ldk + head * HD;
+    const bf16_t* Vb = V + tok0 * ldv + head * HD;
+    const uint8_t* kmb = key_mask ? key_mask + tok0 : nullptr;
+    const int q_wmin = q0 + 32 * w, q_abs = q_wmin + (l & 31);
+    const int klen = kv_len ? min(S, kv_len[b]) : S;
+    const float scale2 = scale * 1.4426950408889634f;
+
+    s16x8 qf[C::KS];
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+        u32x4 v = zero16();
+        const int col = kk * 16 + h2 * 8;
+        if (q_abs < Sq && col < HD) v = ld16(Qb + (long long)q_abs * ldq + col);
+        qf[kk] = __builtin_bit_cast(s16x8, v);
+    }
+    f32x16 o[C::DT];
+#pragma unroll
+    for (int i = 0; i < C::DT; ++i) o[i] = zero_acc();
+    float m = -INFINITY, lsum = 0.f;
+
+    int kv_end = klen;
+    if (causal) kv_end = min(kv_end, q0 + 256);
+    const int ntiles = (kv_end + 63) / 64;
+
+    // pad columns: K's reduction pad must be zero (Q's is), V's pad only feeds discarded output rows but must not be NaN-free
+    // garbage either way -> zero both once (tile stores never touch them)
+    if (C::HDK != HD || C::VP > HD) {
+        for (int i = t; i < 2 * 64; i += C::NT2) {
+            if (C::HDK != HD) st16(sK + i * C::KP + HD, zero16());
+            for (int c = HD; c < C::VP; c += 8) st16(sV + i * C::VP + c, zero16());
+        }
+    }
+    u32x4 rk[C::NCH], rv[C::NCH];
+    if (ntiles > 0) {
+        tile2_load<HD>(rk, Kb, ldk, 0, S, t);
+        tile2_load<HD>(rv, Vb, ldv, 0, S, t);
+        tile2_store<HD, C::KP>(rk, sK, t);
+        tile2_store<HD, C::VP>(rv, sV, t);
+        if (kmb && t < 64) {
+            const uint8_t mv = t < S ? kmb[t] : 0;
+            sM[t] = mv;
+            const unsigned long long all = ballot(mv != 0);
+            if (t == 0) sFlag[0] = (all == ~0ull);
+        }
+    }
+    for (int it = 0; it < ntiles; ++it) {
+        sync();  // tile `it` complete in buffer it&1; every wave is done reading the other buffer
+        const int cur = it & 1, kv0 = it * 64;
+        const bool more = it + 1 < ntiles;
+        if (more) {
+            tile2_load<HD>(rk, Kb, ldk, kv0 + 64, S, t);
+            tile2_load<HD>(rv, Vb, ldv, kv0 + 64, S, t);
+        }
+        const bf16_t* cK = sK + cur * 64 * C::KP;
+        const bf16_t* cV = sV + cur * 64 * C::VP;
+        if (!(causal && kv0 > q_wmin + 31)) {  // wave-uniform: this wave has at least one visible key in the tile
+            f32x16 st[2];
+            st[0] = zero_acc();
+            st[1] = zero_acc();
+#pragma unroll
+            for (int kk = 0; kk < C::KS; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) st[i] = mfma32(*reinterpret_cast<const s16x8*>(cK + (i * 32 + (l & 31)) * C::KP + kk * 16 + h2 * 8), qf[kk], st[i]);
+            const bool need_mask = (kv0 + 64 > klen) || (causal && kv0 + 63 > q_wmin) || (kmb && !sFlag[cur]);
+            if (need_mask) {
+                const uint8_t* cM = sM + cur * 64;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kvl = i * 32 + acc_row(r, l);
+                        const int kv = kv0 + kvl;
+                        bool dead = kv >= klen || (causal && kv > q_abs);
+                        if (kmb) dead = dead || !cM[kvl];
+                        if (dead) st[i][r] = -INFINITY;
+                    }
+            }
+            float mx = st[0][0];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[i][r]);
+            mx = fmaxf(mx, shfl_xor(mx, 32));
+            const float m_new = fmaxf(m, mx * scale2);
+            const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+            if (ballot(m_new > m) != 0ull) {  // wave-uniform lazy rescale: exact (alpha == 1 whenever it is skipped)
+                const float alpha = exp2_fast(m - m_safe);
+                lsum *= alpha;
+#pragma unroll
+                for (int i = 0; i < C::DT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                m = m_new;
+            }
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = exp2_fast(st[i][r] * scale2 - m_safe);
+                    st[i][r] = p;
+                    ps += p;
+                }
+            lsum += ps;
+            // O^T += V^T P^T
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const s16x8 pf = pack_frag(st[i], u);
+                    const bf16_t* vrow = cV + (i * 32 + 16 * u + 4 * h2 + ((l & 15) >> 2)) * C::VP + 16 * ((l >> 4) & 1) + 4 * (l & 3);
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; ++dt) {
+                        const s16x4 a0 = ds_read_tr16(vrow + 32 * dt);
+                        const s16x4 a1 = ds_read_tr16(vrow + 8 * C::VP + 32 * dt);
+                        s16x8 vf;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            vf[e] = a0[e];
+                            vf[4 + e] = a1[e];
+                        }
+                        o[dt] = mfma32(vf, pf, o[dt]);
+                    }
+                }
+        }
+        if (more) {  // stage tile it+1 into the other buffer (nobody reads it before the next barrier)
+            const int nb = cur ^ 1, kvn = kv0 + 64;
+            tile2_store<HD, C::KP>(rk, sK + nb * 64 * C::KP, t);
+            tile2_store<HD, C::VP>(rv, sV + nb * 64 * C::VP, t);
+            if (kmb && t < 64) {
+                const uint8_t mv = (kvn + t < S) ? kmb[kvn + t] : 0;
+                sM[nb * 64 + t] = mv;
+                const unsigned long long all = ballot(mv != 0);
+                if (t == 0) sFlag[nb] = (all == ~0ull);
+            }
+        }
+    }
+    const float ltot = lsum + shfl_xor(lsum, 32);
+    const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+    if (q_abs < Sq) {
+        if (h2 == 0 && LSE)
+            LSE[((long long)b * H + head) * Sq + q_abs] = (ltot > 0.f) ? (m + log2f(ltot)) * 0.6931471805599453f : -INFINITY;
+        bf16_t* orow = O + (tokq0 + q_abs) * ldo + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d0 = 32 * dt + 8 * rg + 4 * h2;
+                if (d0 < HD) {
+                    u32x2 v;
+                    v[0] = pack2bf(o[dt][4 * rg] * inv, o[dt][4 * rg + 1] * inv);
+                    v[1] = pack2bf(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
+                    *reinterpret_cast<u32x2*>(orow + d0) = v;
+                }
+            }
+    }
+}
+
 // =========================================================================================== delta = rowsum(O * dO)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* O, const bf16_t* dO, float* delta, int S, int H, int HD,
                                                          long long ldo, long long lddo, long long nrows) {
@@ -495,22 +708,22 @@ int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
                   int64_t B, int64_t Sq, int64_t Skv, int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                   float scale, int causal, void* stream) {
     if (!q || !k || !v || !o || B < 0 || Sq < 0 || Skv < 0 || H <= 0) return ARIA_ERR_INVALID;
-    if (hd != 64 && hd != 128) return ARIA_ERR_UNSUPPORTED;
+    if (hd != 64 && hd != 72 && hd != 128) return ARIA_ERR_UNSUPPORTED;
     if (causal && Sq != Skv) return ARIA_ERR_UNSUPPORTED;
-    if (!al16(q) || !al16(k) || !al16(v) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 1) || (reinterpret_cast<uintptr_t>(o) & 3))
+    if (!al16(q) || !al16(k) || !al16(v) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || (reinterpret_cast<uintptr_t>(o) & 7))
         return ARIA_ERR_ALIGN;
     if (B == 0 || Sq == 0) return ARIA_OK;
-    dim3 grid(unsigned((Sq + 127) / 128), unsigned(H), unsigned(B)), block(NT);
+    dim3 grid(unsigned((Sq + 255) / 256), unsigned(H), unsigned(B)), block(512);
     const bf16_t *Q = static_cast<const bf16_t*>(q), *K = static_cast<const bf16_t*>(k), *V = static_cast<const bf16_t*>(v);
-    if (hd == 128) {
-        const size_t sh = 2 * 64 * Cfg<128>::PITCH * sizeof(bf16_t) + 64;
-        ARIA_LAUNCH((attn_fwd_kernel<128>), grid, block, sh, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq),
-                    int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal);
-    } else {
-        const size_t sh = 2 * 64 * Cfg<64>::PITCH * sizeof(bf16_t) + 64;
-        ARIA_LAUNCH((attn_fwd_kernel<64>), grid, block, sh, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq),
-                    int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal);
-    }
+    if (hd == 128)
+        ARIA_LAUNCH((attn_fwd2_kernel<128>), grid, block, Cfg2<128>::SMEM, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len,
+                    key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal);
+    else if (hd == 72)
+        ARIA_LAUNCH((attn_fwd2_kernel<72>), grid, block, Cfg2<72>::SMEM, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len,
+                    key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal);
+    else
+        ARIA_LAUNCH((attn_fwd2_kernel<64>), grid, block, Cfg2<64>::SMEM, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len,
+                    key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal);
     return aria_check_launch();
 }
 

@@ -110,11 +110,12 @@ class AttnConfig:
     causal: bool = True
 
 
-_SUPPORTED_HD = (64, 128)
+_SUPPORTED_HD = (64, 128)      # forward + backward kernels
+_FWD_ONLY_HD = (64, 72, 128)   # forward kernel (72 = ViT / projector heads, native: no padding)
 
 
-def _pad_hd(hd: int) -> int:
-    for s in _SUPPORTED_HD:
+def _pad_hd(hd: int, need_bwd: bool = True) -> int:
+    for s in (_SUPPORTED_HD if need_bwd else _FWD_ONLY_HD):
         if hd <= s:
             return s
     raise ValueError(f"head_dim {hd} > 128 is not supported")

@@ -67,7 +67,7 @@ class SdpaFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, B, Sq, Skv, H, hd, scale, key_mask):
-        hdp = Fn._pad_hd(hd)
+        hdp = Fn._pad_hd(hd, need_bwd=any(ctx.needs_input_grad[:3]))
         if hdp != hd:
             q, k, v = (Fn._pad_heads(t, H, hd, hdp) for t in (q, k, v))
         o, lse = ops.attention_fwd(q, k, v, B, Sq, H, hdp, scale, False, key_mask=key_mask, Skv=Skv)

@@ -311,6 +311,31 @@ def case_cross_entropy(dev, T, V):
     close(dl, lf.grad, 2e-2, 1e-4)
 
 
+def case_attention_hd72_forward(dev, B, Sq, Skv, H, masked):
+    """native head_dim 72 forward (frozen ViT / projector): reduction padded to 80 in LDS, output tiles 32+32+8."""
+    from aria_amd import ops
+
+    hd = 72
+    D = H * hd
+    q = rnd(B * Sq, D, seed=60)
+    kv = rnd(B * Skv, 2 * D, seed=61)
+    km = None
+    if masked:
+        km = (torch.rand(B, Skv, generator=torch.Generator().manual_seed(62)) > 0.25).to(torch.uint8)
+        km[:, 0] = 1
+    o, lse = ops.attention_fwd(q.to(dev), kv.to(dev)[:, :D], kv.to(dev)[:, D:], B, Sq, H, hd, hd ** -0.5, False,
+                               key_mask=None if km is None else km.to(dev), Skv=Skv)
+    qh = q.float().view(B, Sq, H, hd).transpose(1, 2)
+    kh = kv[:, :D].float().view(B, Skv, H, hd).transpose(1, 2)
+    vh = kv[:, D:].float().view(B, Skv, H, hd).transpose(1, 2)
+    want = O.attention_eager(qh, kh, vh, hd ** -0.5, False, key_padding=None if km is None else (km == 0))
+    close(o, want.transpose(1, 2).reshape(B * Sq, D), 2e-2, 2e-2)
+    s = (qh @ kh.transpose(2, 3)) * hd ** -0.5
+    if km is not None:
+        s = s.masked_fill((km == 0)[:, None, None, :], float("-inf"))
+    close(lse, torch.logsumexp(s, dim=-1), 1e-3, 1e-3)
+
+
 def case_attention_cross_masked(dev, B, Sq, Skv, H, hd):
     """Sq != Skv with an arbitrary (non-prefix) key mask: the projector's cross-attention and the ViT's patch padding."""
     from aria_amd import ops

@@ -80,3 +80,8 @@ def test_attention_fwd_bwd(B, S, H, hd, causal, use_len):
 @pytest.mark.parametrize("B,Sq,Skv,H,hd", [(2, 40, 150, 2, 64), (1, 130, 70, 1, 128)])
 def test_attention_cross_masked(B, Sq, Skv, H, hd):
     C.case_attention_cross_masked(DEV, B, Sq, Skv, H, hd)
+
+
+@pytest.mark.parametrize("B,Sq,Skv,H,masked", [(2, 70, 70, 2, True), (1, 300, 90, 1, False)])
+def test_attention_hd72_forward(B, Sq, Skv, H, masked):
+    C.case_attention_hd72_forward(DEV, B, Sq, Skv, H, masked)
