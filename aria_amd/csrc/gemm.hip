@@ -27,6 +27,8 @@
 //                  length, masked); blockIdx.y = expert.
 #include "aria_device.h"
 #include "aria_hip.h"
+#include "gemm_params.h"
+#include <cstdlib>
 
 namespace {
 using namespace ad;
@@ -35,21 +37,6 @@ constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
 constexpr int PR = BK + 8;   // rc LDS pitch (elements): 144 B -> 16 rows hit 16 distinct 16-B bank slots
 constexpr int PO = 128;      // oc LDS pitch (elements)
 constexpr int TILE_ELEMS = BM * PR;  // 9216 elements = 18432 B  (>= 64 * 128 for the oc image)
-
-struct GemmParams {
-    const bf16_t* A;
-    const bf16_t* B;
-    void* C;
-    const bf16_t* bias;
-    long long lda, ldb, ldc;
-    int M, N, K;
-    int mode;
-    const int* offsets;
-    int E;
-    long long strideB, strideC;
-    int c_f32, accumulate;
-    int ntn;
-};
 
 template <bool OC>
 __device__ __forceinline__ void load_tile(u32x4 (&r)[4], const bf16_t* base, long long ld, int row0, int row_end, int k0,
@@ -273,6 +260,15 @@ int launch_gemm(const GemmParams& p, int a_oc, int b_oc, int grid_x, int grid_y,
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// v1 (128x128 tiles, 3 blocks/CU) wins when the 256x256 grid would not fill the chip; v2 otherwise.
+// ARIA_GEMM_FORCE=1|2 pins a variant (tests exercise both on small problems).
+bool use_v2(long long tiles256) {
+    const char* force = std::getenv("ARIA_GEMM_FORCE");
+    if (force && force[0] == '1') return false;
+    if (force && force[0] == '2') return true;
+    return tiles256 >= 192;
+}
+
 }  // namespace
 
 extern "C" {
@@ -301,6 +297,8 @@ int aria_gemm_bf16(const void* A, const void* B, void* C, const void* bias, int6
     p.accumulate = accumulate;
     p.ntn = int((N + BN - 1) / BN);
     const int ntm = int((M + BM - 1) / BM);
+    const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
+    if (use_v2(t256)) return aria_launch_gemm2(p, a_oc, b_oc, int((M + 255) / 256), 1, stream);
     return launch_gemm(p, a_oc, b_oc, p.ntn * ntm, 1, stream);
 }
 
@@ -328,6 +326,7 @@ int aria_grouped_gemm_bf16(const void* A, const void* B, void* C, const int32_t*
     p.ntn = int((N + BN - 1) / BN);
     // every expert adds at most one partial row tile
     const int max_tm = int(M_total / BM + E);
+    if (use_v2((M_total / 256 + 1) * ((N + 255) / 256))) return aria_launch_gemm2(p, 0, b_oc, int(M_total / 256 + E), 1, stream);
     return launch_gemm(p, 0, b_oc, p.ntn * max_tm, 1, stream);
 }
 
@@ -354,6 +353,7 @@ int aria_grouped_gemm_wgrad_bf16(const void* A, const void* dY, void* dW, const 
     p.accumulate = accumulate;
     p.ntn = int((N + BN - 1) / BN);
     const int ntm = int((K + BM - 1) / BM);
+    if (use_v2(((K + 255) / 256) * ((N + 255) / 256) * E)) return aria_launch_gemm2(p, 1, 1, int((K + 255) / 256), int(E), stream);
     return launch_gemm(p, 1, 1, p.ntn * ntm, int(E), stream);
 }
 

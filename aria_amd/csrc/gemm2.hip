@@ -1,0 +1,250 @@
+// GEMM v2 for gfx950: block tile 256x256x64, 8 waves (2 x 4), wave tile 128x64 = 4x2 v_mfma_f32_32x32x16_bf16 tiles
+// (128 fp32 accumulators per lane), K/V... A/B tiles DOUBLE-BUFFERED in LDS (147 KB) with ONE barrier per K-step:
+//
+//     sync -> write tile k+1 (registers -> other LDS buffer) -> issue HBM loads of tile k+2 -> 32 MFMAs/wave on tile k
+//
+// so the HBM latency has a whole K-step to hide under and the LDS writes of one wave overlap the MFMAs of its SIMD partner
+// (2 waves per SIMD).  Compared with the 128x128 v1 tile this quarters... halves LDS write bytes per flop and cuts
+// LDS fragment reads per flop by a third (6 fragment reads feed 8 MFMAs).
+//
+// Operand forms (same as v1): rc = reduction-contiguous ([rows][k], LDS pitch 72 -> conflict-free ds_read_b128), oc =
+// output-contiguous ([k][rows], exactly as it streams from HBM).  oc fragments are read with ds_read_b64_tr_b16: the
+// hardware transposes 4x16 blocks on the way out of LDS, so a row-major [k][n] expert weight tile yields k-contiguous MFMA
+// fragments with two reads, no VALU repacking and natural column order; the LDS pitch (288 = 16 dwords mod 64) makes the
+// four k-rows of a read land in different bank quarters (conflict-free).
+//
+// Tile order is XCD-aware: workgroup b runs on XCD b % 8, so tile ids are remapped to give every XCD a contiguous run of
+// tiles (same A row-panel, neighbouring B panels) and its private L2 sees the reuse.
+#include "aria_hip.h"
+#include "gemm_params.h"
+
+namespace {
+using namespace ad;
+
+constexpr int BM = 256, BN = 256, BK = 64, NTH = 512;
+constexpr int PR = BK + 8;    // rc pitch (elements)
+constexpr int PO = 256 + 32;  // oc pitch (elements): 144 dwords = 16 (mod 64)
+constexpr int TILE_ELEMS = BM * PR;  // 18432 elements = 36864 B (== 64 * PO)
+static_assert(BM * PR == 64 * PO, "rc and oc images have the same size");
+
+template <bool OC>
+__device__ __forceinline__ void load_tile(u32x4 (&r)[4], const bf16_t* base, long long ld, int row0, int row_end, int k0, int k_end,
+                                          int t) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = t + NTH * p;
+        if (!OC) {
+            const int row = row0 + (c >> 3), k = k0 + (c & 7) * 8;
+            r[p] = (row < row_end && k < k_end) ? ld16(base + (long long)row * ld + k) : zero16();
+        } else {
+            const int k = k0 + (c >> 5), row = row0 + (c & 31) * 8;
+            r[p] = (k < k_end && row < row_end) ? ld16(base + (long long)k * ld + row) : zero16();
+        }
+    }
+}
+
+template <bool OC>
+__device__ __forceinline__ void store_tile(const u32x4 (&r)[4], bf16_t* s, int t) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = t + NTH * p;
+        if (!OC)
+            st16(s + (c >> 3) * PR + (c & 7) * 8, r[p]);
+        else
+            st16(s + (c >> 5) * PO + (c & 31) * 8, r[p]);
+    }
+}
+
+// fragment of 32 consecutive rows starting at `row0` for k-substep kk: lane l <-> row row0 + (l & 31), k = 16 kk + 8 (l >> 5) + e
+template <bool OC>
+__device__ __forceinline__ s16x8 frag(const bf16_t* s, int row0, int kk, int l) {
+    if (!OC) {
+        return *reinterpret_cast<const s16x8*>(s + (row0 + (l & 31)) * PR + kk * 16 + (l >> 5) * 8);
+    } else {
+        const bf16_t* p = s + (kk * 16 + 8 * (l >> 5) + ((l & 15) >> 2)) * PO + row0 + 16 * ((l >> 4) & 1) + 4 * (l & 3);
+        const s16x4 a0 = ds_read_tr16(p);
+        const s16x4 a1 = ds_read_tr16(p + 4 * PO);
+        s16x8 f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[e] = a0[e];
+            f[4 + e] = a1[e];
+        }
+        return f;
+    }
+}
+
+template <bool A_OC, bool B_OC>
+__global__ __launch_bounds__(NTH) void gemm2_kernel(GemmParams p) {
+    ARIA_DYN_SMEM(smem);
+    bf16_t* sbase = reinterpret_cast<bf16_t*>(smem);  // [2 buffers][A tile | B tile]
+    const int t = threadIdx.x, l = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
+
+    // XCD-aware bijective remap of the workgroup id
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tn = tile % p.ntn;
+    int tmi = tile / p.ntn;
+    const bf16_t* A = p.A;
+    const int csz = p.c_f32 ? 4 : 2;
+    long long b_off = 0, c_off = 0;
+    int m0 = 0, m_end = 0, k_begin = 0, k_end = p.K;
+    const int n0 = tn * BN;
+    if (p.mode == 0) {
+        m0 = tmi * BM;
+        m_end = p.M;
+        if (m0 >= m_end) return;
+    } else if (p.mode == 1) {
+        int e_found = -1, start = 0, end = 0, base = 0;
+        for (int e0 = 0; e0 < p.E && e_found < 0; e0 += 64) {
+            const int e = e0 + l;
+            int o0 = 0, o1 = 0;
+            if (e < p.E) {
+                o0 = p.offsets[e];
+                o1 = p.offsets[e + 1];
+            }
+            const int nt = (o1 - o0 + BM - 1) / BM;
+            int incl = nt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = shfl(incl, (l - d) & 63);
+                if (l >= d) incl += v;
+            }
+            const int excl = base + incl - nt;
+            const bool mine = e < p.E && tmi >= excl && tmi < excl + nt;
+            const unsigned long long mask = ballot(mine);
+            if (mask) {
+                const int src = __builtin_ctzll(mask);
+                e_found = e0 + src;
+                start = shfl(o0, src);
+                end = shfl(o1, src);
+                tmi -= shfl(excl, src);
+            }
+            base += shfl(incl, 63);
+        }
+        if (e_found < 0) return;
+        m0 = start + tmi * BM;
+        m_end = end;
+        b_off = (long long)e_found * p.strideB;
+    } else {
+        const int e = blockIdx.y;
+        m0 = tmi * BM;
+        m_end = p.M;
+        if (m0 >= m_end) return;
+        k_begin = p.offsets[e];
+        k_end = p.offsets[e + 1];
+        c_off = (long long)e * p.strideC;
+    }
+    const bf16_t* B = p.B + b_off;
+    char* C = static_cast<char*>(p.C) + c_off * csz;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[4], rb[4];
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+    if (nk > 0) {
+        load_tile<A_OC>(ra, A, p.lda, m0, m_end, k_begin, k_end, t);
+        load_tile<B_OC>(rb, B, p.ldb, n0, p.N, k_begin, k_end, t);
+        store_tile<A_OC>(ra, sbase, t);
+        store_tile<B_OC>(rb, sbase + TILE_ELEMS, t);
+        if (nk > 1) {
+            load_tile<A_OC>(ra, A, p.lda, m0, m_end, k_begin + BK, k_end, t);
+            load_tile<B_OC>(rb, B, p.ldb, n0, p.N, k_begin + BK, k_end, t);
+        }
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        sync();  // tile kt is complete in buffer kt&1; nobody still reads the other buffer
+        const bf16_t* sA = sbase + (kt & 1) * 2 * TILE_ELEMS;
+        const bf16_t* sB = sA + TILE_ELEMS;
+        if (kt + 1 < nk) {
+            bf16_t* nA = sbase + ((kt + 1) & 1) * 2 * TILE_ELEMS;
+            store_tile<A_OC>(ra, nA, t);
+            store_tile<B_OC>(rb, nA + TILE_ELEMS, t);
+        }
+        if (kt + 2 < nk) {
+            const int k0 = k_begin + (kt + 2) * BK;
+            load_tile<A_OC>(ra, A, p.lda, m0, m_end, k0, k_end, t);
+            load_tile<B_OC>(rb, B, p.ldb, n0, p.N, k0, k_end, t);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            s16x8 af[4], bf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = frag<A_OC>(sA, wm * 128 + i * 32, kk, l);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = frag<B_OC>(sB, wn * 64 + j * 32, kk, l);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue: bias, pair exchange so every lane owns two adjacent columns of one row, (accumulate), round, store
+    const int c = l & 31, h = l >> 5, odd = l & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + c;
+        const float bv = (p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f;
+        const int npair = n & ~1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) {  // register pair (2rp, 2rp+1) = two consecutive rows
+                const float v0 = acc[i][j][2 * rp] + bv, v1 = acc[i][j][2 * rp + 1] + bv;
+                const int r = 2 * rp;
+                const int mrow = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (p.c_f32) {
+                    if (n < p.N) {
+                        float* d0 = reinterpret_cast<float*>(C) + (long long)mrow * p.ldc + n;
+                        if (mrow < m_end) *d0 = p.accumulate ? *d0 + v0 : v0;
+                        if (mrow + 1 < m_end) d0[p.ldc] = p.accumulate ? d0[p.ldc] + v1 : v1;
+                    }
+                } else {
+                    const float got = shfl_xor(odd ? v0 : v1, 1);   // wave-uniform control flow: every lane exchanges
+                    const int m = mrow + odd;
+                    float lo = odd ? got : v0, hi = odd ? v1 : got;  // columns npair, npair+1 of row m
+                    if (m < m_end && npair < p.N) {
+                        uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + npair);
+                        if (p.accumulate) {
+                            const uint32_t old = *dst;
+                            lo += bflo(old);
+                            hi += bfhi(old);
+                        }
+                        *dst = pack2bf(lo, hi);
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int aria_launch_gemm2(const GemmParams& p, int a_oc, int b_oc, int ntm, int grid_y, void* stream) {
+    const size_t shmem = size_t(2) * 2 * TILE_ELEMS * sizeof(bf16_t);
+    const int ntn = (p.N + BN - 1) / BN;
+    GemmParams q = p;
+    q.ntn = ntn;
+    dim3 grid(unsigned(ntn * ntm), unsigned(grid_y)), block(NTH);
+    if (ntn * ntm <= 0 || grid_y <= 0) return ARIA_OK;
+    if (!a_oc && !b_oc)
+        ARIA_LAUNCH((gemm2_kernel<false, false>), grid, block, shmem, stream, q);
+    else if (!a_oc && b_oc)
+        ARIA_LAUNCH((gemm2_kernel<false, true>), grid, block, shmem, stream, q);
+    else if (a_oc && b_oc)
+        ARIA_LAUNCH((gemm2_kernel<true, true>), grid, block, shmem, stream, q);
+    else
+        return ARIA_ERR_INVALID;
+    return aria_check_launch();
+}

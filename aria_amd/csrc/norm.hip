@@ -129,13 +129,23 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, cons
         dw_partial[(long long)blockIdx.x * D + d] = red[d] + red[D + d] + red[2 * D + d] + red[3 * D + d];
 }
 
+// 32 columns x 8 row-groups per block: 128-byte row segments, 8x the parallelism of one-thread-per-column
 __global__ __launch_bounds__(256) void colsum_kernel(const float* partial, bf16_t* out, int nrows, int D, int accumulate) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= D) return;
+    ARIA_SMEM_STATIC float red[8][32];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int d = blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int r = 0; r < nrows; ++r) s += partial[(long long)r * D + d];
-    if (accumulate) s += bf2f(out[d]);
-    out[d] = f2bf(s);
+    if (d < D)
+        for (int r = rg; r < nrows; r += 8) s += partial[(long long)r * D + d];
+    red[rg][c] = s;
+    sync();
+    if (rg == 0 && d < D) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += red[k][c];
+        if (accumulate) tot += bf2f(out[d]);
+        out[d] = f2bf(tot);
+    }
 }
 
 // in-place half-split RoPE on n_heads consecutive heads of each row
@@ -220,7 +230,7 @@ int aria_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* 
 
 int aria_colsum_f32(const float* partial, void* out, int64_t nrows, int64_t D, int accumulate, void* stream) {
     if (!partial || !out || nrows < 0 || D <= 0) return ARIA_ERR_INVALID;
-    ARIA_LAUNCH(colsum_kernel, dim3(int((D + 255) / 256)), dim3(256), 0, stream, partial, static_cast<bf16_t*>(out), int(nrows),
+    ARIA_LAUNCH(colsum_kernel, dim3(int((D + 31) / 32)), dim3(256), 0, stream, partial, static_cast<bf16_t*>(out), int(nrows),
                 int(D), accumulate);
     return aria_check_launch();
 }

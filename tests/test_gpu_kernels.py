@@ -93,3 +93,23 @@ def test_attention_cross_masked(B, Sq, Skv, H, hd):
 @pytest.mark.parametrize("B,Sq,Skv,H,masked", [(2, 70, 70, 2, True), (1, 300, 90, 1, False), (2, 4900, 4900, 4, True), (3, 256, 4900, 16, True)])
 def test_attention_hd72_forward(B, Sq, Skv, H, masked):
     C.case_attention_hd72_forward(DEV, B, Sq, Skv, H, masked)
+
+
+@pytest.fixture
+def force_gemm_v2(monkeypatch):
+    monkeypatch.setenv("ARIA_GEMM_FORCE", "2")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (264, 136, 200), (8, 8, 8), (2048, 3328, 2560)])
+@pytest.mark.parametrize("a_oc,b_oc", [(False, False), (False, True), (True, True)])
+def test_gemm_v2_layouts(force_gemm_v2, M, N, K, a_oc, b_oc):
+    C.case_gemm_layouts(DEV, M, N, K, a_oc, b_oc)
+
+
+@pytest.mark.parametrize("counts", [[3, 0, 130, 5, 0, 0, 300, 1], [0, 0], [1, 1, 1], [37 * (i % 5) + (i * 7) % 11 for i in range(64)]])
+def test_grouped_gemm_v2(force_gemm_v2, counts):
+    C.case_grouped_gemm(DEV, counts)
+
+
+def test_grouped_gemm_v2_aria_width(force_gemm_v2):
+    C.case_grouped_gemm(DEV, [130, 0, 777, 300], K=2560, N=3328)
