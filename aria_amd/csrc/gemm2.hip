@@ -27,9 +27,21 @@ constexpr int PO = 256 + 32;  // oc pitch (elements): 144 dwords = 16 (mod 64)
 constexpr int TILE_ELEMS = BM * PR;  // 18432 elements = 36864 B (== 64 * PO)
 static_assert(BM * PR == 64 * PO, "rc and oc images have the same size");
 
-template <bool OC>
+// FULL: the whole 256 x 64 tile is in range (block-uniform) -> unpredicated loads, no exec-mask juggling in the K loop
+template <bool OC, bool FULL>
 __device__ __forceinline__ void load_tile(u32x4 (&r)[4], const bf16_t* base, long long ld, int row0, int row_end, int k0, int k_end,
                                           int t) {
+    if (FULL) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = t + NTH * p;
+            if (!OC)
+                r[p] = ld16(base + (long long)(row0 + (c >> 3)) * ld + k0 + (c & 7) * 8);
+            else
+                r[p] = ld16(base + (long long)(k0 + (c >> 5)) * ld + row0 + (c & 31) * 8);
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int c = t + NTH * p;
@@ -71,6 +83,55 @@ __device__ __forceinline__ s16x8 frag(const bf16_t* s, int row0, int kk, int l) 
             f[4 + e] = a1[e];
         }
         return f;
+    }
+}
+
+template <bool A_OC, bool B_OC>
+__device__ __forceinline__ void compute_tile(f32x16 (&acc)[4][2], const bf16_t* sA, const bf16_t* sB, int l, int wm, int wn) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+        s16x8 af[4], bf[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = frag<A_OC>(sA, wm * 128 + i * 32, kk, l);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = frag<B_OC>(sB, wn * 64 + j * 32, kk, l);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+    }
+}
+
+template <bool A_OC, bool B_OC, bool STAGE_FIRST, bool FULL>
+__device__ __forceinline__ void k_loop(f32x16 (&acc)[4][2], bf16_t* sbase, const bf16_t* A, const bf16_t* B, long long lda,
+                                       long long ldb, int m0, int m_end, int n0, int N, int k_begin, int k_end, int nk, int t, int l,
+                                       int wm, int wn) {
+    u32x4 ra[4], rb[4];
+    if (nk > 0) {
+        load_tile<A_OC, FULL>(ra, A, lda, m0, m_end, k_begin, k_end, t);
+        load_tile<B_OC, FULL>(rb, B, ldb, n0, N, k_begin, k_end, t);
+        store_tile<A_OC>(ra, sbase, t);
+        store_tile<B_OC>(rb, sbase + TILE_ELEMS, t);
+        if (nk > 1) {
+            load_tile<A_OC, FULL>(ra, A, lda, m0, m_end, k_begin + BK, k_end, t);
+            load_tile<B_OC, FULL>(rb, B, ldb, n0, N, k_begin + BK, k_end, t);
+        }
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        sync();  // tile kt is complete in buffer kt&1; nobody still reads the other buffer
+        const bf16_t* sA = sbase + (kt & 1) * 2 * TILE_ELEMS;
+        bf16_t* nA = sbase + ((kt + 1) & 1) * 2 * TILE_ELEMS;
+        if (!STAGE_FIRST) compute_tile<A_OC, B_OC>(acc, sA, sA + TILE_ELEMS, l, wm, wn);
+        if (kt + 1 < nk) {
+            store_tile<A_OC>(ra, nA, t);
+            store_tile<B_OC>(rb, nA + TILE_ELEMS, t);
+        }
+        if (kt + 2 < nk) {
+            const int k0 = k_begin + (kt + 2) * BK;
+            load_tile<A_OC, FULL>(ra, A, lda, m0, m_end, k0, k_end, t);
+            load_tile<B_OC, FULL>(rb, B, ldb, n0, N, k0, k_end, t);
+        }
+        if (STAGE_FIRST) compute_tile<A_OC, B_OC>(acc, sA, sA + TILE_ELEMS, l, wm, wn);
     }
 }
 
@@ -150,44 +211,22 @@ __global__ __launch_bounds__(NTH) void gemm2_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[4], rb[4];
     const int nk = (k_end - k_begin + BK - 1) / BK;
-    if (nk > 0) {
-        load_tile<A_OC>(ra, A, p.lda, m0, m_end, k_begin, k_end, t);
-        load_tile<B_OC>(rb, B, p.ldb, n0, p.N, k_begin, k_end, t);
-        store_tile<A_OC>(ra, sbase, t);
-        store_tile<B_OC>(rb, sbase + TILE_ELEMS, t);
-        if (nk > 1) {
-            load_tile<A_OC>(ra, A, p.lda, m0, m_end, k_begin + BK, k_end, t);
-            load_tile<B_OC>(rb, B, p.ldb, n0, p.N, k_begin + BK, k_end, t);
-        }
-    }
-    for (int kt = 0; kt < nk; ++kt) {
-        sync();  // tile kt is complete in buffer kt&1; nobody still reads the other buffer
-        const bf16_t* sA = sbase + (kt & 1) * 2 * TILE_ELEMS;
-        const bf16_t* sB = sA + TILE_ELEMS;
-        if (kt + 1 < nk) {
-            bf16_t* nA = sbase + ((kt + 1) & 1) * 2 * TILE_ELEMS;
-            store_tile<A_OC>(ra, nA, t);
-            store_tile<B_OC>(rb, nA + TILE_ELEMS, t);
-        }
-        if (kt + 2 < nk) {
-            const int k0 = k_begin + (kt + 2) * BK;
-            load_tile<A_OC>(ra, A, p.lda, m0, m_end, k0, k_end, t);
-            load_tile<B_OC>(rb, B, p.ldb, n0, p.N, k0, k_end, t);
-        }
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            s16x8 af[4], bf[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = frag<A_OC>(sA, wm * 128 + i * 32, kk, l);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = frag<B_OC>(sB, wn * 64 + j * 32, kk, l);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
-        }
+    const bool full = (m0 + BM <= m_end) && (n0 + BN <= p.N) && ((k_end - k_begin) % BK == 0);
+    // The two waves that share a SIMD (w and w+4) run the K-step in opposite orders: waves 0-3 stage the next tile
+    // (LDS writes + HBM loads) and then compute, waves 4-7 compute and then stage -- one of the two is always feeding
+    // the matrix pipe.  Legal because staging only touches the OTHER LDS buffer, which nobody reads between two barriers.
+    const bool stage_first = first_lane(w) < 4;
+    if (full) {
+        if (stage_first)
+            k_loop<A_OC, B_OC, true, true>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
+        else
+            k_loop<A_OC, B_OC, false, true>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
+    } else {
+        if (stage_first)
+            k_loop<A_OC, B_OC, true, false>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
+        else
+            k_loop<A_OC, B_OC, false, false>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
     }
 
     // ---- epilogue: bias, pair exchange so every lane owns two adjacent columns of one row, (accumulate), round, store
