@@ -17,23 +17,26 @@
 // tiles (same A row-panel, neighbouring B panels) and its private L2 sees the reuse.
 #include "aria_hip.h"
 #include "gemm_params.h"
+#include <cstdlib>
 
 namespace {
 using namespace ad;
 
-constexpr int BM = 256, BN = 256, BK = 64, NTH = 512;
+constexpr int BM = 256, BN = 256, BK = 64;
+template <int NW> struct WCfg { static constexpr int NTH = NW * 64, SP = 2048 / (NW * 64), NJ = NW == 8 ? 2 : 4, WNW = NJ * 32; };
 constexpr int PR = BK + 8;    // rc pitch (elements)
 constexpr int PO = 256 + 32;  // oc pitch (elements): 144 dwords = 16 (mod 64)
 constexpr int TILE_ELEMS = BM * PR;  // 18432 elements = 36864 B (== 64 * PO)
 static_assert(BM * PR == 64 * PO, "rc and oc images have the same size");
 
 // FULL: the whole 256 x 64 tile is in range (block-uniform) -> unpredicated loads, no exec-mask juggling in the K loop
-template <bool OC, bool FULL>
-__device__ __forceinline__ void load_tile(u32x4 (&r)[4], const bf16_t* base, long long ld, int row0, int row_end, int k0, int k_end,
-                                          int t) {
+template <bool OC, bool FULL, int NW>
+__device__ __forceinline__ void load_tile(u32x4 (&r)[WCfg<NW>::SP], const bf16_t* base, long long ld, int row0, int row_end, int k0,
+                                          int k_end, int t) {
+    constexpr int NTH = WCfg<NW>::NTH, SP = WCfg<NW>::SP;
     if (FULL) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < SP; ++p) {
             const int c = t + NTH * p;
             if (!OC)
                 r[p] = ld16(base + (long long)(row0 + (c >> 3)) * ld + k0 + (c & 7) * 8);
@@ -43,7 +46,7 @@ __device__ __forceinline__ void load_tile(u32x4 (&r)[4], const bf16_t* base, lon
         return;
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < SP; ++p) {
         const int c = t + NTH * p;
         if (!OC) {
             const int row = row0 + (c >> 3), k = k0 + (c & 7) * 8;
@@ -55,10 +58,11 @@ __device__ __forceinline__ void load_tile(u32x4 (&r)[4], const bf16_t* base, lon
     }
 }
 
-template <bool OC>
-__device__ __forceinline__ void store_tile(const u32x4 (&r)[4], bf16_t* s, int t) {
+template <bool OC, int NW>
+__device__ __forceinline__ void store_tile(const u32x4 (&r)[WCfg<NW>::SP], bf16_t* s, int t) {
+    constexpr int NTH = WCfg<NW>::NTH, SP = WCfg<NW>::SP;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < SP; ++p) {
         const int c = t + NTH * p;
         if (!OC)
             st16(s + (c >> 3) * PR + (c & 7) * 8, r[p]);
@@ -86,70 +90,87 @@ __device__ __forceinline__ s16x8 frag(const bf16_t* s, int row0, int kk, int l) 
     }
 }
 
-template <bool A_OC, bool B_OC>
-__device__ __forceinline__ void compute_tile(f32x16 (&acc)[4][2], const bf16_t* sA, const bf16_t* sB, int l, int wm, int wn) {
+template <bool A_OC, bool B_OC, int NW>
+__device__ __forceinline__ void compute_tile(f32x16 (&acc)[4][WCfg<NW>::NJ], const bf16_t* sA, const bf16_t* sB, int l, int wm, int wn) {
+    constexpr int NJ = WCfg<NW>::NJ, WNW = WCfg<NW>::WNW;
+    // fragments are double-buffered in registers: the LDS reads of k-substep kk+1 are in flight under the MFMAs of kk
+    s16x8 af[2][4], bf[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[0][i] = frag<A_OC>(sA, wm * 128 + i * 32, 0, l);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bf[0][j] = frag<B_OC>(sB, wn * WNW + j * 32, 0, l);
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-        s16x8 af[4], bf[2];
+        if (kk + 1 < BK / 16) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = frag<A_OC>(sA, wm * 128 + i * 32, kk, l);
+            for (int i = 0; i < 4; ++i) af[(kk + 1) & 1][i] = frag<A_OC>(sA, wm * 128 + i * 32, kk + 1, l);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = frag<B_OC>(sB, wn * 64 + j * 32, kk, l);
+            for (int j = 0; j < NJ; ++j) bf[(kk + 1) & 1][j] = frag<B_OC>(sB, wn * WNW + j * 32, kk + 1, l);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+            for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(af[kk & 1][i], bf[kk & 1][j], acc[i][j]);
     }
 }
 
-template <bool A_OC, bool B_OC, bool STAGE_FIRST, bool FULL>
-__device__ __forceinline__ void k_loop(f32x16 (&acc)[4][2], bf16_t* sbase, const bf16_t* A, const bf16_t* B, long long lda,
+template <bool A_OC, bool B_OC, bool STAGE_FIRST, bool FULL, int NW>
+__device__ __forceinline__ void k_loop(f32x16 (&acc)[4][WCfg<NW>::NJ], bf16_t* sbase, const bf16_t* A, const bf16_t* B, long long lda,
                                        long long ldb, int m0, int m_end, int n0, int N, int k_begin, int k_end, int nk, int t, int l,
                                        int wm, int wn) {
-    u32x4 ra[4], rb[4];
+    u32x4 ra[WCfg<NW>::SP], rb[WCfg<NW>::SP];
     if (nk > 0) {
-        load_tile<A_OC, FULL>(ra, A, lda, m0, m_end, k_begin, k_end, t);
-        load_tile<B_OC, FULL>(rb, B, ldb, n0, N, k_begin, k_end, t);
-        store_tile<A_OC>(ra, sbase, t);
-        store_tile<B_OC>(rb, sbase + TILE_ELEMS, t);
+        load_tile<A_OC, FULL, NW>(ra, A, lda, m0, m_end, k_begin, k_end, t);
+        load_tile<B_OC, FULL, NW>(rb, B, ldb, n0, N, k_begin, k_end, t);
+        store_tile<A_OC, NW>(ra, sbase, t);
+        store_tile<B_OC, NW>(rb, sbase + TILE_ELEMS, t);
         if (nk > 1) {
-            load_tile<A_OC, FULL>(ra, A, lda, m0, m_end, k_begin + BK, k_end, t);
-            load_tile<B_OC, FULL>(rb, B, ldb, n0, N, k_begin + BK, k_end, t);
+            load_tile<A_OC, FULL, NW>(ra, A, lda, m0, m_end, k_begin + BK, k_end, t);
+            load_tile<B_OC, FULL, NW>(rb, B, ldb, n0, N, k_begin + BK, k_end, t);
         }
     }
     for (int kt = 0; kt < nk; ++kt) {
         sync();  // tile kt is complete in buffer kt&1; nobody still reads the other buffer
         const bf16_t* sA = sbase + (kt & 1) * 2 * TILE_ELEMS;
         bf16_t* nA = sbase + ((kt + 1) & 1) * 2 * TILE_ELEMS;
-        if (!STAGE_FIRST) compute_tile<A_OC, B_OC>(acc, sA, sA + TILE_ELEMS, l, wm, wn);
+        if (!STAGE_FIRST) compute_tile<A_OC, B_OC, NW>(acc, sA, sA + TILE_ELEMS, l, wm, wn);
         if (kt + 1 < nk) {
-            store_tile<A_OC>(ra, nA, t);
-            store_tile<B_OC>(rb, nA + TILE_ELEMS, t);
+            store_tile<A_OC, NW>(ra, nA, t);
+            store_tile<B_OC, NW>(rb, nA + TILE_ELEMS, t);
         }
         if (kt + 2 < nk) {
             const int k0 = k_begin + (kt + 2) * BK;
-            load_tile<A_OC, FULL>(ra, A, lda, m0, m_end, k0, k_end, t);
-            load_tile<B_OC, FULL>(rb, B, ldb, n0, N, k0, k_end, t);
+            load_tile<A_OC, FULL, NW>(ra, A, lda, m0, m_end, k0, k_end, t);
+            load_tile<B_OC, FULL, NW>(rb, B, ldb, n0, N, k0, k_end, t);
         }
-        if (STAGE_FIRST) compute_tile<A_OC, B_OC>(acc, sA, sA + TILE_ELEMS, l, wm, wn);
+        if (STAGE_FIRST) compute_tile<A_OC, B_OC, NW>(acc, sA, sA + TILE_ELEMS, l, wm, wn);
     }
 }
 
-template <bool A_OC, bool B_OC>
-__global__ __launch_bounds__(NTH) void gemm2_kernel(GemmParams p) {
+template <bool A_OC, bool B_OC, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmParams p) {
+    constexpr int NJ = WCfg<NW>::NJ, WNW = WCfg<NW>::WNW;
     ARIA_DYN_SMEM(smem);
     bf16_t* sbase = reinterpret_cast<bf16_t*>(smem);  // [2 buffers][A tile | B tile]
-    const int t = threadIdx.x, l = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
+    const int t = threadIdx.x, l = t & 63, w = t >> 6, wm = NW == 8 ? w >> 2 : w >> 1, wn = NW == 8 ? w & 3 : w & 1;
 
     // XCD-aware bijective remap of the workgroup id
-    int tile;
-    {
+    int tile = blockIdx.x;
+    if (p.order != 1) {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tn = tile % p.ntn;
+    int tn = tile % p.ntn;
     int tmi = tile / p.ntn;
+    if (p.order >= 2) {  // groups of GM row-tiles, column-major inside a group: concurrent tiles form a GM x (32/GM) patch
+        const int GM = p.order, per = GM * p.ntn;
+        const int g = tile / per, in = tile % per;
+        const int ntm_total = gridDim.x / p.ntn;
+        const int gm = min(GM, ntm_total - g * GM);
+        tn = in / gm;
+        tmi = g * GM + in % gm;
+    }
     const bf16_t* A = p.A;
     const int csz = p.c_f32 ? 4 : 2;
     long long b_off = 0, c_off = 0;
@@ -203,11 +224,11 @@ __global__ __launch_bounds__(NTH) void gemm2_kernel(GemmParams p) {
     const bf16_t* B = p.B + b_off;
     char* C = static_cast<char*>(p.C) + c_off * csz;
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -216,24 +237,24 @@ __global__ __launch_bounds__(NTH) void gemm2_kernel(GemmParams p) {
     // The two waves that share a SIMD (w and w+4) run the K-step in opposite orders: waves 0-3 stage the next tile
     // (LDS writes + HBM loads) and then compute, waves 4-7 compute and then stage -- one of the two is always feeding
     // the matrix pipe.  Legal because staging only touches the OTHER LDS buffer, which nobody reads between two barriers.
-    const bool stage_first = first_lane(w) < 4;
+    const bool stage_first = NW == 4 || first_lane(w) < 4;
     if (full) {
         if (stage_first)
-            k_loop<A_OC, B_OC, true, true>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
+            k_loop<A_OC, B_OC, true, true, NW>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
         else
-            k_loop<A_OC, B_OC, false, true>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
+            k_loop<A_OC, B_OC, false, true, NW>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
     } else {
         if (stage_first)
-            k_loop<A_OC, B_OC, true, false>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
+            k_loop<A_OC, B_OC, true, false, NW>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
         else
-            k_loop<A_OC, B_OC, false, false>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
+            k_loop<A_OC, B_OC, false, false, NW>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
     }
 
     // ---- epilogue: bias, pair exchange so every lane owns two adjacent columns of one row, (accumulate), round, store
     const int c = l & 31, h = l >> 5, odd = l & 1;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + c;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * WNW + j * 32 + c;
         const float bv = (p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f;
         const int npair = n & ~1;
 #pragma unroll
@@ -275,15 +296,27 @@ int aria_launch_gemm2(const GemmParams& p, int a_oc, int b_oc, int ntm, int grid
     const int ntn = (p.N + BN - 1) / BN;
     GemmParams q = p;
     q.ntn = ntn;
-    dim3 grid(unsigned(ntn * ntm), unsigned(grid_y)), block(NTH);
+    const char* ord = std::getenv("ARIA_GEMM_ORDER");
+    q.order = ord ? std::atoi(ord) : 2;  // measured best on MI355X (profiles/r01_gemm_tuning.md)
+    const char* nwv = std::getenv("ARIA_GEMM_WAVES");
+    const int nw = nwv ? std::atoi(nwv) : 8;
+    dim3 grid(unsigned(ntn * ntm), unsigned(grid_y)), block(nw * 64);
     if (ntn * ntm <= 0 || grid_y <= 0) return ARIA_OK;
-    if (!a_oc && !b_oc)
-        ARIA_LAUNCH((gemm2_kernel<false, false>), grid, block, shmem, stream, q);
-    else if (!a_oc && b_oc)
-        ARIA_LAUNCH((gemm2_kernel<false, true>), grid, block, shmem, stream, q);
-    else if (a_oc && b_oc)
-        ARIA_LAUNCH((gemm2_kernel<true, true>), grid, block, shmem, stream, q);
-    else
-        return ARIA_ERR_INVALID;
+    if (a_oc && !b_oc) return ARIA_ERR_INVALID;
+    if (nw == 4) {
+        if (!a_oc && !b_oc)
+            ARIA_LAUNCH((gemm2_kernel<false, false, 4>), grid, block, shmem, stream, q);
+        else if (!a_oc && b_oc)
+            ARIA_LAUNCH((gemm2_kernel<false, true, 4>), grid, block, shmem, stream, q);
+        else
+            ARIA_LAUNCH((gemm2_kernel<true, true, 4>), grid, block, shmem, stream, q);
+    } else {
+        if (!a_oc && !b_oc)
+            ARIA_LAUNCH((gemm2_kernel<false, false, 8>), grid, block, shmem, stream, q);
+        else if (!a_oc && b_oc)
+            ARIA_LAUNCH((gemm2_kernel<false, true, 8>), grid, block, shmem, stream, q);
+        else
+            ARIA_LAUNCH((gemm2_kernel<true, true, 8>), grid, block, shmem, stream, q);
+    }
     return aria_check_launch();
 }

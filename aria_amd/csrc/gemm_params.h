@@ -15,6 +15,7 @@ struct GemmParams {
     long long strideB, strideC;
     int c_f32, accumulate;
     int ntn;
+    int order;  // tile-order variant (tuning knob, see gemm2.hip)
 };
 
 // v2 launcher (gemm2.hip); returns ARIA_* status
