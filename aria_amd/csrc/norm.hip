@@ -194,6 +194,29 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* a, const bf16_t*
     }
 }
 
+// gptfast RoPE (gptfast/model.py:519-531): interleaved pairs (x[2i], x[2i+1]), bf16 freqs_cis cache [S, hd/2, 2] = (cos, sin),
+// arithmetic in fp32 with ONE rounding; position of row t = pos[t] (device int32, e.g. the decode cursor) or t % S.
+__global__ __launch_bounds__(256) void rope_interleaved_kernel(bf16_t* x, const bf16_t* fc, const int32_t* pos, long long nitems,
+                                                               int S, int n_heads, int hd, long long ld) {
+    const int cph = hd >> 3;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < nitems; it += (long long)gridDim.x * blockDim.x) {
+        const int c = int(it % cph);
+        const long long r = it / cph;
+        const int head = int(r % n_heads);
+        const long long t = r / n_heads;
+        const int ps = pos ? pos[t] : int(t % S);
+        bf16_t* p = x + t * ld + (long long)head * hd + c * 8;
+        const u32x4 a = ld16(p), f = ld16(fc + (long long)ps * hd + c * 8);
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x0 = bflo(a[q]), x1 = bfhi(a[q]), cs = bflo(f[q]), sn = bfhi(f[q]);
+            o[q] = pack2bf(x0 * cs - x1 * sn, x1 * cs + x0 * sn);
+        }
+        st16(p, o);
+    }
+}
+
 int grid1d(long long n, int per_block, int cap = 4096) {
     long long g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -253,6 +276,17 @@ int aria_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stre
     if (n == 0) return ARIA_OK;
     ARIA_LAUNCH(add_kernel, dim3(grid1d(n / 8, 256)), dim3(256), 0, stream, static_cast<const bf16_t*>(a),
                 static_cast<const bf16_t*>(b), static_cast<bf16_t*>(out), (long long)(n / 8));
+    return aria_check_launch();
+}
+
+int aria_rope_interleaved_inplace(void* x, const void* freqs_cis, const int32_t* pos, int64_t T, int64_t S, int64_t n_heads,
+                                  int64_t hd, int64_t ld, void* stream) {
+    if (!x || !freqs_cis || T < 0 || S <= 0 || n_heads <= 0 || hd <= 0) return ARIA_ERR_INVALID;
+    if ((hd & 7) || (ld & 7)) return ARIA_ERR_ALIGN;
+    if (T == 0) return ARIA_OK;
+    const long long nitems = T * n_heads * (hd / 8);
+    ARIA_LAUNCH(rope_interleaved_kernel, dim3(grid1d(nitems, 256)), dim3(256), 0, stream, static_cast<bf16_t*>(x),
+                static_cast<const bf16_t*>(freqs_cis), pos, nitems, int(S), int(n_heads), int(hd), (long long)ld);
     return aria_check_launch();
 }
 

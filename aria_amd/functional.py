@@ -91,8 +91,9 @@ def moe_bwd(dout, ctx, router_w, fc1, fc2, gate_w, up_w, down_w):
     d_gu = ops.swiglu_bwd(ctx["gu"], d_sact)
     ops.gemm(d_gu[:, :I2], gate_w, b_oc=True, out=dx, accumulate=True)
     ops.gemm(d_gu[:, I2:], up_w, b_oc=True, out=dx, accumulate=True)
-    g_gate = ops.gemm(d_gu[:, :I2], x, a_oc=True, b_oc=True)
-    g_up = ops.gemm(d_gu[:, I2:], x, a_oc=True, b_oc=True)
+    # gate and up weight gradients as ONE wide GEMM ([2*I2, D] = d_gu^T x): 260 tiles of 256x256 instead of 2 x 130
+    g_gu = ops.gemm(d_gu, x, a_oc=True, b_oc=True)
+    g_gate, g_up = g_gu[:I2], g_gu[I2:]
     # router (top-k softmax + z-loss + load-balancing loss gradients)
     dlogits = ops.moe_route_bwd(ctx["logits"], ctx["idx"], ctx["scores"], dscores, ctx["counts"], cfg.z_loss_coeff,
                                 cfg.aux_loss_coeff, cfg.aux_scale)
@@ -190,9 +191,9 @@ def attn_block_bwd(dout, ctx, wq, wk, wv, wo, cos, sin):
     dx = ops.gemm(dqkv[:, :Dq], wq, b_oc=True)
     ops.gemm(dqkv[:, Dq:2 * Dq], wk, b_oc=True, out=dx, accumulate=True)
     ops.gemm(dqkv[:, 2 * Dq:], wv, b_oc=True, out=dx, accumulate=True)
-    g_wq = ops.gemm(dqkv[:, :Dq], x, a_oc=True, b_oc=True)
-    g_wk = ops.gemm(dqkv[:, Dq:2 * Dq], x, a_oc=True, b_oc=True)
-    g_wv = ops.gemm(dqkv[:, 2 * Dq:], x, a_oc=True, b_oc=True)
+    # q, k, v weight gradients as ONE wide GEMM ([3*Dq, D] = dqkv^T x)
+    g_qkv = ops.gemm(dqkv, x, a_oc=True, b_oc=True)
+    g_wq, g_wk, g_wv = g_qkv[:Dq], g_qkv[Dq:2 * Dq], g_qkv[2 * Dq:]
     return dx, dict(q=g_wq, k=g_wk, v=g_wv, o=g_wo)
 
 

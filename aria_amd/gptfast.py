@@ -1,0 +1,344 @@
+"""gptfast-compatible inference surface (seam B4) on the HIP kernels: mirror of ``gptfast/model.py`` (ModelArgs :38-60,
+KVCache :67-93, Transformer :96-234, MOEFeedForward / ConditionalFeedForward :300-366, Attention :389-447, RMSNorm :461-472,
+precompute_freqs_cis / apply_rotary_emb :500-531, Aria :534-609) and of the sampling loop in ``gptfast/generate.py:35-177``.
+
+The ``model.pth`` wire format of ``gptfast/scripts/convert_hf_checkpoint.py:90-162`` loads unchanged:
+``wqkv.weight [3D, D]`` (q/k rows permuted for interleaved RoPE), ``cond_ffn.w1 / w3 [E, I, D]``, ``cond_ffn.w2 [E, D, I]``
+-- those expert layouts are *reduction-contiguous*, i.e. exactly the fast (rc, rc) form of the grouped MFMA GEMM, so no weight
+is converted or transposed.  One MoE path serves prefill and decode (the reference switches to a gather+einsum path below 50
+tokens, ``model.py:318-325``; the results are the same function).  The decode step allocates nothing data-dependent and reads
+the cursor from device memory, so it can be captured in a HIP graph (``torch.cuda.CUDAGraph``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from . import ops
+from .modeling_aria import AriaConfig
+from .vision import AriaProjector, AriaVisionConfig, AriaVisionModel
+
+bf16 = torch.bfloat16
+
+
+@dataclass
+class ModelArgs:
+    block_size: int = 16384
+    vocab_size: int = 100352
+    n_layer: int = 28
+    n_head: int = 20
+    dim: int = 2560
+    intermediate_size: int = 1664
+    n_local_heads: int = -1
+    head_dim: int = 64
+    rope_base: float = 5000000
+    norm_eps: float = 1e-5
+    num_experts: int = 64
+    router_topk: int = 6
+    num_shared_experts: int = 2
+    image_token_index: int = 9
+
+    def __post_init__(self):
+        if self.n_local_heads == -1:
+            self.n_local_heads = self.n_head
+        self.head_dim = self.dim // self.n_head
+        if self.n_local_heads != self.n_head:
+            raise NotImplementedError("Aria is MHA (gptfast/model.py:56-58)")
+
+
+def precompute_freqs_cis(seq_len: int, n_elem: int, base: float = 10000, dtype=bf16) -> torch.Tensor:
+    """gptfast/model.py:500-516 (built on the host, bf16 cache [S, n_elem/2, 2])."""
+    freqs = 1.0 / (base ** (torch.arange(0, n_elem, 2)[: (n_elem // 2)].float() / n_elem))
+    freqs = torch.outer(torch.arange(seq_len), freqs)
+    fc = torch.polar(torch.ones_like(freqs), freqs)
+    return torch.stack([fc.real, fc.imag], dim=-1).to(dtype)
+
+
+def _p(*shape):
+    return nn.Parameter(torch.empty(*shape, dtype=bf16), requires_grad=False)
+
+
+class _W(nn.Module):
+    """holder with a `.weight` so state-dict keys read `<name>.weight`"""
+
+    def __init__(self, *shape):
+        super().__init__()
+        self.weight = _p(*shape)
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim: int, eps: float):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim, dtype=bf16), requires_grad=False)
+
+    def forward(self, x2d):
+        return ops.rmsnorm(x2d, self.weight, self.eps, want_rstd=False)[0]
+
+
+class KVCache:
+    """Static cache [B, S_max, H*hd] per layer (token-major so the attention kernel reads it in place)."""
+
+    def __init__(self, max_batch_size, max_seq_length, n_heads, head_dim, device):
+        self.k = torch.zeros((max_batch_size, max_seq_length, n_heads * head_dim), dtype=bf16, device=device)
+        self.v = torch.zeros_like(self.k)
+
+
+class Attention(nn.Module):
+    def __init__(self, config: ModelArgs):
+        super().__init__()
+        self.config = config
+        self.wqkv = _W(3 * config.dim, config.dim)
+        self.wo = _W(config.dim, config.dim)
+        self.kv_cache: Optional[KVCache] = None
+        self.hdp = Fn._pad_hd(config.head_dim, need_bwd=False)  # kernels are native for 64 / 72 / 128
+
+    def forward(self, x2d, B, S, freqs_cis, pos32, kv_len, prefill: bool):
+        c = self.config
+        D, H, hd, hdp = c.dim, c.n_head, c.head_dim, self.hdp
+        qkv = ops.gemm(x2d, self.wqkv.weight)
+        ops.rope_interleaved_(qkv[:, :2 * D], freqs_cis, 2 * H, hd, pos32)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        if hdp != hd:  # toy head dims only (tests)
+            q, k, v = (Fn._pad_heads(t, H, hd, hdp) for t in (q, k, v))
+        Dp = H * hdp
+        cache = self.kv_cache
+        if cache is None or prefill:
+            if cache is not None:  # k/v rows go into the cache (positions 0..S-1)
+                cache.k[:B, :S].copy_(k.reshape(B, S, Dp))
+                cache.v[:B, :S].copy_(v.reshape(B, S, Dp))
+            o, _ = ops.attention_fwd(q, k, v, B, S, H, hdp, hd ** -0.5, True)
+        else:  # decode: one token per sequence, cursor on the device (graph-capturable)
+            Smax = cache.k.shape[1]
+            rows = torch.arange(B, device=x2d.device) * Smax + pos32.long()
+            cache.k.view(-1, Dp).index_copy_(0, rows, k)
+            cache.v.view(-1, Dp).index_copy_(0, rows, v)
+            o, _ = ops.attention_fwd(q, cache.k.view(-1, Dp), cache.v.view(-1, Dp), B, 1, H, hdp, hd ** -0.5, False,
+                                     kv_len=kv_len, Skv=Smax)
+        if hdp != hd:
+            o = Fn._unpad_heads(o, H, hd, hdp).contiguous()
+        return ops.gemm(o, self.wo.weight)
+
+
+class ConditionalFeedForward(nn.Module):
+    def __init__(self, config: ModelArgs):
+        super().__init__()
+        E, I, D = config.num_experts, config.intermediate_size, config.dim
+        self.w1, self.w2, self.w3 = _p(E, I, D), _p(E, D, I), _p(E, I, D)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, inter):
+        super().__init__()
+        self.w1, self.w3, self.w2 = _W(inter, dim), _W(inter, dim), _W(dim, inter)
+
+
+class MOEFeedForward(nn.Module):
+    def __init__(self, config: ModelArgs):
+        super().__init__()
+        self.config = config
+        self.gate = _W(config.num_experts, config.dim)
+        self.cond_ffn = ConditionalFeedForward(config)
+        self.shared_ffn = FeedForward(config.dim, config.intermediate_size * config.num_shared_experts)
+
+    def forward(self, x2d):
+        k = self.config.router_topk
+        logits = ops.gemm(x2d, self.gate.weight)
+        scores, idx, counts = ops.moe_route(logits, k)                 # topk + softmax (model.py:359-363)
+        offsets, sorted_src, inv = ops.moe_sort(idx, counts)           # token_permutation (:243-254)
+        perm = ops.moe_permute(x2d, sorted_src, k)
+        cf = self.cond_ffn
+        h1 = ops.grouped_gemm(perm, cf.w1, offsets, w_is_kn=False)     # sequential_gemm(w1) (:278-297): w1[e] is [I, D] = rc form
+        h3 = ops.grouped_gemm(perm, cf.w3, offsets, w_is_kn=False)
+        eo = ops.grouped_gemm(ops.swiglu(h1, h3), cf.w2, offsets, w_is_kn=False)
+        sf = self.shared_ffn
+        sh = ops.gemm(ops.swiglu(ops.gemm(x2d, sf.w1.weight), ops.gemm(x2d, sf.w3.weight)), sf.w2.weight)
+        return ops.moe_unpermute(eo, inv, scores, k, add=sh)
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, config: ModelArgs):
+        super().__init__()
+        self.attention = Attention(config)
+        self.feed_forward = MOEFeedForward(config)
+        self.ffn_norm = RMSNorm(config.dim, config.norm_eps)
+        self.attention_norm = RMSNorm(config.dim, config.norm_eps)
+
+    def forward(self, x2d, B, S, freqs_cis, pos32, kv_len, prefill):
+        h = ops.add(x2d, self.attention(self.attention_norm(x2d), B, S, freqs_cis, pos32, kv_len, prefill))
+        return ops.add(h, self.feed_forward(self.ffn_norm(h)))
+
+
+class Transformer(nn.Module):
+    def __init__(self, config: ModelArgs):
+        super().__init__()
+        self.config = config
+        self.tok_embeddings = nn.Embedding(config.vocab_size, config.dim, dtype=bf16)
+        self.layers = nn.ModuleList(TransformerBlock(config) for _ in range(config.n_layer))
+        self.norm = RMSNorm(config.dim, config.norm_eps)
+        self.output = _W(config.vocab_size, config.dim)
+        self.freqs_cis: Optional[torch.Tensor] = None
+        self.max_batch_size = self.max_seq_length = -1
+
+    def setup_caches(self, max_batch_size, max_seq_length, training: bool = False, **_):
+        """gptfast/model.py:113-166 (no S x S mask is ever built: the attention kernel masks in-register)."""
+        dev = self.output.weight.device
+        self.max_batch_size, self.max_seq_length = max_batch_size, (max_seq_length + 7) // 8 * 8
+        for b in self.layers:
+            b.attention.kv_cache = None if training else KVCache(max_batch_size, self.max_seq_length, self.config.n_head,
+                                                                 b.attention.hdp, dev)
+        self.freqs_cis = precompute_freqs_cis(max(self.config.block_size, self.max_seq_length), self.config.head_dim,
+                                              self.config.rope_base).to(dev).contiguous()
+
+    def forward(self, idx: Optional[torch.Tensor], input_pos: Optional[torch.Tensor] = None,
+                input_embeds: Optional[torch.Tensor] = None, last_only: bool = False) -> torch.Tensor:
+        """idx [B,S]; input_pos [S] (prefill, = arange) or [1] / [B] device tensor (decode cursor).  -> logits [B,S,V]."""
+        x = self.tok_embeddings(idx) if input_embeds is None else input_embeds
+        B, S, D = x.shape
+        x2d = x.reshape(B * S, D).contiguous()
+        prefill = S > 1 or input_pos is None
+        if input_pos is None:
+            input_pos = torch.arange(S, device=x.device)
+        if prefill:
+            pos32 = input_pos.to(torch.int32).reshape(1, S).expand(B, S).reshape(-1).contiguous()
+            kv_len = None
+        else:
+            pos32 = input_pos.to(torch.int32).reshape(-1).expand(B).contiguous()
+            kv_len = pos32 + 1
+        for layer in self.layers:
+            x2d = layer(x2d, B, S, self.freqs_cis, pos32, kv_len, prefill)
+        h = self.norm(x2d)
+        if last_only:
+            h = h.view(B, S, D)[:, -1].contiguous()
+            return ops.gemm(h, self.output.weight).view(B, 1, -1)
+        return ops.gemm(h, self.output.weight).view(B, S, -1)
+
+
+class Aria(nn.Module):
+    """gptfast/model.py:534-609: vision_tower + multi_modal_projector (HF key names) + llm (gptfast key names)."""
+
+    def __init__(self, config: ModelArgs, vision_config: Optional[AriaVisionConfig] = None, patch_to_query=None):
+        super().__init__()
+        self.config = config
+        vc = vision_config or AriaVisionConfig()
+        self.vision_tower = AriaVisionModel(vc)
+        self.multi_modal_projector = AriaProjector(patch_to_query or {1225: 128, 4900: 256}, vc.hidden_size, vc.num_attention_heads,
+                                                   vc.hidden_size, config.dim, config.dim)
+        self.llm = Transformer(config)
+
+    def setup_caches(self, *a, **k):
+        self.llm.setup_caches(*a, **k)
+
+    @torch.no_grad()
+    def prepare_embeddings(self, idx, pixel_values=None, pixel_mask=None):
+        emb = self.llm.tok_embeddings(idx)
+        if pixel_values is not None:
+            feat, atts = self.vision_tower(pixel_values, pixel_mask)
+            img = self.multi_modal_projector(feat, attn_mask=atts)
+            mask = (idx == self.config.image_token_index).unsqueeze(-1).expand_as(emb)
+            emb = emb.masked_scatter(mask, img.to(emb.dtype))
+        return emb
+
+    def forward(self, idx, input_pos=None, input_embeds=None, last_only=False):
+        return self.llm(idx, input_pos, input_embeds, last_only=last_only)
+
+
+# ------------------------------------------------------------------------------------------------- generate.py
+def multinomial_sample_one_no_sync(probs_sort):
+    q = torch.empty_like(probs_sort).exponential_(1)
+    return torch.argmax(probs_sort / q, dim=-1, keepdim=True).to(dtype=torch.int)
+
+
+def logits_to_probs(logits, temperature: float = 1.0, top_k: Optional[int] = None):
+    logits = logits.float() / max(temperature, 1e-5)
+    if top_k is not None:
+        v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
+        logits = torch.where(logits < v.select(-1, -1).unsqueeze(-1), -float("Inf"), logits)
+    return torch.softmax(logits, dim=-1)
+
+
+def sample(logits, temperature: float = 1.0, top_k: Optional[int] = None):
+    probs = logits_to_probs(logits[0, -1], temperature, top_k)
+    return multinomial_sample_one_no_sync(probs), probs
+
+
+class DecodeGraph:
+    """decode_one_token captured once in a HIP graph (the reference uses torch.compile(mode="reduce-overhead"),
+    gptfast/generate.py:232-238): static token / cursor buffers, replay per token."""
+
+    def __init__(self, model: Aria, temperature: float, top_k: Optional[int], use_graph: bool = True):
+        self.model, self.temperature, self.top_k = model, temperature, top_k
+        dev = model.llm.output.weight.device
+        self.tok = torch.zeros((1, 1), dtype=torch.long, device=dev)
+        self.pos = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.out = torch.zeros((1,), dtype=torch.int, device=dev)
+        self.graph = None
+        if use_graph and dev.type == "cuda":
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    self._step()
+            torch.cuda.current_stream().wait_stream(s)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._step()
+
+    def _step(self):
+        logits = self.model(self.tok, self.pos, last_only=True)
+        nxt, _ = sample(logits, self.temperature, self.top_k)
+        self.out.copy_(nxt.view(-1))
+
+    def __call__(self, token: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+        self.tok.copy_(token.view(1, 1))
+        self.pos.copy_(pos.view(1))
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step()
+        return self.out.clone()
+
+
+@torch.no_grad()
+def generate(model: Aria, input_ids: torch.Tensor, max_new_tokens: int, *, pixel_values=None, pixel_mask=None,
+             temperature: float = 0.8, top_k: Optional[int] = 200, decoder: Optional[DecodeGraph] = None,
+             stop_token: Optional[int] = None) -> Tuple[torch.Tensor, Optional[DecodeGraph]]:
+    """gptfast/generate.py:112-177: prefill (ViT + projector + full prompt) then token-by-token decode."""
+    T = input_ids.size(1)
+    dev = input_ids.device
+    if model.llm.max_seq_length < T + max_new_tokens:
+        model.setup_caches(1, T + max_new_tokens)
+        decoder = None
+    emb = model.prepare_embeddings(input_ids, pixel_values, pixel_mask)
+    input_pos = torch.arange(0, T, device=dev)
+    logits = model(None, input_pos, emb, last_only=True)
+    nxt, _ = sample(logits, temperature, top_k)
+    if decoder is None:
+        decoder = DecodeGraph(model, temperature, top_k)
+    toks: List[torch.Tensor] = [nxt.view(1)]
+    pos = torch.tensor([T], device=dev, dtype=torch.int32)
+    for _ in range(max_new_tokens - 1):
+        nxt = decoder(toks[-1].long(), pos)
+        toks.append(nxt.view(1))
+        pos += 1
+        if stop_token is not None and int(nxt) == stop_token:
+            break
+    return torch.cat([input_ids.view(-1), torch.cat(toks).long()]), decoder
+
+
+def load_model_pth(model: Aria, state_dict: dict, strict: bool = False):
+    """Load a gptfast ``model.pth`` state dict (convert_hf_checkpoint.py output: ``llm.*`` gptfast names, vision / projector HF
+    names) -- tensors are copied as they are, no layout conversion."""
+    own = model.state_dict()
+    missing = [k for k in own if k not in state_dict]
+    if strict and missing:
+        raise KeyError(f"missing keys {missing[:5]}")
+    with torch.no_grad():
+        for k, v in own.items():
+            if k in state_dict:
+                v.copy_(state_dict[k].to(v.dtype))
+    return missing

@@ -258,6 +258,18 @@ def rope_(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, S: int, n_heads
     return x
 
 
+def rope_interleaved_(x: torch.Tensor, freqs_cis: torch.Tensor, n_heads: int, hd: int, pos: Optional[torch.Tensor] = None):
+    """gptfast RoPE in place on the first n_heads*hd columns of x [T, >=n_heads*hd]; freqs_cis bf16 [S, hd/2, 2]."""
+    _chk(x, name="x"), _chk(freqs_cis, name="freqs_cis")
+    assert freqs_cis.is_contiguous() and freqs_cis.shape[1] * 2 == hd
+    if pos is not None:
+        _chk(pos, torch.int32, "pos")
+        assert pos.numel() == x.shape[0]
+    hip.get_lib().call("aria_rope_interleaved_inplace", _p(x), _p(freqs_cis), _p(pos), x.shape[0], freqs_cis.shape[0], n_heads, hd,
+                       _rowmajor_2d(x, "x"), _stream(x))
+    return x
+
+
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     _chk(a, name="a"), _chk(b, name="b")
     assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape

@@ -130,6 +130,12 @@ int aria_colsum_f32(const float* partial, void* out, int64_t nrows, int64_t D, i
 int aria_rope_inplace(void* x, const void* cos, const void* sin, int64_t T, int64_t S, int64_t n_heads, int64_t hd,
                       int64_t ld, int inverse, void* stream);
 
+/* gptfast apply_rotary_emb (gptfast/model.py:519-531) with the bf16 freqs_cis cache of precompute_freqs_cis (:500-516,
+ * [S, hd/2, 2]): interleaved pairs, fp32 arithmetic, one rounding; in place on n_heads consecutive heads of each row.
+ * pos int32[T] (device; the decode cursor) or NULL (position = t % S). */
+int aria_rope_interleaved_inplace(void* x, const void* freqs_cis, const int32_t* pos, int64_t T, int64_t S, int64_t n_heads,
+                                  int64_t hd, int64_t ld, void* stream);
+
 /* out = bf16(a + b), n elements (n % 8 == 0) */
 int aria_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 

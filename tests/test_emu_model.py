@@ -33,3 +33,7 @@ def test_vit_projector_golden(golden):
 
 def test_aria_full_golden(golden):
     M.case_aria_full_golden(DEV, golden)
+
+
+def test_gptfast_golden(golden):
+    M.case_gptfast_golden(DEV, golden)
