@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--new", type=int, default=200)
     ap.add_argument("--runs", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="HIP-graph decode (known unstable across prefills in round 1)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     from aria_amd.vision import AriaVisionConfig
@@ -48,12 +48,12 @@ def main():
     pv = torch.randn((1, 3, 980, 980), generator=g, device=dev).clamp_(-1, 1).to(bf16)
     pm = torch.ones((1, 980, 980), dtype=torch.bool, device=dev)
     model.setup_caches(1, 280 + a.new)
-    decoder = None if not a.no_graph else G.DecodeGraph(model, 0.8, 200, use_graph=False)
+    decoder = None
     lat, ntok = [], []
     for i in range(a.warmup + a.runs):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out, decoder = G.generate(model, ids, a.new, pixel_values=pv, pixel_mask=pm, temperature=0.8, top_k=200, decoder=decoder)
+        out, decoder = G.generate(model, ids, a.new, pixel_values=pv, pixel_mask=pm, temperature=0.8, top_k=200, decoder=decoder, use_graph=a.graph)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if i >= a.warmup:
@@ -82,7 +82,7 @@ def main():
            "decode_ms_per_token": round(t_dec * 1e3, 3), "decode_tok_s": round(1 / t_dec, 1),
            "decode_roofline": {"bound": "hbm", "achieved": round(weight_bytes / t_dec / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(weight_bytes / t_dec / 8e12, 4)},
-           "config": {"layers": a.layers, "vit_layers": a.vit_layers, "hip_graph": not a.no_graph}}
+           "config": {"layers": a.layers, "vit_layers": a.vit_layers, "hip_graph": bool(a.graph)}}
     print(json.dumps(res))
 
 
