@@ -698,6 +698,298 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const bf16_t* Q, const 
     }
 }
 
+// =========================================================================================== backward v2
+// Same two-kernel split as v1, cheaper inner loops: K/V (dQ kernel) or Q/dO (dK/dV kernel) tiles double-buffered in LDS with
+// one barrier per tile, token-strided operands through ds_read_b64_tr_b16 (natural feature order, no VALU repacking), mask
+// arithmetic only on edge / diagonal / padded tiles, probabilities as exp2(s * scale*log2e - lse*log2e).
+
+// fragment of 32 consecutive feature columns d0..d0+31 whose 8 k-slots are token rows rb + 4h + (e&3) + 8(e>>2)
+template <int HD>
+__device__ __forceinline__ s16x8 frag_tr(const bf16_t* s, int rb, int d0, int l) {
+    const bf16_t* p = s + (rb + 4 * (l >> 5) + ((l & 15) >> 2)) * Cfg<HD>::PITCH + d0 + 16 * ((l >> 4) & 1) + 4 * (l & 3);
+    const s16x4 a0 = ds_read_tr16(p);
+    const s16x4 a1 = ds_read_tr16(p + 8 * Cfg<HD>::PITCH);
+    s16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[e] = a0[e];
+        f[4 + e] = a1[e];
+    }
+    return f;
+}
+
+template <int HD>
+__global__ __launch_bounds__(NT) void attn_bwd2_dkdv_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
+                                                            const float* LSE, const float* DELTA, bf16_t* dK, bf16_t* dV,
+                                                            const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
+                                                            long long ldq, long long ldk, long long ldv, long long lddo,
+                                                            long long lddk, long long lddv, float scale, int causal) {
+    using C = Cfg<HD>;
+    constexpr int DT = HD / 32;
+    ARIA_DYN_SMEM(smem);
+    bf16_t* sQ = reinterpret_cast<bf16_t*>(smem);       // [2][64][PITCH]
+    bf16_t* sdO = sQ + 2 * 64 * C::PITCH;               // [2][64][PITCH]
+    float* sLse = reinterpret_cast<float*>(sdO + 2 * 64 * C::PITCH);  // [2][64]  (lse * log2e)
+    float* sDel = sLse + 128;                           // [2][64]
+    const int t = threadIdx.x, l = t & 63, w = t >> 6, h2 = l >> 5;
+    const int b = blockIdx.z, head = blockIdx.y, kv0 = blockIdx.x * 128;
+    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
+    const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
+    const bf16_t* Kb = K + tok0 * ldk + head * HD;
+    const bf16_t* Vb = V + tok0 * ldv + head * HD;
+    const bf16_t* dOb = dO + tokq0 * lddo + head * HD;
+    const float* lseb = LSE + ((long long)b * H + head) * Sq;
+    const float* delb = DELTA + ((long long)b * H + head) * Sq;
+    const int kv_wmin = kv0 + 32 * w, kv_abs = kv_wmin + (l & 31);
+    const int klen = kv_len ? min(S, kv_len[b]) : S;
+    const bool key_ok = kv_abs < klen && (!key_mask || key_mask[tok0 + kv_abs] != 0);
+    const bool all_keys_ok = ballot(key_ok) == ~0ull;
+    const float scale2 = scale * 1.4426950408889634f;
+
+    s16x8 kf[C::KS], vf[C::KS];
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+        u32x4 a = zero16(), c = zero16();
+        if (kv_abs < S) {
+            a = ld16(Kb + (long long)kv_abs * ldk + kk * 16 + h2 * 8);
+            c = ld16(Vb + (long long)kv_abs * ldv + kk * 16 + h2 * 8);
+        }
+        kf[kk] = __builtin_bit_cast(s16x8, a);
+        vf[kk] = __builtin_bit_cast(s16x8, c);
+    }
+    f32x16 dk[DT], dv[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+        dk[i] = zero_acc();
+        dv[i] = zero_acc();
+    }
+    const int q_begin = causal ? (kv0 / 64) * 64 : 0;
+    const int ntiles = kv0 < klen ? (Sq - q_begin + 63) / 64 : 0;
+    u32x4 rq[C::NCH64], rdo[C::NCH64];
+    if (ntiles > 0) {
+        tile_load<HD>(rq, Qb, ldq, q_begin, Sq, t);
+        tile_load<HD>(rdo, dOb, lddo, q_begin, Sq, t);
+        tile_store<HD>(rq, sQ, t);
+        tile_store<HD>(rdo, sdO, t);
+        if (t < 64) {
+            const int q = q_begin + t;
+            sLse[t] = q < Sq ? lseb[q] * 1.4426950408889634f : 0.f;
+            sDel[t] = q < Sq ? delb[q] : 0.f;
+        }
+    }
+    for (int it = 0; it < ntiles; ++it) {
+        sync();
+        const int cur = it & 1, qt0 = q_begin + it * 64;
+        const bool more = it + 1 < ntiles;
+        if (more) {
+            tile_load<HD>(rq, Qb, ldq, qt0 + 64, Sq, t);
+            tile_load<HD>(rdo, dOb, lddo, qt0 + 64, Sq, t);
+        }
+        const bf16_t* cQ = sQ + cur * 64 * C::PITCH;
+        const bf16_t* cdO = sdO + cur * 64 * C::PITCH;
+        const float* cL = sLse + cur * 64;
+        const float* cD = sDel + cur * 64;
+        if (!(causal && kv_wmin > qt0 + 63)) {  // wave-uniform: some query of the tile can see some key of this wave
+            f32x16 sc[2], dp[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                sc[i] = zero_acc();
+                dp[i] = zero_acc();
+            }
+#pragma unroll
+            for (int kk = 0; kk < C::KS; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    sc[i] = mfma32(frag_rc<HD>(cQ, i * 32 + (l & 31), kk, l), kf[kk], sc[i]);
+                    dp[i] = mfma32(frag_rc<HD>(cdO, i * 32 + (l & 31), kk, l), vf[kk], dp[i]);
+                }
+            const bool need_mask = !all_keys_ok || (qt0 + 64 > Sq) || (causal && kv_wmin + 31 > qt0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = i * 32 + acc_row(r, l);
+                    float p = exp2_fast(sc[i][r] * scale2 - cL[ql]);
+                    if (need_mask) {
+                        const int q = qt0 + ql;
+                        if (!(q < Sq && key_ok && !(causal && kv_abs > q))) p = 0.f;
+                    }
+                    sc[i][r] = p;
+                    dp[i][r] = p * (dp[i][r] - cD[ql]) * scale;
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const s16x8 pf = pack_frag(sc[i], u);
+                    const s16x8 dsf = pack_frag(dp[i], u);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        dv[dt] = mfma32(pf, frag_tr<HD>(cdO, i * 32 + 16 * u, 32 * dt, l), dv[dt]);
+                        dk[dt] = mfma32(dsf, frag_tr<HD>(cQ, i * 32 + 16 * u, 32 * dt, l), dk[dt]);
+                    }
+                }
+        }
+        if (more) {
+            const int nb = cur ^ 1;
+            tile_store<HD>(rq, sQ + nb * 64 * C::PITCH, t);
+            tile_store<HD>(rdo, sdO + nb * 64 * C::PITCH, t);
+            if (t < 64) {
+                const int q = qt0 + 64 + t;
+                sLse[nb * 64 + t] = q < Sq ? lseb[q] * 1.4426950408889634f : 0.f;
+                sDel[nb * 64 + t] = q < Sq ? delb[q] : 0.f;
+            }
+        }
+    }
+    // accumulators: rows = keys kv_wmin + acc_row, cols = features 32 dt + (l & 31)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kv = kv_wmin + acc_row(r, l);
+            if (kv >= S) continue;
+            const int d = 32 * dt + (l & 31);
+            dK[(tok0 + kv) * lddk + head * HD + d] = f2bf(dk[dt][r]);
+            dV[(tok0 + kv) * lddv + head * HD + d] = f2bf(dv[dt][r]);
+        }
+}
+
+template <int HD>
+__global__ __launch_bounds__(NT) void attn_bwd2_dq_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
+                                                          const float* LSE, const float* DELTA, bf16_t* dQ, const int32_t* kv_len,
+                                                          const uint8_t* key_mask, int Sq, int S, int H, long long ldq,
+                                                          long long ldk, long long ldv, long long lddo, long long lddq,
+                                                          float scale, int causal) {
+    using C = Cfg<HD>;
+    constexpr int DT = HD / 32;
+    ARIA_DYN_SMEM(smem);
+    bf16_t* sK = reinterpret_cast<bf16_t*>(smem);   // [2][64][PITCH]
+    bf16_t* sV = sK + 2 * 64 * C::PITCH;            // [2][64][PITCH]
+    uint8_t* sM = reinterpret_cast<uint8_t*>(sV + 2 * 64 * C::PITCH);  // [2][64]
+    int* sFlag = reinterpret_cast<int*>(sM + 128);
+    const int t = threadIdx.x, l = t & 63, w = t >> 6, h2 = l >> 5;
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
+    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
+    const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
+    const bf16_t* Kb = K + tok0 * ldk + head * HD;
+    const bf16_t* Vb = V + tok0 * ldv + head * HD;
+    const bf16_t* dOb = dO + tokq0 * lddo + head * HD;
+    const uint8_t* kmb = key_mask ? key_mask + tok0 : nullptr;
+    const int q_wmin = q0 + 32 * w, q_abs = q_wmin + (l & 31);
+    const int klen = kv_len ? min(S, kv_len[b]) : S;
+    const float scale2 = scale * 1.4426950408889634f;
+    s16x8 qf[C::KS], dof[C::KS];
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+        u32x4 a = zero16(), c = zero16();
+        if (q_abs < Sq) {
+            a = ld16(Qb + (long long)q_abs * ldq + kk * 16 + h2 * 8);
+            c = ld16(dOb + (long long)q_abs * lddo + kk * 16 + h2 * 8);
+        }
+        qf[kk] = __builtin_bit_cast(s16x8, a);
+        dof[kk] = __builtin_bit_cast(s16x8, c);
+    }
+    float lse2 = 0.f, del = 0.f;
+    if (q_abs < Sq) {
+        lse2 = LSE[((long long)b * H + head) * Sq + q_abs] * 1.4426950408889634f;
+        del = DELTA[((long long)b * H + head) * Sq + q_abs];
+    }
+    const bool all_q_ok = q_wmin + 31 < Sq;
+    f32x16 dq[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) dq[i] = zero_acc();
+    int kv_end = klen;
+    if (causal) kv_end = min(kv_end, q0 + 128);
+    const int ntiles = (kv_end + 63) / 64;
+    u32x4 rk[C::NCH64], rv[C::NCH64];
+    if (ntiles > 0) {
+        tile_load<HD>(rk, Kb, ldk, 0, S, t);
+        tile_load<HD>(rv, Vb, ldv, 0, S, t);
+        tile_store<HD>(rk, sK, t);
+        tile_store<HD>(rv, sV, t);
+        if (kmb && t < 64) {
+            const uint8_t mv = t < S ? kmb[t] : 0;
+            sM[t] = mv;
+            const unsigned long long all = ballot(mv != 0);
+            if (t == 0) sFlag[0] = (all == ~0ull);
+        }
+    }
+    for (int it = 0; it < ntiles; ++it) {
+        sync();
+        const int cur = it & 1, kv0 = it * 64;
+        const bool more = it + 1 < ntiles;
+        if (more) {
+            tile_load<HD>(rk, Kb, ldk, kv0 + 64, S, t);
+            tile_load<HD>(rv, Vb, ldv, kv0 + 64, S, t);
+        }
+        const bf16_t* cK = sK + cur * 64 * C::PITCH;
+        const bf16_t* cV = sV + cur * 64 * C::PITCH;
+        if (!(causal && kv0 > q_wmin + 31)) {
+            f32x16 st[2], dpt[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                st[i] = zero_acc();
+                dpt[i] = zero_acc();
+            }
+#pragma unroll
+            for (int kk = 0; kk < C::KS; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    st[i] = mfma32(frag_rc<HD>(cK, i * 32 + (l & 31), kk, l), qf[kk], st[i]);
+                    dpt[i] = mfma32(frag_rc<HD>(cV, i * 32 + (l & 31), kk, l), dof[kk], dpt[i]);
+                }
+            const bool need_mask = !all_q_ok || (kv0 + 64 > klen) || (causal && kv0 + 63 > q_wmin) || (kmb && !sFlag[cur]);
+            const uint8_t* cM = sM + cur * 64;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float p = exp2_fast(st[i][r] * scale2 - lse2);
+                    if (need_mask) {
+                        const int kvl = i * 32 + acc_row(r, l);
+                        const int kv = kv0 + kvl;
+                        bool ok = q_abs < Sq && kv < klen && !(causal && kv > q_abs);
+                        if (kmb) ok = ok && cM[kvl];
+                        if (!ok) p = 0.f;
+                    }
+                    dpt[i][r] = p * (dpt[i][r] - del) * scale;
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const s16x8 dsf = pack_frag(dpt[i], u);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) dq[dt] = mfma32(frag_tr<HD>(cK, i * 32 + 16 * u, 32 * dt, l), dsf, dq[dt]);
+                }
+        }
+        if (more) {
+            const int nb = cur ^ 1, kvn = kv0 + 64;
+            tile_store<HD>(rk, sK + nb * 64 * C::PITCH, t);
+            tile_store<HD>(rv, sV + nb * 64 * C::PITCH, t);
+            if (kmb && t < 64) {
+                const uint8_t mv = (kvn + t < S) ? kmb[kvn + t] : 0;
+                sM[nb * 64 + t] = mv;
+                const unsigned long long all = ballot(mv != 0);
+                if (t == 0) sFlag[nb] = (all == ~0ull);
+            }
+        }
+    }
+    if (q_abs < Sq) {
+        bf16_t* row = dQ + (tokq0 + q_abs) * lddq + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d0 = 32 * dt + 8 * rg + 4 * h2;
+                u32x2 v;
+                v[0] = pack2bf(dq[dt][4 * rg], dq[dt][4 * rg + 1]);
+                v[1] = pack2bf(dq[dt][4 * rg + 2], dq[dt][4 * rg + 3]);
+                *reinterpret_cast<u32x2*>(row + d0) = v;
+            }
+    }
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -736,7 +1028,7 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
     if (hd != 64 && hd != 128) return ARIA_ERR_UNSUPPORTED;
     if (causal && Sq != Skv) return ARIA_ERR_UNSUPPORTED;
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(d_o) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) ||
-        (lddq & 1) || (lddk & 1) || (lddv & 1))
+        (lddq & 3) || (lddk & 1) || (lddv & 1) || (reinterpret_cast<uintptr_t>(dq) & 7))
         return ARIA_ERR_ALIGN;
     if (B == 0 || Sq == 0 || Skv == 0) return ARIA_OK;
     const bf16_t *Q = static_cast<const bf16_t*>(q), *K = static_cast<const bf16_t*>(k), *V = static_cast<const bf16_t*>(v);
@@ -751,20 +1043,20 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
     dim3 block(NT);
     if (hd == 128) {
         using C = Cfg<128>;
-        ARIA_LAUNCH((attn_bwd_dkdv_kernel<128>), gridk, block, size_t(2 * 64 * C::PITCH * 2 + 128 * 4), stream, Q, K, V, dO, lse,
+        ARIA_LAUNCH((attn_bwd2_dkdv_kernel<128>), gridk, block, size_t(4 * 64 * C::PITCH * 2 + 256 * 4), stream, Q, K, V, dO, lse,
                     (const float*)delta, static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), kv_len, key_mask, int(Sq), int(Skv),
                     int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddk, (long long)lddv, scale,
                     causal);
-        ARIA_LAUNCH((attn_bwd_dq_kernel<128>), gridq, block, size_t(2 * 64 * C::PITCH * 2 + 64), stream, Q, K, V, dO, lse,
+        ARIA_LAUNCH((attn_bwd2_dq_kernel<128>), gridq, block, size_t(4 * 64 * C::PITCH * 2 + 128 + 16), stream, Q, K, V, dO, lse,
                     (const float*)delta, static_cast<bf16_t*>(dq), kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq,
                     (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddq, scale, causal);
     } else {
         using C = Cfg<64>;
-        ARIA_LAUNCH((attn_bwd_dkdv_kernel<64>), gridk, block, size_t(2 * 64 * C::PITCH * 2 + 128 * 4), stream, Q, K, V, dO, lse,
+        ARIA_LAUNCH((attn_bwd2_dkdv_kernel<64>), gridk, block, size_t(4 * 64 * C::PITCH * 2 + 256 * 4), stream, Q, K, V, dO, lse,
                     (const float*)delta, static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), kv_len, key_mask, int(Sq), int(Skv),
                     int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddk, (long long)lddv, scale,
                     causal);
-        ARIA_LAUNCH((attn_bwd_dq_kernel<64>), gridq, block, size_t(2 * 64 * C::PITCH * 2 + 64), stream, Q, K, V, dO, lse,
+        ARIA_LAUNCH((attn_bwd2_dq_kernel<64>), gridq, block, size_t(4 * 64 * C::PITCH * 2 + 128 + 16), stream, Q, K, V, dO, lse,
                     (const float*)delta, static_cast<bf16_t*>(dq), kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq,
                     (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddq, scale, causal);
     }
