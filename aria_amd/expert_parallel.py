@@ -1,0 +1,189 @@
+"""Expert parallelism for the Aria MoE block (BASELINE.json config #5; an ADDITION: the reference's TokenDispatcher is the
+Megatron "allgather-free" LOCAL dispatcher with the all-to-all stripped, aria/model/moe_lm.py:296-365).
+
+64 experts are sharded over the W ranks of a process group (rank g owns experts [g*E/W, (g+1)*E/W)); every rank routes its own
+tokens, rows travel to the owning rank with an all-to-all(v) (RCCL over xGMI: 7/8 of the rows leave the GPU, 30 720 B per token
+per layer each way), the local grouped GEMM runs over E/W experts, and a second all-to-all brings the expert outputs back to be
+combined with the local scores and the (replicated) shared expert.  Expert weight gradients are complete on the owning rank
+(no DP reduction when EP = world); replicated parameters (router, shared expert, attention, norms) are reduced by
+``aria_amd.parallel.GradSync`` as usual.
+
+Everything is built from small autograd Functions over the C-ABI kernels, so the same pieces are the differentiable form of
+the reference's dispatcher seam.  The exchange uses ``all_to_all_single`` on RCCL and falls back to pairwise isend/irecv on
+backends without all-to-all (gloo: used by the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import autograd as AG
+from . import functional as Fn
+from . import ops
+
+bf16 = torch.bfloat16
+
+
+# --------------------------------------------------------------------------------------------- differentiable dispatcher pieces
+class RouteFn(torch.autograd.Function):
+    """logits -> scores (differentiable, incl. the training-only z / load-balancing loss gradients); idx, counts are integers."""
+
+    @staticmethod
+    def forward(ctx, logits, cfg: Fn.MoEConfig):
+        scores, idx, counts = ops.moe_route(logits, cfg.topk)
+        ctx.save_for_backward(logits, scores, idx, counts)
+        ctx.cfg = cfg
+        ctx.mark_non_differentiable(idx, counts)
+        return scores, idx, counts
+
+    @staticmethod
+    def backward(ctx, dscores, _di, _dc):
+        logits, scores, idx, counts = ctx.saved_tensors
+        c = ctx.cfg
+        return ops.moe_route_bwd(logits, idx, scores, AG._c(dscores), counts, c.z_loss_coeff, c.aux_loss_coeff, c.aux_scale), None
+
+
+class PermuteFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sorted_src, inv, k):
+        ctx.save_for_backward(inv)
+        ctx.k = k
+        return ops.moe_permute(x, sorted_src, k)
+
+    @staticmethod
+    def backward(ctx, dperm):
+        (inv,) = ctx.saved_tensors
+        return ops.moe_unpermute(AG._c(dperm), inv, None, ctx.k), None, None, None
+
+
+class UnpermuteFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eo, inv, scores, add, k):
+        ctx.save_for_backward(eo, inv, scores)
+        ctx.k = k
+        return ops.moe_unpermute(eo, inv, scores, k, add=add)
+
+    @staticmethod
+    def backward(ctx, dout):
+        eo, inv, scores = ctx.saved_tensors
+        dout = AG._c(dout)
+        d_eo, dscores = ops.moe_unpermute_bwd(dout, eo, inv, scores, ctx.k)
+        return d_eo, None, dscores, dout, None
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """out[i] = x[index[i]] for a PERMUTATION index (backward = gather with the inverse permutation)."""
+
+    @staticmethod
+    def forward(ctx, x, index, inverse):
+        ctx.save_for_backward(index, inverse)
+        return ops.moe_permute(x, index, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        index, inverse = ctx.saved_tensors
+        return ops.moe_permute(AG._c(dy), inverse, 1), None, None
+
+
+def _all_to_all_rows(rows: torch.Tensor, send_splits: List[int], recv_splits: List[int], group) -> torch.Tensor:
+    D = rows.shape[1]
+    out = torch.empty((sum(recv_splits), D), dtype=rows.dtype, device=rows.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all_single(out, rows, recv_splits, send_splits, group=group)
+        return out
+    # pairwise exchange (gloo has no all-to-all)
+    rank, W = dist.get_rank(group), dist.get_world_size(group)
+    so = [0]
+    ro = [0]
+    for a, b in zip(send_splits, recv_splits):
+        so.append(so[-1] + a)
+        ro.append(ro[-1] + b)
+    out[ro[rank]:ro[rank + 1]] = rows[so[rank]:so[rank + 1]]
+    reqs, keep = [], []
+    for peer in range(W):
+        if peer == rank:
+            continue
+        if send_splits[peer]:
+            chunk = rows[so[peer]:so[peer + 1]].contiguous()
+            keep.append(chunk)
+            reqs.append(dist.isend(chunk, dist.get_global_rank(group, peer) if group else peer, group=group))
+        if recv_splits[peer]:
+            buf = torch.empty((recv_splits[peer], D), dtype=rows.dtype, device=rows.device)
+            reqs.append((dist.irecv(buf, dist.get_global_rank(group, peer) if group else peer, group=group), buf, peer))
+    for r in reqs:
+        if isinstance(r, tuple):
+            r[0].wait()
+            out[ro[r[2]]:ro[r[2] + 1]] = r[1]
+        else:
+            r.wait()
+    return out
+
+
+class AllToAllRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, send_splits, recv_splits, group):
+        ctx.meta = (send_splits, recv_splits, group)
+        return _all_to_all_rows(AG._c(rows), send_splits, recv_splits, group)
+
+    @staticmethod
+    def backward(ctx, dy):
+        send_splits, recv_splits, group = ctx.meta
+        return _all_to_all_rows(AG._c(dy), recv_splits, send_splits, group), None, None, None
+
+
+# --------------------------------------------------------------------------------------------- the EP MoE block
+def shard_expert_weights(fc1: torch.Tensor, fc2: torch.Tensor, rank: int, world: int):
+    """Views of the local experts' weights ([E/W, D, 2I], [E/W, I, D])."""
+    per = fc1.shape[0] // world
+    return fc1[rank * per:(rank + 1) * per], fc2[rank * per:(rank + 1) * per]
+
+
+def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w, down_w, cfg: Fn.MoEConfig,
+                   group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """MoELayer.forward with the routed experts sharded over `group`.  x [T, D] (this rank's tokens) -> [T, D].
+    One small host sync per call for the row counts of the all-to-all (as in Megatron's alltoall dispatcher)."""
+    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    E, k = cfg.num_experts, cfg.topk
+    El = E // W
+    assert fc1_local.shape[0] == El
+    logits = AG.linear(x, router_w)
+    scores, idx, counts = RouteFn.apply(logits, cfg)
+    offsets, sorted_src, inv = ops.moe_sort(idx, counts)
+    perm = PermuteFn.apply(x, sorted_src, inv, k)                                  # expert-major == destination-rank-major
+    # exchange per-(rank, local expert) row counts
+    send_counts = counts.view(W, El).contiguous()
+    recv_counts = torch.empty_like(send_counts)                                    # [source rank, local expert]
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all_single(recv_counts, send_counts, group=group)
+    else:
+        gathered = [torch.empty_like(send_counts) for _ in range(W)]
+        dist.all_gather(gathered, send_counts, group=group)
+        recv_counts = torch.stack([g[rank] for g in gathered])
+    send_splits = send_counts.sum(1).tolist()
+    rc = recv_counts.cpu()
+    recv_splits = rc.sum(1).tolist()
+    rows = AllToAllRowsFn.apply(perm, send_splits, recv_splits, group)             # ordered (source rank, local expert)
+    # reorder to local-expert-major for the grouped GEMM
+    R = rows.shape[0]
+    seg_start = torch.zeros((W, El), dtype=torch.long)
+    flat = rc.reshape(-1).long()
+    seg_start.view(-1)[1:] = torch.cumsum(flat, 0)[:-1]
+    order_parts = [torch.arange(int(seg_start[s, e]), int(seg_start[s, e]) + int(rc[s, e])) for e in range(El) for s in range(W)]
+    order = (torch.cat(order_parts) if order_parts else torch.zeros(0, dtype=torch.long)).to(torch.int32).to(x.device)
+    inverse = torch.empty_like(order)
+    inverse[order.long()] = torch.arange(R, dtype=torch.int32, device=x.device)
+    local_in = GatherRowsFn.apply(rows, order, inverse)
+    local_off = torch.zeros(El + 1, dtype=torch.int32)
+    local_off[1:] = torch.cumsum(rc.sum(0), 0).to(torch.int32)
+    local_off = local_off.to(x.device)
+    h1 = AG.ExpertsGemmFn.apply(local_in, fc1_local, local_off)
+    eo_local = AG.ExpertsGemmFn.apply(AG.SwiGLUFn.apply(h1), fc2_local, local_off)
+    back = GatherRowsFn.apply(eo_local, inverse, order)                            # (source rank, local expert) order again
+    eo = AllToAllRowsFn.apply(back, recv_splits, send_splits, group)               # my rows, original expert-major order
+    # shared expert (replicated) and weighted combine
+    I2 = gate_w.shape[0]
+    gu = torch.cat([AG.linear(x, gate_w), AG.linear(x, up_w)], dim=-1)
+    sh = AG.linear(AG.SwiGLUFn.apply(gu), down_w)
+    return UnpermuteFn.apply(eo, inv, scores, sh, k)
