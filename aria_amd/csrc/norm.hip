@@ -3,6 +3,7 @@
 // (inherited by aria/model/moe_lm.py:580-602); gptfast/model.py:461-472.
 #include "aria_device.h"
 #include "aria_hip.h"
+#include <cmath>
 
 namespace {
 using namespace ad;
@@ -217,6 +218,30 @@ __global__ __launch_bounds__(256) void rope_interleaved_kernel(bf16_t* x, const 
     }
 }
 
+// AdamW with fp32 master weights (decoupled weight decay, bias correction), one pass over HBM:
+//   g = grad (bf16) * grad_scale; m, v updated; master -= lr * (m_hat / (sqrt(v_hat) + eps) + wd * master); param = bf16(master)
+__global__ __launch_bounds__(256) void adamw_kernel(bf16_t* param, const bf16_t* grad, float* master, float* m, float* v,
+                                                    long long n, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                    float bc2, float grad_scale) {
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += (long long)gridDim.x * blockDim.x * 2) {
+        const uint32_t gw = *reinterpret_cast<const uint32_t*>(grad + i);
+        float out[2];
+#pragma unroll
+        for (int z = 0; z < 2; ++z) {
+            const float g = (z ? bfhi(gw) : bflo(gw)) * grad_scale;
+            const float mm = b1 * m[i + z] + (1.f - b1) * g;
+            const float vv = b2 * v[i + z] + (1.f - b2) * g * g;
+            m[i + z] = mm;
+            v[i + z] = vv;
+            float w = master[i + z];
+            w -= lr * ((mm / bc1) / (sqrtf(vv / bc2) + eps) + wd * w);
+            master[i + z] = w;
+            out[z] = w;
+        }
+        *reinterpret_cast<uint32_t*>(param + i) = pack2bf(out[0], out[1]);
+    }
+}
+
 int grid1d(long long n, int per_block, int cap = 4096) {
     long long g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -287,6 +312,17 @@ int aria_rope_interleaved_inplace(void* x, const void* freqs_cis, const int32_t*
     const long long nitems = T * n_heads * (hd / 8);
     ARIA_LAUNCH(rope_interleaved_kernel, dim3(grid1d(nitems, 256)), dim3(256), 0, stream, static_cast<bf16_t*>(x),
                 static_cast<const bf16_t*>(freqs_cis), pos, nitems, int(S), int(n_heads), int(hd), (long long)ld);
+    return aria_check_launch();
+}
+
+int aria_adamw_step(void* param, const void* grad, float* master, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+    if (!param || !grad || !master || !m || !v || n < 0 || step <= 0) return ARIA_ERR_INVALID;
+    if ((n & 1) || (reinterpret_cast<uintptr_t>(param) & 3) || (reinterpret_cast<uintptr_t>(grad) & 3)) return ARIA_ERR_ALIGN;
+    if (n == 0) return ARIA_OK;
+    const float bc1 = 1.f - powf(beta1, float(step)), bc2 = 1.f - powf(beta2, float(step));
+    ARIA_LAUNCH(adamw_kernel, dim3(grid1d(n / 2, 256)), dim3(256), 0, stream, static_cast<bf16_t*>(param),
+                static_cast<const bf16_t*>(grad), master, m, v, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
     return aria_check_launch();
 }
 

