@@ -59,6 +59,17 @@ def init_params(model, seed):
                     flat[o:o + chunk].normal_(0.0, 0.02, generator=g)
 
 
+def pmc_traffic():
+    """HBM bytes per fc1 launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    tools/gemm_pmc_target.py = the same kernel and shape; gfx950 FETCH_SIZE x2 correction applied) -- counters cannot be read
+    inside the timed run.  None if the summary is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_fc1.json")) as f:
+            return round(json.load(f)["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg_kwargs, seconds_budget=40.0):
     """The CPU oracle (oracle/aria_oracle.py, 'port' of the reference algorithm) timed on this host: one full-width decoder
     layer + lm_head/CE, fwd+bwd, fp32, B=1 S=256; extrapolated to 28 layers."""
@@ -223,9 +234,9 @@ def main():
                        "layers": args.layers, "vit_layers": args.vit_layers, "images_per_sample": n_img, "global_batch": world * B, "seq_len": S,
                        "parallelism": f"dp{world}" if world > 1 else "single", "grad_checkpointing": bool(args.recompute),
                        "optimizer_in_step": False, "loss": round(float(loss), 4)},
-            "roofline": {"kernel": "gemm_kernel<rc,oc> grouped-M (experts.fc1 forward)", "bound": "mfma",
+            "roofline": {"kernel": "gemm2_kernel<rc,oc> grouped-M (experts.fc1 forward)", "bound": "mfma",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                         "frac": None if achieved is None else round(achieved / peak, 4), "traffic": None,
+                         "frac": None if achieved is None else round(achieved / peak, 4), "traffic": pmc_traffic(),
                          "launches_timed": len(durs), "avg_launch_ms": round(avg * 1e3, 4),
                          "algorithmic_flops_per_launch": flops_launch},
         }
