@@ -170,6 +170,53 @@ __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 __device__ __forceinline__ u32x4 zero16() { return u32x4{0u, 0u, 0u, 0u}; }
 
+// ---- LDS-DMA (global_load_lds_dwordx4) and the explicit counters / barriers that pipeline it ----
+// Every lane fetches 16 bytes from ITS OWN global address; the wave's 1 KiB lands lane-linearly at lds_wave_base + 16 * lane
+// (lds_wave_base must be wave-uniform: it travels in M0).  Completion is tracked by vmcnt, in issue order.
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+#ifdef ARIA_EMU
+    emu::glds(g, static_cast<char*>(lds_wave_base) + 16 * emu::lane());
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
+#endif
+}
+// wait until at most N of this wave's VMEM operations (LDS-DMA pieces included) are still outstanding
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+#ifdef ARIA_EMU
+    emu::wait_vm(N);
+#else
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ void wait_lds() {  // all of this wave's LDS reads/writes have completed
+#ifndef ARIA_EMU
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+// bare s_barrier: unlike __syncthreads() it carries no fence, so LDS-DMA pieces in flight stay in flight across it
+__device__ __forceinline__ void raw_barrier() {
+#ifdef ARIA_EMU
+    emu::syncthreads();
+#else
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+template <int P>
+__device__ __forceinline__ void wave_prio() {
+#ifndef ARIA_EMU
+    __builtin_amdgcn_s_setprio(P);
+#endif
+}
+__device__ __forceinline__ void sched_fence() {
+#ifndef ARIA_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
 // 2^x straight on v_exp_f32 (no denormal range fix-up: results below 2^-126 flush to 0, which is what softmax wants)

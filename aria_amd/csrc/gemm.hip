@@ -258,6 +258,7 @@ int launch_gemm(const GemmParams& p, int a_oc, int b_oc, int grid_x, int grid_y,
     return aria_check_launch();
 }
 
+thread_local int g_last_variant = 0;
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // v1 (128x128 tiles, 3 blocks/CU) wins when the 256x256 grid would not fill the chip; v2 otherwise.
@@ -269,12 +270,36 @@ bool use_v2(long long tiles256) {
     return tiles256 >= 192;
 }
 
+// v3 (LDS-DMA staged, phase-scheduled 256x256 tile, gemm3.hip): K must be a whole number of 64-deep tiles and the operand
+// byte offsets must fit 32 bits.  ARIA_GEMM_FORCE=3 pins it where eligible.
+bool use_v3(long long tiles256, long long K, long long bytesA, long long bytesB, long long extentA, long long extentB) {
+    if (K < 64 || (K & 63) || bytesA >= (1ll << 32) || bytesB >= (1ll << 32) || extentA < 8 || extentB < 8) return false;
+    const char* force = std::getenv("ARIA_GEMM_FORCE");
+    if (force) return force[0] == '3';
+    const char* v3 = std::getenv("ARIA_GEMM_V3");  // "0" switches the default off (A/B measurements)
+    if (v3 && v3[0] == '0') return false;
+    return tiles256 >= 192;
+}
+
 }  // namespace
 
 extern "C" {
 
+int aria_last_gemm_variant(void) { return g_last_variant; }
+
+int64_t aria_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int a_oc, int b_oc) {
+    if (M <= 0 || N <= 0 || (a_oc && !b_oc)) return 0;
+    return aria_gemm3_workspace_bytes(M, N, K);
+}
+
 int aria_gemm_bf16(const void* A, const void* B, void* C, const void* bias, int64_t M, int64_t N, int64_t K, int a_oc,
                    int b_oc, int64_t lda, int64_t ldb, int64_t ldc, int c_f32, int accumulate, void* stream) {
+    return aria_gemm_bf16_ws(A, B, C, bias, M, N, K, a_oc, b_oc, lda, ldb, ldc, c_f32, accumulate, nullptr, 0, stream);
+}
+
+int aria_gemm_bf16_ws(const void* A, const void* B, void* C, const void* bias, int64_t M, int64_t N, int64_t K, int a_oc,
+                      int b_oc, int64_t lda, int64_t ldb, int64_t ldc, int c_f32, int accumulate, void* workspace,
+                      int64_t workspace_bytes, void* stream) {
     if (!A || !B || !C || M < 0 || N < 0 || K < 0) return ARIA_ERR_INVALID;
     if (M == 0 || N == 0) return ARIA_OK;
     if (!aligned16(A) || !aligned16(B) || (lda & 7) || (ldb & 7) || (N & 1) || (ldc & 1)) return ARIA_ERR_ALIGN;
@@ -298,8 +323,14 @@ int aria_gemm_bf16(const void* A, const void* B, void* C, const void* bias, int6
     p.ntn = int((N + BN - 1) / BN);
     const int ntm = int((M + BM - 1) / BM);
     const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
-    if (use_v2(t256)) return aria_launch_gemm2(p, a_oc, b_oc, int((M + 255) / 256), 1, stream);
-    return launch_gemm(p, a_oc, b_oc, p.ntn * ntm, 1, stream);
+    const long long bytesA = 2 * (a_oc ? K * lda : M * lda), bytesB = 2 * (b_oc ? K * ldb : N * ldb);
+    // with a workspace the partly filled last round of tiles is split along K (gemm3.hip), so small outputs fill the chip too
+    const long long ws_need = workspace ? aria_gemm3_workspace_bytes(M, N, K) : 0;
+    const bool splits = ws_need > 0 && workspace_bytes >= ws_need;
+    if ((!a_oc || b_oc) && use_v3(splits ? (t256 < 192 ? 192 : t256) : t256, K, bytesA, bytesB, M, N))
+        return g_last_variant = 3, aria_launch_gemm3(p, a_oc, b_oc, int((M + 255) / 256), stream, workspace, workspace_bytes);
+    if (use_v2(t256)) return g_last_variant = 2, aria_launch_gemm2(p, a_oc, b_oc, int((M + 255) / 256), 1, stream);
+    return g_last_variant = 1, launch_gemm(p, a_oc, b_oc, p.ntn * ntm, 1, stream);
 }
 
 int aria_grouped_gemm_bf16(const void* A, const void* B, void* C, const int32_t* offsets, int64_t E, int64_t M_total,
@@ -326,8 +357,12 @@ int aria_grouped_gemm_bf16(const void* A, const void* B, void* C, const int32_t*
     p.ntn = int((N + BN - 1) / BN);
     // every expert adds at most one partial row tile
     const int max_tm = int(M_total / BM + E);
-    if (use_v2((M_total / 256 + 1) * ((N + 255) / 256))) return aria_launch_gemm2(p, 0, b_oc, int(M_total / 256 + E), 1, stream);
-    return launch_gemm(p, 0, b_oc, p.ntn * max_tm, 1, stream);
+    const char* force3 = std::getenv("ARIA_GEMM_FORCE");
+    const bool v3_grouped = !b_oc || (force3 && force3[0] == '3');  // [K][N] weights: v3 measured level with v2, keep v2
+    if (v3_grouped && use_v3((M_total / 256 + 1) * ((N + 255) / 256), K, 2 * M_total * lda, 2 * (b_oc ? K * ldb : N * ldb), M_total, N))
+        return g_last_variant = 3, aria_launch_gemm3(p, 0, b_oc, int(M_total / 256 + E), stream);
+    if (use_v2((M_total / 256 + 1) * ((N + 255) / 256))) return g_last_variant = 2, aria_launch_gemm2(p, 0, b_oc, int(M_total / 256 + E), 1, stream);
+    return g_last_variant = 1, launch_gemm(p, 0, b_oc, p.ntn * max_tm, 1, stream);
 }
 
 int aria_grouped_gemm_wgrad_bf16(const void* A, const void* dY, void* dW, const int32_t* offsets, int64_t E, int64_t K,
@@ -353,8 +388,8 @@ int aria_grouped_gemm_wgrad_bf16(const void* A, const void* dY, void* dW, const 
     p.accumulate = accumulate;
     p.ntn = int((N + BN - 1) / BN);
     const int ntm = int((K + BM - 1) / BM);
-    if (use_v2(((K + 255) / 256) * ((N + 255) / 256) * E)) return aria_launch_gemm2(p, 1, 1, int((K + 255) / 256), int(E), stream);
-    return launch_gemm(p, 1, 1, p.ntn * ntm, int(E), stream);
+    if (use_v2(((K + 255) / 256) * ((N + 255) / 256) * E)) return g_last_variant = 2, aria_launch_gemm2(p, 1, 1, int((K + 255) / 256), int(E), stream);
+    return g_last_variant = 1, launch_gemm(p, 1, 1, p.ntn * ntm, int(E), stream);
 }
 
 }  // extern "C"

@@ -90,9 +90,31 @@ __device__ __forceinline__ s16x8 frag(const bf16_t* s, int row0, int kk, int l) 
     }
 }
 
-template <bool A_OC, bool B_OC, int NW>
-__device__ __forceinline__ void compute_tile(f32x16 (&acc)[4][WCfg<NW>::NJ], const bf16_t* sA, const bf16_t* sB, int l, int wm, int wn) {
+// EDGE (block-uniform): the tile hangs over the end of its row group / of N; 32x32 MFMA tiles that lie wholly outside are
+// skipped with their fragment reads (wave-uniform tests) -- a grouped GEMM's last row tile per expert is mostly empty.
+template <bool A_OC, bool B_OC, int NW, bool EDGE>
+__device__ __forceinline__ void compute_tile(f32x16 (&acc)[4][WCfg<NW>::NJ], const bf16_t* sA, const bf16_t* sB, int l, int wm, int wn,
+                                             int rows_left, int cols_left) {
     constexpr int NJ = WCfg<NW>::NJ, WNW = WCfg<NW>::WNW;
+    if (EDGE) {
+        if (rows_left <= 0 || cols_left <= 0) return;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            s16x8 af[4], bf[NJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i * 32 < rows_left) af[i] = frag<A_OC>(sA, wm * 128 + i * 32, kk, l);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (j * 32 < cols_left) bf[j] = frag<B_OC>(sB, wn * WNW + j * 32, kk, l);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (i * 32 < rows_left && j * 32 < cols_left) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+        }
+        return;
+    }
     // fragments are double-buffered in registers: the LDS reads of k-substep kk+1 are in flight under the MFMAs of kk
     s16x8 af[2][4], bf[2][NJ];
 #pragma unroll
@@ -114,36 +136,46 @@ __device__ __forceinline__ void compute_tile(f32x16 (&acc)[4][WCfg<NW>::NJ], con
     }
 }
 
+// FULL: the tile's rows and columns are all in range.  ktail: the LAST K-step is partial (grouped-K wgrad: an expert's token
+// count is arbitrary) -- only that step pays for predicated loads, every other one streams unpredicated.
+template <bool A_OC, bool B_OC, bool FULL, int NW>
+__device__ __forceinline__ void load_step(u32x4 (&ra)[WCfg<NW>::SP], u32x4 (&rb)[WCfg<NW>::SP], const bf16_t* A, const bf16_t* B,
+                                          long long lda, long long ldb, int m0, int m_end, int n0, int N, int k0, int k_end, int t,
+                                          bool partial) {
+    if (FULL && !partial) {
+        load_tile<A_OC, true, NW>(ra, A, lda, m0, m_end, k0, k_end, t);
+        load_tile<B_OC, true, NW>(rb, B, ldb, n0, N, k0, k_end, t);
+    } else {
+        load_tile<A_OC, false, NW>(ra, A, lda, m0, m_end, k0, k_end, t);
+        load_tile<B_OC, false, NW>(rb, B, ldb, n0, N, k0, k_end, t);
+    }
+}
+
 template <bool A_OC, bool B_OC, bool STAGE_FIRST, bool FULL, int NW>
 __device__ __forceinline__ void k_loop(f32x16 (&acc)[4][WCfg<NW>::NJ], bf16_t* sbase, const bf16_t* A, const bf16_t* B, long long lda,
                                        long long ldb, int m0, int m_end, int n0, int N, int k_begin, int k_end, int nk, int t, int l,
-                                       int wm, int wn) {
+                                       int wm, int wn, bool ktail) {
+    const int rows_left = m_end - m0 - wm * 128, cols_left = N - n0 - wn * WCfg<NW>::WNW;
     u32x4 ra[WCfg<NW>::SP], rb[WCfg<NW>::SP];
     if (nk > 0) {
-        load_tile<A_OC, FULL, NW>(ra, A, lda, m0, m_end, k_begin, k_end, t);
-        load_tile<B_OC, FULL, NW>(rb, B, ldb, n0, N, k_begin, k_end, t);
+        load_step<A_OC, B_OC, FULL, NW>(ra, rb, A, B, lda, ldb, m0, m_end, n0, N, k_begin, k_end, t, ktail && nk == 1);
         store_tile<A_OC, NW>(ra, sbase, t);
         store_tile<B_OC, NW>(rb, sbase + TILE_ELEMS, t);
-        if (nk > 1) {
-            load_tile<A_OC, FULL, NW>(ra, A, lda, m0, m_end, k_begin + BK, k_end, t);
-            load_tile<B_OC, FULL, NW>(rb, B, ldb, n0, N, k_begin + BK, k_end, t);
-        }
+        if (nk > 1) load_step<A_OC, B_OC, FULL, NW>(ra, rb, A, B, lda, ldb, m0, m_end, n0, N, k_begin + BK, k_end, t, ktail && nk == 2);
     }
     for (int kt = 0; kt < nk; ++kt) {
         sync();  // tile kt is complete in buffer kt&1; nobody still reads the other buffer
         const bf16_t* sA = sbase + (kt & 1) * 2 * TILE_ELEMS;
         bf16_t* nA = sbase + ((kt + 1) & 1) * 2 * TILE_ELEMS;
-        if (!STAGE_FIRST) compute_tile<A_OC, B_OC, NW>(acc, sA, sA + TILE_ELEMS, l, wm, wn);
+        if (!STAGE_FIRST) compute_tile<A_OC, B_OC, NW, !FULL>(acc, sA, sA + TILE_ELEMS, l, wm, wn, rows_left, cols_left);
         if (kt + 1 < nk) {
             store_tile<A_OC, NW>(ra, nA, t);
             store_tile<B_OC, NW>(rb, nA + TILE_ELEMS, t);
         }
-        if (kt + 2 < nk) {
-            const int k0 = k_begin + (kt + 2) * BK;
-            load_tile<A_OC, FULL, NW>(ra, A, lda, m0, m_end, k0, k_end, t);
-            load_tile<B_OC, FULL, NW>(rb, B, ldb, n0, N, k0, k_end, t);
-        }
-        if (STAGE_FIRST) compute_tile<A_OC, B_OC, NW>(acc, sA, sA + TILE_ELEMS, l, wm, wn);
+        if (kt + 2 < nk)
+            load_step<A_OC, B_OC, FULL, NW>(ra, rb, A, B, lda, ldb, m0, m_end, n0, N, k_begin + (kt + 2) * BK, k_end, t,
+                                            ktail && kt + 3 == nk);
+        if (STAGE_FIRST) compute_tile<A_OC, B_OC, NW, !FULL>(acc, sA, sA + TILE_ELEMS, l, wm, wn, rows_left, cols_left);
     }
 }
 
@@ -155,22 +187,8 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmParams p) {
     const int t = threadIdx.x, l = t & 63, w = t >> 6, wm = NW == 8 ? w >> 2 : w >> 1, wn = NW == 8 ? w & 3 : w & 1;
 
     // XCD-aware bijective remap of the workgroup id
-    int tile = blockIdx.x;
-    if (p.order != 1) {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    int tn = tile % p.ntn;
-    int tmi = tile / p.ntn;
-    if (p.order >= 2) {  // groups of GM row-tiles, column-major inside a group: concurrent tiles form a GM x (32/GM) patch
-        const int GM = p.order, per = GM * p.ntn;
-        const int g = tile / per, in = tile % per;
-        const int ntm_total = gridDim.x / p.ntn;
-        const int gm = min(GM, ntm_total - g * GM);
-        tn = in / gm;
-        tmi = g * GM + in % gm;
-    }
+    int tn, tmi;
+    if (!aria_tile_coords(p, blockIdx.x, gridDim.x, tmi, tn)) return;
     const bf16_t* A = p.A;
     const int csz = p.c_f32 ? 4 : 2;
     long long b_off = 0, c_off = 0;
@@ -233,21 +251,22 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (k_end - k_begin + BK - 1) / BK;
-    const bool full = (m0 + BM <= m_end) && (n0 + BN <= p.N) && ((k_end - k_begin) % BK == 0);
+    const bool full = (m0 + BM <= m_end) && (n0 + BN <= p.N);
+    const bool ktail = (k_end - k_begin) % BK != 0;
     // The two waves that share a SIMD (w and w+4) run the K-step in opposite orders: waves 0-3 stage the next tile
     // (LDS writes + HBM loads) and then compute, waves 4-7 compute and then stage -- one of the two is always feeding
     // the matrix pipe.  Legal because staging only touches the OTHER LDS buffer, which nobody reads between two barriers.
     const bool stage_first = NW == 4 || first_lane(w) < 4;
     if (full) {
         if (stage_first)
-            k_loop<A_OC, B_OC, true, true, NW>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
+            k_loop<A_OC, B_OC, true, true, NW>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn, ktail);
         else
-            k_loop<A_OC, B_OC, false, true, NW>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
+            k_loop<A_OC, B_OC, false, true, NW>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn, ktail);
     } else {
         if (stage_first)
-            k_loop<A_OC, B_OC, true, false, NW>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
+            k_loop<A_OC, B_OC, true, false, NW>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn, ktail);
         else
-            k_loop<A_OC, B_OC, false, false, NW>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn);
+            k_loop<A_OC, B_OC, false, false, NW>(acc, sbase, A, B, p.lda, p.ldb, m0, m_end, n0, p.N, k_begin, k_end, nk, t, l, wm, wn, ktail);
     }
 
     // ---- epilogue: bias, pair exchange so every lane owns two adjacent columns of one row, (accumulate), round, store
@@ -296,27 +315,18 @@ int aria_launch_gemm2(const GemmParams& p, int a_oc, int b_oc, int ntm, int grid
     const int ntn = (p.N + BN - 1) / BN;
     GemmParams q = p;
     q.ntn = ntn;
+    q.ntm = ntm;
     const char* ord = std::getenv("ARIA_GEMM_ORDER");
     q.order = ord ? std::atoi(ord) : 2;  // measured best on MI355X (profiles/r01_gemm_tuning.md)
-    const char* nwv = std::getenv("ARIA_GEMM_WAVES");
-    const int nw = nwv ? std::atoi(nwv) : 8;
-    dim3 grid(unsigned(ntn * ntm), unsigned(grid_y)), block(nw * 64);
     if (ntn * ntm <= 0 || grid_y <= 0) return ARIA_OK;
+    dim3 grid(unsigned(aria_tile_grid(q)), unsigned(grid_y)), block(512);
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
-    if (nw == 4) {
-        if (!a_oc && !b_oc)
-            ARIA_LAUNCH((gemm2_kernel<false, false, 4>), grid, block, shmem, stream, q);
-        else if (!a_oc && b_oc)
-            ARIA_LAUNCH((gemm2_kernel<false, true, 4>), grid, block, shmem, stream, q);
-        else
-            ARIA_LAUNCH((gemm2_kernel<true, true, 4>), grid, block, shmem, stream, q);
-    } else {
-        if (!a_oc && !b_oc)
-            ARIA_LAUNCH((gemm2_kernel<false, false, 8>), grid, block, shmem, stream, q);
-        else if (!a_oc && b_oc)
-            ARIA_LAUNCH((gemm2_kernel<false, true, 8>), grid, block, shmem, stream, q);
-        else
-            ARIA_LAUNCH((gemm2_kernel<true, true, 8>), grid, block, shmem, stream, q);
-    }
+    // (a 4-wave variant with 128x128 wave tiles was measured slower -- profiles/r01_gemm_tuning.md -- and is not instantiated)
+    if (!a_oc && !b_oc)
+        ARIA_LAUNCH((gemm2_kernel<false, false, 8>), grid, block, shmem, stream, q);
+    else if (!a_oc && b_oc)
+        ARIA_LAUNCH((gemm2_kernel<false, true, 8>), grid, block, shmem, stream, q);
+    else
+        ARIA_LAUNCH((gemm2_kernel<true, true, 8>), grid, block, shmem, stream, q);
     return aria_check_launch();
 }

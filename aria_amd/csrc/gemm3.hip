@@ -1,0 +1,461 @@
+// GEMM v3 for gfx950: 256x256x64 block tile, 8 waves, operands staged by LDS-DMA (global_load_lds_dwordx4) with a COUNTED
+// vmcnt, and a K-step cut into four barrier-delimited phases so that exactly one of the two waves that share a SIMD is in
+// its MFMA section while the other one issues LDS reads and the next DMA pieces.
+//
+// Why (measured on MI355X, profiles/r01_gemm_tuning.md): in v2 (register staging, one __syncthreads per K-step) the MFMA +
+// fragment-read section alone costs 3350 cycles per K-step against 2048 of pure MFMA issue, and the staging section (global
+// loads -> VGPRs -> ds_write_b128) adds 1900 more that do not overlap.  Here there are no staging VGPRs and no ds_write pass,
+// two half-tiles stay in flight across every barrier, and the barriers alternate the two wave groups on the matrix pipe.
+//
+// Geometry.  Wave (wm, wn), wm = w >> 2, wn = w & 3, owns rows {a*128 + wm*64 + [0,64)} x cols {b*128 + wn*32 + [0,32)},
+// a, b in {0,1}: four 64x32 quadrants, each = 2 x v_mfma_f32_32x32x16_bf16 tiles x 4 k-substeps.  A "half" of an operand
+// tile is 128 rows x 64 k (16 KiB); every wave needs BOTH halves of A and of B, one quadrant per phase:
+//
+//   phase 1: quadrant (A0,B0)  reads B0 (4 fragments) + A0 (8)      DMA: A1 of tile t+1 -> other buffer (last read: phase 3 of t-1)
+//   phase 2: quadrant (A0,B1)  reads B1 (4)                          DMA: B0 of tile t+1 -> other buffer (last read: phase 4 of t-1)
+//   phase 3: quadrant (A1,B1)  reads A1 (8)                          DMA: A0 of tile t+2 -> this buffer  (last read: phase 1)
+//   phase 4: quadrant (A1,B0)  reads B0 (4)                          DMA: B1 of tile t+2 -> this buffer  (last read: phase 2),
+//                                                                         then s_waitcnt vmcnt(4)
+//
+// so each half-tile slot is refilled TWO phases after its last read (its readers' lgkmcnt(0) is two barriers back for either
+// wave group) and every piece has >= 2 phases to land.  The single vmcnt(4) per K-step leaves the two newest half-tiles
+// (2 pieces per wave each) in flight and retires everything tile t+1 needs; the barrier that follows publishes it.
+// Every phase is
+//
+//   ds_reads | 2 DMA pieces | s_barrier | s_waitcnt lgkmcnt(0) | s_setprio 1 | 8 MFMA | s_setprio 0 | s_barrier
+//
+// and waves 4-7 run one barrier behind waves 0-3, so group 0's MFMA section coincides with group 1's read/DMA section and
+// the LDS latency of one group's reads hides under the other group's read issue.
+//
+// LDS images (128 KiB: operand x half x buffer x 16 KiB).  LDS-DMA writes lane-linearly (wave-uniform base + 16 * lane), so
+// padding is impossible; bank conflicts are avoided by permuting the SOURCE granules instead:
+//   rc operand ([rows][k], k contiguous): row r = 128 B; 16-byte chunk c is stored at chunk c ^ ((r >> 1) & 7) -> the 16 lanes
+//     of every ds_read_b128 service group hit 16 different 16-byte bank groups.
+//   oc operand ([k][rows], rows contiguous, e.g. expert weights [K][N]): k-row = 256 B; 64-byte chunk c is stored at
+//     c ^ (k & 3) -> the four k-rows of a ds_read_b64_tr_b16 (hardware transpose) land in different bank quarters.
+// Both permutations keep every 64/128-byte segment of a cache line inside one DMA instruction (fully coalesced).
+//
+// Scope: K % 64 == 0, modes 0 (dense) and 1 (grouped rows); everything else runs on v2/v1 (gemm2.hip / gemm.hip).  Rows or
+// columns beyond the edge are CLAMPED to the last valid one (the products land in accumulators that are never stored).
+#include "aria_hip.h"
+#include "gemm_params.h"
+#include <cstdlib>
+
+namespace {
+using namespace ad;
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int LDS_OPERAND = 65536, LDS_HALF = 32768, LDS_BUF = 16384;  // byte strides: operand (A,B) / half / buffer
+
+// byte offset (from the operand base pointer, at k = 0) of the 16 bytes lane l of wave w fetches for piece s of a half-tile
+template <bool OC>
+__device__ __forceinline__ uint32_t piece_offset(int s, int w, int l, int first, int limit, long long ld) {
+    const int q = 2 * w + s;  // 1-KiB piece index inside the half-tile
+    if (!OC) {
+        const int r = q * 8 + (l >> 3);
+        const int row = min(first + r, limit - 1);
+        const int chunk = (l & 7) ^ ((r >> 1) & 7);
+        return uint32_t((row * ld + chunk * 8) * 2);
+    } else {
+        const int k = q * 4 + (l >> 4);
+        const int chunk = ((l & 15) >> 2) ^ (k & 3);
+        const int col = min(first + chunk * 32 + (l & 3) * 8, limit - 8);
+        return uint32_t((k * ld + col) * 2);
+    }
+}
+
+// lane-dependent part of the fragment addresses inside a half-tile image (bytes)
+template <bool OC>
+struct FragAddr {
+    uint32_t v[4];
+    __device__ __forceinline__ void init(int tile_base, int l) {  // tile_base: first row of the wave's rows inside the half
+        if (!OC) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) v[kk] = uint32_t((tile_base + (l & 31)) * 128 + (((2 * kk + (l >> 5)) ^ ((l >> 1) & 7)) << 4));
+        } else {
+            const int k = 8 * (l >> 5) + ((l & 15) >> 2), within = 32 * ((l >> 4) & 1) + 8 * (l & 3);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) v[i] = uint32_t(k * 256 + ((((tile_base >> 5) + i) ^ (k & 3)) << 6) + within);
+            v[2] = v[3] = 0;
+        }
+    }
+    // fragment of rows tile_base + 32 i + (l & 31), k = 16 kk + 8 (l >> 5) + 0..7
+    __device__ __forceinline__ s16x8 read(const char* half, int i, int kk) const {
+        if (!OC) {
+            return *reinterpret_cast<const s16x8*>(half + v[kk] + i * 4096);
+        } else {
+            const bf16_t* p = reinterpret_cast<const bf16_t*>(half + v[i] + kk * 4096);
+            const s16x4 a0 = ds_read_tr16(p);
+            const s16x4 a1 = ds_read_tr16(p + 512);  // four k-rows further
+            s16x8 f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[e] = a0[e];
+                f[4 + e] = a1[e];
+            }
+            return f;
+        }
+    }
+};
+
+struct Stage {  // everything a wave needs to issue its two DMA pieces of any half-tile
+    const char* gA;
+    const char* gB;
+    long long kstepA, kstepB;  // bytes per K-tile along k
+    uint32_t offA[2][2], offB[2][2];  // [half][piece]
+    char* lds;                        // smem + 2048 * w  (wave-uniform)
+};
+
+template <int OPERAND, int HALF, int BUF>
+__device__ __forceinline__ void stage_half(const Stage& st, int tile) {
+    const char* g = (OPERAND == 0 ? st.gA + tile * st.kstepA : st.gB + tile * st.kstepB);
+    char* d = st.lds + OPERAND * LDS_OPERAND + HALF * LDS_HALF + BUF * LDS_BUF;
+    const uint32_t o0 = OPERAND == 0 ? st.offA[HALF][0] : st.offB[HALF][0];
+    const uint32_t o1 = OPERAND == 0 ? st.offA[HALF][1] : st.offB[HALF][1];
+    glds16(g + o0, d);
+    glds16(g + o1, d + 1024);
+}
+
+// One phase: quadrant (QA, QB) of the K-tile in buffer BUF.  SO/SH/SB: operand, half, buffer of the DMA issued here.
+// EDGE (block-uniform): the tile hangs over the edge of its row group / of N; 32-row and 32-column MFMA tiles that are wholly
+// outside (wave-uniform tests on rows_left / cols_left, counted from the wave's first row / column) are skipped together with
+// their fragment reads -- a grouped GEMM's last row tile per expert usually holds only a few rows.
+template <bool A_OC, bool B_OC, int QA, int QB, bool LOAD_A, bool LOAD_B, int BUF, int SO, int SH, int SB, bool WAIT, bool EDGE>
+__device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[4], const FragAddr<A_OC>& aa,
+                                      const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int stage_tile, bool do_stage,
+                                      bool more_in_flight, int rows_left, int cols_left) {
+    const bool col_ok = !EDGE || QB * 128 < cols_left;
+    const bool row_ok[2] = {!EDGE || QA * 128 < rows_left, !EDGE || QA * 128 + 32 < rows_left};
+    if (LOAD_B && (!EDGE || (col_ok && rows_left > 0))) {
+        const char* hb = smem + LDS_OPERAND + QB * LDS_HALF + BUF * LDS_BUF;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fb[kk] = ab.read(hb, 0, kk);
+    }
+    sched_fence();
+    if (LOAD_A) {
+        const char* ha = smem + QA * LDS_HALF + BUF * LDS_BUF;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (row_ok[i]) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) fa[i][kk] = aa.read(ha, i, kk);
+            }
+    }
+    sched_fence();
+    if (do_stage) stage_half<SO, SH, SB>(st, stage_tile);
+    if (WAIT) {
+        if (more_in_flight)
+            wait_vm<4>();
+        else
+            wait_vm<0>();
+    }
+    raw_barrier();
+    wait_lds();
+    wave_prio<1>();
+    if (!EDGE) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[QA][i][QB] = mfma32(fa[i][kk], fb[kk], acc[QA][i][QB]);
+    } else if (col_ok) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (row_ok[i]) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc[QA][i][QB] = mfma32(fa[i][kk], fb[kk], acc[QA][i][QB]);
+            }
+    }
+    wave_prio<0>();
+    raw_barrier();
+}
+
+template <bool A_OC, bool B_OC, int BUF, bool EDGE>
+__device__ __forceinline__ void k_tile(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[4], const FragAddr<A_OC>& aa,
+                                       const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int t, int nk, int rl, int cl) {
+    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+    phase<A_OC, B_OC, 0, 0, true, true, BUF, 0, 1, BUF ^ 1, false, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
+    phase<A_OC, B_OC, 0, 1, false, true, BUF, 1, 0, BUF ^ 1, false, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
+    phase<A_OC, B_OC, 1, 1, true, false, BUF, 0, 0, BUF, false, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, false, rl, cl);
+    phase<A_OC, B_OC, 1, 0, false, true, BUF, 1, 1, BUF, true, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, n2, rl, cl);
+}
+
+template <bool A_OC, bool B_OC, bool EDGE>
+__device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[4], const FragAddr<A_OC>& aa,
+                                        const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int nk, int rl, int cl) {
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        k_tile<A_OC, B_OC, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
+        k_tile<A_OC, B_OC, 1, EDGE>(acc, fa, fb, aa, ab, smem, st, kt + 1, nk, rl, cl);
+    }
+    if (kt < nk) k_tile<A_OC, B_OC, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
+}
+
+template <bool A_OC, bool B_OC>
+__global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
+    ARIA_DYN_SMEM(smem);
+    const int t = threadIdx.x, l = t & 63, w = first_lane(t >> 6), wm = w >> 2, wn = w & 3;
+
+    // XCD-aware bijective remap of the workgroup id + grouped tile order (same scheme as v2)
+    int tn, tmi, slab = -1, ks = 0;  // slab >= 0: this workgroup computes one K range of a split tile into ws
+    if (p.split > 1 && int(blockIdx.x) >= p.split_first) {
+        const int r = blockIdx.x - p.split_first;
+        slab = r;
+        ks = r % p.split;
+        if (!aria_tile_from_pos(p, p.split_first + r / p.split, tmi, tn)) return;
+    } else if (!aria_tile_coords(p, blockIdx.x, p.split > 1 ? p.split_first : int(gridDim.x), tmi, tn)) {
+        return;
+    }
+    const int csz = p.c_f32 ? 4 : 2;
+    long long b_off = 0;
+    int m0 = 0, m_end = 0;
+    const int n0 = tn * BN;
+    if (p.mode == 0) {
+        m0 = tmi * BM;
+        m_end = p.M;
+        if (m0 >= m_end) return;
+    } else {
+        int e_found = -1, start = 0, end = 0, base = 0;
+        for (int e0 = 0; e0 < p.E && e_found < 0; e0 += 64) {
+            const int e = e0 + l;
+            int o0 = 0, o1 = 0;
+            if (e < p.E) {
+                o0 = p.offsets[e];
+                o1 = p.offsets[e + 1];
+            }
+            const int nt = (o1 - o0 + BM - 1) / BM;
+            int incl = nt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = shfl(incl, (l - d) & 63);
+                if (l >= d) incl += v;
+            }
+            const int excl = base + incl - nt;
+            const bool mine = e < p.E && tmi >= excl && tmi < excl + nt;
+            const unsigned long long mask = ballot(mine);
+            if (mask) {
+                const int src = __builtin_ctzll(mask);
+                e_found = e0 + src;
+                start = shfl(o0, src);
+                end = shfl(o1, src);
+                tmi -= shfl(excl, src);
+            }
+            base += shfl(incl, 63);
+        }
+        if (e_found < 0) return;
+        m0 = start + tmi * BM;
+        m_end = end;
+        b_off = (long long)e_found * p.strideB;
+    }
+    char* C = static_cast<char*>(p.C);
+    int nk = p.K / BK, kt_first = 0;
+    if (slab >= 0) {  // K-steps [nk * ks / split, nk * (ks + 1) / split)
+        kt_first = int((long long)nk * ks / p.split);
+        nk = int((long long)nk * (ks + 1) / p.split) - kt_first;
+    }
+
+    Stage st;
+    st.kstepA = A_OC ? 2 * BK * p.lda : 2 * BK;
+    st.kstepB = B_OC ? 2 * BK * p.ldb : 2 * BK;
+    st.gA = reinterpret_cast<const char*>(p.A) + kt_first * st.kstepA;
+    st.gB = reinterpret_cast<const char*>(p.B + b_off) + kt_first * st.kstepB;
+    st.lds = smem + 2048 * w;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            st.offA[h][s] = piece_offset<A_OC>(s, w, l, m0 + h * 128, p.M, p.lda);
+            st.offB[h][s] = piece_offset<B_OC>(s, w, l, n0 + h * 128, p.N, p.ldb);
+        }
+    FragAddr<A_OC> aa;
+    FragAddr<B_OC> ab;
+    aa.init(wm * 64, l);
+    ab.init(wn * 32, l);
+
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
+    s16x8 fa[2][4], fb[4];
+
+    // ---- prologue: tile 0 completely, A0 and B1 of tile 1 (phases 1 and 2 of tile 0 issue its A1 and B0) -- the steady-state
+    // queue shape
+    stage_half<0, 0, 0>(st, 0);
+    stage_half<1, 0, 0>(st, 0);
+    stage_half<1, 1, 0>(st, 0);
+    stage_half<0, 1, 0>(st, 0);
+    if (nk > 1) {
+        stage_half<0, 0, 1>(st, 1);
+        stage_half<1, 1, 1>(st, 1);
+        wait_vm<4>();
+    } else {
+        wait_vm<0>();
+    }
+    raw_barrier();
+    if (wm == 1) raw_barrier();  // waves 4-7 run one barrier behind waves 0-3
+
+    // rows / columns of this wave's part of half 0 that are in range (half 1 lies 128 further)
+    const int rows_left = m_end - m0 - wm * 64, cols_left = p.N - n0 - wn * 32;
+    if (m0 + BM <= m_end && n0 + BN <= p.N)
+        k_loop3<A_OC, B_OC, false>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
+    else
+        k_loop3<A_OC, B_OC, true>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
+    if (wm == 0) raw_barrier();  // balance the barrier count of the two groups
+
+    const int c = l & 31, h = l >> 5, odd = l & 1;
+    if (slab >= 0) {  // raw fp32 partial sums, tile-shaped [256][256]; gemm3_reduce_kernel finishes the job
+        float* dst = p.ws + (long long)slab * (BM * BN);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        dst[(a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + b * 128 + wn * 32 + c] = acc[a][i][b][r];
+        return;
+    }
+    // ---- epilogue: bias, pair exchange so every lane owns two adjacent columns of one row, (accumulate), round, store
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + b * 128 + wn * 32 + c;
+        const float bv = (p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f;
+        const int npair = n & ~1;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {  // register pair (2rp, 2rp+1) = two consecutive rows
+                    const float v0 = acc[a][i][b][2 * rp] + bv, v1 = acc[a][i][b][2 * rp + 1] + bv;
+                    const int r = 2 * rp;
+                    const int mrow = m0 + a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (p.c_f32) {
+                        if (n < p.N) {
+                            float* d0 = reinterpret_cast<float*>(C) + (long long)mrow * p.ldc + n;
+                            if (mrow < m_end) *d0 = p.accumulate ? *d0 + v0 : v0;
+                            if (mrow + 1 < m_end) d0[p.ldc] = p.accumulate ? d0[p.ldc] + v1 : v1;
+                        }
+                    } else {
+                        const float got = shfl_xor(odd ? v0 : v1, 1);   // wave-uniform control flow: every lane exchanges
+                        const int m = mrow + odd;
+                        float lo = odd ? got : v0, hi = odd ? v1 : got;  // columns npair, npair+1 of row m
+                        if (m < m_end && npair < p.N) {
+                            uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + npair);
+                            if (p.accumulate) {
+                                const uint32_t old = *dst;
+                                lo += bflo(old);
+                                hi += bfhi(old);
+                            }
+                            *dst = pack2bf(lo, hi);
+                        }
+                    }
+                }
+            }
+    }
+    (void)csz;
+}
+
+// Sums the `split` slabs of every split tile in slab order (deterministic), then bias / accumulate / round exactly like the
+// main epilogue.  grid (split tiles, 16): block (r, part) finishes rows [16 part, 16 part + 16) of split tile r.
+__global__ __launch_bounds__(256) void gemm3_reduce_kernel(GemmParams p) {
+    int tn, tmi;
+    if (!aria_tile_from_pos(p, p.split_first + blockIdx.x, tmi, tn)) return;
+    const int t = threadIdx.x, col = (t & 63) * 4;
+    const float* ws = p.ws + (long long)blockIdx.x * p.split * (BM * BN);
+    const int n = tn * BN + col;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = blockIdx.y * 16 + (t >> 6) + 4 * it;
+        const int m = tmi * BM + row;
+        f32x4 sum = *reinterpret_cast<const f32x4*>(ws + row * BN + col);
+        for (int s = 1; s < p.split; ++s) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (long long)s * (BM * BN) + row * BN + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[e] += v[e];
+        }
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n + e >= p.N) continue;
+            float v = sum[e] + (p.bias ? bf2f(p.bias[n + e]) : 0.f);
+            if (p.c_f32) {
+                float* d = static_cast<float*>(p.C) + (long long)m * p.ldc + n + e;
+                *d = p.accumulate ? *d + v : v;
+            } else {
+                bf16_t* d = static_cast<bf16_t*>(p.C) + (long long)m * p.ldc + n + e;
+                if (p.accumulate) v += bf2f(*d);
+                *d = f2bf(v);
+            }
+        }
+    }
+}
+
+// Remainder split-K plan for a dense problem of `tiles` 256x256 tiles and nk K-steps: the last, partly filled round of
+// R = tiles mod 256 tiles (all of them when tiles < 256) leaves 256 - R CUs idle for a whole tile time; computing each of those R
+// tiles with S workgroups over K/S instead costs ceil(R S / 256) / S tile times plus the slab round trip (~1 MiB per slab pair
+// of write + read against ~K * 29 ns of tile time).  Returns S (1 = do not split).
+int plan_split(long long tiles, long long nk, long long* remainder) {
+    const long long R = tiles % 256;
+    *remainder = R;
+    if (R == 0 || nk < 16) return 1;
+    const double slab_cost = 4.5 * double(R) / double(nk * 64);  // tile times per unit of S
+    double best = 1.0;
+    int best_s = 1;
+    for (int S = 2; S <= 8 && nk / S >= 8; ++S) {
+        const double t = double((R * S + 255) / 256) / S + slab_cost * S;
+        if (t < best) {
+            best = t;
+            best_s = S;
+        }
+    }
+    return best < 0.9 ? best_s : 1;
+}
+
+}  // namespace
+
+long long aria_gemm3_workspace_bytes(long long M, long long N, long long K) {
+    if (K < 64 || (K & 63) || M < 256 || N < 256) return 0;  // at least one full tile each way (not the decode GEMVs)
+    long long R = 0;
+    const int S = plan_split(((M + 255) / 256) * ((N + 255) / 256), K / 64, &R);
+    return S > 1 ? R * S * (long long)(BM * BN) * 4 : 0;
+}
+
+// v3 eligibility is decided by the caller (gemm.hip): K % 64 == 0, K >= 64, mode 0 or 1, operand bytes < 4 GiB
+int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* stream, void* workspace, long long workspace_bytes) {
+    const size_t shmem = size_t(2) * LDS_OPERAND;
+    const int ntn = (p.N + BN - 1) / BN;
+    GemmParams q = p;
+    q.ntn = ntn;
+    q.ntm = ntm;
+    q.split = 1;
+    q.split_first = 0;
+    q.ws = nullptr;
+    long long R = 0;
+    if (p.mode == 0 && workspace) {
+        const int S = plan_split((long long)ntn * ntm, p.K / BK, &R);
+        if (S > 1 && workspace_bytes >= R * S * (long long)(BM * BN) * 4) {
+            q.split = S;
+            q.split_first = int((long long)ntn * ntm - R);
+            q.ws = static_cast<float*>(workspace);
+        }
+    }
+    const char* ord = std::getenv("ARIA_GEMM_ORDER");
+    q.order = ord ? std::atoi(ord) : 4;
+    if (ntn * ntm <= 0) return ARIA_OK;
+    if (a_oc && !b_oc) return ARIA_ERR_INVALID;
+    dim3 grid(unsigned(aria_tile_grid(q))), block(512);
+    if (!a_oc && !b_oc)
+        ARIA_LAUNCH((gemm3_kernel<false, false>), grid, block, shmem, stream, q);
+    else if (!a_oc && b_oc)
+        ARIA_LAUNCH((gemm3_kernel<false, true>), grid, block, shmem, stream, q);
+    else
+        ARIA_LAUNCH((gemm3_kernel<true, true>), grid, block, shmem, stream, q);
+    if (q.split > 1) ARIA_LAUNCH(gemm3_reduce_kernel, dim3(unsigned(R), 16), dim3(256), 0, stream, q);
+    return aria_check_launch();
+}

@@ -22,12 +22,16 @@ ERRORS = {
 }
 
 P, I64, I32, F32 = c_void_p, c_int64, c_int, c_float
+RESTYPES = {"aria_gemm_workspace_bytes": c_int64}  # everything else returns an int status
 
 # name -> argtypes (all return int).  Kept in one table so tests can check that the shared
 # library exports every symbol the header declares.
 SIGNATURES = {
     "aria_abi_version": [],
+    "aria_last_gemm_variant": [],
     "aria_gemm_bf16": [P, P, P, P, I64, I64, I64, I32, I32, I64, I64, I64, I32, I32, P],
+    "aria_gemm_bf16_ws": [P, P, P, P, I64, I64, I64, I32, I32, I64, I64, I64, I32, I32, P, I64, P],
+    "aria_gemm_workspace_bytes": [I64, I64, I64, I32, I32],
     "aria_grouped_gemm_bf16": [P, P, P, P, I64, I64, I64, I64, I32, I64, I64, I64, I64, P],
     "aria_grouped_gemm_wgrad_bf16": [P, P, P, P, I64, I64, I64, I64, I64, I32, I32, P],
     "aria_moe_route": [P, I32, P, P, P, I64, I64, I64, P],
@@ -85,7 +89,7 @@ class HipLibrary:
                 self.missing.append(name)
                 continue
             fn.argtypes = argtypes
-            fn.restype = c_int
+            fn.restype = RESTYPES.get(name, c_int)
 
     def call(self, name: str, *args) -> None:
         rc = getattr(self.cdll, name)(*args)

@@ -60,9 +60,30 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_oc: bool = False, b_oc: bool = F
     c_f32 = {bf16: 0, torch.float32: 1}[out.dtype]
     if bias is not None:
         _chk(bias, name="bias")
-    hip.get_lib().call("aria_gemm_bf16", _p(a), _p(b), _p(out), _p(bias), M, N, K, int(a_oc), int(b_oc), lda, ldb, ldc,
-                       c_f32, int(accumulate), _stream(a))
+    lib = hip.get_lib()
+    need = lib.cdll.aria_gemm_workspace_bytes(M, N, K, int(a_oc), int(b_oc)) if GEMM_SPLIT_K else 0
+    if need > 0:  # small outputs: let the library split the last round of tiles along K (fp32 slabs in a scratch buffer)
+        ws = _gemm_workspace(a.device, _stream(a), need)
+        lib.call("aria_gemm_bf16_ws", _p(a), _p(b), _p(out), _p(bias), M, N, K, int(a_oc), int(b_oc), lda, ldb, ldc,
+                 c_f32, int(accumulate), _p(ws), ws.numel(), _stream(a))
+    else:
+        lib.call("aria_gemm_bf16", _p(a), _p(b), _p(out), _p(bias), M, N, K, int(a_oc), int(b_oc), lda, ldb, ldc,
+                 c_f32, int(accumulate), _stream(a))
     return out
+
+
+_WORKSPACES = {}
+GEMM_SPLIT_K = True  # tools flip this off to compare kernels bit for bit (split-K changes the fp32 summation order)
+
+
+def _gemm_workspace(device, stream, nbytes: int) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, stream): launches on one stream are ordered, so they can share it."""
+    key = (str(device), int(stream or 0))
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = ws
+    return ws
 
 
 def grouped_gemm(a: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, *, w_is_kn: bool = True,

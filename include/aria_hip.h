@@ -28,6 +28,9 @@ extern "C" {
 
 /* Library / ABI version (bumped when a signature changes). */
 int aria_abi_version(void);
+/* Test/diagnostic aid: which GEMM kernel family the calling thread's last aria_*gemm* call dispatched to
+ * (1 = 128x128 tile, 2 = 256x256 register-staged, 3 = 256x256 LDS-DMA phase-scheduled; 0 = none yet). */
+int aria_last_gemm_variant(void);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM family (gemm.hip) -- v_mfma_f32_32x32x16_bf16, fp32 accumulate.
@@ -43,6 +46,14 @@ int aria_abi_version(void);
 int aria_gemm_bf16(const void* A, const void* B, void* C, const void* bias /* bf16[N] or NULL */, int64_t M, int64_t N,
                    int64_t K, int a_oc, int b_oc, int64_t lda, int64_t ldb, int64_t ldc, int c_f32, int accumulate,
                    void* stream);
+/* Same GEMM with a caller-owned scratch buffer.  When the 256x256 tile list ends in a partly filled round (e.g. a
+ * [2560,2560] weight gradient = 100 tiles on 256 CUs) those tiles are computed by several workgroups over disjoint K ranges
+ * into fp32 slabs in `workspace` and summed in a fixed order by a second kernel (deterministic).  aria_gemm_workspace_bytes
+ * returns the size that enables it for a problem (0: no split would be used); a NULL / too small workspace just disables it. */
+int64_t aria_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int a_oc, int b_oc);
+int aria_gemm_bf16_ws(const void* A, const void* B, void* C, const void* bias, int64_t M, int64_t N, int64_t K, int a_oc,
+                      int b_oc, int64_t lda, int64_t ldb, int64_t ldc, int c_f32, int accumulate, void* workspace,
+                      int64_t workspace_bytes, void* stream);
 
 /* experts_gemm(input, weight, tokens_per_expert)  -- seam B1, aria/model/moe_lm.py:431-443 (grouped_gemm.ops.gmm
  * or sequential_gemm :398-428), called from GroupedGEMM.forward :467-484.

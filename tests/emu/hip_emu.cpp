@@ -21,8 +21,33 @@ void yield(int state) {
     swapcontext(&cur->ctx, &sched_ctx);
 }
 
+struct PendingDma {
+    const void* src;
+    void* dst;
+};
+static std::vector<std::vector<PendingDma>> g_dma;  // per thread, oldest first
+static int g_glds_defer = 0;  // re-read from the environment at every launch (run_grid)
+static int glds_defer() { return g_glds_defer; }
+void glds(const void* src, void* dst) {
+    if (!glds_defer()) {
+        std::memcpy(dst, src, 16);
+        return;
+    }
+    if (g_dma.size() <= size_t(cur->linear)) g_dma.resize(cur->linear + 1);
+    g_dma[cur->linear].push_back({src, dst});
+}
+void wait_vm(int keep) {
+    if (g_dma.size() <= size_t(cur->linear)) return;
+    auto& q = g_dma[cur->linear];
+    while (q.size() > size_t(keep)) {
+        std::memcpy(q.front().dst, q.front().src, 16);
+        q.erase(q.begin());
+    }
+}
+
 static void trampoline() {
     g_entry(g_arg);
+    wait_vm(0);
     cur->state = DONE;
     swapcontext(&cur->ctx, &sched_ctx);
 }
@@ -117,6 +142,8 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, void (*entry)(void*), void* a
         abort();
     }
     if (!g_dyn_smem) g_dyn_smem = static_cast<char*>(aligned_alloc(256, kMaxSmem));
+    const char* defer = std::getenv("ARIA_EMU_GLDS_DEFER");
+    g_glds_defer = defer && defer[0] == '1';
     g_entry = entry;
     g_arg = arg;
     g_gridDim = grid;

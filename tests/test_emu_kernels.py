@@ -101,3 +101,39 @@ def test_gemm_v2_layouts(force_gemm_v2, M, N, K, a_oc, b_oc):
 @pytest.mark.parametrize("counts", [[3, 0, 130, 5, 0, 0, 300, 1], [0, 0], [1, 1, 1]])
 def test_grouped_gemm_v2(force_gemm_v2, counts):
     C.case_grouped_gemm(DEV, counts)
+
+
+# v3 (LDS-DMA staged, phase-scheduled).  The emulator's DMA model runs both ways: pieces land at once (a slot restaged too
+# early clobbers its last reader) and pieces land only when a counted vmcnt wait forces them (a read not covered by a wait
+# sees poison) -- together they bracket what the hardware may do.
+@pytest.fixture(params=["0", "1"], ids=["dma-early", "dma-late"])
+def force_gemm_v3(monkeypatch, request):
+    monkeypatch.setenv("ARIA_GEMM_FORCE", "3")
+    monkeypatch.setenv("ARIA_EMU_GLDS_DEFER", request.param)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (264, 136, 192), (40, 520, 128), (256, 256, 320)])
+@pytest.mark.parametrize("a_oc,b_oc", [(False, False), (False, True), (True, True)])
+def test_gemm_v3_layouts(force_gemm_v3, M, N, K, a_oc, b_oc):
+    from aria_amd import hip
+
+    C.case_gemm_layouts(DEV, M, N, K, a_oc, b_oc)
+    assert hip.get_lib().cdll.aria_last_gemm_variant() == 3
+
+
+@pytest.mark.parametrize("a_oc,b_oc", [(False, False), (False, True), (True, True)])
+def test_gemm_v3_split_k(a_oc, b_oc):
+    """Remainder split-K: 4 tiles, 16 K-steps -> every tile is computed by 2 workgroups into fp32 slabs + the reduce kernel
+    (bias, accumulate, fp32 and bf16 outputs all go through it)."""
+    from aria_amd import hip
+
+    lib = hip.get_lib().cdll
+    assert lib.aria_gemm_workspace_bytes(300, 264, 1024, int(a_oc), int(b_oc)) == 4 * 2 * 256 * 256 * 4
+    assert lib.aria_gemm_workspace_bytes(300, 264, 1000, int(a_oc), int(b_oc)) == 0
+    C.case_gemm_layouts(DEV, 300, 264, 1024, a_oc, b_oc)
+    assert lib.aria_last_gemm_variant() == 3
+
+
+@pytest.mark.parametrize("counts", [[3, 0, 130, 5, 0, 0, 300, 1], [1, 1, 1]])
+def test_grouped_gemm_v3(force_gemm_v3, counts):
+    C.case_grouped_gemm(DEV, counts, K=128, N=192)

@@ -113,3 +113,50 @@ def test_grouped_gemm_v2(force_gemm_v2, counts):
 
 def test_grouped_gemm_v2_aria_width(force_gemm_v2):
     C.case_grouped_gemm(DEV, [130, 0, 777, 300], K=2560, N=3328)
+
+
+# v3: LDS-DMA staged, phase-scheduled 256x256 kernel (gemm3.hip); repeated launches double as a race screen
+@pytest.fixture
+def force_gemm_v3(monkeypatch):
+    monkeypatch.setenv("ARIA_GEMM_FORCE", "3")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (264, 136, 192), (40, 520, 128), (2048, 3328, 2560), (1000, 520, 1152)])
+@pytest.mark.parametrize("a_oc,b_oc", [(False, False), (False, True), (True, True)])
+def test_gemm_v3_layouts(force_gemm_v3, M, N, K, a_oc, b_oc):
+    from aria_amd import hip
+
+    for _ in range(3):
+        C.case_gemm_layouts(DEV, M, N, K, a_oc, b_oc)
+    assert hip.get_lib().cdll.aria_last_gemm_variant() == 3
+
+
+@pytest.mark.parametrize("counts", [[3, 0, 130, 5, 0, 0, 300, 1], [1, 1, 1], [37 * (i % 5) + (i * 7) % 11 for i in range(64)]])
+def test_grouped_gemm_v3(force_gemm_v3, counts):
+    C.case_grouped_gemm(DEV, counts, K=128, N=192)
+
+
+def test_grouped_gemm_v3_aria_width(force_gemm_v3):
+    C.case_grouped_gemm(DEV, [130, 0, 777, 300], K=2560, N=3328)
+
+
+@pytest.mark.parametrize("a_oc,b_oc", [(False, False), (False, True), (True, True)])
+def test_gemm_v3_split_k(a_oc, b_oc):
+    """default dispatch: a [2560,2560]-sized output with a long reduction takes the remainder split-K path (workspace + reduce)"""
+    from aria_amd import hip, ops
+
+    lib = hip.get_lib().cdll
+    assert lib.aria_gemm_workspace_bytes(2560, 2560, 16384, int(a_oc), int(b_oc)) > 0
+    C.case_gemm_layouts(DEV, 2560, 2560, 4096, a_oc, b_oc)
+    assert lib.aria_last_gemm_variant() == 3
+    # split and unsplit agree to fp32 summation-order noise
+    import torch
+    a = torch.randn(4096, 2560, device=DEV).to(torch.bfloat16)
+    b = torch.randn(4096, 2560, device=DEV).to(torch.bfloat16)
+    got = ops.gemm(a, b, a_oc=True, b_oc=True, out_dtype=torch.float32)
+    ops.GEMM_SPLIT_K = False
+    try:
+        ref = ops.gemm(a, b, a_oc=True, b_oc=True, out_dtype=torch.float32)
+    finally:
+        ops.GEMM_SPLIT_K = True
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-2)
