@@ -19,6 +19,7 @@
 //  * tensors are [B, S, H, hd] views of token-major activations (row stride ld*): no head transposes in HBM.
 #include "aria_device.h"
 #include "aria_hip.h"
+#include <cstdlib>
 
 namespace {
 using namespace ad;
@@ -222,6 +223,32 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const bf16_t* Q, const bf1
     }
 }
 
+// 1-D grid -> (block along the sequence, head, batch) for the 512-thread kernels.  Workgroup n runs on XCD n % 8 (own L2).
+//  * causal: blocks differ 16x in length, so the sequence block is the SLOWEST index and runs longest-first (`reverse` says whether the
+//    last or the first block is the longest); all blocks of one (b, head) share an XCD when H*B % 8 == 0.
+//  * otherwise: every block of one (b, head) streams the same K/V (or Q/dO), so the sequence block is the FASTEST index inside an
+//    XCD's run and the (b, head) pairs are dealt round-robin to the XCDs: the ~32 blocks an XCD runs at a time share 1-2 K/V sets.
+// The launch uses attn_grid() workgroups; ids that fall past the last (b, head) pair return false.
+__device__ __forceinline__ bool attn_block_coords(int nblk, int H, int B, int causal, bool reverse, int& blk, int& head, int& b) {
+    const int n = blockIdx.x, nbh = H * B;
+    int bh;
+    if (causal) {
+        const int z = n / nbh;
+        if (z >= nblk) return false;
+        bh = n % nbh;
+        blk = reverse ? nblk - 1 - z : z;
+    } else {
+        const int xcd = n & 7, j = n >> 3;
+        blk = j % nblk;
+        bh = (j / nblk) * 8 + xcd;
+    }
+    if (bh >= nbh) return false;
+    head = bh % H;
+    b = bh / H;
+    return true;
+}
+inline unsigned attn_grid(long long nblk, long long H, long long B) { return unsigned(((H * B + 7) & ~7ll) * nblk); }
+
 // =========================================================================================== forward v2
 // 8 waves / 256 queries per block, K/V double-buffered in LDS (ONE barrier per 64-key tile), V fragments through
 // ds_read_b64_tr_b16 (row-major [key][d] tile read as key-contiguous fragments: half the LDS cycles of the dword-pair
@@ -266,7 +293,7 @@ template <int HD>
 __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE,
                                                         const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
                                                         long long ldq, long long ldk, long long ldv, long long ldo, float scale,
-                                                        int causal) {
+                                                        int causal, int nbatch) {
     using C = Cfg2<HD>;
     ARIA_DYN_SMEM(smem);
     bf16_t* sK = reinterpret_cast<bf16_t*>(smem);          // [2][64][KP]
@@ -274,7 +301,9 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* Q, const b
     uint8_t* sM = reinterpret_cast<uint8_t*>(sV + 2 * 64 * C::VP);  // [2][64]
     int* sFlag = reinterpret_cast<int*>(sM + 128);         // [2]
     const int t = threadIdx.x, l = t & 63, w = t >> 6, h2 = l >> 5;
-    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 256;
+    int qblk, head, b;
+    if (!attn_block_coords((Sq + 255) / 256, H, nbatch, causal, true, qblk, head, b)) return;
+    const int q0 = qblk * 256;
     const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
     const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
     const bf16_t* Kb = K + tok0 * ldk + head * HD;
@@ -990,6 +1019,384 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dq_kernel(const bf16_t* Q, const
     }
 }
 
+// =========================================================================================== backward v3 (hd = 128)
+// bwd2 needs 336-472 VGPRs per wave (dK and dV accumulators + K and V fragments + two score tiles), i.e. ONE wave per SIMD, and a
+// lone wave cannot hide its own LDS latency, softmax VALU work and MFMA dependency chains: measured 8 % MFMA utilisation.
+// v3 splits the dK/dV work of a 32-key group between TWO waves that share a SIMD (w and w + 4):
+//
+//     role A (waves 0-3):  S = Q K^T  ->  P = exp2(S*c - lse)  -> publishes P (fp32, lane-linear) in LDS ->  dV += P^T dO
+//     role B (waves 4-7):  dP = dO V^T            .. barrier ..  reads P -> dS = P (dP - delta) scale   ->  dK += dS^T Q
+//
+// Both roles run the SAME instruction stream on different operands (first GEMM: own fragment x rc tile; second GEMM: packed
+// score tile x transposed tile), 16 + 16 MFMAs each per 64-query tile, no redundant GEMM, < 256 VGPRs -> two waves per SIMD,
+// and A's softmax VALU work overlaps B's MFMAs.  Q / dO tiles are stored UNPADDED ([64][128] bf16, 256-byte rows) with the
+// 16-byte chunk index XOR-swizzled by f(row) = ((row & 3) << 2) | ((row >> 2) & 3): conflict-free both for the ds_read_b128
+// row fragments (16 lanes = 16 rows with distinct row & 15 -> 16 distinct chunks) and for the ds_read_b64_tr_b16 transposed
+// fragments (4 rows x 64 bytes -> four different 64-byte bank quarters); bwd2's pitch-136 tiles were 4-way conflicted there.
+template <int HD>
+struct Cfg3 {
+    static constexpr int ROW = HD * 2;                 // bytes per row
+    static constexpr int TILE = 64 * ROW;              // bytes per 64-row tile
+    static constexpr int CPR = HD / 8;                 // 16-byte chunks per row
+    static constexpr int NCH = 64 * CPR / 512;         // chunks per thread per tile (512 threads)
+    static constexpr int KS = HD / 16, DT = HD / 32;
+    static constexpr int SMEM_DKDV = 4 * TILE + 2 * 2 * 64 * 4 + 4 * 8 * 1024;  // Q,dO double-buffered + lse,delta + P exchange
+};
+__device__ __forceinline__ int swz3(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <int HD>
+__device__ __forceinline__ void tile_load3(u32x4 (&r)[Cfg3<HD>::NCH], const bf16_t* base, long long ld, int row0, int row_end, int t) {
+#pragma unroll
+    for (int p = 0; p < Cfg3<HD>::NCH; ++p) {
+        const int c = t + 512 * p;
+        const int row = row0 + c / Cfg3<HD>::CPR, col = (c % Cfg3<HD>::CPR) * 8;
+        r[p] = row < row_end ? ld16(base + (long long)row * ld + col) : zero16();
+    }
+}
+template <int HD>
+__device__ __forceinline__ void tile_store3(const u32x4 (&r)[Cfg3<HD>::NCH], char* s, int t) {
+#pragma unroll
+    for (int p = 0; p < Cfg3<HD>::NCH; ++p) {
+        const int c = t + 512 * p;
+        const int row = c / Cfg3<HD>::CPR, ch = c % Cfg3<HD>::CPR;
+        st16(s + row * Cfg3<HD>::ROW + ((ch ^ swz3(row)) << 4), r[p]);
+    }
+}
+// row fragment: row `row`, reduction indices 16 kk + 8 (l >> 5) + 0..7
+template <int HD>
+__device__ __forceinline__ s16x8 frag_rc3(const char* s, int row, int kk, int l) {
+    return *reinterpret_cast<const s16x8*>(s + row * Cfg3<HD>::ROW + (((2 * kk + (l >> 5)) ^ swz3(row)) << 4));
+}
+// transposed fragment: feature columns d0 .. d0+31 (lane l & 31), k-slots = token rows rb + 4h + (e & 3) + 8 (e >> 2); rb % 16 == 0
+template <int HD>
+__device__ __forceinline__ s16x8 frag_tr3(const char* s, int rb, int d0, int l) {
+    const int row = rb + 4 * (l >> 5) + ((l & 15) >> 2);
+    const int col = d0 + 16 * ((l >> 4) & 1) + 4 * (l & 3);
+    const int ch = col >> 3, within = (col & 7) * 2;
+    const s16x4 a0 = ds_read_tr16(reinterpret_cast<const bf16_t*>(s + row * Cfg3<HD>::ROW + ((ch ^ swz3(row)) << 4) + within));
+    const s16x4 a1 = ds_read_tr16(reinterpret_cast<const bf16_t*>(s + (row + 8) * Cfg3<HD>::ROW + ((ch ^ swz3(row + 8)) << 4) + within));
+    s16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[e] = a0[e];
+        f[4 + e] = a1[e];
+    }
+    return f;
+}
+
+// grid (H, B, ceil(S/128)), 512 threads: wave pair (g, g + 4) owns keys kv0 + 32 g + (l & 31); loop over 64-query tiles
+template <int HD>
+__global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
+                                                             const float* LSE, const float* DELTA, bf16_t* dK, bf16_t* dV,
+                                                             const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
+                                                             long long ldq, long long ldk, long long ldv, long long lddo,
+                                                             long long lddk, long long lddv, float scale, int causal, int nbatch) {
+    using C = Cfg3<HD>;
+    ARIA_DYN_SMEM(smem);
+    char* sQ = smem;                                   // [2] tiles
+    char* sdO = smem + 2 * C::TILE;                    // [2] tiles
+    float* sLse = reinterpret_cast<float*>(smem + 4 * C::TILE);  // [2][64] (lse * log2e)
+    float* sDel = sLse + 128;                          // [2][64]
+    char* sP = reinterpret_cast<char*>(sDel + 128);    // [4 pairs][8][64 lanes] x 16 bytes
+    const int t = threadIdx.x, l = t & 63, w = first_lane(t >> 6), role = w >> 2, g = w & 3, h2 = l >> 5;
+    int kblk, head, b;
+    if (!attn_block_coords((S + 127) / 128, H, nbatch, causal, false, kblk, head, b)) return;  // key block 0 is the longest
+    const int kv0 = kblk * 128;
+    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
+    const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
+    const bf16_t* dOb = dO + tokq0 * lddo + head * HD;
+    const float* lseb = LSE + ((long long)b * H + head) * Sq;
+    const float* delb = DELTA + ((long long)b * H + head) * Sq;
+    const int kv_wmin = kv0 + 32 * g, kv_abs = kv_wmin + (l & 31);
+    const int klen = kv_len ? min(S, kv_len[b]) : S;
+    const bool key_ok = kv_abs < klen && (!key_mask || key_mask[tok0 + kv_abs] != 0);
+    const bool all_keys_ok = ballot(key_ok) == ~0ull;
+    const float scale2 = scale * 1.4426950408889634f;
+
+    // own fragment: K rows (role A) or V rows (role B) of the wave's 32 keys
+    const bf16_t* own = (role ? V + tok0 * ldv : K + tok0 * ldk) + head * HD;
+    const long long ldown = role ? ldv : ldk;
+    s16x8 of[C::KS];
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+        u32x4 a = zero16();
+        if (kv_abs < S) a = ld16(own + (long long)kv_abs * ldown + kk * 16 + h2 * 8);
+        of[kk] = __builtin_bit_cast(s16x8, a);
+    }
+    f32x16 acc[C::DT];  // dV (role A) / dK (role B): rows = keys, cols = features
+#pragma unroll
+    for (int i = 0; i < C::DT; ++i) acc[i] = zero_acc();
+    char* myP = sP + g * 8192 + l * 16;
+
+    const int q_begin = causal ? (kv0 / 64) * 64 : 0;
+    const int ntiles = kv0 < klen ? (Sq - q_begin + 63) / 64 : 0;
+    u32x4 rq[C::NCH], rdo[C::NCH];
+    if (ntiles > 0) {
+        tile_load3<HD>(rq, Qb, ldq, q_begin, Sq, t);
+        tile_load3<HD>(rdo, dOb, lddo, q_begin, Sq, t);
+        tile_store3<HD>(rq, sQ, t);
+        tile_store3<HD>(rdo, sdO, t);
+        if (t < 64) {
+            const int q = q_begin + t;
+            sLse[t] = q < Sq ? lseb[q] * 1.4426950408889634f : 0.f;
+            sDel[t] = q < Sq ? delb[q] : 0.f;
+        }
+    }
+    for (int it = 0; it < ntiles; ++it) {
+        sync();  // tile `it` is complete in buffer it & 1; the other buffer and the P exchange are free
+        const int cur = it & 1, qt0 = q_begin + it * 64;
+        const bool more = it + 1 < ntiles;
+        if (more) {
+            tile_load3<HD>(rq, Qb, ldq, qt0 + 64, Sq, t);
+            tile_load3<HD>(rdo, dOb, lddo, qt0 + 64, Sq, t);
+        }
+        const char* cQ = sQ + cur * C::TILE;
+        const char* cdO = sdO + cur * C::TILE;
+        const char* first = role ? cdO : cQ;   // rc operand of the first GEMM
+        const char* second = role ? cQ : cdO;  // transposed operand of the second GEMM
+        const bool active = !(causal && kv_wmin > qt0 + 63);  // wave-uniform: some query of the tile can see some key of this pair
+        f32x16 sc[2];
+        if (active) {
+            sc[0] = zero_acc();
+            sc[1] = zero_acc();
+#pragma unroll
+            for (int kk = 0; kk < C::KS; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) sc[i] = mfma32(frag_rc3<HD>(first, i * 32 + (l & 31), kk, l), of[kk], sc[i]);
+            if (role == 0) {
+                const float* cL = sLse + cur * 64;
+                const bool need_mask = !all_keys_ok || (qt0 + 64 > Sq) || (causal && kv_wmin + 31 > qt0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const f32x4 ls = *reinterpret_cast<const f32x4*>(cL + i * 32 + 8 * rg + 4 * h2);
+                        f32x4 pv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float p = exp2_fast(sc[i][4 * rg + e] * scale2 - ls[e]);
+                            if (need_mask) {
+                                const int q = qt0 + i * 32 + 8 * rg + 4 * h2 + e;
+                                if (!(q < Sq && key_ok && !(causal && kv_abs > q))) p = 0.f;
+                            }
+                            sc[i][4 * rg + e] = p;
+                            pv[e] = p;
+                        }
+                        *reinterpret_cast<f32x4*>(myP + (i * 4 + rg) * 1024) = pv;
+                    }
+            }
+        }
+        sync();  // P published
+        if (active) {
+            if (role == 1) {
+                const float* cD = sDel + cur * 64;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const f32x4 pv = *reinterpret_cast<const f32x4*>(myP + (i * 4 + rg) * 1024);
+                        const f32x4 dl = *reinterpret_cast<const f32x4*>(cD + i * 32 + 8 * rg + 4 * h2);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sc[i][4 * rg + e] = pv[e] * (sc[i][4 * rg + e] - dl[e]) * scale;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const s16x8 pf = pack_frag(sc[i], u);
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; ++dt) acc[dt] = mfma32(pf, frag_tr3<HD>(second, i * 32 + 16 * u, 32 * dt, l), acc[dt]);
+                }
+        }
+        if (more) {
+            const int nb = cur ^ 1;
+            tile_store3<HD>(rq, sQ + nb * C::TILE, t);
+            tile_store3<HD>(rdo, sdO + nb * C::TILE, t);
+            if (t < 64) {
+                const int q = qt0 + 64 + t;
+                sLse[nb * 64 + t] = q < Sq ? lseb[q] * 1.4426950408889634f : 0.f;
+                sDel[nb * 64 + t] = q < Sq ? delb[q] : 0.f;
+            }
+        }
+    }
+    bf16_t* out = role ? dK : dV;
+    const long long ldout = role ? lddk : lddv;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kv = kv_wmin + acc_row(r, l);
+            if (kv >= S) continue;
+            out[(tok0 + kv) * ldout + head * HD + 32 * dt + (l & 31)] = f2bf(acc[dt][r]);
+        }
+}
+
+
+// dQ, same idea in the transposed layout of the forward (lane owns ONE query, statistics are lane-local): the wave pair
+// (g, g + 4) owns queries q0 + 32 g + (l & 31).  Role A computes S^T = K Q^T and P, role B computes dP^T = V dO^T; they swap P and
+// dP through LDS (fp32, lane-linear), both form dS = P (dP - delta) scale, and each accumulates HALF of the feature columns of
+// dQ^T += K^T dS^T (A: features 0..63, B: 64..127): 16 + 8 MFMAs per wave and 64-key tile, balanced, < 256 VGPRs.
+// grid (H, B, ceil(Sq/128)), 512 threads
+template <int HD>
+__global__ __launch_bounds__(512) void attn_bwd3_dq_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
+                                                           const float* LSE, const float* DELTA, bf16_t* dQ, const int32_t* kv_len,
+                                                           const uint8_t* key_mask, int Sq, int S, int H, long long ldq,
+                                                           long long ldk, long long ldv, long long lddo, long long lddq,
+                                                           float scale, int causal, int nbatch) {
+    using C = Cfg3<HD>;
+    constexpr int DTH = C::DT / 2;  // feature tiles per role
+    ARIA_DYN_SMEM(smem);
+    char* sK = smem;                                   // [2] tiles
+    char* sV = smem + 2 * C::TILE;                     // [2] tiles
+    char* sX = smem + 4 * C::TILE;                     // [2 roles][4 pairs][8][64 lanes] x 16 bytes: P (from A) and dP (from B)
+    uint8_t* sM = reinterpret_cast<uint8_t*>(sX + 2 * 4 * 8192);  // [2][64]
+    int* sFlag = reinterpret_cast<int*>(sM + 128);
+    const int t = threadIdx.x, l = t & 63, w = first_lane(t >> 6), role = w >> 2, g = w & 3, h2 = l >> 5;
+    int qblk, head, b;
+    if (!attn_block_coords((Sq + 127) / 128, H, nbatch, causal, true, qblk, head, b)) return;
+    const int q0 = qblk * 128;
+    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
+    const bf16_t* Kb = K + tok0 * ldk + head * HD;
+    const bf16_t* Vb = V + tok0 * ldv + head * HD;
+    const uint8_t* kmb = key_mask ? key_mask + tok0 : nullptr;
+    const int q_wmin = q0 + 32 * g, q_abs = q_wmin + (l & 31);
+    const int klen = kv_len ? min(S, kv_len[b]) : S;
+    const float scale2 = scale * 1.4426950408889634f;
+    const bf16_t* own = (role ? dO + tokq0 * lddo : Q + tokq0 * ldq) + head * HD;
+    const long long ldown = role ? lddo : ldq;
+    s16x8 of[C::KS];
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+        u32x4 a = zero16();
+        if (q_abs < Sq) a = ld16(own + (long long)q_abs * ldown + kk * 16 + h2 * 8);
+        of[kk] = __builtin_bit_cast(s16x8, a);
+    }
+    float lse2 = 0.f, del = 0.f;
+    if (q_abs < Sq) {
+        lse2 = LSE[((long long)b * H + head) * Sq + q_abs] * 1.4426950408889634f;
+        del = DELTA[((long long)b * H + head) * Sq + q_abs];
+    }
+    const bool all_q_ok = q_wmin + 31 < Sq;
+    f32x16 acc[DTH];
+#pragma unroll
+    for (int i = 0; i < DTH; ++i) acc[i] = zero_acc();
+    char* mine = sX + role * 32768 + g * 8192 + l * 16;          // what this wave publishes
+    const char* theirs = sX + (role ^ 1) * 32768 + g * 8192 + l * 16;
+    int kv_end = klen;
+    if (causal) kv_end = min(kv_end, q0 + 128);
+    const int ntiles = (kv_end + 63) / 64;
+    u32x4 rk[C::NCH], rv[C::NCH];
+    if (ntiles > 0) {
+        tile_load3<HD>(rk, Kb, ldk, 0, S, t);
+        tile_load3<HD>(rv, Vb, ldv, 0, S, t);
+        tile_store3<HD>(rk, sK, t);
+        tile_store3<HD>(rv, sV, t);
+        if (kmb && t < 64) {
+            const uint8_t mv = t < S ? kmb[t] : 0;
+            sM[t] = mv;
+            const unsigned long long all = ballot(mv != 0);
+            if (t == 0) sFlag[0] = (all == ~0ull);
+        }
+    }
+    for (int it = 0; it < ntiles; ++it) {
+        sync();
+        const int cur = it & 1, kv0 = it * 64;
+        const bool more = it + 1 < ntiles;
+        if (more) {
+            tile_load3<HD>(rk, Kb, ldk, kv0 + 64, S, t);
+            tile_load3<HD>(rv, Vb, ldv, kv0 + 64, S, t);
+        }
+        const char* cK = sK + cur * C::TILE;
+        const char* first = role ? sV + cur * C::TILE : cK;
+        const bool active = !(causal && kv0 > q_wmin + 31);
+        f32x16 sc[2];
+        if (active) {
+            sc[0] = zero_acc();
+            sc[1] = zero_acc();
+#pragma unroll
+            for (int kk = 0; kk < C::KS; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) sc[i] = mfma32(frag_rc3<HD>(first, i * 32 + (l & 31), kk, l), of[kk], sc[i]);
+            if (role == 0) {
+                const bool need_mask = !all_q_ok || (kv0 + 64 > klen) || (causal && kv0 + 63 > q_wmin) || (kmb && !sFlag[cur]);
+                const uint8_t* cM = sM + cur * 64;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float p = exp2_fast(sc[i][r] * scale2 - lse2);
+                        if (need_mask) {
+                            const int kvl = i * 32 + acc_row(r, l);
+                            const int kv = kv0 + kvl;
+                            bool ok = q_abs < Sq && kv < klen && !(causal && kv > q_abs);
+                            if (kmb) ok = ok && cM[kvl];
+                            if (!ok) p = 0.f;
+                        }
+                        sc[i][r] = p;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = sc[i][4 * rg + e];
+                    *reinterpret_cast<f32x4*>(mine + (i * 4 + rg) * 1024) = v;
+                }
+        }
+        sync();  // P and dP published
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(theirs + (i * 4 + rg) * 1024);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float p = role ? o[e] : sc[i][4 * rg + e], dp = role ? sc[i][4 * rg + e] : o[e];
+                        sc[i][4 * rg + e] = p * (dp - del) * scale;
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const s16x8 dsf = pack_frag(sc[i], u);
+#pragma unroll
+                    for (int dt = 0; dt < DTH; ++dt)
+                        acc[dt] = mfma32(frag_tr3<HD>(cK, i * 32 + 16 * u, 32 * (role * DTH + dt), l), dsf, acc[dt]);
+                }
+        }
+        if (more) {
+            const int nb = cur ^ 1, kvn = kv0 + 64;
+            tile_store3<HD>(rk, sK + nb * C::TILE, t);
+            tile_store3<HD>(rv, sV + nb * C::TILE, t);
+            if (kmb && t < 64) {
+                const uint8_t mv = (kvn + t < S) ? kmb[kvn + t] : 0;
+                sM[nb * 64 + t] = mv;
+                const unsigned long long all = ballot(mv != 0);
+                if (t == 0) sFlag[nb] = (all == ~0ull);
+            }
+        }
+    }
+    if (q_abs < Sq) {
+        bf16_t* row = dQ + (tokq0 + q_abs) * lddq + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < DTH; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d0 = 32 * (role * DTH + dt) + 8 * rg + 4 * h2;
+                u32x2 v;
+                v[0] = pack2bf(acc[dt][4 * rg], acc[dt][4 * rg + 1]);
+                v[1] = pack2bf(acc[dt][4 * rg + 2], acc[dt][4 * rg + 3]);
+                *reinterpret_cast<u32x2*>(row + d0) = v;
+            }
+    }
+}
+
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -1005,17 +1412,17 @@ int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     if (!al16(q) || !al16(k) || !al16(v) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || (reinterpret_cast<uintptr_t>(o) & 7))
         return ARIA_ERR_ALIGN;
     if (B == 0 || Sq == 0) return ARIA_OK;
-    dim3 grid(unsigned((Sq + 255) / 256), unsigned(H), unsigned(B)), block(512);
+    dim3 grid(attn_grid((Sq + 255) / 256, H, B)), block(512);
     const bf16_t *Q = static_cast<const bf16_t*>(q), *K = static_cast<const bf16_t*>(k), *V = static_cast<const bf16_t*>(v);
     if (hd == 128)
         ARIA_LAUNCH((attn_fwd2_kernel<128>), grid, block, Cfg2<128>::SMEM, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len,
-                    key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal);
+                    key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal, int(B));
     else if (hd == 72)
         ARIA_LAUNCH((attn_fwd2_kernel<72>), grid, block, Cfg2<72>::SMEM, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len,
-                    key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal);
+                    key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal, int(B));
     else
         ARIA_LAUNCH((attn_fwd2_kernel<64>), grid, block, Cfg2<64>::SMEM, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len,
-                    key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal);
+                    key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal, int(B));
     return aria_check_launch();
 }
 
@@ -1043,13 +1450,25 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
     dim3 block(NT);
     if (hd == 128) {
         using C = Cfg<128>;
-        ARIA_LAUNCH((attn_bwd2_dkdv_kernel<128>), gridk, block, size_t(4 * 64 * C::PITCH * 2 + 256 * 4), stream, Q, K, V, dO, lse,
-                    (const float*)delta, static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), kv_len, key_mask, int(Sq), int(Skv),
-                    int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddk, (long long)lddv, scale,
-                    causal);
-        ARIA_LAUNCH((attn_bwd2_dq_kernel<128>), gridq, block, size_t(4 * 64 * C::PITCH * 2 + 128 + 16), stream, Q, K, V, dO, lse,
-                    (const float*)delta, static_cast<bf16_t*>(dq), kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq,
-                    (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddq, scale, causal);
+        const char* old = std::getenv("ARIA_ATTN_BWD");  // "2": previous generation (A/B measurements)
+        if (old && old[0] == '2')
+            ARIA_LAUNCH((attn_bwd2_dkdv_kernel<128>), gridk, block, size_t(4 * 64 * C::PITCH * 2 + 256 * 4), stream, Q, K, V, dO, lse,
+                        (const float*)delta, static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), kv_len, key_mask, int(Sq), int(Skv),
+                        int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddk, (long long)lddv, scale,
+                        causal);
+        else
+            ARIA_LAUNCH((attn_bwd3_dkdv_kernel<128>), dim3(attn_grid((Skv + 127) / 128, H, B)), dim3(512), size_t(Cfg3<128>::SMEM_DKDV), stream, Q, K, V, dO, lse,
+                        (const float*)delta, static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), kv_len, key_mask, int(Sq), int(Skv),
+                        int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddk, (long long)lddv, scale,
+                        causal, int(B));
+        if (old && old[0] == '2')
+            ARIA_LAUNCH((attn_bwd2_dq_kernel<128>), gridq, block, size_t(4 * 64 * C::PITCH * 2 + 128 + 16), stream, Q, K, V, dO, lse,
+                        (const float*)delta, static_cast<bf16_t*>(dq), kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq,
+                        (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddq, scale, causal);
+        else
+            ARIA_LAUNCH((attn_bwd3_dq_kernel<128>), dim3(attn_grid((Sq + 127) / 128, H, B)), dim3(512), size_t(4 * Cfg3<128>::TILE + 2 * 4 * 8192 + 128 + 16), stream, Q,
+                        K, V, dO, lse, (const float*)delta, static_cast<bf16_t*>(dq), kv_len, key_mask, int(Sq), int(Skv), int(H),
+                        (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddq, scale, causal, int(B));
     } else {
         using C = Cfg<64>;
         ARIA_LAUNCH((attn_bwd2_dkdv_kernel<64>), gridk, block, size_t(4 * 64 * C::PITCH * 2 + 256 * 4), stream, Q, K, V, dO, lse,

@@ -72,7 +72,8 @@ def test_cross_entropy(T, V):
 
 
 @pytest.mark.parametrize("B,S,H,hd,causal,use_len", [(2, 70, 2, 64, True, False), (1, 200, 1, 64, False, True),
-                                                     (1, 130, 1, 128, True, False), (2, 64, 1, 64, False, False)])
+                                                     (1, 130, 1, 128, True, False), (2, 64, 1, 64, False, False),
+                                                     (2, 200, 2, 128, False, True), (1, 333, 1, 128, True, False)])
 def test_attention_fwd_bwd(B, S, H, hd, causal, use_len):
     C.case_attention(DEV, B, S, H, hd, causal, use_len)
 
