@@ -270,10 +270,10 @@ bool use_v2(long long tiles256) {
     return tiles256 >= 192;
 }
 
-// v3 (LDS-DMA staged, phase-scheduled 256x256 tile, gemm3.hip): K must be a whole number of 64-deep tiles and the operand
-// byte offsets must fit 32 bits.  ARIA_GEMM_FORCE=3 pins it where eligible.
+// v3 (LDS-DMA staged, phase-scheduled 256x256 tile, gemm3.hip): the operand byte offsets must fit 32 bits.
+// ARIA_GEMM_FORCE=3 pins it where eligible.
 bool use_v3(long long tiles256, long long K, long long bytesA, long long bytesB, long long extentA, long long extentB) {
-    if (K < 64 || (K & 63) || bytesA >= (1ll << 32) || bytesB >= (1ll << 32) || extentA < 8 || extentB < 8) return false;
+    if (K < 64 || bytesA >= (1ll << 32) || bytesB >= (1ll << 32) || extentA < 8 || extentB < 8) return false;
     const char* force = std::getenv("ARIA_GEMM_FORCE");
     if (force) return force[0] == '3';
     const char* v3 = std::getenv("ARIA_GEMM_V3");  // "0" switches the default off (A/B measurements)
@@ -357,9 +357,7 @@ int aria_grouped_gemm_bf16(const void* A, const void* B, void* C, const int32_t*
     p.ntn = int((N + BN - 1) / BN);
     // every expert adds at most one partial row tile
     const int max_tm = int(M_total / BM + E);
-    const char* force3 = std::getenv("ARIA_GEMM_FORCE");
-    const bool v3_grouped = !b_oc || (force3 && force3[0] == '3');  // [K][N] weights: v3 measured level with v2, keep v2
-    if (v3_grouped && use_v3((M_total / 256 + 1) * ((N + 255) / 256), K, 2 * M_total * lda, 2 * (b_oc ? K * ldb : N * ldb), M_total, N))
+    if (use_v3((M_total / 256 + 1) * ((N + 255) / 256), K, 2 * M_total * lda, 2 * (b_oc ? K * ldb : N * ldb), M_total, N))
         return g_last_variant = 3, aria_launch_gemm3(p, 0, b_oc, int(M_total / 256 + E), stream);
     if (use_v2((M_total / 256 + 1) * ((N + 255) / 256))) return g_last_variant = 2, aria_launch_gemm2(p, 0, b_oc, int(M_total / 256 + E), 1, stream);
     return g_last_variant = 1, launch_gemm(p, 0, b_oc, p.ntn * max_tm, 1, stream);
@@ -388,6 +386,13 @@ int aria_grouped_gemm_wgrad_bf16(const void* A, const void* dY, void* dW, const 
     p.accumulate = accumulate;
     p.ntn = int((N + BN - 1) / BN);
     const int ntm = int((K + BM - 1) / BM);
+    // (the reduction length is per expert and data dependent: 64 stands in for "long enough" in the eligibility test)
+    // both operands are token-major (output-contiguous): their per-lane DMA offsets stay inside one 64-token tile, no 4 GiB limit
+    // Measured on MI355X (98304 routed rows, 64 experts): v3 749 TF/s vs v2 800-830 on these short (~24 K-tile) reductions with two
+    // transposed operands -- v3's longer prologue and its 24-read first phase do not pay here, so v2 stays the default.
+    const char* force3 = std::getenv("ARIA_GEMM_FORCE");
+    if (force3 && force3[0] == '3' && use_v3(((K + 255) / 256) * ((N + 255) / 256) * E, 64, 0, 0, K, N))
+        return g_last_variant = 3, aria_launch_gemm3(p, 1, 1, int((K + 255) / 256), stream);
     if (use_v2(((K + 255) / 256) * ((N + 255) / 256) * E)) return g_last_variant = 2, aria_launch_gemm2(p, 1, 1, int((K + 255) / 256), int(E), stream);
     return g_last_variant = 1, launch_gemm(p, 1, 1, p.ntn * ntm, int(E), stream);
 }

@@ -187,49 +187,22 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmParams p) {
     const int t = threadIdx.x, l = t & 63, w = t >> 6, wm = NW == 8 ? w >> 2 : w >> 1, wn = NW == 8 ? w & 3 : w & 1;
 
     // XCD-aware bijective remap of the workgroup id
-    int tn, tmi;
-    if (!aria_tile_coords(p, blockIdx.x, gridDim.x, tmi, tn)) return;
+    int tn = 0, tmi = 0;
+    if (p.mode != 1 && !aria_tile_coords(p, blockIdx.x, gridDim.x, tmi, tn)) return;  // mode 1: aria_grouped_tile below
     const bf16_t* A = p.A;
     const int csz = p.c_f32 ? 4 : 2;
     long long b_off = 0, c_off = 0;
     int m0 = 0, m_end = 0, k_begin = 0, k_end = p.K;
-    const int n0 = tn * BN;
+    int n0 = tn * BN;
     if (p.mode == 0) {
         m0 = tmi * BM;
         m_end = p.M;
         if (m0 >= m_end) return;
     } else if (p.mode == 1) {
-        int e_found = -1, start = 0, end = 0, base = 0;
-        for (int e0 = 0; e0 < p.E && e_found < 0; e0 += 64) {
-            const int e = e0 + l;
-            int o0 = 0, o1 = 0;
-            if (e < p.E) {
-                o0 = p.offsets[e];
-                o1 = p.offsets[e + 1];
-            }
-            const int nt = (o1 - o0 + BM - 1) / BM;
-            int incl = nt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int v = shfl(incl, (l - d) & 63);
-                if (l >= d) incl += v;
-            }
-            const int excl = base + incl - nt;
-            const bool mine = e < p.E && tmi >= excl && tmi < excl + nt;
-            const unsigned long long mask = ballot(mine);
-            if (mask) {
-                const int src = __builtin_ctzll(mask);
-                e_found = e0 + src;
-                start = shfl(o0, src);
-                end = shfl(o1, src);
-                tmi -= shfl(excl, src);
-            }
-            base += shfl(incl, 63);
-        }
-        if (e_found < 0) return;
-        m0 = start + tmi * BM;
-        m_end = end;
-        b_off = (long long)e_found * p.strideB;
+        int expert = 0;
+        if (!aria_grouped_tile(p, blockIdx.x, l, expert, m0, m_end, tn)) return;
+        n0 = tn * BN;
+        b_off = (long long)expert * p.strideB;
     } else {
         const int e = blockIdx.y;
         m0 = tmi * BM;

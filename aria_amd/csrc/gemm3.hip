@@ -35,8 +35,11 @@
 //     c ^ (k & 3) -> the four k-rows of a ds_read_b64_tr_b16 (hardware transpose) land in different bank quarters.
 // Both permutations keep every 64/128-byte segment of a cache line inside one DMA instruction (fully coalesced).
 //
-// Scope: K % 64 == 0, modes 0 (dense) and 1 (grouped rows); everything else runs on v2/v1 (gemm2.hip / gemm.hip).  Rows or
-// columns beyond the edge are CLAMPED to the last valid one (the products land in accumulators that are never stored).
+// Edges.  Rows or columns beyond the edge of the tile's row group / of N are CLAMPED to the last valid one (the products land in
+// accumulators that are never stored).  A reduction that is not a whole number of 64-deep tiles (grouped-K weight gradients: an
+// expert's token count is arbitrary; K = 4304 in the ViT MLP) is handled in the LAST K-tile only: every DMA granule whose
+// reduction index lies past the end takes a 256-byte zero page as its source address instead -- the source is per lane, so the
+// LDS image simply receives zeros there and nothing else in the pipeline changes.
 #include "aria_hip.h"
 #include "gemm_params.h"
 #include <cstdlib>
@@ -98,7 +101,11 @@ struct FragAddr {
     }
 };
 
+// 256 zero bytes: the source of every DMA granule that lies beyond the end of a ragged reduction (last K-tile only)
+__device__ const uint32_t aria_zero_page[64] = {};
+
 struct Stage {  // everything a wave needs to issue its two DMA pieces of any half-tile
+    int w, nk, tail_k;  // wave id, K-tiles of this workgroup, valid reduction indices in the last one (64 = it is full)
     const char* gA;
     const char* gB;
     long long kstepA, kstepB;  // bytes per K-tile along k
@@ -106,14 +113,29 @@ struct Stage {  // everything a wave needs to issue its two DMA pieces of any ha
     char* lds;                        // smem + 2048 * w  (wave-uniform)
 };
 
-template <int OPERAND, int HALF, int BUF>
+template <bool A_OC, bool B_OC, int OPERAND, int HALF, int BUF>
 __device__ __forceinline__ void stage_half(const Stage& st, int tile) {
     const char* g = (OPERAND == 0 ? st.gA + tile * st.kstepA : st.gB + tile * st.kstepB);
     char* d = st.lds + OPERAND * LDS_OPERAND + HALF * LDS_HALF + BUF * LDS_BUF;
-    const uint32_t o0 = OPERAND == 0 ? st.offA[HALF][0] : st.offB[HALF][0];
-    const uint32_t o1 = OPERAND == 0 ? st.offA[HALF][1] : st.offB[HALF][1];
-    glds16(g + o0, d);
-    glds16(g + o1, d + 1024);
+    const char* s0 = g + (OPERAND == 0 ? st.offA[HALF][0] : st.offB[HALF][0]);
+    const char* s1 = g + (OPERAND == 0 ? st.offA[HALF][1] : st.offB[HALF][1]);
+    if (st.tail_k < BK && tile == st.nk - 1) {  // wave-uniform: the ragged end of the reduction -> granules past it read zeros
+        constexpr bool OC = OPERAND == 0 ? A_OC : B_OC;
+        const int l = lane_id();
+        int k0, k1;  // first reduction index (inside the tile) of this lane's 16 bytes, pieces 0 and 1
+        if (!OC) {
+            const int r0 = (2 * st.w) * 8 + (l >> 3), r1 = r0 + 8;
+            k0 = ((l & 7) ^ ((r0 >> 1) & 7)) * 8;
+            k1 = ((l & 7) ^ ((r1 >> 1) & 7)) * 8;
+        } else {
+            k0 = (2 * st.w) * 4 + (l >> 4);
+            k1 = k0 + 4;
+        }
+        if (k0 >= st.tail_k) s0 = reinterpret_cast<const char*>(aria_zero_page) + 16 * (l & 15);
+        if (k1 >= st.tail_k) s1 = reinterpret_cast<const char*>(aria_zero_page) + 16 * (l & 15);
+    }
+    glds16(s0, d);
+    glds16(s1, d + 1024);
 }
 
 // One phase: quadrant (QA, QB) of the K-tile in buffer BUF.  SO/SH/SB: operand, half, buffer of the DMA issued here.
@@ -142,7 +164,7 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
             }
     }
     sched_fence();
-    if (do_stage) stage_half<SO, SH, SB>(st, stage_tile);
+    if (do_stage) stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
     if (WAIT) {
         if (more_in_flight)
             wait_vm<4>();
@@ -196,8 +218,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     const int t = threadIdx.x, l = t & 63, w = first_lane(t >> 6), wm = w >> 2, wn = w & 3;
 
     // XCD-aware bijective remap of the workgroup id + grouped tile order (same scheme as v2)
-    int tn, tmi, slab = -1, ks = 0;  // slab >= 0: this workgroup computes one K range of a split tile into ws
-    if (p.split > 1 && int(blockIdx.x) >= p.split_first) {
+    int tn = 0, tmi = 0, slab = -1, ks = 0;  // slab >= 0: this workgroup computes one K range of a split tile into ws
+    if (p.mode == 1) {
+        // aria_grouped_tile below
+    } else if (p.split > 1 && int(blockIdx.x) >= p.split_first) {
         const int r = blockIdx.x - p.split_first;
         slab = r;
         ks = r % p.split;
@@ -205,49 +229,30 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     } else if (!aria_tile_coords(p, blockIdx.x, p.split > 1 ? p.split_first : int(gridDim.x), tmi, tn)) {
         return;
     }
-    const int csz = p.c_f32 ? 4 : 2;
-    long long b_off = 0;
-    int m0 = 0, m_end = 0;
-    const int n0 = tn * BN;
+    long long b_off = 0, c_off = 0;
+    int m0 = 0, m_end = 0, k_begin = 0, k_len = p.K;
+    int n0 = tn * BN;
     if (p.mode == 0) {
         m0 = tmi * BM;
         m_end = p.M;
         if (m0 >= m_end) return;
+    } else if (p.mode == 2) {  // per-expert weight gradient: the reduction runs over the expert's token rows
+        const int e = blockIdx.y;
+        m0 = tmi * BM;
+        m_end = p.M;
+        if (m0 >= m_end) return;
+        k_begin = p.offsets[e];
+        k_len = p.offsets[e + 1] - k_begin;
+        c_off = (long long)e * p.strideC;
     } else {
-        int e_found = -1, start = 0, end = 0, base = 0;
-        for (int e0 = 0; e0 < p.E && e_found < 0; e0 += 64) {
-            const int e = e0 + l;
-            int o0 = 0, o1 = 0;
-            if (e < p.E) {
-                o0 = p.offsets[e];
-                o1 = p.offsets[e + 1];
-            }
-            const int nt = (o1 - o0 + BM - 1) / BM;
-            int incl = nt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int v = shfl(incl, (l - d) & 63);
-                if (l >= d) incl += v;
-            }
-            const int excl = base + incl - nt;
-            const bool mine = e < p.E && tmi >= excl && tmi < excl + nt;
-            const unsigned long long mask = ballot(mine);
-            if (mask) {
-                const int src = __builtin_ctzll(mask);
-                e_found = e0 + src;
-                start = shfl(o0, src);
-                end = shfl(o1, src);
-                tmi -= shfl(excl, src);
-            }
-            base += shfl(incl, 63);
-        }
-        if (e_found < 0) return;
-        m0 = start + tmi * BM;
-        m_end = end;
-        b_off = (long long)e_found * p.strideB;
+        int expert = 0;
+        if (!aria_grouped_tile(p, blockIdx.x, l, expert, m0, m_end, tn)) return;
+        n0 = tn * BN;
+        b_off = (long long)expert * p.strideB;
     }
-    char* C = static_cast<char*>(p.C);
-    int nk = p.K / BK, kt_first = 0;
+    char* C = static_cast<char*>(p.C) + c_off * (p.c_f32 ? 4 : 2);
+    int nk = (k_len + BK - 1) / BK, kt_first = 0;
+    const int nk_all = nk;
     if (slab >= 0) {  // K-steps [nk * ks / split, nk * (ks + 1) / split)
         kt_first = int((long long)nk * ks / p.split);
         nk = int((long long)nk * (ks + 1) / p.split) - kt_first;
@@ -256,8 +261,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     Stage st;
     st.kstepA = A_OC ? 2 * BK * p.lda : 2 * BK;
     st.kstepB = B_OC ? 2 * BK * p.ldb : 2 * BK;
-    st.gA = reinterpret_cast<const char*>(p.A) + kt_first * st.kstepA;
-    st.gB = reinterpret_cast<const char*>(p.B + b_off) + kt_first * st.kstepB;
+    st.gA = reinterpret_cast<const char*>(p.A) + (A_OC ? 2 * k_begin * p.lda : 2 * (long long)k_begin) + kt_first * st.kstepA;
+    st.gB = reinterpret_cast<const char*>(p.B + b_off) + (B_OC ? 2 * k_begin * p.ldb : 2 * (long long)k_begin) + kt_first * st.kstepB;
+    st.w = w;
+    st.nk = nk;
+    st.tail_k = (kt_first + nk == nk_all && nk_all > 0) ? k_len - (nk_all - 1) * BK : BK;  // only the overall last K-tile is ragged
     st.lds = smem + 2048 * w;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -284,13 +292,15 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
 
     // ---- prologue: tile 0 completely, A0 and B1 of tile 1 (phases 1 and 2 of tile 0 issue its A1 and B0) -- the steady-state
     // queue shape
-    stage_half<0, 0, 0>(st, 0);
-    stage_half<1, 0, 0>(st, 0);
-    stage_half<1, 1, 0>(st, 0);
-    stage_half<0, 1, 0>(st, 0);
+    if (nk > 0) {
+        stage_half<A_OC, B_OC, 0, 0, 0>(st, 0);
+        stage_half<A_OC, B_OC, 1, 0, 0>(st, 0);
+        stage_half<A_OC, B_OC, 1, 1, 0>(st, 0);
+        stage_half<A_OC, B_OC, 0, 1, 0>(st, 0);
+    }
     if (nk > 1) {
-        stage_half<0, 0, 1>(st, 1);
-        stage_half<1, 1, 1>(st, 1);
+        stage_half<A_OC, B_OC, 0, 0, 1>(st, 1);
+        stage_half<A_OC, B_OC, 1, 1, 1>(st, 1);
         wait_vm<4>();
     } else {
         wait_vm<0>();
@@ -358,7 +368,6 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
                 }
             }
     }
-    (void)csz;
 }
 
 // Sums the `split` slabs of every split tile in slab order (deterministic), then bias / accumulate / round exactly like the
@@ -420,14 +429,15 @@ int plan_split(long long tiles, long long nk, long long* remainder) {
 }  // namespace
 
 long long aria_gemm3_workspace_bytes(long long M, long long N, long long K) {
-    if (K < 64 || (K & 63) || M < 256 || N < 256) return 0;  // at least one full tile each way (not the decode GEMVs)
+    if (K < 64 || M < 256 || N < 256) return 0;  // at least one full tile each way (not the decode GEMVs)
     long long R = 0;
-    const int S = plan_split(((M + 255) / 256) * ((N + 255) / 256), K / 64, &R);
+    const int S = plan_split(((M + 255) / 256) * ((N + 255) / 256), (K + 63) / 64, &R);
     return S > 1 ? R * S * (long long)(BM * BN) * 4 : 0;
 }
 
 // v3 eligibility is decided by the caller (gemm.hip): K % 64 == 0, K >= 64, mode 0 or 1, operand bytes < 4 GiB
 int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* stream, void* workspace, long long workspace_bytes) {
+    const unsigned grid_y = p.mode == 2 ? unsigned(p.E) : 1u;
     const size_t shmem = size_t(2) * LDS_OPERAND;
     const int ntn = (p.N + BN - 1) / BN;
     GemmParams q = p;
@@ -438,7 +448,7 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     q.ws = nullptr;
     long long R = 0;
     if (p.mode == 0 && workspace) {
-        const int S = plan_split((long long)ntn * ntm, p.K / BK, &R);
+        const int S = plan_split((long long)ntn * ntm, (p.K + BK - 1) / BK, &R);
         if (S > 1 && workspace_bytes >= R * S * (long long)(BM * BN) * 4) {
             q.split = S;
             q.split_first = int((long long)ntn * ntm - R);
@@ -449,7 +459,7 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     q.order = ord ? std::atoi(ord) : 4;
     if (ntn * ntm <= 0) return ARIA_OK;
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
-    dim3 grid(unsigned(aria_tile_grid(q))), block(512);
+    dim3 grid(unsigned(aria_tile_grid(q)), grid_y), block(512);
     if (!a_oc && !b_oc)
         ARIA_LAUNCH((gemm3_kernel<false, false>), grid, block, shmem, stream, q);
     else if (!a_oc && b_oc)

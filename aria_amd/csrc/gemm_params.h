@@ -39,22 +39,9 @@ __device__ __forceinline__ bool aria_tile_from_pos(const GemmParams& p, int tile
 // Workgroup id -> (row tile, column tile) for the 256x256 kernels (v2, v3).  Workgroup b runs on XCD b % 8 and each XCD has its own
 // L2, so ids are remapped to give every XCD runs of neighbouring tiles: order >= 2 walks groups of GM row tiles column-major, so the
 // ~32 tiles an XCD works on at a time form a GM x (32/GM) patch that shares A row panels and B column panels.
-//   mode 0 / 2: each XCD gets one contiguous chunk of the tile list.
-//   mode 1 (grouped rows): the launch covers M/256 + E row tiles but the real count is data dependent and the empty ones all sit at
-//     the high end, so GROUPS are dealt round-robin to the XCDs (group g -> XCD g % 8) and every XCD gets the same share of real work.
+// Each XCD gets one contiguous chunk of the tile list (modes 0 and 2; mode 1 uses aria_grouped_tile below).
 // Returns false when the workgroup has no tile.
 __device__ __forceinline__ bool aria_tile_coords(const GemmParams& p, int bid, int nwg, int& tmi, int& tn) {
-    if (p.mode == 1 && p.order >= 2) {
-        const int GM = p.order, per = GM * p.ntn;
-        const int xcd = bid & 7, idx = bid >> 3;
-        const int g = (idx / per) * 8 + xcd, in = idx % per;
-        if (g * GM >= p.ntm) return false;
-        const int gm = min(GM, p.ntm - g * GM);
-        if (in >= gm * p.ntn) return false;
-        tn = in / gm;
-        tmi = g * GM + in % gm;
-        return true;
-    }
     int tile = bid;
     if (p.order != 1) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -62,12 +49,59 @@ __device__ __forceinline__ bool aria_tile_coords(const GemmParams& p, int bid, i
     }
     return aria_tile_from_pos(p, tile, tmi, tn);
 }
-// number of workgroups aria_tile_coords needs
-inline int aria_tile_grid(const GemmParams& p) {
-    if (p.mode == 1 && p.order >= 2) {
-        const int GM = p.order, groups = (p.ntm + GM - 1) / GM;
-        return 8 * ((groups + 7) / 8) * GM * p.ntn;
+// Grouped rows (mode 1): expert-major tile list.  The tiles of expert e are its nt_e = ceil(n_e / 256) row tiles x ntn column
+// tiles, walked COLUMN-major (all row tiles of a column first), experts in order; the list (T real tiles -- known only on the
+// device, the offsets never visit the host) is cut into 8 equal contiguous chunks, one per XCD.  So the ~32 tiles an XCD works on at
+// a time belong to one expert and share its weight column panels (each fetched from HBM once instead of once per pair of row
+// tiles) and its row panels, and every XCD gets the same number of REAL tiles however uneven the routing is.
+// Every lane of the calling wave must take part (wave collectives).  Returns false when the workgroup has no tile.
+__device__ __forceinline__ bool aria_grouped_tile(const GemmParams& p, int bid, int l, int& expert, int& m0, int& m_end, int& tn) {
+    int T = 0;
+    for (int e0 = 0; e0 < p.E; e0 += 64) {
+        const int e = e0 + l;
+        int c = 0;
+        if (e < p.E) c = ((p.offsets[e + 1] - p.offsets[e] + 255) / 256) * p.ntn;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += ad::shfl_xor(c, d);
+        T += c;
     }
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int lo = int((long long)T * xcd / 8), hi = int((long long)T * (xcd + 1) / 8);
+    if (idx >= hi - lo) return false;
+    const int v = lo + idx;
+    int base = 0;
+    for (int e0 = 0; e0 < p.E; e0 += 64) {
+        const int e = e0 + l;
+        int o0 = 0, o1 = 0;
+        if (e < p.E) {
+            o0 = p.offsets[e];
+            o1 = p.offsets[e + 1];
+        }
+        const int nt = (o1 - o0 + 255) / 256, c = nt * p.ntn;
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int u = ad::shfl(incl, (l - d) & 63);
+            if (l >= d) incl += u;
+        }
+        const int excl = base + incl - c;
+        const unsigned long long mask = ad::ballot(c > 0 && v >= excl && v < excl + c);
+        if (mask) {
+            const int src = __builtin_ctzll(mask);
+            const int local = v - ad::shfl(excl, src), nts = ad::shfl(nt, src);
+            expert = e0 + src;
+            tn = local / nts;
+            m0 = ad::shfl(o0, src) + (local % nts) * 256;
+            m_end = ad::shfl(o1, src);
+            return true;
+        }
+        base += ad::shfl(incl, 63);
+    }
+    return false;
+}
+// number of workgroups aria_tile_coords / aria_grouped_tile need
+inline int aria_tile_grid(const GemmParams& p) {
+    if (p.mode == 1) return p.ntn * p.ntm + 8;  // aria_grouped_tile: 8 XCD chunks of ceil(T / 8) <= bound / 8 + 1 tiles
     if (p.split > 1) return p.split_first + (p.ntn * p.ntm - p.split_first) * p.split;
     return p.ntn * p.ntm;
 }

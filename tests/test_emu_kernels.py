@@ -113,7 +113,7 @@ def force_gemm_v3(monkeypatch, request):
     monkeypatch.setenv("ARIA_EMU_GLDS_DEFER", request.param)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (264, 136, 192), (40, 520, 128), (256, 256, 320)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (264, 136, 192), (40, 520, 128), (256, 256, 320), (264, 136, 200), (72, 264, 72)])
 @pytest.mark.parametrize("a_oc,b_oc", [(False, False), (False, True), (True, True)])
 def test_gemm_v3_layouts(force_gemm_v3, M, N, K, a_oc, b_oc):
     from aria_amd import hip
@@ -130,11 +130,18 @@ def test_gemm_v3_split_k(a_oc, b_oc):
 
     lib = hip.get_lib().cdll
     assert lib.aria_gemm_workspace_bytes(300, 264, 1024, int(a_oc), int(b_oc)) == 4 * 2 * 256 * 256 * 4
-    assert lib.aria_gemm_workspace_bytes(300, 264, 1000, int(a_oc), int(b_oc)) == 0
+    assert lib.aria_gemm_workspace_bytes(300, 264, 40, int(a_oc), int(b_oc)) == 0
     C.case_gemm_layouts(DEV, 300, 264, 1024, a_oc, b_oc)
     assert lib.aria_last_gemm_variant() == 3
 
 
 @pytest.mark.parametrize("counts", [[3, 0, 130, 5, 0, 0, 300, 1], [1, 1, 1]])
 def test_grouped_gemm_v3(force_gemm_v3, counts):
+    from aria_amd import hip
+
     C.case_grouped_gemm(DEV, counts, K=128, N=192)
+    assert hip.get_lib().cdll.aria_last_gemm_variant() == 3  # the last call is the per-expert weight gradient (ragged reductions)
+
+
+def test_grouped_gemm_v3_ragged_everything(force_gemm_v3):
+    C.case_grouped_gemm(DEV, [3, 0, 130, 5, 0, 0, 300, 1])  # K = 72, N = 136: no dimension is a multiple of the tile

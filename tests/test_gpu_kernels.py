@@ -121,7 +121,8 @@ def force_gemm_v3(monkeypatch):
     monkeypatch.setenv("ARIA_GEMM_FORCE", "3")
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (264, 136, 192), (40, 520, 128), (2048, 3328, 2560), (1000, 520, 1152)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (264, 136, 192), (40, 520, 128), (2048, 3328, 2560), (1000, 520, 1152),
+                                   (264, 136, 200), (72, 264, 72), (1304, 1152, 4304)])
 @pytest.mark.parametrize("a_oc,b_oc", [(False, False), (False, True), (True, True)])
 def test_gemm_v3_layouts(force_gemm_v3, M, N, K, a_oc, b_oc):
     from aria_amd import hip
@@ -133,7 +134,15 @@ def test_gemm_v3_layouts(force_gemm_v3, M, N, K, a_oc, b_oc):
 
 @pytest.mark.parametrize("counts", [[3, 0, 130, 5, 0, 0, 300, 1], [1, 1, 1], [37 * (i % 5) + (i * 7) % 11 for i in range(64)]])
 def test_grouped_gemm_v3(force_gemm_v3, counts):
-    C.case_grouped_gemm(DEV, counts, K=128, N=192)
+    from aria_amd import hip
+
+    for _ in range(3):
+        C.case_grouped_gemm(DEV, counts, K=128, N=192)
+    assert hip.get_lib().cdll.aria_last_gemm_variant() == 3  # the last call is the per-expert weight gradient (ragged reductions)
+
+
+def test_grouped_gemm_v3_ragged_everything(force_gemm_v3):
+    C.case_grouped_gemm(DEV, [3, 0, 130, 5, 0, 0, 300, 1])  # K = 72, N = 136: no dimension is a multiple of the tile
 
 
 def test_grouped_gemm_v3_aria_width(force_gemm_v3):
