@@ -106,6 +106,7 @@ __device__ const uint32_t aria_zero_page[64] = {};
 
 struct Stage {  // everything a wave needs to issue its two DMA pieces of any half-tile
     int w, nk, tail_k;  // wave id, K-tiles of this workgroup, valid reduction indices in the last one (64 = it is full)
+    int late;           // DMA pieces are issued inside the MFMA section instead of before the barrier
     const char* gA;
     const char* gB;
     long long kstepA, kstepB;  // bytes per K-tile along k
@@ -164,28 +165,41 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
             }
     }
     sched_fence();
-    if (do_stage) stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
+    // DMA placement (st.late, wave-uniform): 0 = with the LDS reads, before the barrier; 1 = inside the MFMA section, where the
+    // piece's issue cost hides under the matrix pipe -- the phase-4 wait then sees only phase 3's two pieces as "newer"
+    if (do_stage && !st.late) stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
     if (WAIT) {
-        if (more_in_flight)
-            wait_vm<4>();
-        else
+        if (!more_in_flight)
             wait_vm<0>();
+        else if (st.late)
+            wait_vm<2>();
+        else
+            wait_vm<4>();
     }
     raw_barrier();
     wait_lds();
     wave_prio<1>();
     if (!EDGE) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc[QA][i][QB] = mfma32(fa[i][kk], fb[kk], acc[QA][i][QB]);
-    } else if (col_ok) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            if (row_ok[i]) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc[QA][i][QB] = mfma32(fa[i][kk], fb[kk], acc[QA][i][QB]);
+            if (kk == 0) {
+                sched_fence();
+                if (do_stage && st.late) stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
+                sched_fence();
             }
+        }
+    } else {
+        if (do_stage && st.late) stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
+        if (col_ok) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (row_ok[i]) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc[QA][i][QB] = mfma32(fa[i][kk], fb[kk], acc[QA][i][QB]);
+                }
+        }
     }
     wave_prio<0>();
     raw_barrier();
@@ -264,6 +278,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     st.gA = reinterpret_cast<const char*>(p.A) + (A_OC ? 2 * k_begin * p.lda : 2 * (long long)k_begin) + kt_first * st.kstepA;
     st.gB = reinterpret_cast<const char*>(p.B + b_off) + (B_OC ? 2 * k_begin * p.ldb : 2 * (long long)k_begin) + kt_first * st.kstepB;
     st.w = w;
+    st.late = (p.order >> 8) & 1;
     st.nk = nk;
     st.tail_k = (kt_first + nk == nk_all && nk_all > 0) ? k_len - (nk_all - 1) * BK : BK;  // only the overall last K-tile is ragged
     st.lds = smem + 2048 * w;
@@ -456,7 +471,9 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
         }
     }
     const char* ord = std::getenv("ARIA_GEMM_ORDER");
-    q.order = ord ? std::atoi(ord) : 4;
+    // bit 8 = DMA pieces inside the MFMA section: measured +4..6 % with two k-contiguous operands, -5 % when an operand goes through
+    // the transposing reads (profiles/r01_gemm_tuning.md)
+    q.order = ord ? std::atoi(ord) : (!a_oc && !b_oc ? 256 + 4 : 4);
     if (ntn * ntm <= 0) return ARIA_OK;
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
     dim3 grid(unsigned(aria_tile_grid(q)), grid_y), block(512);

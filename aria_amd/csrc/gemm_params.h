@@ -26,8 +26,8 @@ struct GemmParams {
 __device__ __forceinline__ bool aria_tile_from_pos(const GemmParams& p, int tile, int& tmi, int& tn) {
     tn = tile % p.ntn;
     tmi = tile / p.ntn;
-    if (p.order >= 2) {
-        const int GM = p.order, per = GM * p.ntn;
+    if ((p.order & 255) >= 2) {
+        const int GM = p.order & 255, per = GM * p.ntn;
         const int g = tile / per, in = tile % per;
         const int gm = min(GM, p.ntm - g * GM);
         tn = in / gm;
@@ -43,7 +43,7 @@ __device__ __forceinline__ bool aria_tile_from_pos(const GemmParams& p, int tile
 // Returns false when the workgroup has no tile.
 __device__ __forceinline__ bool aria_tile_coords(const GemmParams& p, int bid, int nwg, int& tmi, int& tn) {
     int tile = bid;
-    if (p.order != 1) {
+    if ((p.order & 255) != 1) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
