@@ -14,7 +14,7 @@
 //   phase 1: quadrant (A0,B0)  reads B0 (4 fragments) + A0 (8)      DMA: A1 of tile t+1 -> other buffer (last read: phase 3 of t-1)
 //   phase 2: quadrant (A0,B1)  reads B1 (4)                          DMA: B0 of tile t+1 -> other buffer (last read: phase 4 of t-1)
 //   phase 3: quadrant (A1,B1)  reads A1 (8)                          DMA: A0 of tile t+2 -> this buffer  (last read: phase 1)
-//   phase 4: quadrant (A1,B0)  reads B0 (4)                          DMA: B1 of tile t+2 -> this buffer  (last read: phase 2),
+//   phase 4: quadrant (A1,B0)  reads nothing (B0 kept)                         DMA: B1 of tile t+2 -> this buffer  (last read: phase 2),
 //                                                                         then s_waitcnt vmcnt(4)
 //
 // so each half-tile slot is refilled TWO phases after its last read (its readers' lgkmcnt(0) is two barriers back for either
@@ -144,7 +144,7 @@ __device__ __forceinline__ void stage_half(const Stage& st, int tile) {
 // outside (wave-uniform tests on rows_left / cols_left, counted from the wave's first row / column) are skipped together with
 // their fragment reads -- a grouped GEMM's last row tile per expert usually holds only a few rows.
 template <bool A_OC, bool B_OC, int QA, int QB, bool LOAD_A, bool LOAD_B, int BUF, int SO, int SH, int SB, bool WAIT, bool EDGE>
-__device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[4], const FragAddr<A_OC>& aa,
+__device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                       const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int stage_tile, bool do_stage,
                                       bool more_in_flight, int rows_left, int cols_left) {
     const bool col_ok = !EDGE || QB * 128 < cols_left;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
     if (LOAD_B && (!EDGE || (col_ok && rows_left > 0))) {
         const char* hb = smem + LDS_OPERAND + QB * LDS_HALF + BUF * LDS_BUF;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fb[kk] = ab.read(hb, 0, kk);
+        for (int kk = 0; kk < 4; ++kk) fb[QB][kk] = ab.read(hb, 0, kk);
     }
     sched_fence();
     if (LOAD_A) {
@@ -183,7 +183,7 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[QA][i][QB] = mfma32(fa[i][kk], fb[kk], acc[QA][i][QB]);
+            for (int i = 0; i < 2; ++i) acc[QA][i][QB] = mfma32(fa[i][kk], fb[QB][kk], acc[QA][i][QB]);
             if (kk == 0) {
                 sched_fence();
                 if (do_stage && st.late) stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
@@ -197,7 +197,7 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
             for (int i = 0; i < 2; ++i)
                 if (row_ok[i]) {
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) acc[QA][i][QB] = mfma32(fa[i][kk], fb[kk], acc[QA][i][QB]);
+                    for (int kk = 0; kk < 4; ++kk) acc[QA][i][QB] = mfma32(fa[i][kk], fb[QB][kk], acc[QA][i][QB]);
                 }
         }
     }
@@ -206,17 +206,17 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
 }
 
 template <bool A_OC, bool B_OC, int BUF, bool EDGE>
-__device__ __forceinline__ void k_tile(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[4], const FragAddr<A_OC>& aa,
+__device__ __forceinline__ void k_tile(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                        const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int t, int nk, int rl, int cl) {
     const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
     phase<A_OC, B_OC, 0, 0, true, true, BUF, 0, 1, BUF ^ 1, false, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
     phase<A_OC, B_OC, 0, 1, false, true, BUF, 1, 0, BUF ^ 1, false, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
     phase<A_OC, B_OC, 1, 1, true, false, BUF, 0, 0, BUF, false, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, false, rl, cl);
-    phase<A_OC, B_OC, 1, 0, false, true, BUF, 1, 1, BUF, true, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, n2, rl, cl);
+    phase<A_OC, B_OC, 1, 0, false, false, BUF, 1, 1, BUF, true, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, n2, rl, cl);
 }
 
 template <bool A_OC, bool B_OC, bool EDGE>
-__device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[4], const FragAddr<A_OC>& aa,
+__device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                         const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int nk, int rl, int cl) {
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
-    s16x8 fa[2][4], fb[4];
+    s16x8 fa[2][4], fb[2][4];  // A fragments of the current A half; B fragments of BOTH halves (B0 is used by phases 1 and 4)
 
     // ---- prologue: tile 0 completely, A0 and B1 of tile 1 (phases 1 and 2 of tile 0 issue its A1 and B0) -- the steady-state
     // queue shape
