@@ -250,14 +250,16 @@ __device__ __forceinline__ bool attn_block_coords(int nblk, int H, int B, int ca
 inline unsigned attn_grid(long long nblk, long long H, long long B) { return unsigned(((H * B + 7) & ~7ll) * nblk); }
 
 // =========================================================================================== forward v2
-// 8 waves / 256 queries per block, K/V double-buffered in LDS (ONE barrier per 64-key tile), V fragments through
+// NW waves / 32 NW queries per block (8 for hd 64/128; 12 for hd 72, whose ~165 VGPRs allow three waves per SIMD -- the extra
+// wave hides LDS / MFMA-result latency that two waves cannot), K/V double-buffered in LDS (ONE barrier per 64-key tile), V fragments through
 // ds_read_b64_tr_b16 (row-major [key][d] tile read as key-contiguous fragments: half the LDS cycles of the dword-pair
 // read and no VALU repacking), softmax in the log2 domain on v_exp_f32 with the scale folded in, lazy (wave-uniform)
 // rescale, mask arithmetic only on edge / diagonal / padded tiles, native head dims 64 / 72 / 128 (72 = ViT and
 // projector: reduction padded to 80, output tiles 32+32+8).
-template <int HD>
+template <int HD, int NW = 8>
 struct Cfg2 {
-    static constexpr int NT2 = 512;
+    static constexpr int NT2 = NW * 64;   // threads per block
+    static constexpr int QB = NW * 32;    // queries per block (32 per wave)
     static constexpr int KS = (HD + 15) / 16;
     static constexpr int HDK = KS * 16;
     static constexpr int DT = (HD + 31) / 32;
@@ -268,10 +270,13 @@ struct Cfg2 {
     static constexpr size_t SMEM = size_t(2) * 64 * (KP + VP) * 2 + 2 * 64 + 16;
 };
 
-template <int HD>
-__device__ __forceinline__ void tile2_load(u32x4 (&r)[Cfg2<HD>::NCH], const bf16_t* base, long long ld, int row0, int row_end,
+template <int HD, int NW>
+using Chunks2 = u32x4[Cfg2<HD, NW>::NCH];
+
+template <int HD, int NW>
+__device__ __forceinline__ void tile2_load(Chunks2<HD, NW>& r, const bf16_t* base, long long ld, int row0, int row_end,
                                            int t) {
-    using C = Cfg2<HD>;
+    using C = Cfg2<HD, NW>;
 #pragma unroll
     for (int p = 0; p < C::NCH; ++p) {
         const int c = t + C::NT2 * p;
@@ -279,9 +284,9 @@ __device__ __forceinline__ void tile2_load(u32x4 (&r)[Cfg2<HD>::NCH], const bf16
         r[p] = (c < 64 * C::CPR && row < row_end) ? ld16(base + (long long)row * ld + col) : zero16();
     }
 }
-template <int HD, int PITCH>
-__device__ __forceinline__ void tile2_store(const u32x4 (&r)[Cfg2<HD>::NCH], bf16_t* s, int t) {
-    using C = Cfg2<HD>;
+template <int HD, int NW, int PITCH>
+__device__ __forceinline__ void tile2_store(const Chunks2<HD, NW>& r, bf16_t* s, int t) {
+    using C = Cfg2<HD, NW>;
 #pragma unroll
     for (int p = 0; p < C::NCH; ++p) {
         const int c = t + C::NT2 * p;
@@ -289,12 +294,12 @@ __device__ __forceinline__ void tile2_store(const u32x4 (&r)[Cfg2<HD>::NCH], bf1
     }
 }
 
-template <int HD>
-__global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE,
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE,
                                                         const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
                                                         long long ldq, long long ldk, long long ldv, long long ldo, float scale,
                                                         int causal, int nbatch) {
-    using C = Cfg2<HD>;
+    using C = Cfg2<HD, NW>;
     ARIA_DYN_SMEM(smem);
     bf16_t* sK = reinterpret_cast<bf16_t*>(smem);          // [2][64][KP]
     bf16_t* sV = sK + 2 * 64 * C::KP;                      // [2][64][VP]
@@ -302,8 +307,8 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* Q, const b
     int* sFlag = reinterpret_cast<int*>(sM + 128);         // [2]
     const int t = threadIdx.x, l = t & 63, w = t >> 6, h2 = l >> 5;
     int qblk, head, b;
-    if (!attn_block_coords((Sq + 255) / 256, H, nbatch, causal, true, qblk, head, b)) return;
-    const int q0 = qblk * 256;
+    if (!attn_block_coords((Sq + C::QB - 1) / C::QB, H, nbatch, causal, true, qblk, head, b)) return;
+    const int q0 = qblk * C::QB;
     const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
     const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
     const bf16_t* Kb = K + tok0 * ldk + head * HD;
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* Q, const b
     float m = -INFINITY, lsum = 0.f;
 
     int kv_end = klen;
-    if (causal) kv_end = min(kv_end, q0 + 256);
+    if (causal) kv_end = min(kv_end, q0 + C::QB);
     const int ntiles = (kv_end + 63) / 64;
 
     // pad columns: K's reduction pad must be zero (Q's is), V's pad only feeds discarded output rows but must not be NaN-free
@@ -340,10 +345,10 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* Q, const b
     }
     u32x4 rk[C::NCH], rv[C::NCH];
     if (ntiles > 0) {
-        tile2_load<HD>(rk, Kb, ldk, 0, S, t);
-        tile2_load<HD>(rv, Vb, ldv, 0, S, t);
-        tile2_store<HD, C::KP>(rk, sK, t);
-        tile2_store<HD, C::VP>(rv, sV, t);
+        tile2_load<HD, NW>(rk, Kb, ldk, 0, S, t);
+        tile2_load<HD, NW>(rv, Vb, ldv, 0, S, t);
+        tile2_store<HD, NW, C::KP>(rk, sK, t);
+        tile2_store<HD, NW, C::VP>(rv, sV, t);
         if (kmb && t < 64) {
             const uint8_t mv = t < S ? kmb[t] : 0;
             sM[t] = mv;
@@ -356,8 +361,8 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* Q, const b
         const int cur = it & 1, kv0 = it * 64;
         const bool more = it + 1 < ntiles;
         if (more) {
-            tile2_load<HD>(rk, Kb, ldk, kv0 + 64, S, t);
-            tile2_load<HD>(rv, Vb, ldv, kv0 + 64, S, t);
+            tile2_load<HD, NW>(rk, Kb, ldk, kv0 + 64, S, t);
+            tile2_load<HD, NW>(rv, Vb, ldv, kv0 + 64, S, t);
         }
         const bf16_t* cK = sK + cur * 64 * C::KP;
         const bf16_t* cV = sV + cur * 64 * C::VP;
@@ -433,8 +438,8 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* Q, const b
         }
         if (more) {  // stage tile it+1 into the other buffer (nobody reads it before the next barrier)
             const int nb = cur ^ 1, kvn = kv0 + 64;
-            tile2_store<HD, C::KP>(rk, sK + nb * 64 * C::KP, t);
-            tile2_store<HD, C::VP>(rv, sV + nb * 64 * C::VP, t);
+            tile2_store<HD, NW, C::KP>(rk, sK + nb * 64 * C::KP, t);
+            tile2_store<HD, NW, C::VP>(rv, sV + nb * 64 * C::VP, t);
             if (kmb && t < 64) {
                 const uint8_t mv = (kvn + t < S) ? kmb[kvn + t] : 0;
                 sM[nb * 64 + t] = mv;
@@ -1412,17 +1417,24 @@ int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     if (!al16(q) || !al16(k) || !al16(v) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || (reinterpret_cast<uintptr_t>(o) & 7))
         return ARIA_ERR_ALIGN;
     if (B == 0 || Sq == 0) return ARIA_OK;
-    dim3 grid(attn_grid((Sq + 255) / 256, H, B)), block(512);
     const bf16_t *Q = static_cast<const bf16_t*>(q), *K = static_cast<const bf16_t*>(k), *V = static_cast<const bf16_t*>(v);
+    const char* nw72 = std::getenv("ARIA_ATTN_HD72_WAVES");  // "8": the two-waves-per-SIMD variant (A/B measurements)
     if (hd == 128)
-        ARIA_LAUNCH((attn_fwd2_kernel<128>), grid, block, Cfg2<128>::SMEM, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len,
-                    key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal, int(B));
+        ARIA_LAUNCH((attn_fwd2_kernel<128, 8>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Cfg2<128>::SMEM), stream, Q, K, V,
+                    static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
+                    (long long)ldv, (long long)ldo, scale, causal, int(B));
+    else if (hd == 72 && nw72 && nw72[0] == '8')
+        ARIA_LAUNCH((attn_fwd2_kernel<72, 8>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Cfg2<72>::SMEM), stream, Q, K, V,
+                    static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
+                    (long long)ldv, (long long)ldo, scale, causal, int(B));
     else if (hd == 72)
-        ARIA_LAUNCH((attn_fwd2_kernel<72>), grid, block, Cfg2<72>::SMEM, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len,
-                    key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal, int(B));
+        ARIA_LAUNCH((attn_fwd2_kernel<72, 12>), dim3(attn_grid((Sq + 383) / 384, H, B)), dim3(768), size_t(Cfg2<72>::SMEM), stream, Q, K, V,
+                    static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
+                    (long long)ldv, (long long)ldo, scale, causal, int(B));
     else
-        ARIA_LAUNCH((attn_fwd2_kernel<64>), grid, block, Cfg2<64>::SMEM, stream, Q, K, V, static_cast<bf16_t*>(o), lse, kv_len,
-                    key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, scale, causal, int(B));
+        ARIA_LAUNCH((attn_fwd2_kernel<64, 8>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Cfg2<64>::SMEM), stream, Q, K, V,
+                    static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
+                    (long long)ldv, (long long)ldo, scale, causal, int(B));
     return aria_check_launch();
 }
 

@@ -83,7 +83,7 @@ def test_attention_cross_masked(B, Sq, Skv, H, hd):
     C.case_attention_cross_masked(DEV, B, Sq, Skv, H, hd)
 
 
-@pytest.mark.parametrize("B,Sq,Skv,H,masked", [(2, 70, 70, 2, True), (1, 300, 90, 1, False)])
+@pytest.mark.parametrize("B,Sq,Skv,H,masked", [(2, 70, 70, 2, True), (1, 300, 90, 1, False), (1, 800, 130, 1, True)])
 def test_attention_hd72_forward(B, Sq, Skv, H, masked):
     C.case_attention_hd72_forward(DEV, B, Sq, Skv, H, masked)
 
