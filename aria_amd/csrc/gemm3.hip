@@ -444,7 +444,9 @@ int plan_split(long long tiles, long long nk, long long* remainder) {
 }  // namespace
 
 long long aria_gemm3_workspace_bytes(long long M, long long N, long long K) {
-    if (K < 64 || M < 256 || N < 256) return 0;  // at least one full tile each way (not the decode GEMVs)
+    // at least one full tile each way -- or a skinny output with a long reduction (router weight gradient [64 x 2560], K = tokens),
+    // but never the decode GEMVs (M = batch)
+    if (K < 64 || M < 32 || N < 32 || ((M < 256 || N < 256) && K < 2048)) return 0;
     long long R = 0;
     const int S = plan_split(((M + 255) / 256) * ((N + 255) / 256), (K + 63) / 64, &R);
     return S > 1 ? R * S * (long long)(BM * BN) * 4 : 0;

@@ -2,6 +2,7 @@
 // ballots for the stable sort, no host round trips).  Reference: aria/model/moe_lm.py:243-365, 505-507.
 #include "aria_device.h"
 #include "aria_hip.h"
+#include <algorithm>
 
 namespace {
 using namespace ad;
@@ -13,6 +14,11 @@ constexpr int kMaxPerLane = 4;  // E <= 256
 template <bool F32>
 __global__ __launch_bounds__(256) void route_kernel(const void* logits_, void* scores_, int32_t* indices, int32_t* counts,
                                                     int T, int E, int k) {
+    // tokens-per-expert histogram: T*k atomics on E global counters serialise in L2 (measured 266 us for 16384 x 6 on 64 counters);
+    // count in LDS per block, then one global atomic per (block, expert)
+    ARIA_SMEM_STATIC int hist[64 * kMaxPerLane];
+    for (int i = threadIdx.x; i < E; i += blockDim.x) hist[i] = 0;
+    sync();
     const int l = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -74,9 +80,12 @@ __global__ __launch_bounds__(256) void route_kernel(const void* logits_, void* s
             else
                 static_cast<bf16_t*>(scores_)[(long long)t * k + l] = f2bf(s);
             indices[(long long)t * k + l] = topi;
-            atomic_add(&counts[topi], 1);
+            atomic_add(&hist[topi], 1);
         }
     }
+    sync();
+    for (int i = threadIdx.x; i < E; i += blockDim.x)
+        if (hist[i]) atomic_add(&counts[i], hist[i]);
 }
 
 // ------------------------------------------------------------------------------------------- stable sort (E <= 64)
@@ -405,7 +414,7 @@ int aria_moe_route(const void* logits, int logits_f32, void* scores, int32_t* in
     if (hipMemsetAsync(counts, 0, sizeof(int32_t) * E, static_cast<hipStream_t>(stream)) != hipSuccess) return ARIA_ERR_LAUNCH;
 #endif
     if (T == 0) return ARIA_OK;
-    dim3 grid(grid_for_waves(T)), block(256);
+    dim3 grid(std::min(grid_for_waves(T), 512)), block(256);  // few enough blocks that the per-block histogram flush stays cheap
     if (logits_f32)
         ARIA_LAUNCH((route_kernel<true>), grid, block, 0, stream, logits, scores, indices, counts, int(T), int(E), int(k));
     else
