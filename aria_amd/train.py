@@ -10,7 +10,7 @@ ShardedAdamW (ZeRO-2-style sharded state, fused HIP AdamW), MoEAuxLossAutoScaler
 
 Out of scope: dataset mixing / chat templating / image decoding (aria/data.py, processing_aria.py) -- without
 network access there is neither a dataset nor a checkpoint, so ``--synthetic`` (default) draws random samples of the configured
-shape; ``model_name_or_path`` is accepted when it points to a local state dict saved by ``torch.save``.
+shape; ``model_name_or_path`` may point to a local HF checkpoint directory (``aria_amd.checkpoint``) or a ``torch.save``d state dict.
 """
 from __future__ import annotations
 
@@ -81,7 +81,11 @@ def build_model(cfg, device):
             else:
                 p.normal_(0.0, 0.02, generator=g)
     path = cfg.get("model_name_or_path")
-    if path and os.path.isfile(str(path)):
+    if path and os.path.isdir(str(path)):  # HF checkpoint directory (sharded safetensors / bin + index), reference key names
+        from .checkpoint import load_checkpoint_dir, load_hf_into
+
+        load_hf_into(model, load_checkpoint_dir(str(path)), strict=False)
+    elif path and os.path.isfile(str(path)):
         sd = torch.load(path, map_location="cpu")
         own = model.state_dict()
         with torch.no_grad():
