@@ -1,0 +1,101 @@
+"""LoRA on the grouped expert GEMM: the reference's cheapest fine-tune recipe
+(recipes/config_lora.yaml:44-59) adapts ``experts.fc1`` / ``experts.fc2`` with per-expert rank-r factors through the same
+``experts_gemm`` seam (aria/lora/layers.py:30-224):
+
+    y = base(x, tpe) + lora_B(lora_A(dropout(x), tpe), tpe) * (lora_alpha / r)        (layers.py:129-139)
+
+``lora_A`` is a GroupedGEMM(in, r, groups) (weight [E, in, r]) and ``lora_B`` a GroupedGEMM(r, out, groups) (weight [E, r, out]); both are
+plain calls of the MI355X grouped GEMM (N = r for A, K = r for B; r must be a multiple of 8 for the 16-byte operand granules).  peft is
+not in this image, so the layer is a stand-alone module with peft's surface for this class: ``merge`` / ``unmerge`` /
+``get_delta_weight`` / ``scaling`` / ``disable_adapters``; ``apply_lora_to_experts`` is the part of ``get_peft_model`` the recipe uses
+(wrap the target modules, freeze everything else).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable
+
+import torch
+from torch import nn
+
+from .moe_lm import GroupedGEMM
+
+
+class GroupedGemmLoraLayer(nn.Module):
+    def __init__(self, base_layer: GroupedGEMM, r: int = 8, lora_alpha: int = 16, lora_dropout: float = 0.0,
+                 init_lora_weights: bool = True):
+        super().__init__()
+        if r <= 0:
+            raise ValueError(f"`r` should be a positive integer value but the value passed is {r}")
+        if r % 8:
+            raise ValueError("r must be a multiple of 8 (16-byte bf16 granules of the grouped GEMM operands)")
+        self.base_layer = base_layer
+        self.in_features, self.out_features, self.groups = base_layer.in_features, base_layer.out_features, base_layer.groups
+        self.r, self.lora_alpha, self.scaling = r, lora_alpha, lora_alpha / r
+        self.lora_dropout = nn.Dropout(p=lora_dropout) if lora_dropout > 0.0 else nn.Identity()
+        self.lora_A = GroupedGEMM(self.in_features, r, self.groups)
+        self.lora_B = GroupedGEMM(r, self.out_features, self.groups)
+        self.lora_A.to(base_layer.weight.device)
+        self.lora_B.to(base_layer.weight.device)
+        self.merged = False
+        self.disable_adapters = False
+        if init_lora_weights:
+            self.reset_lora_parameters()
+        base_layer.weight.requires_grad_(False)
+
+    @property
+    def weight(self):  # peft's LoraLayer exposes the base weight the same way
+        return self.base_layer.weight
+
+    def reset_lora_parameters(self):
+        """peft's default: A ~ kaiming_uniform(a = sqrt(5)), B = 0 -> the adapted layer starts as the base layer."""
+        with torch.no_grad():
+            a = torch.empty(self.lora_A.weight.shape, dtype=torch.float32)
+            nn.init.kaiming_uniform_(a, a=math.sqrt(5))
+            self.lora_A.weight.copy_(a.to(self.lora_A.weight.dtype))
+            self.lora_B.weight.zero_()
+
+    def forward(self, x: torch.Tensor, tokens_per_expert: torch.Tensor) -> torch.Tensor:
+        if self.disable_adapters:
+            if self.merged:
+                self.unmerge()
+            return self.base_layer(x, tokens_per_expert)
+        result = self.base_layer(x, tokens_per_expert)
+        if self.merged:
+            return result
+        dtype = result.dtype
+        x = x.to(self.lora_A.weight.dtype)
+        result = result + self.lora_B(self.lora_A(self.lora_dropout(x), tokens_per_expert), tokens_per_expert) * self.scaling
+        return result.to(dtype)
+
+    def get_delta_weight(self) -> torch.Tensor:
+        """layers.py:196-224: matmul(A, B) * scaling, per expert, in the adapter dtype."""
+        return torch.matmul(self.lora_A.weight, self.lora_B.weight) * self.scaling
+
+    def merge(self) -> None:
+        if not self.merged:
+            self.base_layer.weight.data += self.get_delta_weight()
+            self.merged = True
+
+    def unmerge(self) -> None:
+        if self.merged:
+            self.base_layer.weight.data -= self.get_delta_weight()
+            self.merged = False
+
+
+def apply_lora_to_experts(model: nn.Module, r: int = 8, lora_alpha: int = 16, lora_dropout: float = 0.0,
+                          target_suffixes: Iterable[str] = ("experts.fc1", "experts.fc2")) -> nn.Module:
+    """Freeze every parameter, wrap each ``GroupedGEMM`` whose qualified name ends with one of ``target_suffixes`` (the recipe's
+    ``lora_target_modules`` for the experts, aria/train.py:100-112) and leave only the LoRA factors trainable."""
+    for p in model.parameters():
+        p.requires_grad_(False)
+    targets = [(name, mod) for name, mod in model.named_modules()
+               if isinstance(mod, GroupedGEMM) and any(name.endswith(s) for s in target_suffixes)]
+    for name, mod in targets:
+        parent = model.get_submodule(name.rsplit(".", 1)[0]) if "." in name else model
+        setattr(parent, name.rsplit(".", 1)[-1], GroupedGemmLoraLayer(mod, r, lora_alpha, lora_dropout))
+    return model
+
+
+def lora_state_dict(model: nn.Module) -> Dict[str, torch.Tensor]:
+    return {k: v for k, v in model.state_dict().items() if ".lora_A." in k or ".lora_B." in k}

@@ -213,9 +213,24 @@ class MoELayer(nn.Module):
         x = hidden_states.reshape(-1, shp[-1])
         x = x if x.is_contiguous() else x.contiguous()
         se = self.shared_experts
+        if type(self.experts.fc1) is not GroupedGEMM or type(self.experts.fc2) is not GroupedGEMM:
+            return self.forward_modular(x).view(shp)  # an adapter (LoRA) sits on the expert GEMMs: go through the modules
         out = AG.MoELayerFn.apply(x, self.router.weight, self.experts.fc1.weight, self.experts.fc2.weight,
                                   se.gate_proj.weight, se.up_proj.weight, se.down_proj.weight, self.moe_config())
         return out.view(shp)
+
+    def forward_modular(self, x: torch.Tensor) -> torch.Tensor:
+        """The same layer (moe_lm.py:548-577) built from its differentiable pieces, calling ``self.experts`` / ``self.shared_experts``
+        as MODULES -- the seam a ``GroupedGemmLoraLayer`` wraps (aria/lora/layers.py)."""
+        from .expert_parallel import PermuteFn, RouteFn, UnpermuteFn
+
+        cfg = self.moe_config()
+        logits = AG.linear(x, self.router.weight)
+        scores, idx, counts = RouteFn.apply(logits, cfg)
+        offsets, sorted_src, inv = ops.moe_sort(idx, counts)
+        permuted = PermuteFn.apply(x, sorted_src, inv, cfg.topk)
+        expert_out = self.experts(permuted, counts)
+        return UnpermuteFn.apply(expert_out, inv, scores, self.shared_experts(x), cfg.topk)
 
 
 class AriaAttention(nn.Module):

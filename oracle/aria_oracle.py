@@ -187,6 +187,18 @@ def glu(x: Tensor) -> Tensor:
     return F.silu(a) * b
 
 
+def lora_grouped_gemm(x: Tensor, base: Tensor, lora_a: Tensor, lora_b: Tensor, tpe: Tensor, scaling: float) -> Tensor:
+    """GroupedGemmLoraLayer.forward, aria/lora/layers.py:129-139 (no dropout, no DoRA):
+    result = base_layer(x, tpe) + lora_B(lora_A(x, tpe), tpe) * scaling, with lora_A = GroupedGEMM(in, r) [E,in,r] and
+    lora_B = GroupedGEMM(r, out) [E,r,out] (layers.py:88-93), scaling = lora_alpha / r (:94)."""
+    return sequential_gemm(x, base, tpe) + sequential_gemm(sequential_gemm(x, lora_a, tpe), lora_b, tpe) * scaling
+
+
+def lora_delta_weight(lora_a: Tensor, lora_b: Tensor, scaling: float) -> Tensor:
+    """get_delta_weight, aria/lora/layers.py:196-224: matmul(A, B) * scaling per expert (what merge() adds to the base weight)."""
+    return torch.matmul(lora_a, lora_b) * scaling
+
+
 def grouped_mlp(permuted: Tensor, fc1: Tensor, fc2: Tensor, tpe: Tensor) -> Tensor:
     """GroupedMLP.forward moe_lm.py:511-525."""
     return sequential_gemm(glu(sequential_gemm(permuted, fc1, tpe)), fc2, tpe)

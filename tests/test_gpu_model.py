@@ -33,3 +33,6 @@ def test_aria_full_golden(golden):
 
 def test_gptfast_golden(golden):
     M.case_gptfast_golden(DEV, golden)
+
+def test_lora_grouped_gemm():
+    M.case_lora_grouped_gemm(DEV)

@@ -38,3 +38,25 @@ def test_moe_layer_and_lm_match_live_reference(seed):
     out, im = O.moe_layer(x, wl, "", ocfg, return_intermediates=True)
     assert torch.equal(im["indices"], i) and torch.equal(im["tokens_per_expert"], t)
     assert torch.allclose(out, o, atol=2e-5)
+
+
+def test_lora_restatement_matches_the_reference_grouped_gemm_modules():
+    """aria/lora/layers.py needs peft (absent here); its forward line (:129-139) is three calls of the reference's own GroupedGEMM
+    module, which IS importable -- compose them and pin oracle.lora_grouped_gemm / lora_delta_weight against that."""
+    ns = load_reference()
+    torch.manual_seed(5)
+    E, K, N, r, alpha = 5, 24, 40, 8, 16
+    tpe = torch.tensor([3, 0, 11, 1, 6])
+    base, a, b = ns.moe.GroupedGEMM(K, N, E), ns.moe.GroupedGEMM(K, r, E), ns.moe.GroupedGEMM(r, N, E)
+    with torch.no_grad():
+        for m in (base, a, b):
+            m.weight.normal_(0, 0.3)
+    x = torch.randn(int(tpe.sum()), K)
+    scaling = alpha / r
+    with torch.no_grad():
+        want = base(x, tpe) + b(a(x, tpe), tpe) * scaling
+        got = O.lora_grouped_gemm(x, base.weight, a.weight, b.weight, tpe, scaling)
+        assert torch.allclose(got, want, atol=1e-5, rtol=1e-5)
+        merged = ns.moe.GroupedGEMM(K, N, E)
+        merged.weight.copy_(base.weight + O.lora_delta_weight(a.weight, b.weight, scaling))
+        assert torch.allclose(merged(x, tpe), want, atol=1e-4, rtol=1e-4)
