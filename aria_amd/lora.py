@@ -99,3 +99,38 @@ def apply_lora_to_experts(model: nn.Module, r: int = 8, lora_alpha: int = 16, lo
 
 def lora_state_dict(model: nn.Module) -> Dict[str, torch.Tensor]:
     return {k: v for k, v in model.state_dict().items() if ".lora_A." in k or ".lora_B." in k}
+
+
+def get_lora_target_modules(model_named_modules, cfg) -> list:
+    """aria/lora/utils.py:29-63: every module name that contains one of ``cfg["lora_target_modules"]`` and is not under a frozen
+    part (freeze_vit / freeze_projector / freeze_llm / freeze_llm_layers)."""
+    out = []
+    for key in model_named_modules:
+        if cfg.get("freeze_vit") and "vision_tower" in key:
+            continue
+        if cfg.get("freeze_projector") and "multi_modal_projector" in key:
+            continue
+        if cfg.get("freeze_llm") and "language_model" in key:
+            continue
+        if any(f"language_model.model.layers.{i}." in key for i in (cfg.get("freeze_llm_layers") or [])):
+            continue
+        if any(m in key for m in cfg.get("lora_target_modules") or []):
+            out.append(key)
+    return out
+
+
+def apply_lora_from_config(model: nn.Module, cfg) -> list:
+    """``use_peft: true`` of recipes/config_lora.yaml for the part this package covers: the grouped expert GEMMs among the selected
+    target modules get a ``GroupedGemmLoraLayer``; plain ``nn.Linear``-shaped targets (q/k/v/o_proj, shared experts, lm_head) are
+    reported back as skipped (their LoRA is peft's stock Linear adapter, outside the grouped-GEMM seam)."""
+    names = [n for n, _ in model.named_modules()]
+    targets = get_lora_target_modules(names, cfg)
+    grouped = [n for n in targets if isinstance(model.get_submodule(n), GroupedGEMM)]
+    for p in model.parameters():
+        p.requires_grad_(False)
+    for name in grouped:
+        parent = model.get_submodule(name.rsplit(".", 1)[0])
+        setattr(parent, name.rsplit(".", 1)[-1],
+                GroupedGemmLoraLayer(model.get_submodule(name), int(cfg.get("lora_r", 8)), int(cfg.get("lora_alpha", 32)),
+                                     float(cfg.get("lora_dropout", 0.0))))
+    return [n for n in targets if n not in grouped and not any(n.startswith(g + ".") for g in grouped)]

@@ -279,6 +279,11 @@ class MoEDecoderLayer(nn.Module):
     def forward(self, hidden_states: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
                 kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, S, D = hidden_states.shape
+        m = self.mlp.experts
+        if type(m.fc1) is not GroupedGEMM or type(m.fc2) is not GroupedGEMM:
+            # an adapter (aria_amd/lora.py) wraps an expert GEMM: LlamaDecoderLayer.forward module by module (modeling_llama.py:295-325)
+            h = hidden_states + self.self_attn(self.input_layernorm(hidden_states), cos, sin, kv_len)
+            return h + self.mlp(self.post_attention_layernorm(h))
         x = hidden_states.reshape(B * S, D)
         x = x if x.is_contiguous() else x.contiguous()
         recompute = bool(self.config.gradient_checkpointing and self.training and torch.is_grad_enabled())

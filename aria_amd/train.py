@@ -101,6 +101,12 @@ def build_model(cfg, device):
     for i in (cfg.get("freeze_llm_layers") or []):
         for p in model.language_model.model.layers[int(i)].parameters():
             p.requires_grad = False
+    if cfg.get("use_peft"):  # recipes/config_lora.yaml: adapters on the grouped expert GEMMs (aria_amd/lora.py)
+        from .lora import apply_lora_from_config
+
+        skipped = apply_lora_from_config(model, cfg)
+        if skipped and int(os.environ.get("RANK", "0")) == 0:
+            print(f"[aria_amd.train] LoRA: {len(skipped)} Linear-shaped target modules left without adapter (grouped expert GEMMs only)")
     return model.train(), acfg
 
 
