@@ -219,6 +219,13 @@ __device__ __forceinline__ void sched_fence() {
 
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
+// gelu_pytorch_tanh (ViT MLP activation, transformers ACT2FN["gelu_pytorch_tanh"]); shared by the stand-alone kernel (vit.hip) and
+// the GEMM epilogues so that the fused and the unfused path round identically
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float k = 0.7978845608028654f;  // sqrt(2/pi)
+    return 0.5f * x * (1.f + tanhf(k * (x + 0.044715f * x * x * x)));
+}
+
 // 2^x straight on v_exp_f32 (no denormal range fix-up: results below 2^-126 flush to 0, which is what softmax wants)
 __device__ __forceinline__ float exp2_fast(float x) {
 #ifdef ARIA_EMU

@@ -204,6 +204,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
                     v0 += bf2f(p.bias[n]);
                     v1 += bf2f(p.bias[n + 1]);
                 }
+                v0 = aria_epilogue_act(p, v0);
+                v1 = aria_epilogue_act(p, v1);
                 if (p.c_f32) {
                     float* dst = reinterpret_cast<float*>(C) + (long long)m * p.ldc + n;
                     if (p.accumulate) {
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
                     if (n >= p.N) continue;
                     float v = acc[i][j][r];
                     if (p.bias) v += bf2f(p.bias[n]);
+                    v = aria_epilogue_act(p, v);
                     if (p.c_f32) {
                         float* dst = reinterpret_cast<float*>(C) + (long long)m * p.ldc + n;
                         if (p.accumulate) v += *dst;
@@ -300,6 +303,14 @@ int aria_gemm_bf16(const void* A, const void* B, void* C, const void* bias, int6
 int aria_gemm_bf16_ws(const void* A, const void* B, void* C, const void* bias, int64_t M, int64_t N, int64_t K, int a_oc,
                       int b_oc, int64_t lda, int64_t ldb, int64_t ldc, int c_f32, int accumulate, void* workspace,
                       int64_t workspace_bytes, void* stream) {
+    return aria_gemm_act_bf16(A, B, C, bias, M, N, K, a_oc, b_oc, lda, ldb, ldc, c_f32, accumulate, ARIA_ACT_NONE, workspace,
+                              workspace_bytes, stream);
+}
+
+int aria_gemm_act_bf16(const void* A, const void* B, void* C, const void* bias, int64_t M, int64_t N, int64_t K, int a_oc,
+                       int b_oc, int64_t lda, int64_t ldb, int64_t ldc, int c_f32, int accumulate, int act, void* workspace,
+                       int64_t workspace_bytes, void* stream) {
+    if (act != ARIA_ACT_NONE && act != ARIA_ACT_GELU_TANH) return ARIA_ERR_UNSUPPORTED;
     if (!A || !B || !C || M < 0 || N < 0 || K < 0) return ARIA_ERR_INVALID;
     if (M == 0 || N == 0) return ARIA_OK;
     if (!aligned16(A) || !aligned16(B) || (lda & 7) || (ldb & 7) || (N & 1) || (ldc & 1)) return ARIA_ERR_ALIGN;
@@ -320,6 +331,7 @@ int aria_gemm_bf16_ws(const void* A, const void* B, void* C, const void* bias, i
     p.mode = 0;
     p.c_f32 = c_f32;
     p.accumulate = accumulate;
+    p.act = act;
     p.ntn = int((N + BN - 1) / BN);
     const int ntm = int((M + BM - 1) / BM);
     const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmParams p) {
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int rp = 0; rp < 8; ++rp) {  // register pair (2rp, 2rp+1) = two consecutive rows
-                const float v0 = acc[i][j][2 * rp] + bv, v1 = acc[i][j][2 * rp + 1] + bv;
+                const float v0 = aria_epilogue_act(p, acc[i][j][2 * rp] + bv), v1 = aria_epilogue_act(p, acc[i][j][2 * rp + 1] + bv);
                 const int r = 2 * rp;
                 const int mrow = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (p.c_f32) {

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
                 for (int rp = 0; rp < 8; ++rp) {  // register pair (2rp, 2rp+1) = two consecutive rows
-                    const float v0 = acc[a][i][b][2 * rp] + bv, v1 = acc[a][i][b][2 * rp + 1] + bv;
+                    const float v0 = aria_epilogue_act(p, acc[a][i][b][2 * rp] + bv), v1 = aria_epilogue_act(p, acc[a][i][b][2 * rp + 1] + bv);
                     const int r = 2 * rp;
                     const int mrow = m0 + a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (p.c_f32) {
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void gemm3_reduce_kernel(GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (n + e >= p.N) continue;
-            float v = sum[e] + (p.bias ? bf2f(p.bias[n + e]) : 0.f);
+            float v = aria_epilogue_act(p, sum[e] + (p.bias ? bf2f(p.bias[n + e]) : 0.f));
             if (p.c_f32) {
                 float* d = static_cast<float*>(p.C) + (long long)m * p.ldc + n + e;
                 *d = p.accumulate ? *d + v : v;

@@ -14,6 +14,7 @@ struct GemmParams {
     int E;
     long long strideB, strideC;
     int c_f32, accumulate;
+    int act;  // epilogue activation applied to the bf16-ROUNDED (acc + bias), before any accumulate: 0 none, 1 gelu_tanh
     int ntn, ntm;  // column / row tile counts of the launch (256-wide tiles for v2/v3)
     // v3 remainder split-K (mode 0): tile-list positions >= split_first are each computed by `split` workgroups over disjoint K
     // ranges into fp32 slabs (ws), which a second kernel sums in a fixed order.  split <= 1: off.
@@ -104,6 +105,11 @@ inline int aria_tile_grid(const GemmParams& p) {
     if (p.mode == 1) return p.ntn * p.ntm + 8;  // aria_grouped_tile: 8 XCD chunks of ceil(T / 8) <= bound / 8 + 1 tiles
     if (p.split > 1) return p.split_first + (p.ntn * p.ntm - p.split_first) * p.split;
     return p.ntn * p.ntm;
+}
+
+// the epilogue value of every GEMM kernel: bias added by the caller; activation exactly as a separate elementwise kernel would see it
+__device__ __forceinline__ float aria_epilogue_act(const GemmParams& p, float v) {
+    return p.act == 1 ? ad::gelu_tanh(ad::rbf(v)) : v;
 }
 
 // v2 launcher (gemm2.hip); returns ARIA_* status

@@ -147,10 +147,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* dy, co
 }
 
 // ------------------------------------------------------------------------------------------- GELU (tanh form)
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-    const float k = 0.7978845608028654f;  // sqrt(2/pi)
-    return 0.5f * x * (1.f + tanhf(k * (x + 0.044715f * x * x * x)));
-}
+__device__ __forceinline__ float gelu_tanh_f(float x) { return gelu_tanh(x); }
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
     const float k = 0.7978845608028654f;
     const float u = k * (x + 0.044715f * x * x * x);

@@ -32,6 +32,7 @@ SIGNATURES = {
     "aria_gemm_bf16": [P, P, P, P, I64, I64, I64, I32, I32, I64, I64, I64, I32, I32, P],
     "aria_gemm_bf16_ws": [P, P, P, P, I64, I64, I64, I32, I32, I64, I64, I64, I32, I32, P, I64, P],
     "aria_gemm_workspace_bytes": [I64, I64, I64, I32, I32],
+    "aria_gemm_act_bf16": [P, P, P, P, I64, I64, I64, I32, I32, I64, I64, I64, I32, I32, I32, P, I64, P],
     "aria_grouped_gemm_bf16": [P, P, P, P, I64, I64, I64, I64, I32, I64, I64, I64, I64, P],
     "aria_grouped_gemm_wgrad_bf16": [P, P, P, P, I64, I64, I64, I64, I64, I32, I32, P],
     "aria_moe_route": [P, I32, P, P, P, I64, I64, I64, P],

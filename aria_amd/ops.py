@@ -40,8 +40,11 @@ def _rowmajor_2d(t: torch.Tensor, name="tensor") -> int:
 
 
 # ----------------------------------------------------------------------------- GEMM
+ACTIVATIONS = {None: 0, "gelu_tanh": 1}
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_oc: bool = False, b_oc: bool = False, bias: Optional[torch.Tensor] = None,
-         out: Optional[torch.Tensor] = None, out_dtype=bf16, accumulate: bool = False) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, out_dtype=bf16, accumulate: bool = False, act: Optional[str] = None) -> torch.Tensor:
     """C[M,N] = op(A) op(B) (+bias) (+C).  a: [M,K] (a_oc=False) or [K,M] (a_oc=True);
     b: [N,K] (b_oc=False, i.e. nn.Linear weight) or [K,N] (b_oc=True)."""
     _chk(a, name="a"), _chk(b, name="b")
@@ -62,7 +65,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_oc: bool = False, b_oc: bool = F
         _chk(bias, name="bias")
     lib = hip.get_lib()
     need = lib.cdll.aria_gemm_workspace_bytes(M, N, K, int(a_oc), int(b_oc)) if GEMM_SPLIT_K else 0
-    if need > 0:  # small outputs: let the library split the last round of tiles along K (fp32 slabs in a scratch buffer)
+    if act is not None:  # epilogue activation on bf16(acc + bias), bit-identical to the stand-alone elementwise kernel
+        ws = _gemm_workspace(a.device, _stream(a), need) if need > 0 else None
+        lib.call("aria_gemm_act_bf16", _p(a), _p(b), _p(out), _p(bias), M, N, K, int(a_oc), int(b_oc), lda, ldb, ldc, c_f32,
+                 int(accumulate), ACTIVATIONS[act], _p(ws), ws.numel() if ws is not None else 0, _stream(a))
+    elif need > 0:  # small outputs: let the library split the last round of tiles along K (fp32 slabs in a scratch buffer)
         ws = _gemm_workspace(a.device, _stream(a), need)
         lib.call("aria_gemm_bf16_ws", _p(a), _p(b), _p(out), _p(bias), M, N, K, int(a_oc), int(b_oc), lda, ldb, ldc,
                  c_f32, int(accumulate), _p(ws), ws.numel(), _stream(a))

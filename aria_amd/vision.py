@@ -213,6 +213,34 @@ class VisionEncoderLayer(nn.Module):
         x = AddFn.apply(x, self.self_attn(self.layer_norm1(x), key_mask))
         return AddFn.apply(x, self.mlp(self.layer_norm2(x)))
 
+    def _fused_qkv(self):
+        """[3D, D] weight / [3D] bias of the three projections, built once per weight version (frozen tower: once)."""
+        a = self.self_attn
+        ver = (a.q_proj.weight._version, a.k_proj.weight._version, a.v_proj.weight._version,
+               a.q_proj.bias._version, a.k_proj.bias._version, a.v_proj.bias._version, a.q_proj.weight.data_ptr())
+        if getattr(self, "_qkv_ver", None) != ver:
+            self._qkv_w = torch.cat([a.q_proj.weight.detach(), a.k_proj.weight.detach(), a.v_proj.weight.detach()]).contiguous()
+            self._qkv_b = torch.cat([a.q_proj.bias.detach(), a.k_proj.bias.detach(), a.v_proj.bias.detach()]).contiguous()
+            self._qkv_ver = ver
+        return self._qkv_w, self._qkv_b
+
+    def forward_frozen(self, x2: torch.Tensor, B: int, P: int, key_mask: Optional[torch.Tensor]) -> torch.Tensor:
+        """No-grad forward of the layer on a PRIVATE [B*P, D] buffer, updated in place (the recipe freezes the tower, config_full.yaml:39):
+        one fused q/k/v GEMM, attention on strided views of its output, the two residual adds folded into the out_proj / fc2 GEMM
+        epilogues (accumulate), GELU folded into the fc1 epilogue.  Same arithmetic as forward() except that `x + (h W^T + b)` is
+        rounded to bf16 once instead of twice."""
+        a, m = self.self_attn, self.mlp
+        D, H, hd = x2.shape[1], a.num_heads, a.head_dim
+        h, _, _ = ops.layernorm(x2, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps, want_stats=False)
+        wqkv, bqkv = self._fused_qkv()
+        qkv = ops.gemm(h, wqkv, bias=bqkv)
+        o, _ = ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, P, H, hd, hd ** -0.5, False, key_mask=key_mask)
+        ops.gemm(o, a.out_proj.weight, bias=a.out_proj.bias, out=x2, accumulate=True)
+        h, _, _ = ops.layernorm(x2, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps, want_stats=False)
+        g = ops.gemm(h, m.fc1.weight, bias=m.fc1.bias, act="gelu_tanh")
+        ops.gemm(g, m.fc2.weight, bias=m.fc2.bias, out=x2, accumulate=True)
+        return x2
+
 
 class AddFn(torch.autograd.Function):
     @staticmethod
@@ -260,7 +288,15 @@ class AriaVisionModel(nn.Module):
             key_mask = patch_mask.view(N, Hp * Hp)
             image_atts = key_mask == 0
         x = self.vision_model.embeddings(pixel_values, patch_mask)
-        for layer in self.vision_model.encoder.layers:
+        layers = self.vision_model.encoder.layers
+        frozen = not torch.is_grad_enabled() or not (x.requires_grad or any(p.requires_grad for p in layers.parameters()))
+        if frozen and Fn._pad_hd(cfg.hidden_size // cfg.num_attention_heads, need_bwd=False) == cfg.hidden_size // cfg.num_attention_heads:
+            Bn, P, D = x.shape
+            x2 = x.detach().reshape(Bn * P, D).clone()  # private buffer: the layers update it in place
+            for layer in layers:
+                layer.forward_frozen(x2, Bn, P, key_mask)
+            return x2.view(Bn, P, D), image_atts
+        for layer in layers:
             x = layer(x, key_mask)
         return x, image_atts
 

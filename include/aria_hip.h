@@ -54,6 +54,14 @@ int64_t aria_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int a_oc, int
 int aria_gemm_bf16_ws(const void* A, const void* B, void* C, const void* bias, int64_t M, int64_t N, int64_t K, int a_oc,
                       int b_oc, int64_t lda, int64_t ldb, int64_t ldc, int c_f32, int accumulate, void* workspace,
                       int64_t workspace_bytes, void* stream);
+/* Same, with an epilogue activation fused after the bias: the activation sees bf16(acc + bias), exactly what a separate
+ * elementwise kernel would read, so fused and unfused results are bit-identical (ViT MLP: fc1 + gelu_pytorch_tanh,
+ * modeling_idefics2.py MLP / ACT2FN).  The activation is applied before `accumulate` adds the old C. */
+#define ARIA_ACT_NONE 0
+#define ARIA_ACT_GELU_TANH 1
+int aria_gemm_act_bf16(const void* A, const void* B, void* C, const void* bias, int64_t M, int64_t N, int64_t K, int a_oc,
+                       int b_oc, int64_t lda, int64_t ldb, int64_t ldc, int c_f32, int accumulate, int act, void* workspace,
+                       int64_t workspace_bytes, void* stream);
 
 /* experts_gemm(input, weight, tokens_per_expert)  -- seam B1, aria/model/moe_lm.py:431-443 (grouped_gemm.ops.gmm
  * or sequential_gemm :398-428), called from GroupedGEMM.forward :467-484.

@@ -63,6 +63,22 @@ def case_gemm_layouts(dev, M, N, K, a_oc, b_oc):
     close(accb, (want + 1.0).to(bf16), 1e-2, 1e-2 * K ** 0.5)
 
 
+def case_gemm_fused_gelu(dev, M, N, K):
+    """fc1 + gelu_pytorch_tanh in the GEMM epilogue == the GEMM followed by the stand-alone GELU kernel, bit for bit (the activation
+    sees bf16(acc + bias) in both), also through accumulate (x += gelu(...) is never used, but the order act -> accumulate is ABI)."""
+    from aria_amd import ops
+
+    a = rnd(M, K, seed=11).to(dev)
+    w = rnd(N, K, seed=12, scale=0.3).to(dev)
+    bias = rnd(N, seed=13).to(dev)
+    want = ops.gelu_tanh(ops.gemm(a, w, bias=bias))
+    got = ops.gemm(a, w, bias=bias, act="gelu_tanh")
+    assert torch.equal(got, want)
+    acc = torch.ones(M, N, dtype=bf16, device=dev)
+    ops.gemm(a, w, bias=bias, act="gelu_tanh", out=acc, accumulate=True)
+    close(acc, (want.float() + 1.0).to(bf16), 2 ** -7, 2 ** -7)  # (the unrounded activation is added: one rounding fewer)
+
+
 def case_gemm_strided_views(dev):
     from aria_amd import ops
 

@@ -95,6 +95,14 @@ def test_attention_hd72_forward(B, Sq, Skv, H, masked):
     C.case_attention_hd72_forward(DEV, B, Sq, Skv, H, masked)
 
 
+@pytest.mark.parametrize("force", ["1", "2", "3", None])
+@pytest.mark.parametrize("M,N,K", [(40, 72, 64), (264, 136, 192), (2048, 4304, 1152), (2560, 2560, 4096)])
+def test_gemm_fused_gelu(monkeypatch, force, M, N, K):
+    if force:
+        monkeypatch.setenv("ARIA_GEMM_FORCE", force)
+    C.case_gemm_fused_gelu(DEV, M, N, K)
+
+
 @pytest.fixture
 def force_gemm_v2(monkeypatch):
     monkeypatch.setenv("ARIA_GEMM_FORCE", "2")
