@@ -262,6 +262,7 @@ int launch_gemm(const GemmParams& p, int a_oc, int b_oc, int grid_x, int grid_y,
 }
 
 thread_local int g_last_variant = 0;
+constexpr int GROUPED_V3_DEFAULT = 1;  // in-bench A/B: v3 wins the [N,K]-weight form by 17 %, loses the [K,N] form (fc1 forward) by 7 %
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // v1 (128x128 tiles, 3 blocks/CU) wins when the 256x256 grid would not fill the chip; v2 otherwise.
@@ -369,7 +370,13 @@ int aria_grouped_gemm_bf16(const void* A, const void* B, void* C, const int32_t*
     p.ntn = int((N + BN - 1) / BN);
     // every expert adds at most one partial row tile
     const int max_tm = int(M_total / BM + E);
-    if (use_v3((M_total / 256 + 1) * ((N + 255) / 256), K, 2 * M_total * lda, 2 * (b_oc ? K * ldb : N * ldb), M_total, N))
+    // ARIA_GEMM_GROUPED_V3 (bit 0: [N,K] weights = dgrad, bit 1: [K,N] weights = forward) picks v3 per operand form; see the
+    // in-bench A/B in profiles/r01_gemm_tuning.md for the default
+    const char* gsel = std::getenv("ARIA_GEMM_GROUPED_V3");
+    const int gmask = gsel ? std::atoi(gsel) : GROUPED_V3_DEFAULT;
+    const char* gforce = std::getenv("ARIA_GEMM_FORCE");
+    const bool gv3 = (gforce && gforce[0] == '3') || ((gmask >> (b_oc ? 1 : 0)) & 1);
+    if (gv3 && use_v3((M_total / 256 + 1) * ((N + 255) / 256), K, 2 * M_total * lda, 2 * (b_oc ? K * ldb : N * ldb), M_total, N))
         return g_last_variant = 3, aria_launch_gemm3(p, 0, b_oc, int(M_total / 256 + E), stream);
     if (use_v2((M_total / 256 + 1) * ((N + 255) / 256))) return g_last_variant = 2, aria_launch_gemm2(p, 0, b_oc, int(M_total / 256 + E), 1, stream);
     return g_last_variant = 1, launch_gemm(p, 0, b_oc, p.ntn * max_tm, 1, stream);

@@ -9,7 +9,7 @@ per-GPU shape (per_device_train_batch_size 8 x max_seq_length 2048, recipes/conf
 Aria-25.3B MoE decoder (28 layers, 64 experts top-6, vocab 100352, random-init bf16 weights N(0,0.02)), shifted masked
 cross-entropy, full backward incl. router aux-loss gradients; data-parallel gradient all-reduce overlapped with backward
 when N > 1 (weak scaling: per-GPU work fixed).  Inputs are resident in HBM before the timed region.
-Prints ONE JSON line (rank 0) with the driver's contract fields + `roofline` (dominant kernel: the fc1 grouped expert GEMM (gemm3.hip),
+Prints ONE JSON line (rank 0) with the driver's contract fields + `roofline` (dominant kernel: the fc1 grouped expert GEMM (gemm2.hip),
 timed live with HIP events on the launch stream) + `cpu_baseline` (the CPU oracle timed on the host cores, N=1 only).
 """
 from __future__ import annotations
@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--time-grouped", action="store_true", help="diagnostics: HIP-event time of every grouped-M GEMM class -> stderr")
     ap.add_argument("--batch", type=int, default=8, help="per-GPU micro-batch (config_full.yaml: 8)")
     ap.add_argument("--seq", type=int, default=2048, help="max_seq_length (config_full.yaml: 2048)")
     ap.add_argument("--layers", type=int, default=28, help="debug only: fewer layers makes the number INVALID")
@@ -170,7 +171,17 @@ def main():
     fc1_events = []
     orig_gg = ops.grouped_gemm
 
+    other_events = {}  # --time-grouped: every other grouped-M launch class (diagnostics only, printed to stderr)
+
     def timed_grouped_gemm(a, w, offsets, *, w_is_kn=True, out=None):
+        if args.time_grouped and timed_grouped_gemm.on and not (w_is_kn and w.shape[1] == cfg.hidden_size):
+            key = ("fwd" if w_is_kn else "dgrad") + f"_K{a.shape[1]}"
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_gg(a, w, offsets, w_is_kn=w_is_kn, out=out)
+            e.record()
+            other_events.setdefault(key, []).append((s, e))
+            return r
         if w_is_kn and w.shape[1] == cfg.hidden_size and fc1_events is not None and timed_grouped_gemm.on:
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -220,6 +231,12 @@ def main():
         M = B * S * cfg.moe_topk
         flops_launch = 2.0 * M * cfg.hidden_size * (2 * cfg.moe_intermediate_size)
         durs = [s.elapsed_time(e) * 1e-3 for s, e in fc1_events]
+        if args.time_grouped:
+            import sys as _sys
+
+            diag = {k: round(sum(s.elapsed_time(e) for s, e in v) / len(v), 4) for k, v in other_events.items()}
+            diag["fwd_fc1"] = round(sum(durs) / max(1, len(durs)) * 1e3, 4)
+            print("grouped-M avg launch ms: " + json.dumps(diag), file=_sys.stderr, flush=True)
         avg = sum(durs) / max(1, len(durs))
         achieved = flops_launch / avg / 1e12 if durs else None
         peak = 2500.0
@@ -234,7 +251,7 @@ def main():
                        "layers": args.layers, "vit_layers": args.vit_layers, "images_per_sample": n_img, "global_batch": world * B, "seq_len": S,
                        "parallelism": f"dp{world}" if world > 1 else "single", "grad_checkpointing": bool(args.recompute),
                        "optimizer_in_step": False, "loss": round(float(loss), 4)},
-            "roofline": {"kernel": "gemm3_kernel<rc,oc> grouped-M (experts.fc1 forward)", "bound": "mfma",
+            "roofline": {"kernel": "gemm2_kernel<rc,oc> grouped-M (experts.fc1 forward)", "bound": "mfma",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / peak, 4), "traffic": pmc_traffic(),
                          "launches_timed": len(durs), "avg_launch_ms": round(avg * 1e3, 4),
