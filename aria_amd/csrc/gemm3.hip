@@ -12,14 +12,15 @@
 // tile is 128 rows x 64 k (16 KiB); every wave needs BOTH halves of A and of B, one quadrant per phase:
 //
 //   phase 1: quadrant (A0,B0)  reads B0 (4 fragments) + A0 (8)      DMA: A1 of tile t+1 -> other buffer (last read: phase 3 of t-1)
-//   phase 2: quadrant (A0,B1)  reads B1 (4)                          DMA: B0 of tile t+1 -> other buffer (last read: phase 4 of t-1)
+//   phase 2: quadrant (A0,B1)  reads B1 (4)                          DMA: B1 of tile t+1 -> other buffer (last read: phase 2 of t-1)
 //   phase 3: quadrant (A1,B1)  reads A1 (8)                          DMA: A0 of tile t+2 -> this buffer  (last read: phase 1)
-//   phase 4: quadrant (A1,B0)  reads nothing (B0 kept)                         DMA: B1 of tile t+2 -> this buffer  (last read: phase 2),
-//                                                                         then s_waitcnt vmcnt(4)
+//   phase 4: quadrant (A1,B0)  reads nothing (B0 kept)               DMA: B0 of tile t+2 -> this buffer  (last read: phase 1)
 //
-// so each half-tile slot is refilled TWO phases after its last read (its readers' lgkmcnt(0) is two barriers back for either
-// wave group) and every piece has >= 2 phases to land.  The single vmcnt(4) per K-step leaves the two newest half-tiles
-// (2 pieces per wave each) in flight and retires everything tile t+1 needs; the barrier that follows publishes it.
+// so each half-tile slot is refilled at least TWO phases after its last read (its readers' lgkmcnt(0) is two barriers back for either
+// wave group) and every piece has at least FOUR phases (~2000 cycles, about 1 us) to land -- the loads stream from HBM when the
+// operands are big (1.09 GB of expert weights), and a 2-phase budget measurably stalled there.  Two counted waits per K-tile: phase 4
+// waits until A0/B0 of the next tile are in (vmcnt(8): the four newer half-tiles stay in flight), phase 1 until B1/A1 of the current
+// one are (vmcnt(6)); a barrier follows each before the first read.  Up to 64 KiB per CU are in flight.
 // Every phase is
 //
 //   ds_reads | 2 DMA pieces | s_barrier | s_waitcnt lgkmcnt(0) | s_setprio 1 | 8 MFMA | s_setprio 0 | s_barrier
@@ -143,7 +144,7 @@ __device__ __forceinline__ void stage_half(const Stage& st, int tile) {
 // EDGE (block-uniform): the tile hangs over the edge of its row group / of N; 32-row and 32-column MFMA tiles that are wholly
 // outside (wave-uniform tests on rows_left / cols_left, counted from the wave's first row / column) are skipped together with
 // their fragment reads -- a grouped GEMM's last row tile per expert usually holds only a few rows.
-template <bool A_OC, bool B_OC, int QA, int QB, bool LOAD_A, bool LOAD_B, int BUF, int SO, int SH, int SB, bool WAIT, bool EDGE>
+template <bool A_OC, bool B_OC, int QA, int QB, bool LOAD_A, bool LOAD_B, int BUF, int SO, int SH, int SB, int WAIT, bool EDGE>
 __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                       const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int stage_tile, bool do_stage,
                                       bool more_in_flight, int rows_left, int cols_left) {
@@ -166,15 +167,23 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
     }
     sched_fence();
     // DMA placement (st.late, wave-uniform): 0 = with the LDS reads, before the barrier; 1 = inside the MFMA section, where the
-    // piece's issue cost hides under the matrix pipe -- the phase-4 wait then sees only phase 3's two pieces as "newer"
+    // piece's issue cost hides under the matrix pipe (this phase's two pieces are then not yet issued at the wait)
     if (do_stage && !st.late) stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
-    if (WAIT) {
+    if (WAIT == 1) {  // phase 1: B1 and A1 of THIS tile must have landed; newer = A0, B0 (and, early placement, A1) of the next tile
         if (!more_in_flight)
             wait_vm<0>();
         else if (st.late)
-            wait_vm<2>();
-        else
             wait_vm<4>();
+        else
+            wait_vm<6>();
+    }
+    if (WAIT == 4) {  // phase 4: A0 and B0 of the NEXT tile must have landed; newer = its A1, B1 and A0 (, B0) of the tile after
+        if (!more_in_flight)
+            wait_vm<0>();
+        else if (st.late)
+            wait_vm<6>();
+        else
+            wait_vm<8>();
     }
     raw_barrier();
     wait_lds();
@@ -209,10 +218,10 @@ template <bool A_OC, bool B_OC, int BUF, bool EDGE>
 __device__ __forceinline__ void k_tile(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                        const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int t, int nk, int rl, int cl) {
     const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-    phase<A_OC, B_OC, 0, 0, true, true, BUF, 0, 1, BUF ^ 1, false, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
-    phase<A_OC, B_OC, 0, 1, false, true, BUF, 1, 0, BUF ^ 1, false, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
-    phase<A_OC, B_OC, 1, 1, true, false, BUF, 0, 0, BUF, false, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, false, rl, cl);
-    phase<A_OC, B_OC, 1, 0, false, false, BUF, 1, 1, BUF, true, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, n2, rl, cl);
+    phase<A_OC, B_OC, 0, 0, true, true, BUF, 0, 1, BUF ^ 1, 1, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, n1, rl, cl);
+    phase<A_OC, B_OC, 0, 1, false, true, BUF, 1, 1, BUF ^ 1, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
+    phase<A_OC, B_OC, 1, 1, true, false, BUF, 0, 0, BUF, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, false, rl, cl);
+    phase<A_OC, B_OC, 1, 0, false, false, BUF, 1, 0, BUF, 4, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, n2, rl, cl);
 }
 
 template <bool A_OC, bool B_OC, bool EDGE>
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
                 for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
     s16x8 fa[2][4], fb[2][4];  // A fragments of the current A half; B fragments of BOTH halves (B0 is used by phases 1 and 4)
 
-    // ---- prologue: tile 0 completely, A0 and B1 of tile 1 (phases 1 and 2 of tile 0 issue its A1 and B0) -- the steady-state
+    // ---- prologue: tile 0 completely, A0 and B0 of tile 1 (phases 1 and 2 of tile 0 issue its A1 and B1) -- the steady-state
     // queue shape
     if (nk > 0) {
         stage_half<A_OC, B_OC, 0, 0, 0>(st, 0);
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     }
     if (nk > 1) {
         stage_half<A_OC, B_OC, 0, 0, 1>(st, 1);
-        stage_half<A_OC, B_OC, 1, 1, 1>(st, 1);
+        stage_half<A_OC, B_OC, 1, 0, 1>(st, 1);
         wait_vm<4>();
     } else {
         wait_vm<0>();
