@@ -57,7 +57,17 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, static_cast<__bf16>(f));  // v_cvt_pk_bf16_f32 (RNE)
 #endif
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return uint32_t(f2bf(lo)) | (uint32_t(f2bf(hi)) << 16); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+#ifdef ARIA_EMU
+    return uint32_t(f2bf(lo)) | (uint32_t(f2bf(hi)) << 16);
+#else
+    // ONE v_cvt_pk_bf16_f32 (two separate conversions + shift + or cost 4 VALU slots; the softmax / epilogue code packs thousands)
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+#endif
+}
 __device__ __forceinline__ float bflo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 // round an fp32 value through bf16 (mirrors a bf16 tensor op whose result is materialised)
