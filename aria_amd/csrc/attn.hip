@@ -267,6 +267,10 @@ struct Cfg2 {
     static constexpr int KP = HDK + 8;                 // K tile pitch (elements): conflict-free ds_read_b128 fragments
     static constexpr int VP = HD == 128 ? 160 : 96;    // V tile pitch: 16 (mod 64) dwords apart rows -> conflict-free tr reads
     static constexpr int NCH = (64 * CPR + NT2 - 1) / NT2;
+    // hd 72: the output tiles cover 96 feature rows, 24 of them padding.  V's pad column HD is set to 1.0, so feature row HD of O^T
+    // accumulates sum_k P[k][q] on the matrix pipe -- the softmax denominator for free (33 v_add_f32 per tile less on a VALU-bound
+    // kernel), rescaled together with O.  It sums the bf16-rounded P that also multiplies V (self-consistent normalisation).
+    static constexpr bool ROWSUM_IN_MFMA = (DT * 32 > HD);
     static constexpr size_t SMEM = size_t(2) * 64 * (KP + VP) * 2 + 2 * 64 + 16;
 };
 
@@ -341,6 +345,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
         for (int i = t; i < 2 * 64; i += C::NT2) {
             if (C::HDK != HD) st16(sK + i * C::KP + HD, zero16());
             for (int c = HD; c < C::VP; c += 8) st16(sV + i * C::VP + c, zero16());
+            if (C::ROWSUM_IN_MFMA) sV[i * C::VP + HD] = 0x3F80;  // bf16 1.0: the "ones" column
         }
     }
     u32x4 rk[C::NCH], rv[C::NCH];
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
             const float m_safe = m_new == -INFINITY ? 0.f : m_new;
             if (ballot(m_new > m) != 0ull) {  // wave-uniform lazy rescale: exact (alpha == 1 whenever it is skipped)
                 const float alpha = exp2_fast(m - m_safe);
-                lsum *= alpha;
+                if (!C::ROWSUM_IN_MFMA) lsum *= alpha;
 #pragma unroll
                 for (int i = 0; i < C::DT; ++i)
 #pragma unroll
@@ -412,9 +417,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
                 for (int r = 0; r < 16; ++r) {
                     const float p = exp2_fast(st[i][r] * scale2 - m_safe);
                     st[i][r] = p;
-                    ps += p;
+                    if (!C::ROWSUM_IN_MFMA) ps += p;
                 }
-            lsum += ps;
+            if (!C::ROWSUM_IN_MFMA) lsum += ps;
             // O^T += V^T P^T
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -448,7 +453,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
             }
         }
     }
-    const float ltot = lsum + shfl_xor(lsum, 32);
+    // ROWSUM_IN_MFMA: feature row HD = 32 (DT-1) + 8 sits in accumulator register 4 of the lanes with h2 == 0
+    const float ltot = C::ROWSUM_IN_MFMA ? shfl(o[C::DT - 1][4], l & 31) : lsum + shfl_xor(lsum, 32);
     const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
     if (q_abs < Sq) {
         if (h2 == 0 && LSE)
