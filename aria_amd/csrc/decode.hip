@@ -1,0 +1,291 @@
+// Single-token decode engine for the gptfast surface (gptfast/model.py:178-234 Transformer.forward with one new token;
+// ConditionalFeedForward's T < 50 path :318-325; KVCache.update :67-93): BASELINE.md's only published numbers are the reference's
+// generate() tokens/s, and one token is 7.7 GB of weights against ~0.4 GF per GB -- an HBM-streaming problem, not an MFMA one.
+//
+// The tile GEMMs spend a token on ~24 launches per layer from Python (16.7 ms/token, launch-bound) and, with one valid row in a
+// 128-row tile, keep only N/128 workgroups busy.  Here:
+//   * every projection is a GEMV: a wave owns R weight rows, lanes stride the reduction in 16-byte chunks (fully coalesced row reads),
+//     fp32 accumulate, wave reduce -- N / (4 R) workgroups, so even N = 2560 fills the chip;
+//   * RMSNorm is folded into the consumer GEMV (each wave re-normalises the 2560-vector it needs anyway, with the same lane <-> chunk
+//     mapping and reduction order as rmsnorm_fwd_kernel: identical rstd), residual adds into the GEMV epilogue, SwiGLU into the
+//     up-projection pair, RoPE + KV-cache write into one kernel, the six routed experts are indexed on the device (no gather of weights);
+//   * ONE C call walks all layers and enqueues ~13 launches per layer back to back (no Python, no allocation, no host sync): the
+//     position lives on the device, so the same enqueue sequence is valid for every token.
+// Rounding points mirror the tile path (GEMM outputs, norm, SwiGLU, residual adds are each rounded to bf16 where the reference
+// materialises a bf16 tensor); only the fp32 summation ORDER inside a dot product differs from the MFMA kernels.
+#include "aria_device.h"
+#include "aria_hip.h"
+#include <cmath>
+
+namespace {
+using namespace ad;
+
+constexpr int CPL = 8;  // 16-byte chunks per lane: reductions up to 64 * 8 * 8 = 4096 elements
+
+__device__ __forceinline__ float silu(float a) { return a / (1.f + expf(-a)); }
+
+// x[K] (bf16) -> this lane's chunks c = l + 64 i as fp32, optionally RMS-normalised exactly like rmsnorm_fwd_kernel (norm.hip)
+__device__ __forceinline__ void load_vector(float (&v)[CPL][8], const bf16_t* x, const bf16_t* norm_w, float eps, int K, int l) {
+    const int nch = K >> 3;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = l + 64 * i;
+        if (c < nch) {
+            const u32x4 a = ld16(x + c * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[i][2 * q] = bflo(a[q]);
+                v[i][2 * q + 1] = bfhi(a[q]);
+                ss += v[i][2 * q] * v[i][2 * q] + v[i][2 * q + 1] * v[i][2 * q + 1];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
+    }
+    if (!norm_w) return;
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / float(K) + eps);
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = l + 64 * i;
+        if (c < nch) {
+            const u32x4 wv = ld16(norm_w + c * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[i][2 * q] = rbf(bflo(wv[q]) * rbf(v[i][2 * q] * r));
+                v[i][2 * q + 1] = rbf(bfhi(wv[q]) * rbf(v[i][2 * q + 1] * r));
+            }
+        }
+    }
+}
+
+// dot products of R consecutive weight rows with the lane-distributed vector; every lane returns the full sums
+template <int R>
+__device__ __forceinline__ void dot_rows(float (&acc)[R], const bf16_t* w, long long ldw, int row0, int nrows, const float (&v)[CPL][8],
+                                         int K, int l) {
+    const int nch = K >> 3;
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = l + 64 * i;
+        if (c < nch) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (row0 + r < nrows) {
+                    const u32x4 a = ld16(w + (long long)(row0 + r) * ldw + c * 8);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[r] += bflo(a[q]) * v[i][2 * q] + bfhi(a[q]) * v[i][2 * q + 1];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+}
+
+// y[n] = bf16(W[n,:] . xn) (+ residual[n], added to the ROUNDED product like the stand-alone add kernel)
+template <int R>
+__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w, float eps, int K,
+                                                   int N, const bf16_t* residual, bf16_t* y) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + w) * R;
+    if (row0 >= N) return;
+    float v[CPL][8], acc[R];
+    load_vector(v, x, norm_w, eps, K, l);
+    dot_rows<R>(acc, W, ldw, row0, N, v, K, l);
+    if (l == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (row0 + r < N) y[row0 + r] = residual ? f2bf(bf2f(residual[row0 + r]) + rbf(acc[r])) : f2bf(acc[r]);
+    }
+}
+
+// act[j][n] = bf16( bf16(silu(bf16(W1[e_j][n,:] . xn))) * bf16(W3[e_j][n,:] . xn) ),  e_j = idx[j] (or 0 when idx == nullptr)
+template <int R>
+__global__ __launch_bounds__(256) void expert_up_kernel(const bf16_t* W1, const bf16_t* W3, long long strideE, long long ldw,
+                                                        const int32_t* idx, const bf16_t* x, const bf16_t* norm_w, float eps, int K, int I,
+                                                        bf16_t* act) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, j = blockIdx.y;
+    const int row0 = (blockIdx.x * 4 + w) * R;
+    if (row0 >= I) return;
+    const long long e = idx ? idx[j] : 0;
+    float v[CPL][8], a1[R], a3[R];
+    load_vector(v, x, norm_w, eps, K, l);
+    dot_rows<R>(a1, W1 + e * strideE, ldw, row0, I, v, K, l);
+    dot_rows<R>(a3, W3 + e * strideE, ldw, row0, I, v, K, l);
+    if (l == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (row0 + r < I) act[(long long)j * I + row0 + r] = f2bf(rbf(silu(rbf(a1[r]))) * rbf(a3[r]));
+    }
+}
+
+// out[j][n] = bf16(W2[e_j][n,:] . act[j])
+template <int R>
+__global__ __launch_bounds__(256) void expert_down_kernel(const bf16_t* W2, long long strideE, long long ldw, const int32_t* idx,
+                                                          const bf16_t* act, int K, int N, bf16_t* out) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, j = blockIdx.y;
+    const int row0 = (blockIdx.x * 4 + w) * R;
+    if (row0 >= N) return;
+    const long long e = idx ? idx[j] : 0;
+    float v[CPL][8], acc[R];
+    load_vector(v, act + (long long)j * K, nullptr, 0.f, K, l);
+    dot_rows<R>(acc, W2 + e * strideE, ldw, row0, N, v, K, l);
+    if (l == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (row0 + r < N) out[(long long)j * N + row0 + r] = f2bf(acc[r]);
+    }
+}
+
+// RoPE (interleaved pairs, bf16 freqs_cis cache, one rounding: rope_interleaved_kernel of norm.hip) on q in place and on k while it
+// moves into the cache at the device-side position; v is copied.  Also publishes kv_len = pos + 1 and the identity slot map.
+__global__ __launch_bounds__(256) void rope_cache_kernel(bf16_t* qkv, const bf16_t* fc, const int32_t* pos, bf16_t* k_cache,
+                                                         bf16_t* v_cache, int D, int hd, int32_t* kv_len, int32_t* inv, int topk) {
+    const int ps = pos[0];
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        if (threadIdx.x == 0) kv_len[0] = ps + 1;
+        if (int(threadIdx.x) < topk) inv[threadIdx.x] = threadIdx.x;
+    }
+    const int nch = D >> 3, cph = hd >> 3;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < 3 * nch; c += gridDim.x * blockDim.x) {
+        const int part = c / nch, cc = c % nch;
+        const u32x4 a = ld16(qkv + (long long)part * D + cc * 8);
+        if (part == 2) {
+            st16(v_cache + (long long)ps * D + cc * 8, a);
+            continue;
+        }
+        const u32x4 f = ld16(fc + (long long)ps * hd + (cc % cph) * 8);
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x0 = bflo(a[q]), x1 = bfhi(a[q]), cs = bflo(f[q]), sn = bfhi(f[q]);
+            o[q] = pack2bf(x0 * cs - x1 * sn, x1 * cs + x0 * sn);
+        }
+        if (part == 0)
+            st16(qkv + cc * 8, o);
+        else
+            st16(k_cache + (long long)ps * D + cc * 8, o);
+    }
+}
+
+template <class... A>
+int launch_gemv(int N, void* stream, A... args) {
+    // rows per wave: 4 when that still gives >= 512 workgroups' worth of rows, else 2 (small N must still cover 256 CUs)
+    if (N >= 8192) {
+        ARIA_LAUNCH((gemv_kernel<4>), dim3((N + 15) / 16), dim3(256), 0, stream, args...);
+    } else {
+        ARIA_LAUNCH((gemv_kernel<2>), dim3((N + 7) / 8), dim3(256), 0, stream, args...);
+    }
+    return aria_check_launch();
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct Scratch {
+    bf16_t *xa, *xb, *qkv, *ao, *rl, *scores, *act, *eo, *sact, *sh, *m;
+    int32_t *idx, *counts, *inv, *kv_len;
+    size_t bytes;
+};
+
+Scratch carve(char* base, int64_t D, int64_t E, int64_t k, int64_t I, int64_t Is) {
+    Scratch s{};
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        char* p = base ? base + off : nullptr;
+        off += align256(n);
+        return p;
+    };
+    s.xa = reinterpret_cast<bf16_t*>(take(D * 2));
+    s.xb = reinterpret_cast<bf16_t*>(take(D * 2));
+    s.qkv = reinterpret_cast<bf16_t*>(take(3 * D * 2));
+    s.ao = reinterpret_cast<bf16_t*>(take(D * 2));
+    s.rl = reinterpret_cast<bf16_t*>(take(E * 2));
+    s.scores = reinterpret_cast<bf16_t*>(take(k * 2));
+    s.act = reinterpret_cast<bf16_t*>(take(k * I * 2));
+    s.eo = reinterpret_cast<bf16_t*>(take(k * D * 2));
+    s.sact = reinterpret_cast<bf16_t*>(take(Is * 2));
+    s.sh = reinterpret_cast<bf16_t*>(take(D * 2));
+    s.m = reinterpret_cast<bf16_t*>(take(D * 2));
+    s.idx = reinterpret_cast<int32_t*>(take(k * 4));
+    s.counts = reinterpret_cast<int32_t*>(take(E * 4));
+    s.inv = reinterpret_cast<int32_t*>(take(k * 4));
+    s.kv_len = reinterpret_cast<int32_t*>(take(4));
+    s.bytes = off;
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t aria_decode_scratch_bytes(const int64_t* dims) {
+    if (!dims) return 0;
+    return int64_t(carve(nullptr, dims[1], dims[4], dims[5], dims[6], dims[7]).bytes);
+}
+
+int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, void* stream) {
+    if (!ptrs || !dims) return ARIA_ERR_INVALID;
+    const int64_t L = dims[0], D = dims[1], H = dims[2], hd = dims[3], E = dims[4], k = dims[5], I = dims[6], Is = dims[7], V = dims[8],
+                  Smax = dims[9];
+    if (L <= 0 || D <= 0 || H * hd != D || (D & 7) || (I & 7) || (Is & 7) || D > 4096 || I > 4096 || Is > 4096 || k > 8 || E > 256)
+        return ARIA_ERR_UNSUPPORTED;
+    if (hd != 64 && hd != 128) return ARIA_ERR_UNSUPPORTED;
+    for (int i = 0; i < ARIA_DECODE_HEADER_PTRS + ARIA_DECODE_LAYER_PTRS * L; ++i)
+        if (!ptrs[i]) return ARIA_ERR_INVALID;
+    const bf16_t* freqs = static_cast<const bf16_t*>(ptrs[0]);
+    const bf16_t* final_norm = static_cast<const bf16_t*>(ptrs[1]);
+    const bf16_t* out_w = static_cast<const bf16_t*>(ptrs[2]);
+    const Scratch s = carve(static_cast<char*>(const_cast<void*>(ptrs[3])), D, E, k, I, Is);
+    const int32_t* pos = static_cast<const int32_t*>(ptrs[4]);
+    const bf16_t* x = static_cast<const bf16_t*>(ptrs[5]);
+    bf16_t* logits = static_cast<bf16_t*>(const_cast<void*>(ptrs[6]));
+    int rc;
+#define ARIA_TRY(call)              \
+    do {                            \
+        rc = (call);                \
+        if (rc != ARIA_OK) return rc; \
+    } while (0)
+    for (int64_t li = 0; li < L; ++li) {
+        const void* const* lp = ptrs + ARIA_DECODE_HEADER_PTRS + ARIA_DECODE_LAYER_PTRS * li;
+        const bf16_t *attn_norm = static_cast<const bf16_t*>(lp[0]), *wqkv = static_cast<const bf16_t*>(lp[1]),
+                     *wo = static_cast<const bf16_t*>(lp[2]), *ffn_norm = static_cast<const bf16_t*>(lp[3]),
+                     *gate = static_cast<const bf16_t*>(lp[4]), *w1 = static_cast<const bf16_t*>(lp[5]),
+                     *w3 = static_cast<const bf16_t*>(lp[6]), *w2 = static_cast<const bf16_t*>(lp[7]),
+                     *sw1 = static_cast<const bf16_t*>(lp[8]), *sw3 = static_cast<const bf16_t*>(lp[9]),
+                     *sw2 = static_cast<const bf16_t*>(lp[10]);
+        bf16_t *kc = static_cast<bf16_t*>(const_cast<void*>(lp[11])), *vc = static_cast<bf16_t*>(const_cast<void*>(lp[12]));
+        bf16_t* h = s.xa;  // hidden state after the attention block
+        // attention block: h = x + wo( attn( rope(wqkv(norm(x))) ) )
+        ARIA_TRY(launch_gemv(int(3 * D), stream, wqkv, (long long)D, x, attn_norm, eps, int(D), int(3 * D), (const bf16_t*)nullptr, s.qkv));
+        ARIA_LAUNCH(rope_cache_kernel, dim3(unsigned((3 * D / 8 + 255) / 256)), dim3(256), 0, stream, s.qkv, freqs, pos, kc, vc, int(D),
+                    int(hd), s.kv_len, s.inv, int(k));
+        ARIA_TRY(aria_check_launch());
+        ARIA_TRY(aria_attn_fwd(s.qkv, kc, vc, s.ao, nullptr, s.kv_len, nullptr, 1, 1, Smax, H, hd, D, D, D, D, 1.0f / sqrtf(float(hd)), 0,
+                               stream));
+        ARIA_TRY(launch_gemv(int(D), stream, wo, (long long)D, (const bf16_t*)s.ao, (const bf16_t*)nullptr, 0.f, int(D), int(D), x, h));
+        // MoE block on hn = norm(h): out = h + ( sum_j score_j * expert_j(hn) + shared(hn) )
+        ARIA_TRY(launch_gemv(int(E), stream, gate, (long long)D, (const bf16_t*)h, ffn_norm, eps, int(D), int(E), (const bf16_t*)nullptr, s.rl));
+        ARIA_TRY(aria_moe_route(s.rl, 0, s.scores, s.idx, s.counts, 1, E, k, stream));
+        ARIA_LAUNCH((expert_up_kernel<2>), dim3(unsigned((I + 7) / 8), unsigned(k)), dim3(256), 0, stream, w1, w3, (long long)(I * D),
+                    (long long)D, (const int32_t*)s.idx, (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act);
+        ARIA_LAUNCH((expert_down_kernel<2>), dim3(unsigned((D + 7) / 8), unsigned(k)), dim3(256), 0, stream, w2, (long long)(D * I),
+                    (long long)I, (const int32_t*)s.idx, (const bf16_t*)s.act, int(I), int(D), s.eo);
+        ARIA_LAUNCH((expert_up_kernel<2>), dim3(unsigned((Is + 7) / 8), 1u), dim3(256), 0, stream, sw1, sw3, 0ll, (long long)D,
+                    (const int32_t*)nullptr, (const bf16_t*)h, ffn_norm, eps, int(D), int(Is), s.sact);
+        ARIA_LAUNCH((expert_down_kernel<2>), dim3(unsigned((D + 7) / 8), 1u), dim3(256), 0, stream, sw2, 0ll, (long long)Is,
+                    (const int32_t*)nullptr, (const bf16_t*)s.sact, int(Is), int(D), s.sh);
+        ARIA_TRY(aria_check_launch());
+        ARIA_TRY(aria_moe_unpermute(s.eo, s.inv, s.scores, s.sh, s.m, 1, D, k, stream));
+        ARIA_TRY(aria_add_bf16(h, s.m, s.xb, D, stream));
+        x = s.xb;  // the next layer reads x = xb and writes its h into xa again (h is dead once this add has run)
+    }
+    ARIA_TRY(launch_gemv(int(V), stream, out_w, (long long)D, x, final_norm, eps, int(D), int(V), (const bf16_t*)nullptr, logits));
+#undef ARIA_TRY
+    return ARIA_OK;
+}
+
+}  // extern "C"

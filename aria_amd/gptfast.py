@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
-from . import ops
+from . import hip, ops
 from .modeling_aria import AriaConfig
 from .vision import AriaProjector, AriaVisionConfig, AriaVisionModel
 
@@ -183,6 +183,16 @@ class Transformer(nn.Module):
         self.output = _W(config.vocab_size, config.dim)
         self.freqs_cis: Optional[torch.Tensor] = None
         self.max_batch_size = self.max_seq_length = -1
+        self.use_decode_engine = True     # batch-1 single-token steps go through aria_decode_token (csrc/decode.hip)
+        self._engine: Optional["DecodeEngine"] = None
+
+    def _engine_ok(self) -> bool:
+        att = self.layers[0].attention
+        if att.kv_cache is None or att.hdp != self.config.head_dim or self.config.head_dim not in (64, 128):
+            return False
+        if self._engine is None or not self._engine.valid_for(self):
+            self._engine = DecodeEngine(self)
+        return True
 
     def setup_caches(self, max_batch_size, max_seq_length, training: bool = False, **_):
         """gptfast/model.py:113-166 (no S x S mask is ever built: the attention kernel masks in-register)."""
@@ -201,6 +211,8 @@ class Transformer(nn.Module):
         B, S, D = x.shape
         x2d = x.reshape(B * S, D).contiguous()
         prefill = S > 1 or input_pos is None
+        if not prefill and B == 1 and self.use_decode_engine and self._engine_ok():
+            return self._engine.step(x, input_pos)
         if input_pos is None:
             input_pos = torch.arange(S, device=x.device)
         if prefill:
@@ -216,6 +228,59 @@ class Transformer(nn.Module):
             h = h.view(B, S, D)[:, -1].contiguous()
             return ops.gemm(h, self.output.weight).view(B, 1, -1)
         return ops.gemm(h, self.output.weight).view(B, S, -1)
+
+
+class DecodeEngine:
+    """One-call-per-token decode (aria_decode_token, csrc/decode.hip) for batch 1: builds the pointer / dims tables the C entry point
+    wants from the module's own tensors (the model.pth layout, unchanged) and owns the small scratch buffers."""
+
+    def __init__(self, model: "Transformer"):
+        import ctypes
+
+        import numpy as np
+
+        c = model.config
+        att0 = model.layers[0].attention
+        if att0.kv_cache is None:
+            raise RuntimeError("DecodeEngine needs setup_caches() first")
+        if att0.hdp != c.head_dim or c.head_dim not in (64, 128):
+            raise RuntimeError("DecodeEngine: head_dim must be 64 or 128 (native attention head dims)")
+        dev = model.output.weight.device
+        Is = c.intermediate_size * c.num_shared_experts
+        self.dims = np.array([c.n_layer, c.dim, c.n_head, c.head_dim, c.num_experts, c.router_topk, c.intermediate_size, Is, c.vocab_size,
+                              model.max_seq_length], dtype=np.int64)
+        lib = hip.get_lib()
+        self._lib = lib
+        self._dims_p = self.dims.ctypes.data_as(ctypes.c_void_p)
+        nbytes = int(lib.cdll.aria_decode_scratch_bytes(self._dims_p))
+        self.scratch = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.x_in = torch.zeros(c.dim, dtype=bf16, device=dev)
+        self.logits = torch.zeros(c.vocab_size, dtype=bf16, device=dev)
+        self.eps = float(c.norm_eps)
+        tensors = [model.freqs_cis, model.norm.weight, model.output.weight, self.scratch, self.pos, self.x_in, self.logits, self.pos]
+        for blk in model.layers:
+            a, f = blk.attention, blk.feed_forward
+            tensors += [blk.attention_norm.weight, a.wqkv.weight, a.wo.weight, blk.ffn_norm.weight, f.gate.weight, f.cond_ffn.w1,
+                        f.cond_ffn.w3, f.cond_ffn.w2, f.shared_ffn.w1.weight, f.shared_ffn.w3.weight, f.shared_ffn.w2.weight,
+                        a.kv_cache.k, a.kv_cache.v]
+        for t in tensors:
+            assert t.is_contiguous() and t.device == dev
+        self._keep = tensors  # the table holds raw addresses: keep the tensors alive and detect re-allocation
+        self._addr = [t.data_ptr() for t in tensors]
+        self.ptrs = (ctypes.c_void_p * len(tensors))(*self._addr)
+
+    def valid_for(self, model: "Transformer") -> bool:
+        return all(t.data_ptr() == a for t, a in zip(self._keep, self._addr)) and int(self.dims[9]) == model.max_seq_length
+
+    def step(self, x_embed: torch.Tensor, input_pos: torch.Tensor) -> torch.Tensor:
+        """x_embed [1,1,D] (embedding of the new token), input_pos: device tensor with the cursor -> logits [1,1,V] (a view of the
+        engine's buffer: consume it before the next step)."""
+        self.x_in.copy_(x_embed.reshape(-1))
+        self.pos.copy_(input_pos.reshape(-1)[:1])
+        stream = torch.cuda.current_stream(self.x_in.device).cuda_stream if self.x_in.is_cuda else None
+        self._lib.call("aria_decode_token", self.ptrs, self._dims_p, self.eps, stream)
+        return self.logits.view(1, 1, -1)
 
 
 class Aria(nn.Module):

@@ -225,6 +225,25 @@ int aria_cross_entropy(const void* logits, const int32_t* labels, float* loss_su
 /* hardware-semantics probe (ds_read_b64_tr_b16 lane mapping); test-only, see csrc/probe.hip */
 int aria_probe_tr16(void* out /* u16[256] */, int mode, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Single-token decode engine (decode.hip) -- gptfast/model.py:178-234 (Transformer.forward, one new token, batch 1),
+ * :318-366 (MOEFeedForward, T < 50 path), :67-93 (KVCache.update), :413-447 (Attention with the static cache).
+ * ONE call enqueues every kernel of every layer for one token: GEMV projections with RMSNorm / residual / SwiGLU folded in,
+ * RoPE + KV-cache write, flash attention over the cache, device-indexed routed experts.  The position is read from device
+ * memory (ptrs[4]), so the call needs no host sync and its launch sequence is identical for every token.
+ *
+ * ptrs (host array of device pointers): [0] freqs_cis bf16 [S_max, hd/2, 2]   [1] final norm weight [D]   [2] output weight [V, D]
+ *   [3] scratch (aria_decode_scratch_bytes)   [4] pos int32 [1]   [5] input embedding bf16 [D]   [6] logits out bf16 [V]   [7] unused (non-NULL)
+ *   then per layer (13 each): attention_norm [D], wqkv [3D, D] (q/k rows permuted for interleaved RoPE), wo [D, D], ffn_norm [D],
+ *   gate [E, D], cond_ffn.w1 [E, I, D], w3 [E, I, D], w2 [E, D, I], shared_ffn.w1 [Is, D], w3 [Is, D], w2 [D, Is],
+ *   k_cache [S_max, D], v_cache [S_max, D]      (= the gptfast model.pth tensors, unchanged)
+ * dims (host int64): n_layers, D, n_heads, head_dim (64 | 128), E, top_k, I, I_shared, V, S_max.
+ * ------------------------------------------------------------------------------------------------ */
+#define ARIA_DECODE_HEADER_PTRS 8
+#define ARIA_DECODE_LAYER_PTRS 13
+int64_t aria_decode_scratch_bytes(const int64_t* dims);
+int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 /* internal helper shared by the translation units */

@@ -36,3 +36,8 @@ def test_gptfast_golden(golden):
 
 def test_lora_grouped_gemm():
     M.case_lora_grouped_gemm(DEV)
+
+
+@pytest.mark.parametrize("head_dim", [64, 128])
+def test_decode_engine(head_dim):
+    M.case_decode_engine(DEV, head_dim)
