@@ -288,4 +288,68 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
     return ARIA_OK;
 }
 
+// The enqueue sequence of aria_decode_token reads the position (and through it the KV-cache slot and kv_len) from DEVICE memory, so it
+// is the same for every token: capture it once into a HIP graph and replay it with one launch per token (the ~400 tiny launches of a
+// token cost more host time than their kernels run).  Captured on a private stream; replayed on the caller's stream.
+struct AriaDecodeGraph {
+#ifndef ARIA_EMU
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+#else
+    const void* const* ptrs = nullptr;
+    const int64_t* dims = nullptr;
+    float eps = 0.f;
+#endif
+};
+
+void* aria_decode_graph_create(const void* const* ptrs, const int64_t* dims, float eps) {
+    AriaDecodeGraph* g = new AriaDecodeGraph();
+#ifndef ARIA_EMU
+    hipStream_t cap = nullptr;
+    if (hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) {
+        delete g;
+        return nullptr;
+    }
+    bool ok = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+        const int rc = aria_decode_token(ptrs, dims, eps, cap);
+        const hipError_t e = hipStreamEndCapture(cap, &g->graph);
+        ok = rc == ARIA_OK && e == hipSuccess && g->graph;
+    }
+    if (ok) ok = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) == hipSuccess;
+    (void)hipStreamDestroy(cap);
+    if (!ok) {
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        (void)hipGetLastError();
+        delete g;
+        return nullptr;
+    }
+#else
+    g->ptrs = ptrs;  // the emulator has no graphs: replay = enqueue again (the caller keeps the tables alive)
+    g->dims = dims;
+    g->eps = eps;
+#endif
+    return g;
+}
+
+int aria_decode_graph_launch(void* handle, void* stream) {
+    if (!handle) return ARIA_ERR_INVALID;
+    AriaDecodeGraph* g = static_cast<AriaDecodeGraph*>(handle);
+#ifndef ARIA_EMU
+    return hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)) == hipSuccess ? ARIA_OK : ARIA_ERR_LAUNCH;
+#else
+    return aria_decode_token(g->ptrs, g->dims, g->eps, stream);
+#endif
+}
+
+void aria_decode_graph_destroy(void* handle) {
+    if (!handle) return;
+    AriaDecodeGraph* g = static_cast<AriaDecodeGraph*>(handle);
+#ifndef ARIA_EMU
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+#endif
+    delete g;
+}
+
 }  // extern "C"

@@ -184,6 +184,7 @@ class Transformer(nn.Module):
         self.freqs_cis: Optional[torch.Tensor] = None
         self.max_batch_size = self.max_seq_length = -1
         self.use_decode_engine = True     # batch-1 single-token steps go through aria_decode_token (csrc/decode.hip)
+        self.decode_graph = True          # ... replayed from a natively captured HIP graph (one launch per token)
         self._engine: Optional["DecodeEngine"] = None
 
     def _engine_ok(self) -> bool:
@@ -269,6 +270,15 @@ class DecodeEngine:
         self._keep = tensors  # the table holds raw addresses: keep the tensors alive and detect re-allocation
         self._addr = [t.data_ptr() for t in tensors]
         self.ptrs = (ctypes.c_void_p * len(tensors))(*self._addr)
+        # one graph launch per token instead of ~13 launches per layer (None: capture failed or disabled -> plain enqueue)
+        self.graph = lib.cdll.aria_decode_graph_create(self.ptrs, self._dims_p, self.eps) if model.decode_graph else None
+
+    def __del__(self):
+        try:
+            if getattr(self, "graph", None):
+                self._lib.cdll.aria_decode_graph_destroy(self.graph)
+        except Exception:
+            pass
 
     def valid_for(self, model: "Transformer") -> bool:
         return all(t.data_ptr() == a for t, a in zip(self._keep, self._addr)) and int(self.dims[9]) == model.max_seq_length
@@ -279,7 +289,10 @@ class DecodeEngine:
         self.x_in.copy_(x_embed.reshape(-1))
         self.pos.copy_(input_pos.reshape(-1)[:1])
         stream = torch.cuda.current_stream(self.x_in.device).cuda_stream if self.x_in.is_cuda else None
-        self._lib.call("aria_decode_token", self.ptrs, self._dims_p, self.eps, stream)
+        if self.graph:
+            self._lib.call("aria_decode_graph_launch", self.graph, stream)
+        else:
+            self._lib.call("aria_decode_token", self.ptrs, self._dims_p, self.eps, stream)
         return self.logits.view(1, 1, -1)
 
 

@@ -243,6 +243,11 @@ int aria_probe_tr16(void* out /* u16[256] */, int mode, void* stream);
 #define ARIA_DECODE_LAYER_PTRS 13
 int64_t aria_decode_scratch_bytes(const int64_t* dims);
 int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, void* stream);
+/* The same enqueue sequence captured once into a HIP graph (valid for every token because the position is device-side) and
+ * replayed with one launch per token.  create returns NULL on failure (use aria_decode_token then); the tables must stay alive. */
+void* aria_decode_graph_create(const void* const* ptrs, const int64_t* dims, float eps);
+int aria_decode_graph_launch(void* graph, void* stream);
+void aria_decode_graph_destroy(void* graph);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_symbols():
     src = open(os.path.join(ROOT, "include", "aria_hip.h")).read()
     src = src.split("#ifdef __cplusplus\n}")[0]  # C declarations only
-    return sorted(set(re.findall(r"^(?:int|int64_t) (aria_\w+)\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|int64_t|void\*|void) (aria_\w+)\(", src, flags=re.M)))
 
 
 def test_header_and_ctypes_table_agree():
