@@ -9,7 +9,7 @@
 //   * RMSNorm is folded into the consumer GEMV (each wave re-normalises the 2560-vector it needs anyway, with the same lane <-> chunk
 //     mapping and reduction order as rmsnorm_fwd_kernel: identical rstd), residual adds into the GEMV epilogue, SwiGLU into the
 //     up-projection pair, RoPE + KV-cache write into one kernel, the six routed experts are indexed on the device (no gather of weights);
-//   * ONE C call walks all layers and enqueues ~13 launches per layer back to back (no Python, no allocation, no host sync): the
+//   * ONE C call walks all layers and enqueues 8 launches per layer back to back (no Python, no allocation, no host sync): the
 //     position lives on the device, so the same enqueue sequence is valid for every token.
 // Rounding points mirror the tile path (GEMM outputs, norm, SwiGLU, residual adds are each rounded to bf16 where the reference
 // materialises a bf16 tensor); only the fp32 summation ORDER inside a dot product differs from the MFMA kernels.
@@ -103,19 +103,23 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* W, long long ld
     }
 }
 
-// act[j][n] = bf16( bf16(silu(bf16(W1[e_j][n,:] . xn))) * bf16(W3[e_j][n,:] . xn) ),  e_j = idx[j] (or 0 when idx == nullptr)
+// Up-projection pair + SwiGLU for the k routed experts (e_j = idx[j]) AND the shared expert in one launch: grid.y = k + ns, the shared
+// expert's [ns*I, D] matrices are ns further "experts" of I rows each, so act rows k .. k+ns-1 are its activation vector of length ns*I.
+//   act[j][n] = bf16( bf16(silu(bf16(W1[n,:] . xn))) * bf16(W3[n,:] . xn) )
 template <int R>
-__global__ __launch_bounds__(256) void expert_up_kernel(const bf16_t* W1, const bf16_t* W3, long long strideE, long long ldw,
-                                                        const int32_t* idx, const bf16_t* x, const bf16_t* norm_w, float eps, int K, int I,
-                                                        bf16_t* act) {
+__global__ __launch_bounds__(256) void expert_up_kernel(const bf16_t* W1, const bf16_t* W3, const bf16_t* S1, const bf16_t* S3,
+                                                        const int32_t* idx, int k, const bf16_t* x, const bf16_t* norm_w, float eps, int K,
+                                                        int I, bf16_t* act) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, j = blockIdx.y;
     const int row0 = (blockIdx.x * 4 + w) * R;
     if (row0 >= I) return;
-    const long long e = idx ? idx[j] : 0;
+    const long long stride = (long long)I * K;
+    const bf16_t* w1 = j < k ? W1 + (long long)idx[j] * stride : S1 + (long long)(j - k) * stride;
+    const bf16_t* w3 = j < k ? W3 + (long long)idx[j] * stride : S3 + (long long)(j - k) * stride;
     float v[CPL][8], a1[R], a3[R];
     load_vector(v, x, norm_w, eps, K, l);
-    dot_rows<R>(a1, W1 + e * strideE, ldw, row0, I, v, K, l);
-    dot_rows<R>(a3, W3 + e * strideE, ldw, row0, I, v, K, l);
+    dot_rows<R>(a1, w1, K, row0, I, v, K, l);
+    dot_rows<R>(a3, w3, K, row0, I, v, K, l);
     if (l == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -123,17 +127,19 @@ __global__ __launch_bounds__(256) void expert_up_kernel(const bf16_t* W1, const 
     }
 }
 
-// out[j][n] = bf16(W2[e_j][n,:] . act[j])
+// Down-projections: out[j] = bf16(W2[e_j] . act[j]) for the routed experts (reduction I) and out[k] = bf16(S2 . act[k..]) for the
+// shared expert (reduction ns*I), grid.y = k + 1
 template <int R>
-__global__ __launch_bounds__(256) void expert_down_kernel(const bf16_t* W2, long long strideE, long long ldw, const int32_t* idx,
-                                                          const bf16_t* act, int K, int N, bf16_t* out) {
+__global__ __launch_bounds__(256) void expert_down_kernel(const bf16_t* W2, const bf16_t* S2, const int32_t* idx, int k, int ns,
+                                                          const bf16_t* act, int I, int N, bf16_t* out) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, j = blockIdx.y;
     const int row0 = (blockIdx.x * 4 + w) * R;
     if (row0 >= N) return;
-    const long long e = idx ? idx[j] : 0;
+    const int K = j < k ? I : ns * I;
+    const bf16_t* w2 = j < k ? W2 + (long long)idx[j] * N * I : S2;
     float v[CPL][8], acc[R];
-    load_vector(v, act + (long long)j * K, nullptr, 0.f, K, l);
-    dot_rows<R>(acc, W2 + e * strideE, ldw, row0, N, v, K, l);
+    load_vector(v, act + (long long)j * I, nullptr, 0.f, K, l);
+    dot_rows<R>(acc, w2, K, row0, N, v, K, l);
     if (l == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -141,15 +147,104 @@ __global__ __launch_bounds__(256) void expert_down_kernel(const bf16_t* W2, long
     }
 }
 
-// RoPE (interleaved pairs, bf16 freqs_cis cache, one rounding: rope_interleaved_kernel of norm.hip) on q in place and on k while it
-// moves into the cache at the device-side position; v is copied.  Also publishes kv_len = pos + 1 and the identity slot map.
-__global__ __launch_bounds__(256) void rope_cache_kernel(bf16_t* qkv, const bf16_t* fc, const int32_t* pos, bf16_t* k_cache,
-                                                         bf16_t* v_cache, int D, int hd, int32_t* kv_len, int32_t* inv, int topk) {
-    const int ps = pos[0];
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        if (threadIdx.x == 0) kv_len[0] = ps + 1;
-        if (int(threadIdx.x) < topk) inv[threadIdx.x] = threadIdx.x;
+// Router in one workgroup: logits = bf16(gate . norm(h)) (the GEMV), then TopKRouter.routing exactly as route_kernel (moe.hip): k rounds
+// of arg-max with ties to the lowest expert id, softmax over the selected logits in fp32, scores cast to bf16.
+__global__ __launch_bounds__(256) void router_kernel(const bf16_t* gate, const bf16_t* x, const bf16_t* norm_w, float eps, int K, int E,
+                                                     int k, bf16_t* scores, int32_t* idx) {
+    ARIA_SMEM_STATIC float lg[256];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float v[CPL][8], acc[4];
+    load_vector(v, x, norm_w, eps, K, l);
+    for (int row0 = w * 4; row0 < E; row0 += 16) {  // wave-uniform trip count
+        dot_rows<4>(acc, gate, K, row0, E, v, K, l);
+        if (l == 0)
+            for (int r = 0; r < 4; ++r)
+                if (row0 + r < E) lg[row0 + r] = rbf(acc[r]);
     }
+    sync();
+    if (w != 0) return;
+    float val[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) val[i] = (l + 64 * i < E) ? lg[l + 64 * i] : -INFINITY;
+    float top[8];
+    int topi = -1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        top[j] = -INFINITY;
+        if (j < k) {
+            float bv = val[0];
+            int bi = l;
+#pragma unroll
+            for (int i = 1; i < 4; ++i)
+                if (val[i] > bv) {
+                    bv = val[i];
+                    bi = l + 64 * i;
+                }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float ov = shfl_xor(bv, d);
+                const int oi = shfl_xor(bi, d);
+                if (ov > bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            top[j] = bv;
+            if (l == j) topi = bi;
+            if ((bi & 63) == l) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i == (bi >> 6)) val[i] = -INFINITY;
+            }
+        }
+    }
+    const float mx = top[0];
+    float den = 0.f, mine = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < k) den += expf(top[j] - mx);
+        if (j == l) mine = top[j];
+    }
+    if (l < k) {
+        scores[l] = f2bf(expf(mine - mx) / den);
+        idx[l] = topi;
+    }
+}
+
+// token_unpermutation + shared add + residual in one pass (unpermute_kernel of moe.hip followed by add_kernel of norm.hip):
+//   m = bf16( bf16(sum_j bf16(eo_j * score_j)) + shared ),  out = bf16(h + m)
+__global__ __launch_bounds__(256) void combine_kernel(const bf16_t* eo, const bf16_t* scores, int k, const bf16_t* shared, const bf16_t* h,
+                                                      bf16_t* out, int D) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (D >> 3)) return;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const float sc = bf2f(scores[j]);
+        const u32x4 v = ld16(eo + (long long)j * D + c * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[2 * q] += rbf(bflo(v[q]) * sc);
+            acc[2 * q + 1] += rbf(bfhi(v[q]) * sc);
+        }
+    }
+    const u32x4 a = ld16(shared + c * 8), hv = ld16(h + c * 8);
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float m0 = rbf(rbf(acc[2 * q]) + bflo(a[q])), m1 = rbf(rbf(acc[2 * q + 1]) + bfhi(a[q]));
+        o[q] = pack2bf(bflo(hv[q]) + m0, bfhi(hv[q]) + m1);
+    }
+    st16(out + c * 8, o);
+}
+
+// RoPE (interleaved pairs, bf16 freqs_cis cache, one rounding: rope_interleaved_kernel of norm.hip) on q in place and on k while it
+// moves into the cache at the device-side position; v is copied.  Also publishes kv_len = pos + 1 for the attention kernel.
+__global__ __launch_bounds__(256) void rope_cache_kernel(bf16_t* qkv, const bf16_t* fc, const int32_t* pos, bf16_t* k_cache,
+                                                         bf16_t* v_cache, int D, int hd, int32_t* kv_len) {
+    const int ps = pos[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) kv_len[0] = ps + 1;
     const int nch = D >> 3, cph = hd >> 3;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < 3 * nch; c += gridDim.x * blockDim.x) {
         const int part = c / nch, cc = c % nch;
@@ -186,12 +281,12 @@ int launch_gemv(int N, void* stream, A... args) {
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct Scratch {
-    bf16_t *xa, *xb, *qkv, *ao, *rl, *scores, *act, *eo, *sact, *sh, *m;
-    int32_t *idx, *counts, *inv, *kv_len;
+    bf16_t *xa, *xb, *qkv, *ao, *scores, *act, *eo;
+    int32_t *idx, *kv_len;
     size_t bytes;
 };
 
-Scratch carve(char* base, int64_t D, int64_t E, int64_t k, int64_t I, int64_t Is) {
+Scratch carve(char* base, int64_t D, int64_t k, int64_t I, int64_t Is) {
     Scratch s{};
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -203,16 +298,10 @@ Scratch carve(char* base, int64_t D, int64_t E, int64_t k, int64_t I, int64_t Is
     s.xb = reinterpret_cast<bf16_t*>(take(D * 2));
     s.qkv = reinterpret_cast<bf16_t*>(take(3 * D * 2));
     s.ao = reinterpret_cast<bf16_t*>(take(D * 2));
-    s.rl = reinterpret_cast<bf16_t*>(take(E * 2));
     s.scores = reinterpret_cast<bf16_t*>(take(k * 2));
-    s.act = reinterpret_cast<bf16_t*>(take(k * I * 2));
-    s.eo = reinterpret_cast<bf16_t*>(take(k * D * 2));
-    s.sact = reinterpret_cast<bf16_t*>(take(Is * 2));
-    s.sh = reinterpret_cast<bf16_t*>(take(D * 2));
-    s.m = reinterpret_cast<bf16_t*>(take(D * 2));
+    s.act = reinterpret_cast<bf16_t*>(take((k * I + Is) * 2));  // routed rows, then the shared expert's activation vector
+    s.eo = reinterpret_cast<bf16_t*>(take((k + 1) * D * 2));     // routed outputs, then the shared expert's output
     s.idx = reinterpret_cast<int32_t*>(take(k * 4));
-    s.counts = reinterpret_cast<int32_t*>(take(E * 4));
-    s.inv = reinterpret_cast<int32_t*>(take(k * 4));
     s.kv_len = reinterpret_cast<int32_t*>(take(4));
     s.bytes = off;
     return s;
@@ -224,7 +313,7 @@ extern "C" {
 
 int64_t aria_decode_scratch_bytes(const int64_t* dims) {
     if (!dims) return 0;
-    return int64_t(carve(nullptr, dims[1], dims[4], dims[5], dims[6], dims[7]).bytes);
+    return int64_t(carve(nullptr, dims[1], dims[5], dims[6], dims[7]).bytes);
 }
 
 int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, void* stream) {
@@ -234,12 +323,14 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
     if (L <= 0 || D <= 0 || H * hd != D || (D & 7) || (I & 7) || (Is & 7) || D > 4096 || I > 4096 || Is > 4096 || k > 8 || E > 256)
         return ARIA_ERR_UNSUPPORTED;
     if (hd != 64 && hd != 128) return ARIA_ERR_UNSUPPORTED;
+    if (Is % I) return ARIA_ERR_UNSUPPORTED;  // the shared expert is handled as Is / I further experts of width I
+    const int ns = int(Is / I);
     for (int i = 0; i < ARIA_DECODE_HEADER_PTRS + ARIA_DECODE_LAYER_PTRS * L; ++i)
         if (!ptrs[i]) return ARIA_ERR_INVALID;
     const bf16_t* freqs = static_cast<const bf16_t*>(ptrs[0]);
     const bf16_t* final_norm = static_cast<const bf16_t*>(ptrs[1]);
     const bf16_t* out_w = static_cast<const bf16_t*>(ptrs[2]);
-    const Scratch s = carve(static_cast<char*>(const_cast<void*>(ptrs[3])), D, E, k, I, Is);
+    const Scratch s = carve(static_cast<char*>(const_cast<void*>(ptrs[3])), D, k, I, Is);
     const int32_t* pos = static_cast<const int32_t*>(ptrs[4]);
     const bf16_t* x = static_cast<const bf16_t*>(ptrs[5]);
     bf16_t* logits = static_cast<bf16_t*>(const_cast<void*>(ptrs[6]));
@@ -262,25 +353,21 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
         // attention block: h = x + wo( attn( rope(wqkv(norm(x))) ) )
         ARIA_TRY(launch_gemv(int(3 * D), stream, wqkv, (long long)D, x, attn_norm, eps, int(D), int(3 * D), (const bf16_t*)nullptr, s.qkv));
         ARIA_LAUNCH(rope_cache_kernel, dim3(unsigned((3 * D / 8 + 255) / 256)), dim3(256), 0, stream, s.qkv, freqs, pos, kc, vc, int(D),
-                    int(hd), s.kv_len, s.inv, int(k));
+                    int(hd), s.kv_len);
         ARIA_TRY(aria_check_launch());
         ARIA_TRY(aria_attn_fwd(s.qkv, kc, vc, s.ao, nullptr, s.kv_len, nullptr, 1, 1, Smax, H, hd, D, D, D, D, 1.0f / sqrtf(float(hd)), 0,
                                stream));
         ARIA_TRY(launch_gemv(int(D), stream, wo, (long long)D, (const bf16_t*)s.ao, (const bf16_t*)nullptr, 0.f, int(D), int(D), x, h));
-        // MoE block on hn = norm(h): out = h + ( sum_j score_j * expert_j(hn) + shared(hn) )
-        ARIA_TRY(launch_gemv(int(E), stream, gate, (long long)D, (const bf16_t*)h, ffn_norm, eps, int(D), int(E), (const bf16_t*)nullptr, s.rl));
-        ARIA_TRY(aria_moe_route(s.rl, 0, s.scores, s.idx, s.counts, 1, E, k, stream));
-        ARIA_LAUNCH((expert_up_kernel<2>), dim3(unsigned((I + 7) / 8), unsigned(k)), dim3(256), 0, stream, w1, w3, (long long)(I * D),
-                    (long long)D, (const int32_t*)s.idx, (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act);
-        ARIA_LAUNCH((expert_down_kernel<2>), dim3(unsigned((D + 7) / 8), unsigned(k)), dim3(256), 0, stream, w2, (long long)(D * I),
-                    (long long)I, (const int32_t*)s.idx, (const bf16_t*)s.act, int(I), int(D), s.eo);
-        ARIA_LAUNCH((expert_up_kernel<2>), dim3(unsigned((Is + 7) / 8), 1u), dim3(256), 0, stream, sw1, sw3, 0ll, (long long)D,
-                    (const int32_t*)nullptr, (const bf16_t*)h, ffn_norm, eps, int(D), int(Is), s.sact);
-        ARIA_LAUNCH((expert_down_kernel<2>), dim3(unsigned((D + 7) / 8), 1u), dim3(256), 0, stream, sw2, 0ll, (long long)Is,
-                    (const int32_t*)nullptr, (const bf16_t*)s.sact, int(Is), int(D), s.sh);
+        // MoE block on hn = norm(h): out = h + ( sum_j score_j * expert_j(hn) + shared(hn) ) -- four launches
+        ARIA_LAUNCH(router_kernel, dim3(1), dim3(256), 0, stream, gate, (const bf16_t*)h, ffn_norm, eps, int(D), int(E), int(k), s.scores,
+                    s.idx);
+        ARIA_LAUNCH((expert_up_kernel<2>), dim3(unsigned((I + 7) / 8), unsigned(k + ns)), dim3(256), 0, stream, w1, w3, sw1, sw3,
+                    (const int32_t*)s.idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act);
+        ARIA_LAUNCH((expert_down_kernel<2>), dim3(unsigned((D + 7) / 8), unsigned(k + 1)), dim3(256), 0, stream, w2, sw2,
+                    (const int32_t*)s.idx, int(k), ns, (const bf16_t*)s.act, int(I), int(D), s.eo);
+        ARIA_LAUNCH(combine_kernel, dim3(unsigned((D / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)s.eo, (const bf16_t*)s.scores,
+                    int(k), (const bf16_t*)(s.eo + k * D), (const bf16_t*)h, s.xb, int(D));
         ARIA_TRY(aria_check_launch());
-        ARIA_TRY(aria_moe_unpermute(s.eo, s.inv, s.scores, s.sh, s.m, 1, D, k, stream));
-        ARIA_TRY(aria_add_bf16(h, s.m, s.xb, D, stream));
         x = s.xb;  // the next layer reads x = xb and writes its h into xa again (h is dead once this add has run)
     }
     ARIA_TRY(launch_gemv(int(V), stream, out_w, (long long)D, x, final_norm, eps, int(D), int(V), (const bf16_t*)nullptr, logits));

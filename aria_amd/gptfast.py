@@ -184,7 +184,8 @@ class Transformer(nn.Module):
         self.freqs_cis: Optional[torch.Tensor] = None
         self.max_batch_size = self.max_seq_length = -1
         self.use_decode_engine = True     # batch-1 single-token steps go through aria_decode_token (csrc/decode.hip)
-        self.decode_graph = True          # ... replayed from a natively captured HIP graph (one launch per token)
+        self.decode_graph = False         # ... optionally replayed from a natively captured HIP graph (measured SLOWER than the plain
+        #                                   enqueue on ROCm 7.2: 6.2 vs 4.8 ms/token -- graph kernel nodes cost more than stream launches)
         self._engine: Optional["DecodeEngine"] = None
 
     def _engine_ok(self) -> bool:
