@@ -70,6 +70,15 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ float bflo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+// c + a.lo * b.lo + a.hi * b.hi on packed bf16 pairs, fp32 accumulate (v_dot2c_f32_bf16: no unpacking of either operand)
+__device__ __forceinline__ float dot2bf(uint32_t a, uint32_t b, float c) {
+#ifdef ARIA_EMU
+    return c + bflo(a) * bflo(b) + bfhi(a) * bfhi(b);
+#else
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+#endif
+}
 // round an fp32 value through bf16 (mirrors a bf16 tensor op whose result is materialised)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 

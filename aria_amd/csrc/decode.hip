@@ -20,82 +20,76 @@
 namespace {
 using namespace ad;
 
-constexpr int CPL = 8;  // 16-byte chunks per lane: reductions up to 64 * 8 * 8 = 4096 elements
-
 __device__ __forceinline__ float silu(float a) { return a / (1.f + expf(-a)); }
 
-// x[K] (bf16) -> this lane's chunks c = l + 64 i as fp32, optionally RMS-normalised exactly like rmsnorm_fwd_kernel (norm.hip)
-__device__ __forceinline__ void load_vector(float (&v)[CPL][8], const bf16_t* x, const bf16_t* norm_w, float eps, int K, int l) {
+// x[K] (bf16) -> this lane's chunks c = l + 64 i (i < NC) as packed bf16 pairs, optionally RMS-normalised exactly like
+// rmsnorm_fwd_kernel (norm.hip: same lane <-> chunk mapping and reduction order, so the same rstd).  Chunks past K read as zeros;
+// no branches, so all loads are in flight together.
+template <int NC>
+__device__ __forceinline__ void load_vector(u32x4 (&xv)[NC], const bf16_t* x, const bf16_t* norm_w, float eps, int K, int l) {
     const int nch = K >> 3;
-    float ss = 0.f;
+    u32x4 wv[NC];
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        const int c = l + 64 * i;
-        if (c < nch) {
-            const u32x4 a = ld16(x + c * 8);
+    for (int i = 0; i < NC; ++i) {
+        const int c = l + 64 * i, cc = min(c, nch - 1);
+        const u32x4 a = ld16(x + cc * 8);
+        if (norm_w) wv[i] = ld16(norm_w + cc * 8);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v[i][2 * q] = bflo(a[q]);
-                v[i][2 * q + 1] = bfhi(a[q]);
-                ss += v[i][2 * q] * v[i][2 * q] + v[i][2 * q + 1] * v[i][2 * q + 1];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-        }
+        for (int q = 0; q < 4; ++q) xv[i][q] = c < nch ? a[q] : 0u;
     }
     if (!norm_w) return;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v0 = bflo(xv[i][q]), v1 = bfhi(xv[i][q]);
+            ss += v0 * v0 + v1 * v1;
+        }
     ss = wave_sum(ss);
     const float r = rsqrtf(ss / float(K) + eps);
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        const int c = l + 64 * i;
-        if (c < nch) {
-            const u32x4 wv = ld16(norm_w + c * 8);
+    for (int i = 0; i < NC; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v[i][2 * q] = rbf(bflo(wv[q]) * rbf(v[i][2 * q] * r));
-                v[i][2 * q + 1] = rbf(bfhi(wv[q]) * rbf(v[i][2 * q + 1] * r));
-            }
-        }
-    }
+        for (int q = 0; q < 4; ++q)
+            xv[i][q] = pack2bf(bflo(wv[i][q]) * rbf(bflo(xv[i][q]) * r), bfhi(wv[i][q]) * rbf(bfhi(xv[i][q]) * r));
 }
 
-// dot products of R consecutive weight rows with the lane-distributed vector; every lane returns the full sums
-template <int R>
-__device__ __forceinline__ void dot_rows(float (&acc)[R], const bf16_t* w, long long ldw, int row0, int nrows, const float (&v)[CPL][8],
+// dot products of R consecutive weight rows with the lane-distributed vector; every lane returns the full sums.  Rows past the end
+// are clamped (their results are never stored) and every load is issued before the first use: R * NC 16-byte loads in flight per lane.
+template <int R, int NC>
+__device__ __forceinline__ void dot_rows(float (&acc)[R], const bf16_t* w, long long ldw, int row0, int nrows, const u32x4 (&xv)[NC],
                                          int K, int l) {
     const int nch = K >> 3;
+    u32x4 a[R][NC];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const bf16_t* row = w + (long long)min(row0 + r, nrows - 1) * ldw;
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        const int c = l + 64 * i;
-        if (c < nch) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (row0 + r < nrows) {
-                    const u32x4 a = ld16(w + (long long)(row0 + r) * ldw + c * 8);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[r] += bflo(a[q]) * v[i][2 * q] + bfhi(a[q]) * v[i][2 * q + 1];
-                }
-            }
-        }
+        for (int i = 0; i < NC; ++i) a[r][i] = ld16(row + min(l + 64 * i, nch - 1) * 8);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+    for (int r = 0; r < R; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s = dot2bf(a[r][i][q], xv[i][q], s);
+        acc[r] = wave_sum(s);
+    }
 }
 
 // y[n] = bf16(W[n,:] . xn) (+ residual[n], added to the ROUNDED product like the stand-alone add kernel)
-template <int R>
+template <int R, int NC>
 __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w, float eps, int K,
                                                    int N, const bf16_t* residual, bf16_t* y) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int row0 = (blockIdx.x * 4 + w) * R;
     if (row0 >= N) return;
-    float v[CPL][8], acc[R];
-    load_vector(v, x, norm_w, eps, K, l);
-    dot_rows<R>(acc, W, ldw, row0, N, v, K, l);
+    u32x4 xv[NC];
+    float acc[R];
+    load_vector<NC>(xv, x, norm_w, eps, K, l);
+    dot_rows<R, NC>(acc, W, ldw, row0, N, xv, K, l);
     if (l == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -106,7 +100,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* W, long long ld
 // Up-projection pair + SwiGLU for the k routed experts (e_j = idx[j]) AND the shared expert in one launch: grid.y = k + ns, the shared
 // expert's [ns*I, D] matrices are ns further "experts" of I rows each, so act rows k .. k+ns-1 are its activation vector of length ns*I.
 //   act[j][n] = bf16( bf16(silu(bf16(W1[n,:] . xn))) * bf16(W3[n,:] . xn) )
-template <int R>
+template <int R, int NC>
 __global__ __launch_bounds__(256) void expert_up_kernel(const bf16_t* W1, const bf16_t* W3, const bf16_t* S1, const bf16_t* S3,
                                                         const int32_t* idx, int k, const bf16_t* x, const bf16_t* norm_w, float eps, int K,
                                                         int I, bf16_t* act) {
@@ -116,10 +110,11 @@ __global__ __launch_bounds__(256) void expert_up_kernel(const bf16_t* W1, const 
     const long long stride = (long long)I * K;
     const bf16_t* w1 = j < k ? W1 + (long long)idx[j] * stride : S1 + (long long)(j - k) * stride;
     const bf16_t* w3 = j < k ? W3 + (long long)idx[j] * stride : S3 + (long long)(j - k) * stride;
-    float v[CPL][8], a1[R], a3[R];
-    load_vector(v, x, norm_w, eps, K, l);
-    dot_rows<R>(a1, w1, K, row0, I, v, K, l);
-    dot_rows<R>(a3, w3, K, row0, I, v, K, l);
+    u32x4 xv[NC];
+    float a1[R], a3[R];
+    load_vector<NC>(xv, x, norm_w, eps, K, l);
+    dot_rows<R, NC>(a1, w1, K, row0, I, xv, K, l);
+    dot_rows<R, NC>(a3, w3, K, row0, I, xv, K, l);
     if (l == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -127,19 +122,24 @@ __global__ __launch_bounds__(256) void expert_up_kernel(const bf16_t* W1, const 
     }
 }
 
-// Down-projections: out[j] = bf16(W2[e_j] . act[j]) for the routed experts (reduction I) and out[k] = bf16(S2 . act[k..]) for the
-// shared expert (reduction ns*I), grid.y = k + 1
-template <int R>
+// Down-projections: out[j] = bf16(W2[e_j] . act[j]) for the routed experts (reduction I, NCI chunks per lane) and
+// out[k] = bf16(S2 . act[k..]) for the shared expert (reduction ns*I, NCS chunks per lane), grid.y = k + 1
+template <int R, int NCI, int NCS>
 __global__ __launch_bounds__(256) void expert_down_kernel(const bf16_t* W2, const bf16_t* S2, const int32_t* idx, int k, int ns,
                                                           const bf16_t* act, int I, int N, bf16_t* out) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, j = blockIdx.y;
     const int row0 = (blockIdx.x * 4 + w) * R;
     if (row0 >= N) return;
-    const int K = j < k ? I : ns * I;
-    const bf16_t* w2 = j < k ? W2 + (long long)idx[j] * N * I : S2;
-    float v[CPL][8], acc[R];
-    load_vector(v, act + (long long)j * I, nullptr, 0.f, K, l);
-    dot_rows<R>(acc, w2, K, row0, N, v, K, l);
+    float acc[R];
+    if (j < k) {  // block-uniform
+        u32x4 xv[NCI];
+        load_vector<NCI>(xv, act + (long long)j * I, nullptr, 0.f, I, l);
+        dot_rows<R, NCI>(acc, W2 + (long long)idx[j] * N * I, I, row0, N, xv, I, l);
+    } else {
+        u32x4 xv[NCS];
+        load_vector<NCS>(xv, act + (long long)j * I, nullptr, 0.f, ns * I, l);
+        dot_rows<R, NCS>(acc, S2, (long long)ns * I, row0, N, xv, ns * I, l);
+    }
     if (l == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -149,14 +149,16 @@ __global__ __launch_bounds__(256) void expert_down_kernel(const bf16_t* W2, cons
 
 // Router in one workgroup: logits = bf16(gate . norm(h)) (the GEMV), then TopKRouter.routing exactly as route_kernel (moe.hip): k rounds
 // of arg-max with ties to the lowest expert id, softmax over the selected logits in fp32, scores cast to bf16.
+template <int NC>
 __global__ __launch_bounds__(256) void router_kernel(const bf16_t* gate, const bf16_t* x, const bf16_t* norm_w, float eps, int K, int E,
                                                      int k, bf16_t* scores, int32_t* idx) {
     ARIA_SMEM_STATIC float lg[256];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float v[CPL][8], acc[4];
-    load_vector(v, x, norm_w, eps, K, l);
+    u32x4 xv[NC];
+    float acc[4];
+    load_vector<NC>(xv, x, norm_w, eps, K, l);
     for (int row0 = w * 4; row0 < E; row0 += 16) {  // wave-uniform trip count
-        dot_rows<4>(acc, gate, K, row0, E, v, K, l);
+        dot_rows<4, NC>(acc, gate, K, row0, E, xv, K, l);
         if (l == 0)
             for (int r = 0; r < 4; ++r)
                 if (row0 + r < E) lg[row0 + r] = rbf(acc[r]);
@@ -267,13 +269,31 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(bf16_t* qkv, const bf16
     }
 }
 
-template <class... A>
-int launch_gemv(int N, void* stream, A... args) {
-    // rows per wave: 4 when that still gives >= 512 workgroups' worth of rows, else 2 (small N must still cover 256 CUs)
+// NC = 16-byte chunks per lane = ceil(K / 512), a template parameter so that every load of a wave is issued up front
+#define ARIA_NC_SWITCH(nc, CALL)   \
+    switch (nc) {                  \
+        case 1: CALL(1); break;    \
+        case 2: CALL(2); break;    \
+        case 3: CALL(3); break;    \
+        case 4: CALL(4); break;    \
+        case 5: CALL(5); break;    \
+        case 6: CALL(6); break;    \
+        case 7: CALL(7); break;    \
+        default: CALL(8); break;   \
+    }
+inline int chunks_per_lane(long long K) { return int((K / 8 + 63) / 64); }
+
+int launch_gemv(int N, void* stream, const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w, float eps, int K,
+                const bf16_t* residual, bf16_t* y) {
+    // rows per wave: 4 when that still leaves thousands of waves, else 2 (small N must still cover 256 CUs)
     if (N >= 8192) {
-        ARIA_LAUNCH((gemv_kernel<4>), dim3((N + 15) / 16), dim3(256), 0, stream, args...);
+#define CALL(NC) ARIA_LAUNCH((gemv_kernel<4, NC>), dim3((N + 15) / 16), dim3(256), 0, stream, W, ldw, x, norm_w, eps, K, N, residual, y)
+        ARIA_NC_SWITCH(chunks_per_lane(K), CALL)
+#undef CALL
     } else {
-        ARIA_LAUNCH((gemv_kernel<2>), dim3((N + 7) / 8), dim3(256), 0, stream, args...);
+#define CALL(NC) ARIA_LAUNCH((gemv_kernel<2, NC>), dim3((N + 7) / 8), dim3(256), 0, stream, W, ldw, x, norm_w, eps, K, N, residual, y)
+        ARIA_NC_SWITCH(chunks_per_lane(K), CALL)
+#undef CALL
     }
     return aria_check_launch();
 }
@@ -320,7 +340,7 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
     if (!ptrs || !dims) return ARIA_ERR_INVALID;
     const int64_t L = dims[0], D = dims[1], H = dims[2], hd = dims[3], E = dims[4], k = dims[5], I = dims[6], Is = dims[7], V = dims[8],
                   Smax = dims[9];
-    if (L <= 0 || D <= 0 || H * hd != D || (D & 7) || (I & 7) || (Is & 7) || D > 4096 || I > 4096 || Is > 4096 || k > 8 || E > 256)
+    if (L <= 0 || D <= 0 || H * hd != D || (D & 7) || (I & 7) || (Is & 7) || D > 4096 || I > 4096 || Is > 4096 || k > 8 || E > 256)  // 8 chunks/lane
         return ARIA_ERR_UNSUPPORTED;
     if (hd != 64 && hd != 128) return ARIA_ERR_UNSUPPORTED;
     if (Is % I) return ARIA_ERR_UNSUPPORTED;  // the shared expert is handled as Is / I further experts of width I
@@ -351,26 +371,42 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
         bf16_t *kc = static_cast<bf16_t*>(const_cast<void*>(lp[11])), *vc = static_cast<bf16_t*>(const_cast<void*>(lp[12]));
         bf16_t* h = s.xa;  // hidden state after the attention block
         // attention block: h = x + wo( attn( rope(wqkv(norm(x))) ) )
-        ARIA_TRY(launch_gemv(int(3 * D), stream, wqkv, (long long)D, x, attn_norm, eps, int(D), int(3 * D), (const bf16_t*)nullptr, s.qkv));
+        ARIA_TRY(launch_gemv(int(3 * D), stream, wqkv, (long long)D, x, attn_norm, eps, int(D), nullptr, s.qkv));
         ARIA_LAUNCH(rope_cache_kernel, dim3(unsigned((3 * D / 8 + 255) / 256)), dim3(256), 0, stream, s.qkv, freqs, pos, kc, vc, int(D),
                     int(hd), s.kv_len);
         ARIA_TRY(aria_check_launch());
         ARIA_TRY(aria_attn_fwd(s.qkv, kc, vc, s.ao, nullptr, s.kv_len, nullptr, 1, 1, Smax, H, hd, D, D, D, D, 1.0f / sqrtf(float(hd)), 0,
                                stream));
-        ARIA_TRY(launch_gemv(int(D), stream, wo, (long long)D, (const bf16_t*)s.ao, (const bf16_t*)nullptr, 0.f, int(D), int(D), x, h));
+        ARIA_TRY(launch_gemv(int(D), stream, wo, (long long)D, s.ao, nullptr, 0.f, int(D), x, h));
         // MoE block on hn = norm(h): out = h + ( sum_j score_j * expert_j(hn) + shared(hn) ) -- four launches
-        ARIA_LAUNCH(router_kernel, dim3(1), dim3(256), 0, stream, gate, (const bf16_t*)h, ffn_norm, eps, int(D), int(E), int(k), s.scores,
-                    s.idx);
-        ARIA_LAUNCH((expert_up_kernel<2>), dim3(unsigned((I + 7) / 8), unsigned(k + ns)), dim3(256), 0, stream, w1, w3, sw1, sw3,
-                    (const int32_t*)s.idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act);
-        ARIA_LAUNCH((expert_down_kernel<2>), dim3(unsigned((D + 7) / 8), unsigned(k + 1)), dim3(256), 0, stream, w2, sw2,
-                    (const int32_t*)s.idx, int(k), ns, (const bf16_t*)s.act, int(I), int(D), s.eo);
+        const int ncD = chunks_per_lane(D), ncI = chunks_per_lane(I), ncS = chunks_per_lane(Is);
+#define CALL(NC) ARIA_LAUNCH((router_kernel<NC>), dim3(1), dim3(256), 0, stream, gate, (const bf16_t*)h, ffn_norm, eps, int(D), int(E), int(k), s.scores, s.idx)
+        ARIA_NC_SWITCH(ncD, CALL)
+#undef CALL
+#define CALL(NC)                                                                                                                      \
+    ARIA_LAUNCH((expert_up_kernel<2, NC>), dim3(unsigned((I + 7) / 8), unsigned(k + ns)), dim3(256), 0, stream, w1, w3, sw1, sw3, \
+                (const int32_t*)s.idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act)
+        ARIA_NC_SWITCH(ncD, CALL)
+#undef CALL
+#define DOWN(NCI, NCS)                                                                                                               \
+    ARIA_LAUNCH((expert_down_kernel<2, NCI, NCS>), dim3(unsigned((D + 7) / 8), unsigned(k + 1)), dim3(256), 0, stream, w2, sw2, \
+                (const int32_t*)s.idx, int(k), ns, (const bf16_t*)s.act, int(I), int(D), s.eo)
+        if (ncI == 4 && ncS == 7) {  // Aria: I = 1664, shared 3328
+            DOWN(4, 7);
+        } else if (ncI == 1 && ncS == 1) {
+            DOWN(1, 1);
+        } else if (ncI <= 2 && ncS <= 4) {
+            DOWN(2, 4);
+        } else {
+            DOWN(8, 8);  // any other width: correct (chunks past the end read as zeros), more load instructions than needed
+        }
+#undef DOWN
         ARIA_LAUNCH(combine_kernel, dim3(unsigned((D / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)s.eo, (const bf16_t*)s.scores,
                     int(k), (const bf16_t*)(s.eo + k * D), (const bf16_t*)h, s.xb, int(D));
         ARIA_TRY(aria_check_launch());
         x = s.xb;  // the next layer reads x = xb and writes its h into xa again (h is dead once this add has run)
     }
-    ARIA_TRY(launch_gemv(int(V), stream, out_w, (long long)D, x, final_norm, eps, int(D), int(V), (const bf16_t*)nullptr, logits));
+    ARIA_TRY(launch_gemv(int(V), stream, out_w, (long long)D, x, final_norm, eps, int(D), nullptr, logits));
 #undef ARIA_TRY
     return ARIA_OK;
 }
