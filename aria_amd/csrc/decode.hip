@@ -150,14 +150,14 @@ __global__ __launch_bounds__(256) void expert_down_kernel(const bf16_t* W2, cons
 // Router in one workgroup: logits = bf16(gate . norm(h)) (the GEMV), then TopKRouter.routing exactly as route_kernel (moe.hip): k rounds
 // of arg-max with ties to the lowest expert id, softmax over the selected logits in fp32, scores cast to bf16.
 template <int NC>
-__global__ __launch_bounds__(256) void router_kernel(const bf16_t* gate, const bf16_t* x, const bf16_t* norm_w, float eps, int K, int E,
+__global__ __launch_bounds__(1024) void router_kernel(const bf16_t* gate, const bf16_t* x, const bf16_t* norm_w, float eps, int K, int E,
                                                      int k, bf16_t* scores, int32_t* idx) {
     ARIA_SMEM_STATIC float lg[256];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     u32x4 xv[NC];
     float acc[4];
     load_vector<NC>(xv, x, norm_w, eps, K, l);
-    for (int row0 = w * 4; row0 < E; row0 += 16) {  // wave-uniform trip count
+    for (int row0 = w * 4; row0 < E; row0 += 64) {  // 16 waves x 4 rows per pass; wave-uniform trip count
         dot_rows<4, NC>(acc, gate, K, row0, E, xv, K, l);
         if (l == 0)
             for (int r = 0; r < 4; ++r)
@@ -380,14 +380,22 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
         ARIA_TRY(launch_gemv(int(D), stream, wo, (long long)D, s.ao, nullptr, 0.f, int(D), x, h));
         // MoE block on hn = norm(h): out = h + ( sum_j score_j * expert_j(hn) + shared(hn) ) -- four launches
         const int ncD = chunks_per_lane(D), ncI = chunks_per_lane(I), ncS = chunks_per_lane(Is);
-#define CALL(NC) ARIA_LAUNCH((router_kernel<NC>), dim3(1), dim3(256), 0, stream, gate, (const bf16_t*)h, ffn_norm, eps, int(D), int(E), int(k), s.scores, s.idx)
+#define CALL(NC) ARIA_LAUNCH((router_kernel<NC>), dim3(1), dim3(1024), 0, stream, gate, (const bf16_t*)h, ffn_norm, eps, int(D), int(E), int(k), s.scores, s.idx)
         ARIA_NC_SWITCH(ncD, CALL)
 #undef CALL
+        if (I * (k + ns) >= 8192) {  // enough rows for 4 per wave (8 row reads of 5 KiB in flight per wave) and still > 2000 waves
+#define CALL(NC)                                                                                                                       \
+    ARIA_LAUNCH((expert_up_kernel<4, NC>), dim3(unsigned((I + 15) / 16), unsigned(k + ns)), dim3(256), 0, stream, w1, w3, sw1, sw3, \
+                (const int32_t*)s.idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act)
+            ARIA_NC_SWITCH(ncD, CALL)
+#undef CALL
+        } else {
 #define CALL(NC)                                                                                                                      \
     ARIA_LAUNCH((expert_up_kernel<2, NC>), dim3(unsigned((I + 7) / 8), unsigned(k + ns)), dim3(256), 0, stream, w1, w3, sw1, sw3, \
                 (const int32_t*)s.idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act)
-        ARIA_NC_SWITCH(ncD, CALL)
+            ARIA_NC_SWITCH(ncD, CALL)
 #undef CALL
+        }
 #define DOWN(NCI, NCS)                                                                                                               \
     ARIA_LAUNCH((expert_down_kernel<2, NCI, NCS>), dim3(unsigned((D + 7) / 8), unsigned(k + 1)), dim3(256), 0, stream, w2, sw2, \
                 (const int32_t*)s.idx, int(k), ns, (const bf16_t*)s.act, int(I), int(D), s.eo)
