@@ -9,7 +9,7 @@
 //   * RMSNorm is folded into the consumer GEMV (each wave re-normalises the 2560-vector it needs anyway, with the same lane <-> chunk
 //     mapping and reduction order as rmsnorm_fwd_kernel: identical rstd), residual adds into the GEMV epilogue, SwiGLU into the
 //     up-projection pair, RoPE + KV-cache write into one kernel, the six routed experts are indexed on the device (no gather of weights);
-//   * ONE C call walks all layers and enqueues 8 launches per layer back to back (no Python, no allocation, no host sync): the
+//   * ONE C call walks all layers and enqueues 9 launches per layer back to back (no Python, no allocation, no host sync): the
 //     position lives on the device, so the same enqueue sequence is valid for every token.
 // Rounding points mirror the tile path (GEMM outputs, norm, SwiGLU, residual adds are each rounded to bf16 where the reference
 // materialises a bf16 tensor); only the fp32 summation ORDER inside a dot product differs from the MFMA kernels.
@@ -147,27 +147,14 @@ __global__ __launch_bounds__(256) void expert_down_kernel(const bf16_t* W2, cons
     }
 }
 
-// Router in one workgroup: logits = bf16(gate . norm(h)) (the GEMV), then TopKRouter.routing exactly as route_kernel (moe.hip): k rounds
-// of arg-max with ties to the lowest expert id, softmax over the selected logits in fp32, scores cast to bf16.
-template <int NC>
-__global__ __launch_bounds__(1024) void router_kernel(const bf16_t* gate, const bf16_t* x, const bf16_t* norm_w, float eps, int K, int E,
-                                                     int k, bf16_t* scores, int32_t* idx) {
-    ARIA_SMEM_STATIC float lg[256];
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    u32x4 xv[NC];
-    float acc[4];
-    load_vector<NC>(xv, x, norm_w, eps, K, l);
-    for (int row0 = w * 4; row0 < E; row0 += 64) {  // 16 waves x 4 rows per pass; wave-uniform trip count
-        dot_rows<4, NC>(acc, gate, K, row0, E, xv, K, l);
-        if (l == 0)
-            for (int r = 0; r < 4; ++r)
-                if (row0 + r < E) lg[row0 + r] = rbf(acc[r]);
-    }
-    sync();
-    if (w != 0) return;
+// TopKRouter.routing on the E logits of one token, exactly as route_kernel (moe.hip): k rounds of arg-max with ties to the lowest expert
+// id, softmax over the selected logits in fp32, scores cast to bf16.  One wave; the logits come from a regular (multi-workgroup) GEMV --
+// a single workgroup reading the whole 320 KB gate matrix cost 16 us per layer.
+__global__ __launch_bounds__(64) void router_topk_kernel(const bf16_t* logits, int E, int k, bf16_t* scores, int32_t* idx) {
+    const int l = threadIdx.x & 63;
     float val[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) val[i] = (l + 64 * i < E) ? lg[l + 64 * i] : -INFINITY;
+    for (int i = 0; i < 4; ++i) val[i] = (l + 64 * i < E) ? bf2f(logits[l + 64 * i]) : -INFINITY;
     float top[8];
     int topi = -1;
 #pragma unroll
@@ -269,6 +256,110 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(bf16_t* qkv, const bf16
     }
 }
 
+// Attention of ONE new token over the static cache, fused with RoPE and the cache write (gptfast/model.py:413-447, KVCache.update
+// :67-93): grid = heads, 4 waves.  HD/8 lanes share a key (8 features each, one 16-byte load per lane and key), so a wave works on
+// 64/(HD/8) keys at a time, 4 deep (all K and V loads of an iteration are issued before the first use); every lane group keeps an online
+// softmax state (m, l, o[8]) which is merged across groups and waves at the end (flash-decoding).  Softmax in the log2 domain, P rounded
+// to bf16 before it multiplies V (what the flash kernel feeds its MFMA), fp32 accumulation.  The generic flash kernel spends ~19 us per
+// layer on this (20 workgroups built for 256 queries); this one ~5.
+template <int HD>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, const bf16_t* fc, const int32_t* pos, bf16_t* k_cache,
+                                                          bf16_t* v_cache, bf16_t* out, int D, float scale) {
+    constexpr int LPK = HD / 8, KPW = 64 / LPK, U = 4;
+    ARIA_SMEM_STATIC float red[4][LPK][10];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, sub = l % LPK, grp = l / LPK, head = blockIdx.x;
+    const int ps = pos[0], nkeys = ps + 1;
+    const long long col = (long long)head * HD + sub * 8;
+    const u32x4 f = ld16(fc + (long long)ps * HD + sub * 8);
+    auto rope = [&](const u32x4& a) {
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x0 = bflo(a[q]), x1 = bfhi(a[q]), cs = bflo(f[q]), sn = bfhi(f[q]);
+            o[q] = pack2bf(x0 * cs - x1 * sn, x1 * cs + x0 * sn);
+        }
+        return o;
+    };
+    const u32x4 qr = rope(ld16(qkv + col));
+    if (w == 0 && grp == 0) {  // this head's slice of the new key / value goes into the cache first; it is read back below
+        st16(k_cache + (long long)ps * D + col, rope(ld16(qkv + D + col)));
+        st16(v_cache + (long long)ps * D + col, ld16(qkv + 2 * D + col));
+    }
+    sync();
+    const float scale2 = scale * 1.4426950408889634f;
+    float m = -INFINITY, lsum = 0.f, o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    const int per_iter = 4 * KPW * U;
+    for (int j0 = 0; j0 < nkeys; j0 += per_iter) {  // block-uniform trip count
+        u32x4 kx[U], vx[U];
+        int key[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            key[u] = j0 + (w * U + u) * KPW + grp;
+            const long long row = (long long)min(key[u], nkeys - 1) * D + col;
+            kx[u] = ld16(k_cache + row);
+            vx[u] = ld16(v_cache + row);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float sc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sc = dot2bf(kx[u][q], qr[q], sc);
+#pragma unroll
+            for (int d = 1; d < LPK; d <<= 1) sc += shfl_xor(sc, d);
+            const float s2 = key[u] < nkeys ? sc * scale2 : -INFINITY;
+            const float m_new = fmaxf(m, s2);
+            if (m_new == -INFINITY) continue;  // nothing seen yet by this lane group (uniform within the group)
+            const float alpha = exp2_fast(m - m_new), p = exp2_fast(s2 - m_new), pb = rbf(p);
+            lsum = lsum * alpha + p;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o[2 * q] = o[2 * q] * alpha + pb * bflo(vx[u][q]);
+                o[2 * q + 1] = o[2 * q + 1] * alpha + pb * bfhi(vx[u][q]);
+            }
+            m = m_new;
+        }
+    }
+    // merge the lane groups of a wave (lanes with equal `sub`), then the four waves through LDS
+    auto merge = [&](float m2, float l2, const float (&o2)[8]) {
+        const float mm = fmaxf(m, m2);
+        const float a = mm == -INFINITY ? 0.f : exp2_fast(m - mm), b = mm == -INFINITY ? 0.f : exp2_fast(m2 - mm);
+        lsum = lsum * a + l2 * b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * a + o2[e] * b;
+        m = mm;
+    };
+#pragma unroll
+    for (int d = LPK; d < 64; d <<= 1) {
+        float o2[8];
+        const float m2 = shfl_xor(m, d), l2 = shfl_xor(lsum, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o2[e] = shfl_xor(o[e], d);
+        merge(m2, l2, o2);
+    }
+    if (grp == 0) {
+        red[w][sub][0] = m;
+        red[w][sub][1] = lsum;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[w][sub][2 + e] = o[e];
+    }
+    sync();
+    if (w == 0 && grp == 0) {
+        for (int ww = 1; ww < 4; ++ww) {
+            float o2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o2[e] = red[ww][sub][2 + e];
+            merge(red[ww][sub][0], red[ww][sub][1], o2);
+        }
+        const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+        u32x4 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = pack2bf(o[2 * q] * inv, o[2 * q + 1] * inv);
+        st16(out + col, r);
+    }
+}
+
 // NC = 16-byte chunks per lane = ceil(K / 512), a template parameter so that every load of a wave is issued up front
 #define ARIA_NC_SWITCH(nc, CALL)   \
     switch (nc) {                  \
@@ -301,12 +392,12 @@ int launch_gemv(int N, void* stream, const bf16_t* W, long long ldw, const bf16_
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct Scratch {
-    bf16_t *xa, *xb, *qkv, *ao, *scores, *act, *eo;
+    bf16_t *xa, *xb, *qkv, *ao, *rl, *scores, *act, *eo;
     int32_t *idx, *kv_len;
     size_t bytes;
 };
 
-Scratch carve(char* base, int64_t D, int64_t k, int64_t I, int64_t Is) {
+Scratch carve(char* base, int64_t D, int64_t E, int64_t k, int64_t I, int64_t Is) {
     Scratch s{};
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -318,6 +409,7 @@ Scratch carve(char* base, int64_t D, int64_t k, int64_t I, int64_t Is) {
     s.xb = reinterpret_cast<bf16_t*>(take(D * 2));
     s.qkv = reinterpret_cast<bf16_t*>(take(3 * D * 2));
     s.ao = reinterpret_cast<bf16_t*>(take(D * 2));
+    s.rl = reinterpret_cast<bf16_t*>(take(E * 2));
     s.scores = reinterpret_cast<bf16_t*>(take(k * 2));
     s.act = reinterpret_cast<bf16_t*>(take((k * I + Is) * 2));  // routed rows, then the shared expert's activation vector
     s.eo = reinterpret_cast<bf16_t*>(take((k + 1) * D * 2));     // routed outputs, then the shared expert's output
@@ -333,7 +425,7 @@ extern "C" {
 
 int64_t aria_decode_scratch_bytes(const int64_t* dims) {
     if (!dims) return 0;
-    return int64_t(carve(nullptr, dims[1], dims[5], dims[6], dims[7]).bytes);
+    return int64_t(carve(nullptr, dims[1], dims[4], dims[5], dims[6], dims[7]).bytes);
 }
 
 int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, void* stream) {
@@ -350,7 +442,7 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
     const bf16_t* freqs = static_cast<const bf16_t*>(ptrs[0]);
     const bf16_t* final_norm = static_cast<const bf16_t*>(ptrs[1]);
     const bf16_t* out_w = static_cast<const bf16_t*>(ptrs[2]);
-    const Scratch s = carve(static_cast<char*>(const_cast<void*>(ptrs[3])), D, k, I, Is);
+    const Scratch s = carve(static_cast<char*>(const_cast<void*>(ptrs[3])), D, E, k, I, Is);
     const int32_t* pos = static_cast<const int32_t*>(ptrs[4]);
     const bf16_t* x = static_cast<const bf16_t*>(ptrs[5]);
     bf16_t* logits = static_cast<bf16_t*>(const_cast<void*>(ptrs[6]));
@@ -372,17 +464,27 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
         bf16_t* h = s.xa;  // hidden state after the attention block
         // attention block: h = x + wo( attn( rope(wqkv(norm(x))) ) )
         ARIA_TRY(launch_gemv(int(3 * D), stream, wqkv, (long long)D, x, attn_norm, eps, int(D), nullptr, s.qkv));
-        ARIA_LAUNCH(rope_cache_kernel, dim3(unsigned((3 * D / 8 + 255) / 256)), dim3(256), 0, stream, s.qkv, freqs, pos, kc, vc, int(D),
-                    int(hd), s.kv_len);
-        ARIA_TRY(aria_check_launch());
-        ARIA_TRY(aria_attn_fwd(s.qkv, kc, vc, s.ao, nullptr, s.kv_len, nullptr, 1, 1, Smax, H, hd, D, D, D, D, 1.0f / sqrtf(float(hd)), 0,
-                               stream));
+        if (Smax <= 16384) {  // one workgroup per head walks the whole context (longer ones: the generic flash kernel below)
+            const float sc = 1.0f / sqrtf(float(hd));
+            if (hd == 128)
+                ARIA_LAUNCH((decode_attn_kernel<128>), dim3(unsigned(H)), dim3(256), 0, stream, (const bf16_t*)s.qkv, freqs, pos, kc, vc, s.ao,
+                            int(D), sc);
+            else
+                ARIA_LAUNCH((decode_attn_kernel<64>), dim3(unsigned(H)), dim3(256), 0, stream, (const bf16_t*)s.qkv, freqs, pos, kc, vc, s.ao,
+                            int(D), sc);
+            ARIA_TRY(aria_check_launch());
+        } else {
+            ARIA_LAUNCH(rope_cache_kernel, dim3(unsigned((3 * D / 8 + 255) / 256)), dim3(256), 0, stream, s.qkv, freqs, pos, kc, vc, int(D),
+                        int(hd), s.kv_len);
+            ARIA_TRY(aria_check_launch());
+            ARIA_TRY(aria_attn_fwd(s.qkv, kc, vc, s.ao, nullptr, s.kv_len, nullptr, 1, 1, Smax, H, hd, D, D, D, D, 1.0f / sqrtf(float(hd)),
+                                   0, stream));
+        }
         ARIA_TRY(launch_gemv(int(D), stream, wo, (long long)D, s.ao, nullptr, 0.f, int(D), x, h));
         // MoE block on hn = norm(h): out = h + ( sum_j score_j * expert_j(hn) + shared(hn) ) -- four launches
         const int ncD = chunks_per_lane(D), ncI = chunks_per_lane(I), ncS = chunks_per_lane(Is);
-#define CALL(NC) ARIA_LAUNCH((router_kernel<NC>), dim3(1), dim3(1024), 0, stream, gate, (const bf16_t*)h, ffn_norm, eps, int(D), int(E), int(k), s.scores, s.idx)
-        ARIA_NC_SWITCH(ncD, CALL)
-#undef CALL
+        ARIA_TRY(launch_gemv(int(E), stream, gate, (long long)D, h, ffn_norm, eps, int(D), nullptr, s.rl));
+        ARIA_LAUNCH(router_topk_kernel, dim3(1), dim3(64), 0, stream, (const bf16_t*)s.rl, int(E), int(k), s.scores, s.idx);
         if (I * (k + ns) >= 8192) {  // enough rows for 4 per wave (8 row reads of 5 KiB in flight per wave) and still > 2000 waves
 #define CALL(NC)                                                                                                                       \
     ARIA_LAUNCH((expert_up_kernel<4, NC>), dim3(unsigned((I + 15) / 16), unsigned(k + ns)), dim3(256), 0, stream, w1, w3, sw1, sw3, \
