@@ -9,7 +9,7 @@
 //   * RMSNorm is folded into the consumer GEMV (each wave re-normalises the 2560-vector it needs anyway, with the same lane <-> chunk
 //     mapping and reduction order as rmsnorm_fwd_kernel: identical rstd), residual adds into the GEMV epilogue, SwiGLU into the
 //     up-projection pair, RoPE + KV-cache write into one kernel, the six routed experts are indexed on the device (no gather of weights);
-//   * ONE C call walks all layers and enqueues 9 launches per layer back to back (no Python, no allocation, no host sync): the
+//   * ONE C call walks all layers and enqueues 7 launches per layer back to back (no Python, no allocation, no host sync): the
 //     position lives on the device, so the same enqueue sequence is valid for every token.
 // Rounding points mirror the tile path (GEMM outputs, norm, SwiGLU, residual adds are each rounded to bf16 where the reference
 // materialises a bf16 tensor); only the fp32 summation ORDER inside a dot product differs from the MFMA kernels.
@@ -97,19 +97,30 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* W, long long ld
     }
 }
 
+__device__ __forceinline__ int route_one_token(const bf16_t* logits, int E, int k, int l, int want, float& my_score, int& my_idx);
+
 // Up-projection pair + SwiGLU for the k routed experts (e_j = idx[j]) AND the shared expert in one launch: grid.y = k + ns, the shared
 // expert's [ns*I, D] matrices are ns further "experts" of I rows each, so act rows k .. k+ns-1 are its activation vector of length ns*I.
 //   act[j][n] = bf16( bf16(silu(bf16(W1[n,:] . xn))) * bf16(W3[n,:] . xn) )
+// `logits` (E router logits of the token): every wave derives the routing itself (one load + ~40 shuffles: cheaper than a launch of
+// its own); workgroup (0, 0) publishes scores / idx for the down-projection and the combine.
 template <int R, int NC>
 __global__ __launch_bounds__(256) void expert_up_kernel(const bf16_t* W1, const bf16_t* W3, const bf16_t* S1, const bf16_t* S3,
-                                                        const int32_t* idx, int k, const bf16_t* x, const bf16_t* norm_w, float eps, int K,
-                                                        int I, bf16_t* act) {
+                                                        const bf16_t* logits, int E, bf16_t* scores, int32_t* idx, int k, const bf16_t* x,
+                                                        const bf16_t* norm_w, float eps, int K, int I, bf16_t* act) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, j = blockIdx.y;
     const int row0 = (blockIdx.x * 4 + w) * R;
     if (row0 >= I) return;
+    float my_score;
+    int my_idx;
+    const int e = route_one_token(logits, E, k, l, j, my_score, my_idx);
+    if (blockIdx.x == 0 && j == 0 && w == 0 && l < k) {
+        scores[l] = f2bf(my_score);
+        idx[l] = my_idx;
+    }
     const long long stride = (long long)I * K;
-    const bf16_t* w1 = j < k ? W1 + (long long)idx[j] * stride : S1 + (long long)(j - k) * stride;
-    const bf16_t* w3 = j < k ? W3 + (long long)idx[j] * stride : S3 + (long long)(j - k) * stride;
+    const bf16_t* w1 = j < k ? W1 + (long long)e * stride : S1 + (long long)(j - k) * stride;
+    const bf16_t* w3 = j < k ? W3 + (long long)e * stride : S3 + (long long)(j - k) * stride;
     u32x4 xv[NC];
     float a1[R], a3[R];
     load_vector<NC>(xv, x, norm_w, eps, K, l);
@@ -150,6 +161,56 @@ __global__ __launch_bounds__(256) void expert_down_kernel(const bf16_t* W2, cons
 // TopKRouter.routing on the E logits of one token, exactly as route_kernel (moe.hip): k rounds of arg-max with ties to the lowest expert
 // id, softmax over the selected logits in fp32, scores cast to bf16.  One wave; the logits come from a regular (multi-workgroup) GEMV --
 // a single workgroup reading the whole 320 KB gate matrix cost 16 us per layer.
+// returns the expert id of slot `want` (wave-uniform); lanes < k also get (score, id) of their own slot
+__device__ __forceinline__ int route_one_token(const bf16_t* logits, int E, int k, int l, int want, float& my_score, int& my_idx) {
+    float val[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) val[i] = (l + 64 * i < E) ? bf2f(logits[l + 64 * i]) : -INFINITY;
+    float top[8];
+    int topi = -1, wanted = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        top[j] = -INFINITY;
+        if (j < k) {
+            float bv = val[0];
+            int bi = l;
+#pragma unroll
+            for (int i = 1; i < 4; ++i)
+                if (val[i] > bv) {
+                    bv = val[i];
+                    bi = l + 64 * i;
+                }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float ov = shfl_xor(bv, d);
+                const int oi = shfl_xor(bi, d);
+                if (ov > bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            top[j] = bv;
+            if (l == j) topi = bi;
+            if (j == want) wanted = bi;
+            if ((bi & 63) == l) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i == (bi >> 6)) val[i] = -INFINITY;
+            }
+        }
+    }
+    const float mx = top[0];
+    float den = 0.f, mine = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < k) den += expf(top[j] - mx);
+        if (j == l) mine = top[j];
+    }
+    my_score = expf(mine - mx) / den;
+    my_idx = topi;
+    return wanted;
+}
+
 __global__ __launch_bounds__(64) void router_topk_kernel(const bf16_t* logits, int E, int k, bf16_t* scores, int32_t* idx) {
     const int l = threadIdx.x & 63;
     float val[4];
@@ -376,8 +437,8 @@ inline int chunks_per_lane(long long K) { return int((K / 8 + 63) / 64); }
 
 int launch_gemv(int N, void* stream, const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w, float eps, int K,
                 const bf16_t* residual, bf16_t* y) {
-    // rows per wave: 4 when that still leaves thousands of waves, else 2 (small N must still cover 256 CUs)
-    if (N >= 8192) {
+    // rows per wave: 4 when that still leaves well over a thousand waves, else 2 (small N must still cover 256 CUs)
+    if (N >= 4096) {
 #define CALL(NC) ARIA_LAUNCH((gemv_kernel<4, NC>), dim3((N + 15) / 16), dim3(256), 0, stream, W, ldw, x, norm_w, eps, K, N, residual, y)
         ARIA_NC_SWITCH(chunks_per_lane(K), CALL)
 #undef CALL
@@ -484,17 +545,17 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
         // MoE block on hn = norm(h): out = h + ( sum_j score_j * expert_j(hn) + shared(hn) ) -- four launches
         const int ncD = chunks_per_lane(D), ncI = chunks_per_lane(I), ncS = chunks_per_lane(Is);
         ARIA_TRY(launch_gemv(int(E), stream, gate, (long long)D, h, ffn_norm, eps, int(D), nullptr, s.rl));
-        ARIA_LAUNCH(router_topk_kernel, dim3(1), dim3(64), 0, stream, (const bf16_t*)s.rl, int(E), int(k), s.scores, s.idx);
+        // (top-k + softmax of the router run inside expert_up_kernel; router_topk_kernel is the stand-alone form)
         if (I * (k + ns) >= 8192) {  // enough rows for 4 per wave (8 row reads of 5 KiB in flight per wave) and still > 2000 waves
 #define CALL(NC)                                                                                                                       \
     ARIA_LAUNCH((expert_up_kernel<4, NC>), dim3(unsigned((I + 15) / 16), unsigned(k + ns)), dim3(256), 0, stream, w1, w3, sw1, sw3, \
-                (const int32_t*)s.idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act)
+                (const bf16_t*)s.rl, int(E), s.scores, s.idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act)
             ARIA_NC_SWITCH(ncD, CALL)
 #undef CALL
         } else {
 #define CALL(NC)                                                                                                                      \
     ARIA_LAUNCH((expert_up_kernel<2, NC>), dim3(unsigned((I + 7) / 8), unsigned(k + ns)), dim3(256), 0, stream, w1, w3, sw1, sw3, \
-                (const int32_t*)s.idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act)
+                (const bf16_t*)s.rl, int(E), s.scores, s.idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act)
             ARIA_NC_SWITCH(ncD, CALL)
 #undef CALL
         }
