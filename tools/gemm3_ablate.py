@@ -1,4 +1,7 @@
-"""v3 GEMM ablation (flags in bits 12..15 of ARIA_GEMM_ORDER; results are wrong by construction, only the time matters)"""
+"""v3 GEMM ablation (flags in bits 12..15 of ARIA_GEMM_ORDER; results are wrong by construction, only the time matters)
+NOTE: the skip flags this tool drives (bits 12..15 of ARIA_GEMM_ORDER in gemm3.hip) were compiled in only for the measurement
+recorded in profiles/r01_gemm_tuning.md / r01_gemm3_ablate.json and are not in the product kernel; re-apply them to re-run.
+"""
 import os, sys, json, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 from aria_amd import ops

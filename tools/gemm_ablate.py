@@ -1,3 +1,6 @@
+"""NOTE: the skip flags this tool drives (bits 8..11 of ARIA_GEMM_ORDER in gemm2.hip) were compiled in only for the measurement
+recorded in profiles/r01_gemm_tuning.md and have been removed from the product kernel again; re-apply them to re-run.
+"""
 import os, sys, json, torch
 sys.path.insert(0, ".")
 from aria_amd import ops
