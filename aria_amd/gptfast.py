@@ -383,10 +383,13 @@ class DecodeGraph:
         return sample(self.logits, self.temperature, self.top_k)[0].view(-1)
 
 
-def _dbg(msg):
-    import os
+import os as _os
 
-    if os.environ.get("ARIA_DEBUG_GEN"):
+_DEBUG_GEN = bool(_os.environ.get("ARIA_DEBUG_GEN"))
+
+
+def _dbg(msg):
+    if _DEBUG_GEN:
         torch.cuda.synchronize()
         print("[gen]", msg, flush=True)
 
@@ -419,7 +422,8 @@ def generate(model: Aria, input_ids: torch.Tensor, max_new_tokens: int, *, pixel
     pos = torch.tensor([T], device=dev, dtype=torch.int32)
     for _ in range(max_new_tokens - 1):
         nxt = decoder(toks[-1].long(), pos)
-        _dbg(f"decode pos {int(pos)} tok {int(nxt)}")
+        if _DEBUG_GEN:  # (formatting the message reads two device scalars: never on the normal path, it would sync every token)
+            _dbg(f"decode pos {int(pos)} tok {int(nxt)}")
         toks.append(nxt.view(1))
         pos += 1
         if stop_token is not None and int(nxt) == stop_token:

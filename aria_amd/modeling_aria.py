@@ -79,6 +79,51 @@ class AriaForConditionalGeneration(nn.Module):
     def set_moe_aux_loss_coeff(self, value: float):
         self.language_model.set_aux_loss_coeff(value)
 
+    # ---- inference bridge: HF surface (training layout) -> gptfast surface (inference layout)
+    def to_gptfast(self):
+        """An ``aria_amd.gptfast.Aria`` twin of this model: the weights go through the reference's own conversion
+        (gptfast/scripts/convert_hf_checkpoint.py = ``aria_amd.checkpoint.hf_to_gptfast``: q/k rows permuted for interleaved RoPE,
+        ``wqkv`` fusion, experts ``fc1 -> w1/w3 [E,I,K]``, ``fc2 -> w2``), so a model trained or loaded on the HF surface decodes
+        through the fast path (tile kernels for the prefill, the native one-call-per-token engine for decode).  The twin owns a
+        converted COPY of the language model (expert matrices change layout); vision tower and projector tensors are shared."""
+        from . import gptfast as G
+        from .checkpoint import hf_to_gptfast
+
+        t, v = self.config.text_config, self.config.vision_config
+        args = G.ModelArgs(block_size=t.max_position_embeddings, vocab_size=t.vocab_size, n_layer=t.num_hidden_layers,
+                           n_head=t.num_attention_heads, dim=t.hidden_size, intermediate_size=t.moe_intermediate_size,
+                           n_local_heads=t.num_key_value_heads, rope_base=t.rope_theta, norm_eps=t.rms_norm_eps,
+                           num_experts=t.moe_num_experts, router_topk=t.moe_topk, num_shared_experts=t.moe_num_shared_experts,
+                           image_token_index=self.config.image_token_index)
+        dev = self.language_model.lm_head.weight.device
+        prev = torch.get_default_device() if hasattr(torch, "get_default_device") else None
+        torch.set_default_device(dev)
+        try:
+            twin = G.Aria(args, v, self.config.projector_patch_to_query_dict)
+        finally:
+            torch.set_default_device(prev if prev is not None else "cpu")
+        sd = {k: p.detach() for k, p in self.state_dict().items()}
+        conv = hf_to_gptfast(sd, t.num_attention_heads, t.head_dim, t.num_key_value_heads)
+        G.load_model_pth(twin, conv, strict=True)
+        twin.vision_tower, twin.multi_modal_projector = self.vision_tower, self.multi_modal_projector  # share, do not copy
+        return twin.eval()
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor] = None, pixel_mask: Optional[torch.Tensor] = None,
+                 max_new_tokens: int = 128, temperature: float = 0.8, top_k: Optional[int] = 200, stop_token: Optional[int] = None,
+                 refresh: bool = False) -> torch.Tensor:
+        """Sampling loop of gptfast/generate.py:112-177 on the gptfast twin (built on first use; ``refresh=True`` rebuilds it after
+        the weights changed).  input_ids [1, T] -> 1-D tensor prompt + new tokens."""
+        from . import gptfast as G
+
+        if refresh or getattr(self, "_gptfast_twin", None) is None:
+            object.__setattr__(self, "_gptfast_twin", self.to_gptfast())
+            object.__setattr__(self, "_gptfast_decoder", None)
+        out, dec = G.generate(self._gptfast_twin, input_ids, max_new_tokens, pixel_values=pixel_values, pixel_mask=pixel_mask,
+                              temperature=temperature, top_k=top_k, decoder=self._gptfast_decoder, stop_token=stop_token)
+        object.__setattr__(self, "_gptfast_decoder", dec)
+        return out
+
     def image_features(self, pixel_values: torch.Tensor, pixel_mask: Optional[torch.Tensor]) -> torch.Tensor:
         feat, atts = self.vision_tower(pixel_values, pixel_mask)
         return self.multi_modal_projector(feat, attn_mask=atts)

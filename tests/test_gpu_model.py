@@ -41,3 +41,7 @@ def test_lora_grouped_gemm():
 @pytest.mark.parametrize("head_dim", [64, 128])
 def test_decode_engine(head_dim):
     M.case_decode_engine(DEV, head_dim)
+
+
+def test_hf_to_gptfast_bridge(golden):
+    M.case_hf_to_gptfast_bridge(DEV, golden)
