@@ -10,6 +10,24 @@ def short(name):
     return name[:110]
 
 
+def by_grid(path, pattern, top=12):
+    """the launches of kernels whose name contains `pattern`, split by grid size (e.g. fc1 vs fc2 launches of the grouped GEMM)"""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else "kernel_name"
+    gcols = [c for c in ("grid_x", "grid_size_x", "grid_size") if c in cols]
+    if not gcols:
+        print("(no grid column in this rocpd schema: " + ", ".join(cols) + ")")
+        return
+    g = gcols[0]
+    rows = cur.execute(f"select {name_col}, {g}, count(*), avg(end-start), min(end-start), max(end-start) from kernels where {name_col} like ? "
+                       f"group by {name_col}, {g} order by 3 desc", (f"%{pattern}%",)).fetchall()
+    print(f"-- launches of *{pattern}* by {g}")
+    for n, gx, c, a, mn, mx in rows[:top]:
+        print(f"{short(n)[:70]:70s} {g}={gx:<10} calls={c:<6d} avg_us={a/1e3:10.2f} min_us={mn/1e3:9.2f} max_us={mx/1e3:9.2f}")
+
+
 def main(path, top=40):
     db = sqlite3.connect(path)
     cur = db.cursor()
@@ -26,3 +44,5 @@ def main(path, top=40):
 
 if __name__ == "__main__":
     main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+    for pat in sys.argv[3:]:
+        by_grid(sys.argv[1], pat)
