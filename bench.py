@@ -194,6 +194,25 @@ def main():
     timed_grouped_gemm.on = False
     ops.grouped_gemm = timed_grouped_gemm
 
+    dense_events = {}  # --time-grouped also classifies the dense GEMMs by operand form and size class (diagnostics)
+    orig_gemm = ops.gemm
+
+    def timed_gemm(a, b, **kw):
+        if not (args.time_grouped and timed_grouped_gemm.on):
+            return orig_gemm(a, b, **kw)
+        a_oc, b_oc = bool(kw.get("a_oc")), bool(kw.get("b_oc"))
+        M, K = (a.shape[1], a.shape[0]) if a_oc else (a.shape[0], a.shape[1])
+        N = b.shape[1] if b_oc else b.shape[0]
+        key = f"{'oc' if a_oc else 'rc'},{'oc' if b_oc else 'rc'} M{M} N{N} K{K}"
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = orig_gemm(a, b, **kw)
+        e.record()
+        dense_events.setdefault(key, []).append((s, e))
+        return r
+
+    ops.gemm = timed_gemm
+
     def step():
         model.zero_grad(set_to_none=True)
         out = model(input_ids=ids, pixel_values=pixel_values, pixel_mask=pixel_mask, labels=labels, return_logits=False,
@@ -237,6 +256,9 @@ def main():
             diag = {k: round(sum(s.elapsed_time(e) for s, e in v) / len(v), 4) for k, v in other_events.items()}
             diag["fwd_fc1"] = round(sum(durs) / max(1, len(durs)) * 1e3, 4)
             print("grouped-M avg launch ms: " + json.dumps(diag), file=_sys.stderr, flush=True)
+            dd = {k: [len(v) // args.steps, round(sum(s.elapsed_time(e) for s, e in v) / args.steps, 3)] for k, v in dense_events.items()}
+            dd = dict(sorted(dd.items(), key=lambda kv: -kv[1][1])[:14])
+            print("dense GEMM classes [launches/step, ms/step]: " + json.dumps(dd), file=_sys.stderr, flush=True)
         avg = sum(durs) / max(1, len(durs))
         achieved = flops_launch / avg / 1e12 if durs else None
         peak = 2500.0
