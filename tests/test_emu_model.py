@@ -49,3 +49,7 @@ def test_decode_engine(head_dim):
 
 def test_hf_to_gptfast_bridge(golden):
     M.case_hf_to_gptfast_bridge(DEV, golden)
+
+
+def test_decode_engine_reference_golden(golden):
+    M.case_decode_engine_reference_golden(DEV, golden)
