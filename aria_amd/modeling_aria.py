@@ -79,6 +79,53 @@ class AriaForConditionalGeneration(nn.Module):
     def set_moe_aux_loss_coeff(self, value: float):
         self.language_model.set_aux_loss_coeff(value)
 
+    # ---- HF checkpoint directory <-> module (config.json + sharded safetensors, the layout `from_pretrained("rhymes-ai/Aria")` reads)
+    @classmethod
+    def from_pretrained(cls, path: str, device="cpu", strict: bool = True) -> "AriaForConditionalGeneration":
+        """``config.json`` (``vision_config`` / ``text_config`` dicts, ``projector_patch_to_query_dict``, ``image_token_index``:
+        configuration_aria.py:31-111) + the weight shards of a local checkpoint directory.  Unknown config keys are kept in ``.extra``."""
+        import json
+        import os
+
+        from .checkpoint import load_checkpoint_dir, load_hf_into
+
+        with open(os.path.join(path, "config.json")) as f:
+            raw = json.load(f)
+        keys = ("vision_config", "text_config", "projector_patch_to_query_dict", "ignore_index", "image_token_index")
+        config = AriaConfig(**{k: raw[k] for k in keys if k in raw}, **{k: v for k, v in raw.items() if k not in keys})
+        prev = torch.get_default_device() if hasattr(torch, "get_default_device") else None
+        torch.set_default_device(device)
+        try:
+            model = cls(config)
+        finally:
+            torch.set_default_device(prev if prev is not None else "cpu")
+        load_hf_into(model, load_checkpoint_dir(path), strict=strict)
+        return model.eval()
+
+    def save_pretrained(self, path: str, max_shard_bytes: int = 5 << 30) -> None:
+        import json
+        import os
+
+        from .checkpoint import save_checkpoint_dir
+
+        os.makedirs(path, exist_ok=True)
+        t, v = self.config.text_config, self.config.vision_config
+        text = dict(model_type=t.model_type, moe_intermediate_size=t.moe_intermediate_size, moe_num_experts=t.moe_num_experts,
+                    moe_topk=t.moe_topk, moe_z_loss_coeff=t.moe_z_loss_coeff, moe_aux_loss_coeff=t.moe_aux_loss_coeff,
+                    moe_num_shared_experts=t.moe_num_shared_experts, hidden_size=t.hidden_size, num_hidden_layers=t.num_hidden_layers,
+                    num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads, vocab_size=t.vocab_size,
+                    rms_norm_eps=t.rms_norm_eps, rope_theta=t.rope_theta, max_position_embeddings=t.max_position_embeddings,
+                    pad_token_id=t.pad_token_id)
+        vision = dict(model_type=v.model_type, hidden_size=v.hidden_size, num_hidden_layers=v.num_hidden_layers,
+                      num_attention_heads=v.num_attention_heads, intermediate_size=v.intermediate_size, patch_size=v.patch_size,
+                      image_size=v.image_size, num_channels=v.num_channels, layer_norm_eps=v.layer_norm_eps)
+        cfg = dict(model_type=self.config.model_type, architectures=["AriaForConditionalGeneration"], text_config=text, vision_config=vision,
+                   projector_patch_to_query_dict={str(k): q for k, q in self.config.projector_patch_to_query_dict.items()},
+                   ignore_index=self.config.ignore_index, image_token_index=self.config.image_token_index, torch_dtype="bfloat16")
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=2)
+        save_checkpoint_dir(self.state_dict(), path, max_shard_bytes=max_shard_bytes)
+
     # ---- inference bridge: HF surface (training layout) -> gptfast surface (inference layout)
     def to_gptfast(self):
         """An ``aria_amd.gptfast.Aria`` twin of this model: the weights go through the reference's own conversion

@@ -72,3 +72,25 @@ def test_load_hf_into_module_checks_shapes_and_names():
         pass
     else:
         raise AssertionError("shape mismatch must raise")
+
+
+def test_save_and_from_pretrained_round_trip(tmp_path):
+    """config.json + sharded safetensors written by save_pretrained come back through from_pretrained bit for bit (no kernels involved)."""
+    from aria_amd.modeling_aria import AriaConfig, AriaForConditionalGeneration
+
+    cfg = AriaConfig(vision_config=dict(hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=48, image_size=28),
+                     text_config=dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=2, vocab_size=96, moe_intermediate_size=16,
+                                      moe_num_experts=4, moe_topk=2, max_position_embeddings=128),
+                     projector_patch_to_query_dict={4: 2}, image_token_index=7)
+    model = AriaForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_((torch.randn(p.shape) * 0.1).to(p.dtype))
+    d = str(tmp_path / "aria_ckpt")
+    model.save_pretrained(d, max_shard_bytes=32 << 10)
+    again = AriaForConditionalGeneration.from_pretrained(d)
+    a, b = model.state_dict(), again.state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    assert again.config.image_token_index == 7 and again.config.projector_patch_to_query_dict == {4: 2}
+    assert again.config.text_config.moe_num_experts == 4 and again.config.vision_config.image_size == 28
+    assert again.config.text_config.max_position_embeddings == 128
