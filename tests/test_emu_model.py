@@ -42,9 +42,9 @@ def test_lora_grouped_gemm():
     M.case_lora_grouped_gemm(DEV)
 
 
-@pytest.mark.parametrize("head_dim", [64, 128])
-def test_decode_engine(head_dim):
-    M.case_decode_engine(DEV, head_dim)
+@pytest.mark.parametrize("head_dim,max_seq", [(64, 24), (128, 24), (128, 16400)])
+def test_decode_engine(head_dim, max_seq):
+    M.case_decode_engine(DEV, head_dim, max_seq)
 
 
 def test_hf_to_gptfast_bridge(golden):
