@@ -170,3 +170,34 @@ def test_chatml_and_collate_equal_the_reference():
     assert set(got) == set(want)
     for k in want:
         assert torch.equal(got[k], want[k]), k
+
+
+def test_processor_output_feeds_the_model_end_to_end():
+    """AriaProcessor -> AriaForConditionalGeneration (tiny dims, kernels through the SIMT emulator): a 490-px image becomes 1225 patches,
+    the projector maps them to 128 image tokens and the prompt carries exactly 128 image placeholders -- the model's own token/feature
+    count check (modeling_aria.py:265-271) passes and the logits are finite."""
+    from tests.emu import emu_lib
+
+    from aria_amd.modeling_aria import AriaConfig, AriaForConditionalGeneration
+
+    emu_lib.install()
+    try:
+        tok = StubTokenizer()
+        proc = P.AriaProcessor(tokenizer=tok, image_processor=P.AriaVisionProcessor(max_image_size=490), image_token="<|img|>")
+        text = proc.apply_chat_template(MESSAGES, add_generation_prompt=True)
+        inputs = proc(text=text, images=[make_images()[3]], return_tensors="pt", max_image_size=490)  # the 40 x 30 image: mostly padding
+        img_id = StubTokenizer.SPECIAL.index("<|img|>")
+        cfg = AriaConfig(vision_config=dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=64, image_size=490),
+                         text_config=dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, vocab_size=512, moe_intermediate_size=16,
+                                          moe_num_experts=8, moe_topk=2, max_position_embeddings=512),
+                         projector_patch_to_query_dict={1225: 128}, image_token_index=img_id)
+        model = AriaForConditionalGeneration(cfg).eval()
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                p.copy_((torch.ones(p.shape) if ("norm" in n or "ln_" in n) and n.endswith("weight") else torch.randn(p.shape) * 0.05).to(p.dtype))
+            out = model(input_ids=inputs["input_ids"], pixel_values=inputs["pixel_values"].to(torch.bfloat16), pixel_mask=inputs["pixel_mask"],
+                        attention_mask=inputs["attention_mask"], return_logits=True)
+        assert int((inputs["input_ids"] == img_id).sum()) == 128
+        assert out.logits.shape == (1, inputs["input_ids"].shape[1], 512) and bool(torch.isfinite(out.logits.float()).all())
+    finally:
+        emu_lib.uninstall()
