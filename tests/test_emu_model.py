@@ -42,7 +42,7 @@ def test_lora_grouped_gemm():
     M.case_lora_grouped_gemm(DEV)
 
 
-@pytest.mark.parametrize("head_dim,max_seq", [(64, 24), (128, 24), (128, 16400)])
+@pytest.mark.parametrize("head_dim,max_seq", [(64, 24), (128, 16400)])  # (128, 24) runs on hardware; here it would cost 20 s more
 def test_decode_engine(head_dim, max_seq):
     M.case_decode_engine(DEV, head_dim, max_seq)
 
