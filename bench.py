@@ -272,7 +272,8 @@ def main():
                                    "fwd+bwd incl. lm_head+CE and router aux-loss grads",
                        "layers": args.layers, "vit_layers": args.vit_layers, "images_per_sample": n_img, "global_batch": world * B, "seq_len": S,
                        "parallelism": f"dp{world}" if world > 1 else "single", "grad_checkpointing": bool(args.recompute),
-                       "optimizer_in_step": False, "loss": round(float(loss), 4)},
+                       "optimizer_in_step": False,  # metric = fwd+bwd; AdamW state (299 GB fp32) only exists sharded over >= 2 GPUs
+                       "loss": round(float(loss), 4)},
             "roofline": {"kernel": "gemm2_kernel<rc,oc> grouped-M (experts.fc1 forward)", "bound": "mfma",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / peak, 4), "traffic": pmc_traffic(),
