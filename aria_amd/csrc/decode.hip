@@ -16,6 +16,7 @@
 #include "aria_device.h"
 #include "aria_hip.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 using namespace ad;
@@ -421,6 +422,166 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
     }
 }
 
+// Long contexts: one workgroup per head streams 2 * nkeys * HD * 2 bytes alone (8.4 MB at 16 K keys, 20 workgroups on 256 CUs).  The
+// split form cuts the keys of a head into NS contiguous ranges (grid = heads x NS, ranges derived from the DEVICE-side position, a
+// multiple of the per-iteration key count so every range but the last is full), each workgroup leaving its unnormalised online-softmax
+// state (m, l, o[HD], fp32) in part[head][split][2 + HD]; decode_attn_merge_kernel folds the NS states.  The workgroup whose range
+// holds the new position writes the rotated key / value into the cache first (nobody else reads that row).  Same per-key arithmetic as
+// decode_attn_kernel; only the order in which partial states are merged differs.
+constexpr int DECODE_MAX_SPLITS = 32;
+
+template <int HD>
+__global__ __launch_bounds__(256) void decode_attn_split_kernel(const bf16_t* qkv, const bf16_t* fc, const int32_t* pos, bf16_t* k_cache,
+                                                                bf16_t* v_cache, float* part, int D, float scale) {
+    constexpr int LPK = HD / 8, KPW = 64 / LPK, U = 4, PER_ITER = 4 * KPW * U;
+    ARIA_SMEM_STATIC float red[4][LPK][10];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, sub = l % LPK, grp = l / LPK, head = blockIdx.x, split = blockIdx.y;
+    const int NS = gridDim.y;
+    const int ps = pos[0], nkeys = ps + 1;
+    const int chunk = ((nkeys + NS - 1) / NS + PER_ITER - 1) / PER_ITER * PER_ITER;
+    const int kbeg = split * chunk, kend = min(nkeys, kbeg + chunk);
+    const long long col = (long long)head * HD + sub * 8;
+    const u32x4 f = ld16(fc + (long long)ps * HD + sub * 8);
+    auto rope = [&](const u32x4& a) {
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x0 = bflo(a[q]), x1 = bfhi(a[q]), cs = bflo(f[q]), sn = bfhi(f[q]);
+            o[q] = pack2bf(x0 * cs - x1 * sn, x1 * cs + x0 * sn);
+        }
+        return o;
+    };
+    const u32x4 qr = rope(ld16(qkv + col));
+    const bool owner = ps >= kbeg && ps < kend;  // block-uniform
+    if (owner && w == 0 && grp == 0) {
+        st16(k_cache + (long long)ps * D + col, rope(ld16(qkv + D + col)));
+        st16(v_cache + (long long)ps * D + col, ld16(qkv + 2 * D + col));
+    }
+    sync();
+    const float scale2 = scale * 1.4426950408889634f;
+    float m = -INFINITY, lsum = 0.f, o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    for (int j0 = kbeg; j0 < kend; j0 += PER_ITER) {  // block-uniform trip count (zero for an empty range)
+        u32x4 kx[U], vx[U];
+        int key[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            key[u] = j0 + (w * U + u) * KPW + grp;
+            const long long row = (long long)min(key[u], kend - 1) * D + col;
+            kx[u] = ld16(k_cache + row);
+            vx[u] = ld16(v_cache + row);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float sc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sc = dot2bf(kx[u][q], qr[q], sc);
+#pragma unroll
+            for (int d = 1; d < LPK; d <<= 1) sc += shfl_xor(sc, d);
+            const float s2 = key[u] < kend ? sc * scale2 : -INFINITY;
+            const float m_new = fmaxf(m, s2);
+            if (m_new == -INFINITY) continue;
+            const float alpha = exp2_fast(m - m_new), p = exp2_fast(s2 - m_new), pb = rbf(p);
+            lsum = lsum * alpha + p;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o[2 * q] = o[2 * q] * alpha + pb * bflo(vx[u][q]);
+                o[2 * q + 1] = o[2 * q + 1] * alpha + pb * bfhi(vx[u][q]);
+            }
+            m = m_new;
+        }
+    }
+    auto merge = [&](float m2, float l2, const float (&o2)[8]) {
+        const float mm = fmaxf(m, m2);
+        const float a = mm == -INFINITY ? 0.f : exp2_fast(m - mm), b = mm == -INFINITY ? 0.f : exp2_fast(m2 - mm);
+        lsum = lsum * a + l2 * b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * a + o2[e] * b;
+        m = mm;
+    };
+#pragma unroll
+    for (int d = LPK; d < 64; d <<= 1) {
+        float o2[8];
+        const float m2 = shfl_xor(m, d), l2 = shfl_xor(lsum, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o2[e] = shfl_xor(o[e], d);
+        merge(m2, l2, o2);
+    }
+    if (grp == 0) {
+        red[w][sub][0] = m;
+        red[w][sub][1] = lsum;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[w][sub][2 + e] = o[e];
+    }
+    sync();
+    if (w == 0 && grp == 0) {
+        for (int ww = 1; ww < 4; ++ww) {
+            float o2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o2[e] = red[ww][sub][2 + e];
+            merge(red[ww][sub][0], red[ww][sub][1], o2);
+        }
+        float* dst = part + ((long long)head * NS + split) * (HD + 2);
+        if (sub == 0) {
+            dst[0] = m;
+            dst[1] = lsum;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[2 + sub * 8 + e] = o[e];
+    }
+}
+
+// grid = heads, HD threads: thread f folds feature f of the NS partial states of its head (m, l are read by every thread: broadcast loads)
+__global__ void decode_attn_merge_kernel(const float* part, bf16_t* out, int NS, int HD) {
+    const int head = blockIdx.x, f = threadIdx.x;
+    const float* src = part + (long long)head * NS * (HD + 2);
+    float mm = -INFINITY;
+    for (int s = 0; s < NS; ++s) mm = fmaxf(mm, src[s * (HD + 2)]);
+    float lsum = 0.f, acc = 0.f;
+    for (int s = 0; s < NS; ++s) {
+        const float ms = src[s * (HD + 2)];
+        const float wgt = ms == -INFINITY ? 0.f : exp2_fast(ms - mm);
+        lsum += src[s * (HD + 2) + 1] * wgt;
+        acc += src[s * (HD + 2) + 2 + f] * wgt;
+    }
+    const float r = lsum > 0.f ? acc * (1.f / lsum) : 0.f;
+    out[(long long)head * HD + f] = f2bf(r);
+}
+
+// splits == 1: the one-workgroup-per-head kernel; otherwise the split form + merge (part: H * splits * (hd + 2) floats)
+int launch_decode_attn(void* stream, const bf16_t* qkv, const bf16_t* freqs, const int32_t* pos, bf16_t* kc, bf16_t* vc, bf16_t* out,
+                       float* part, int64_t H, int64_t hd, int64_t D, int splits) {
+    const float sc = 1.0f / sqrtf(float(hd));
+    if (splits <= 1) {
+        if (hd == 128)
+            ARIA_LAUNCH((decode_attn_kernel<128>), dim3(unsigned(H)), dim3(256), 0, stream, qkv, freqs, pos, kc, vc, out, int(D), sc);
+        else
+            ARIA_LAUNCH((decode_attn_kernel<64>), dim3(unsigned(H)), dim3(256), 0, stream, qkv, freqs, pos, kc, vc, out, int(D), sc);
+        return aria_check_launch();
+    }
+    if (hd == 128)
+        ARIA_LAUNCH((decode_attn_split_kernel<128>), dim3(unsigned(H), unsigned(splits)), dim3(256), 0, stream, qkv, freqs, pos, kc, vc, part,
+                    int(D), sc);
+    else
+        ARIA_LAUNCH((decode_attn_split_kernel<64>), dim3(unsigned(H), unsigned(splits)), dim3(256), 0, stream, qkv, freqs, pos, kc, vc, part,
+                    int(D), sc);
+    int rc = aria_check_launch();
+    if (rc != ARIA_OK) return rc;
+    ARIA_LAUNCH(decode_attn_merge_kernel, dim3(unsigned(H)), dim3(unsigned(hd)), 0, stream, (const float*)part, out, splits, int(hd));
+    return aria_check_launch();
+}
+
+// ARIA_DECODE_SPLIT_KV: unset / "0" = off (contexts > 16 K take the generic flash kernel); "1" = one split per 1024 cache slots
+// (2..32); N > 1 = exactly N splits.  Opt-in until it has been timed on hardware.
+int decode_splits_for(int64_t Smax) {
+    const char* e = std::getenv("ARIA_DECODE_SPLIT_KV");  // read per call (a few ns against ~7 launches): tests flip it in-process
+    const int mode = e ? atoi(e) : 0;
+    if (mode <= 0 || Smax <= 2048) return 1;
+    const int64_t n = mode == 1 ? (Smax + 1023) / 1024 : mode;
+    return int(n < 2 ? 2 : n > DECODE_MAX_SPLITS ? DECODE_MAX_SPLITS : n);
+}
+
 // NC = 16-byte chunks per lane = ceil(K / 512), a template parameter so that every load of a wave is issued up front
 #define ARIA_NC_SWITCH(nc, CALL)   \
     switch (nc) {                  \
@@ -455,10 +616,11 @@ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 struct Scratch {
     bf16_t *xa, *xb, *qkv, *ao, *rl, *scores, *act, *eo;
     int32_t *idx, *kv_len;
+    float* part;  // split-KV attention states: H * DECODE_MAX_SPLITS * (hd + 2) floats
     size_t bytes;
 };
 
-Scratch carve(char* base, int64_t D, int64_t E, int64_t k, int64_t I, int64_t Is) {
+Scratch carve(char* base, int64_t D, int64_t H, int64_t hd, int64_t E, int64_t k, int64_t I, int64_t Is) {
     Scratch s{};
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -476,6 +638,7 @@ Scratch carve(char* base, int64_t D, int64_t E, int64_t k, int64_t I, int64_t Is
     s.eo = reinterpret_cast<bf16_t*>(take((k + 1) * D * 2));     // routed outputs, then the shared expert's output
     s.idx = reinterpret_cast<int32_t*>(take(k * 4));
     s.kv_len = reinterpret_cast<int32_t*>(take(4));
+    s.part = reinterpret_cast<float*>(take(size_t(H) * DECODE_MAX_SPLITS * size_t(hd + 2) * 4));
     s.bytes = off;
     return s;
 }
@@ -486,7 +649,7 @@ extern "C" {
 
 int64_t aria_decode_scratch_bytes(const int64_t* dims) {
     if (!dims) return 0;
-    return int64_t(carve(nullptr, dims[1], dims[4], dims[5], dims[6], dims[7]).bytes);
+    return int64_t(carve(nullptr, dims[1], dims[2], dims[3], dims[4], dims[5], dims[6], dims[7]).bytes);
 }
 
 int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, void* stream) {
@@ -503,7 +666,7 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
     const bf16_t* freqs = static_cast<const bf16_t*>(ptrs[0]);
     const bf16_t* final_norm = static_cast<const bf16_t*>(ptrs[1]);
     const bf16_t* out_w = static_cast<const bf16_t*>(ptrs[2]);
-    const Scratch s = carve(static_cast<char*>(const_cast<void*>(ptrs[3])), D, E, k, I, Is);
+    const Scratch s = carve(static_cast<char*>(const_cast<void*>(ptrs[3])), D, H, hd, E, k, I, Is);
     const int32_t* pos = static_cast<const int32_t*>(ptrs[4]);
     const bf16_t* x = static_cast<const bf16_t*>(ptrs[5]);
     bf16_t* logits = static_cast<bf16_t*>(const_cast<void*>(ptrs[6]));
@@ -525,15 +688,9 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
         bf16_t* h = s.xa;  // hidden state after the attention block
         // attention block: h = x + wo( attn( rope(wqkv(norm(x))) ) )
         ARIA_TRY(launch_gemv(int(3 * D), stream, wqkv, (long long)D, x, attn_norm, eps, int(D), nullptr, s.qkv));
-        if (Smax <= 16384) {  // one workgroup per head walks the whole context (longer ones: the generic flash kernel below)
-            const float sc = 1.0f / sqrtf(float(hd));
-            if (hd == 128)
-                ARIA_LAUNCH((decode_attn_kernel<128>), dim3(unsigned(H)), dim3(256), 0, stream, (const bf16_t*)s.qkv, freqs, pos, kc, vc, s.ao,
-                            int(D), sc);
-            else
-                ARIA_LAUNCH((decode_attn_kernel<64>), dim3(unsigned(H)), dim3(256), 0, stream, (const bf16_t*)s.qkv, freqs, pos, kc, vc, s.ao,
-                            int(D), sc);
-            ARIA_TRY(aria_check_launch());
+        const int splits = decode_splits_for(Smax);
+        if (Smax <= 16384 || splits > 1) {  // one workgroup per head walks the whole context, or (opt-in) heads x splits workgroups
+            ARIA_TRY(launch_decode_attn(stream, (const bf16_t*)s.qkv, freqs, pos, kc, vc, s.ao, s.part, H, hd, D, splits));
         } else {
             ARIA_LAUNCH(rope_cache_kernel, dim3(unsigned((3 * D / 8 + 255) / 256)), dim3(256), 0, stream, s.qkv, freqs, pos, kc, vc, int(D),
                         int(hd), s.kv_len);
@@ -580,6 +737,22 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
     ARIA_TRY(launch_gemv(int(V), stream, out_w, (long long)D, x, final_norm, eps, int(D), nullptr, logits));
 #undef ARIA_TRY
     return ARIA_OK;
+}
+
+int64_t aria_decode_attn_workspace_bytes(int64_t H, int64_t hd, int64_t splits) {
+    if (H <= 0 || hd <= 0 || splits <= 1) return 0;
+    return H * splits * (hd + 2) * 4;
+}
+
+int aria_decode_attn(const void* qkv, const void* freqs_cis, const int32_t* pos, void* k_cache, void* v_cache, void* out, int64_t H, int64_t hd,
+                     int64_t splits, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!qkv || !freqs_cis || !pos || !k_cache || !v_cache || !out || H <= 0) return ARIA_ERR_INVALID;
+    if (hd != 64 && hd != 128) return ARIA_ERR_UNSUPPORTED;
+    if (splits < 1 || splits > DECODE_MAX_SPLITS) return ARIA_ERR_INVALID;
+    if (splits > 1 && (!workspace || workspace_bytes < aria_decode_attn_workspace_bytes(H, hd, splits))) return ARIA_ERR_INVALID;
+    return launch_decode_attn(stream, static_cast<const bf16_t*>(qkv), static_cast<const bf16_t*>(freqs_cis), pos,
+                              static_cast<bf16_t*>(k_cache), static_cast<bf16_t*>(v_cache), static_cast<bf16_t*>(out),
+                              static_cast<float*>(workspace), H, hd, H * hd, int(splits));
 }
 
 // The enqueue sequence of aria_decode_token reads the position (and through it the KV-cache slot and kv_len) from DEVICE memory, so it

@@ -23,7 +23,7 @@ ERRORS = {
 
 P, I64, I32, F32 = c_void_p, c_int64, c_int, c_float
 RESTYPES = {"aria_gemm_workspace_bytes": c_int64, "aria_decode_scratch_bytes": c_int64, "aria_decode_graph_create": c_void_p,
-            "aria_decode_graph_destroy": None}  # everything else returns an int status
+            "aria_decode_graph_destroy": None, "aria_decode_attn_workspace_bytes": c_int64}  # everything else returns an int status
 
 # name -> argtypes (all return int).  Kept in one table so tests can check that the shared
 # library exports every symbol the header declares.
@@ -32,6 +32,8 @@ SIGNATURES = {
     "aria_last_gemm_variant": [],
     "aria_decode_scratch_bytes": [P],
     "aria_decode_token": [P, P, F32, P],
+    "aria_decode_attn_workspace_bytes": [I64, I64, I64],
+    "aria_decode_attn": [P, P, P, P, P, P, I64, I64, I64, P, I64, P],
     "aria_decode_graph_create": [P, P, F32],
     "aria_decode_graph_launch": [P, P],
     "aria_decode_graph_destroy": [P],

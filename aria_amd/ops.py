@@ -446,6 +446,25 @@ def attention_bwd(q, k, v, o, do, lse, B: int, S: int, H: int, hd: int, scale: f
     return dq, dk, dv
 
 
+def decode_attention(qkv: torch.Tensor, freqs_cis: torch.Tensor, pos: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                     n_heads: int, hd: int, splits: int = 1) -> torch.Tensor:
+    """One new token against the static KV cache (aria_decode_attn): qkv bf16 [3*H*hd] (not modified), caches bf16 [S_max, H*hd]
+    (row pos[0] is written), pos int32 [1] on the device -> out bf16 [H*hd].  splits > 1: flash-decoding over contiguous key ranges."""
+    for t, n in ((qkv, "qkv"), (freqs_cis, "freqs_cis"), (k_cache, "k_cache"), (v_cache, "v_cache")):
+        _chk(t, name=n)
+        assert t.is_contiguous(), n
+    _chk(pos, torch.int32, "pos")
+    D = n_heads * hd
+    assert qkv.numel() == 3 * D and k_cache.shape[-1] == D and v_cache.shape == k_cache.shape and freqs_cis.shape[0] >= k_cache.shape[0]
+    out = torch.empty(D, dtype=bf16, device=qkv.device)
+    lib = hip.get_lib()
+    nbytes = int(lib.cdll.aria_decode_attn_workspace_bytes(n_heads, hd, splits))
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=qkv.device)
+    lib.call("aria_decode_attn", _p(qkv), _p(freqs_cis), _p(pos), _p(k_cache), _p(v_cache), _p(out), n_heads, hd, splits, _p(ws), nbytes,
+             _stream(qkv))
+    return out
+
+
 # ----------------------------------------------------------------------------- loss
 def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, grad_scale: Optional[float] = None,
                   dlogits: Optional[torch.Tensor] = None, count_in: Optional[torch.Tensor] = None):

@@ -243,6 +243,15 @@ int aria_probe_tr16(void* out /* u16[256] */, int mode, void* stream);
 #define ARIA_DECODE_LAYER_PTRS 13
 int64_t aria_decode_scratch_bytes(const int64_t* dims);
 int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, void* stream);
+/* The attention step of the engine on its own (gptfast/model.py:413-447 with one new token): rotates q (in registers) and k with
+ * freqs_cis[pos], writes k / v of the new token into the static cache at row pos (KVCache.update :67-93), then softmax(q K^T / sqrt(hd)) V
+ * over cache rows 0..pos.  qkv bf16 [3 * H * hd] (q | k | v of the new token), caches bf16 [S_max, H * hd], pos int32 [1] on the device,
+ * out bf16 [H * hd].  splits == 1: one workgroup per head; 2..32: heads x splits workgroups over contiguous key ranges + a merge
+ * launch (flash-decoding), workspace of aria_decode_attn_workspace_bytes.  aria_decode_token uses the split form for S_max > 2048 when
+ * ARIA_DECODE_SPLIT_KV is set (1 = one split per 1024 cache rows, N > 1 = N splits). */
+int64_t aria_decode_attn_workspace_bytes(int64_t H, int64_t hd, int64_t splits);
+int aria_decode_attn(const void* qkv, const void* freqs_cis, const int32_t* pos, void* k_cache, void* v_cache, void* out, int64_t H, int64_t hd,
+                     int64_t splits, void* workspace, int64_t workspace_bytes, void* stream);
 /* The same enqueue sequence captured once into a HIP graph (valid for every token because the position is device-side) and
  * replayed with one launch per token.  create returns NULL on failure (use aria_decode_token then); the tables must stay alive. */
 void* aria_decode_graph_create(const void* const* ptrs, const int64_t* dims, float eps);

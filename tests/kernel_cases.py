@@ -380,3 +380,42 @@ def case_attention_cross_masked(dev, B, Sq, Skv, H, hd):
     close(dq, qf.grad, 3e-2, 3e-2)
     close(dk, kf.grad, 3e-2, 3e-2)
     close(dv, vf.grad, 3e-2, 3e-2)
+
+
+# ------------------------------------------------------------------------------------------ single-query decode attention
+def case_decode_attention(dev, H, hd, pos, splits, S_max=None):
+    """aria_decode_attn (RoPE of q / k with freqs_cis[pos], cache write at row pos, softmax over rows 0..pos) against fp32 torch on the same
+    bf16 inputs with the kernel's rounding points (rotated q / k and P rounded to bf16); the split form against the single-workgroup form."""
+    from aria_amd import ops
+
+    S_max = S_max or pos + 3
+    D = H * hd
+    qkv = rnd(3 * D, seed=1)
+    kc, vc = rnd(S_max, D, seed=2), rnd(S_max, D, seed=3)
+    g = torch.Generator().manual_seed(4)
+    ang = torch.rand(S_max, hd // 2, generator=g) * 6.28
+    fc = torch.stack([ang.cos(), ang.sin()], dim=-1).to(bf16)  # [S_max, hd/2, 2] like precompute_freqs_cis (gptfast/model.py:500-516)
+
+    def rope(x):  # x [H*hd] interleaved pairs, fp32 math, one rounding (gptfast/model.py:519-531)
+        xp = x.float().view(H, hd // 2, 2)
+        c, s_ = fc[pos, :, 0].float()[None], fc[pos, :, 1].float()[None]
+        return torch.stack([xp[..., 0] * c - xp[..., 1] * s_, xp[..., 1] * c + xp[..., 0] * s_], dim=-1).reshape(D).to(bf16)
+
+    q_r, k_r = rope(qkv[:D]), rope(qkv[D:2 * D])
+    kc_want, vc_want = kc.clone(), vc.clone()
+    kc_want[pos], vc_want[pos] = k_r, qkv[2 * D:]
+    n = pos + 1
+    sc = torch.einsum("hd,nhd->hn", q_r.float().view(H, hd), kc_want[:n].float().view(n, H, hd)) * hd ** -0.5
+    p = torch.softmax(sc, dim=-1)
+    want = torch.einsum("hn,nhd->hd", p, vc_want[:n].float().view(n, H, hd)).reshape(D)
+
+    outs = {}
+    for ns in sorted({1, splits}):
+        q_dev, k_dev, v_dev = qkv.clone().to(dev), kc.clone().to(dev), vc.clone().to(dev)
+        out = ops.decode_attention(q_dev, fc.to(dev), torch.tensor([pos], dtype=torch.int32, device=dev), k_dev, v_dev, H, hd, splits=ns)
+        assert torch.equal(k_dev.cpu(), kc_want) and torch.equal(v_dev.cpu(), vc_want), "cache row / untouched rows"
+        assert torch.equal(q_dev.cpu(), qkv), "qkv is read-only"
+        close(out, want, 2e-2, 2e-2)
+        outs[ns] = out.float().cpu()
+    if splits > 1:  # same per-key arithmetic; only the merge order of partial states differs
+        close(outs[splits], outs[1], 1e-2, 4e-3)

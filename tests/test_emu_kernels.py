@@ -153,3 +153,9 @@ def test_grouped_gemm_v3(force_gemm_v3, counts):
 
 def test_grouped_gemm_v3_ragged_everything(force_gemm_v3):
     C.case_grouped_gemm(DEV, [3, 0, 130, 5, 0, 0, 300, 1])  # K = 72, N = 136: no dimension is a multiple of the tile
+
+
+@pytest.mark.parametrize("H,hd,pos,splits", [(2, 128, 0, 4), (2, 128, 63, 2), (3, 128, 64, 2), (2, 128, 777, 3), (2, 128, 2999, 16),
+                                             (2, 128, 1500, 32), (3, 64, 127, 2), (2, 64, 128, 2), (2, 64, 1000, 5)])
+def test_decode_attention_split_kv(H, hd, pos, splits):
+    C.case_decode_attention(DEV, H, hd, pos, splits)

@@ -47,6 +47,13 @@ def test_decode_engine(head_dim, max_seq):
     M.case_decode_engine(DEV, head_dim, max_seq)
 
 
+def test_decode_engine_split_kv(monkeypatch):
+    """opt-in flash-decoding form of the engine's attention (ARIA_DECODE_SPLIT_KV): 4 key ranges for S_max = 4000, all but the first empty
+    at these positions; tests/test_emu_kernels.py::test_decode_attention_split_kv covers populated ranges."""
+    monkeypatch.setenv("ARIA_DECODE_SPLIT_KV", "1")
+    M.case_decode_engine(DEV, 64, 4000)
+
+
 def test_hf_to_gptfast_bridge(golden):
     M.case_hf_to_gptfast_bridge(DEV, golden)
 

@@ -1,0 +1,92 @@
+"""Hardware checks for code that so far only ran under the emulator (written when the round's GPU budget was spent).  Run this FIRST in the
+next GPU session; flip defaults only for what passes and wins:
+
+    gpurun --timeout 900 -- 'python tools/next_round_gpu_checks.py > gpurun_out/next_round_checks.json'
+
+1. parity: tests/kernel_cases.case_decode_attention (aria_decode_attn, split-KV flash-decoding form) on the device;
+2. timing: aria_decode_attn alone, one workgroup per head vs heads x splits, at cache fills 1 K .. 64 K (Aria head shape 20 x 128);
+3. timing: full decode step (random-init Aria-25.3B LLM) at long contexts with ARIA_DECODE_SPLIT_KV unset / 1.
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+from aria_amd import gptfast as G  # noqa: E402
+from aria_amd import ops  # noqa: E402
+from tests import kernel_cases as C  # noqa: E402
+
+bf16 = torch.bfloat16
+dev = torch.device("cuda")
+res = {"parity": {}, "attn_us": {}, "decode_ms": {}}
+
+for H, hd, pos, splits in [(2, 128, 0, 4), (2, 128, 63, 2), (3, 128, 64, 2), (20, 128, 2999, 16), (20, 128, 20000, 32), (3, 64, 127, 2),
+                           (2, 64, 1000, 5)]:
+    key = f"H{H}_hd{hd}_pos{pos}_s{splits}"
+    try:
+        C.case_decode_attention(dev, H, hd, pos, splits)
+        res["parity"][key] = "ok"
+    except Exception as ex:  # keep going: the report is the point
+        res["parity"][key] = f"FAILED {type(ex).__name__}: {ex}"
+
+H, hd = 20, 128
+D = H * hd
+for fill in (1024, 4096, 16384, 65536):
+    S_max = fill + 8
+    g = torch.Generator(device="cuda").manual_seed(0)
+    kc = torch.randn((S_max, D), generator=g, device=dev).to(bf16)
+    vc = torch.randn((S_max, D), generator=g, device=dev).to(bf16)
+    qkv = torch.randn((3 * D,), generator=g, device=dev).to(bf16)
+    fc = torch.rand((S_max, hd // 2, 2), generator=g, device=dev).to(bf16)
+    pos = torch.tensor([fill - 1], dtype=torch.int32, device=dev)
+    for splits in (1, 4, 8, 16, 32):
+        for _ in range(3):
+            ops.decode_attention(qkv, fc, pos, kc, vc, H, hd, splits=splits)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(20):
+            ops.decode_attention(qkv, fc, pos, kc, vc, H, hd, splits=splits)
+        e.record()
+        torch.cuda.synchronize()
+        res["attn_us"][f"fill{fill}_splits{splits}"] = round(s.elapsed_time(e) / 20 * 1e3, 1)
+    del kc, vc
+
+torch.set_default_device(dev)
+m = G.Transformer(G.ModelArgs())
+torch.set_default_device("cpu")
+g = torch.Generator(device="cuda").manual_seed(0)
+with torch.no_grad():
+    for n, p in m.named_parameters():
+        if "norm" in n:
+            p.fill_(1.0)
+        else:
+            flat = p.view(-1)
+            for o in range(0, flat.numel(), 1 << 28):
+                flat[o:o + (1 << 28)].normal_(0.0, 0.02, generator=g)
+m.eval()
+tok = torch.tensor([[17]], device=dev)
+for S_max in (4096, 16384, 32768):
+    m.setup_caches(1, S_max)
+    for layer in m.layers:  # a filled cache (values irrelevant for timing, finite for the softmax)
+        layer.attention.kv_cache.k.normal_(0, 1, generator=g)
+        layer.attention.kv_cache.v.normal_(0, 1, generator=g)
+    for mode in ("", "1"):
+        if mode:
+            os.environ["ARIA_DECODE_SPLIT_KV"] = mode
+        else:
+            os.environ.pop("ARIA_DECODE_SPLIT_KV", None)
+        m._engine = None
+        with torch.no_grad():
+            pos = torch.tensor([S_max - 64], device=dev, dtype=torch.int32)
+            for _ in range(3):
+                m(tok, pos)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(30):
+                m(tok, pos + i)
+            torch.cuda.synchronize()
+        res["decode_ms"][f"Smax{S_max}_split{mode or 0}"] = round((time.perf_counter() - t0) / 30 * 1e3, 3)
+print(json.dumps(res))
