@@ -349,7 +349,7 @@ class DecodeGraph:
     """The decode model step captured once in a HIP graph (the reference uses torch.compile(mode="reduce-overhead"),
     gptfast/generate.py:232-238): static token / cursor / logits buffers, one replay per token.  Sampling (a handful of tiny
     torch kernels using the RNG) runs eagerly after the replay: capturing torch's RNG kernels in the same graph as the HIP
-    launches faulted on the second replay on ROCm 7.2 / torch 2.10 (bisected in tools/debug_graph4.py)."""
+    launches faulted on the second replay on ROCm 7.2 / torch 2.10 (bisected in tools/bisect/debug_graph4.py)."""
 
     def __init__(self, model: Aria, temperature: float, top_k: Optional[int], use_graph: bool = True):
         self.model, self.temperature, self.top_k = model, temperature, top_k
@@ -414,7 +414,7 @@ def generate(model: Aria, input_ids: torch.Tensor, max_new_tokens: int, *, pixel
     _dbg("sample")
     if decoder is None:
         # KNOWN ISSUE (round 1): a HIP-graph-captured decode step replays correctly inside one generate() call but faults
-        # when replayed after a second image prefill (ROCm 7.2 / torch 2.10; bisection scripts tools/debug_graph*.py).
+        # when replayed after a second image prefill (ROCm 7.2 / torch 2.10; bisection scripts tools/bisect/debug_graph*.py).
         # Decode therefore runs eagerly unless use_graph is requested explicitly.
         decoder = DecodeGraph(model, temperature, top_k, use_graph=use_graph)
         _dbg("capture")
