@@ -60,13 +60,13 @@ def init_params(model, seed):
                     flat[o:o + chunk].normal_(0.0, 0.02, generator=g)
 
 
-def pmc_traffic():
-    """HBM bytes per fc1 launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
-    tools/gemm_pmc_target.py = the same kernel and shape; gfx950 FETCH_SIZE x2 correction applied) -- counters cannot be read
-    inside the timed run.  None if the summary is missing."""
+def pmc_traffic(variant=2):
+    """HBM bytes per fc1 launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    tools/gemm_pmc_target.py = the same shape; gfx950 FETCH_SIZE x2 correction applied), for the kernel family the run dispatched
+    to -- counters cannot be read inside the timed run.  None if there is no pass for that kernel."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_fc1.json")) as f:
-            return round(json.load(f)["hbm_bytes_per_launch"])
+            return round(json.load(f)["kernels"][f"gemm{variant}_kernel<rc,oc>"]["hbm_bytes_per_launch"])
     except Exception:
         return None
 
@@ -132,7 +132,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from aria_amd import ops
+    from aria_amd import hip, ops
     from aria_amd.modeling_aria import AriaConfig, AriaForConditionalGeneration
     from aria_amd.moe_lm import AriaMoELMConfig
     from aria_amd.parallel import GradSync
@@ -188,10 +188,12 @@ def main():
             r = orig_gg(a, w, offsets, w_is_kn=w_is_kn, out=out)
             e.record()
             fc1_events.append((s, e))
+            timed_grouped_gemm.variant = hip.get_lib().cdll.aria_last_gemm_variant()  # which kernel family the library dispatched to
             return r
         return orig_gg(a, w, offsets, w_is_kn=w_is_kn, out=out)
 
     timed_grouped_gemm.on = False
+    timed_grouped_gemm.variant = 0
     ops.grouped_gemm = timed_grouped_gemm
 
     dense_events = {}  # --time-grouped also classifies the dense GEMMs by operand form and size class (diagnostics)
@@ -274,9 +276,11 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single", "grad_checkpointing": bool(args.recompute),
                        "optimizer_in_step": False,  # metric = fwd+bwd; AdamW state (299 GB fp32) only exists sharded over >= 2 GPUs
                        "loss": round(float(loss), 4)},
-            "roofline": {"kernel": "gemm2_kernel<rc,oc> grouped-M (experts.fc1 forward)", "bound": "mfma",
+            "roofline": {"kernel": {1: "gemm_kernel", 2: "gemm2_kernel", 3: "gemm3_kernel"}.get(timed_grouped_gemm.variant, "gemm?_kernel")
+                                   + "<rc,oc> grouped-M (experts.fc1 forward)", "bound": "mfma",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                         "frac": None if achieved is None else round(achieved / peak, 4), "traffic": pmc_traffic(),
+                         "frac": None if achieved is None else round(achieved / peak, 4),
+                         "traffic": pmc_traffic(timed_grouped_gemm.variant),
                          "launches_timed": len(durs), "avg_launch_ms": round(avg * 1e3, 4),
                          "algorithmic_flops_per_launch": flops_launch},
         }
