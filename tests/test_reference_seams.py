@@ -160,3 +160,26 @@ def test_b2_attention_class_with_the_4_46_signature():
     with pytest.raises(NotImplementedError):
         left = add_mask.flip(-1)
         mine(hidden_states=x0, attention_mask=left, position_embeddings=(cos, sin))
+
+
+def test_b2_hf_generate_with_a_kv_cache_through_the_seam():
+    """The reference's HF ``generate()`` (README.md:45-88 quick-start path, ``aria/inference.py:102-130``) with ``attn_implementation="aria_hip"``:
+    prefill (causal, Sq == Skv) and single-query steps against the growing DynamicCache (Sq == 1 < Skv) both go through
+    aria_amd.seams.attention_interface; greedy scores match eager attention step by step for as long as both picked the same tokens."""
+    from aria_amd import seams
+
+    ns = load_reference()
+    name = seams.register_attention("aria_hip")
+    eager, ours = _lm(ns, "eager").eval(), _lm(ns, name).eval()
+    ours.load_state_dict(eager.state_dict())
+    ids = torch.randint(1, 128, (1, 12), generator=torch.Generator().manual_seed(3))
+    kw = dict(max_new_tokens=6, do_sample=False, output_scores=True, return_dict_in_generate=True)
+    with torch.no_grad():
+        a, b = eager.generate(ids, **kw), ours.generate(ids, **kw)
+    assert len(a.scores) == len(b.scores) == 6
+    for step, (x, y) in enumerate(zip(a.scores, b.scores)):
+        rel_close(y, x, 3e-2, f"greedy scores at step {step}")
+        if int(a.sequences[0, 12 + step]) != int(b.sequences[0, 12 + step]):
+            top2 = torch.topk(x.float().flatten(), 2).values
+            assert float(top2[0] - top2[1]) <= 3e-2 * float(x.float().abs().max()), "a clear winner must be the same token"
+            break
