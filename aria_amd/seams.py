@@ -62,8 +62,8 @@ def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, Sq: int, Skv
 def attention_interface(module, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attention_mask: Optional[torch.Tensor],
                         dropout: float = 0.0, scaling: Optional[float] = None, **kwargs):
     """``ALL_ATTENTION_FUNCTIONS`` entry (transformers >= 4.48; same contract as ``sdpa_attention_forward``): query [B,H,Sq,hd],
-    key/value [B,Hkv,Skv,hd] -> (attn_output [B,Sq,H,hd], None).  ``attention_mask`` is what an unregistered mask interface hands
-    through: ``None`` or the 2-D padding mask [B,Skv] (1 = attend).  Causal when the module says so and Sq == Skv (prefill / training);
+    key/value [B,Hkv,Skv,hd] -> (attn_output [B,Sq,H,hd], None).  ``attention_mask`` is what the mask interface registered next to it
+    (``flash_attention_mask``) produces: ``None`` or the 2-D padding mask [B,Skv] (1 = attend).  Causal when the module says so and Sq == Skv (prefill / training);
     a single new query against a cache (Sq == 1) needs no causal mask."""
     if dropout:
         raise NotImplementedError("aria_hip attention: attention dropout is not implemented (Aria trains with attention_dropout = 0)")
@@ -152,6 +152,11 @@ def register_attention(name: str = "aria_hip") -> str:
         ml.LLAMA_ATTENTION_CLASSES[name] = hf_attention_class()
         return name
     AttentionInterface.register(name, attention_interface)
+    # the mask the function is handed: without an entry here transformers DROPS the padding mask for unknown implementation names
+    # (masking_utils._preprocess_mask_arguments), which only right-padded causal batches survive; the FA2 form is the 2-D mask or None
+    from transformers.masking_utils import AttentionMaskInterface, flash_attention_mask
+
+    AttentionMaskInterface.register(name, flash_attention_mask)
     classes = getattr(ml, "LLAMA_ATTENTION_CLASSES", None)
     if isinstance(classes, dict):  # a compatibility dict someone re-created for moe_lm.py:31: the stock class dispatches on the name
         classes[name] = ml.LlamaAttention

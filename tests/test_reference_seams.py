@@ -183,3 +183,71 @@ def test_b2_hf_generate_with_a_kv_cache_through_the_seam():
             top2 = torch.topk(x.float().flatten(), 2).values
             assert float(top2[0] - top2[1]) <= 3e-2 * float(x.float().abs().max()), "a clear winner must be the same token"
             break
+
+
+def test_full_reference_model_with_both_seams():
+    """The reference's AriaForConditionalGeneration (Idefics2 ViT with a padded pixel_mask -> projector -> MoE LM, loss + backward) with
+    ``attn_implementation="aria_hip"`` on BOTH towers (non-causal ViT attention with the patch padding mask, causal LM attention) and the
+    experts_gemm seam installed, against the unmodified model on the same bf16 weights and inputs.  Both runs are bf16 end to end, so
+    near-tied router logits may route a token differently (model_cases.py header): logits are compared per position (95 % within 3e-2 of
+    the scale, all within 2e-1), gradients by direction (cosine)."""
+    from aria_amd import seams
+    from oracle.make_golden import IMG_TOKEN, P2Q, VISION
+    from oracle.make_golden import TEXT as GTEXT
+
+    ns = load_reference()
+    name = seams.register_attention("aria_hip")
+
+    def build(attn):
+        acfg = ns.cfg.AriaConfig(vision_config={**VISION, "model_type": "aria_vision_model"}, text_config={**GTEXT, "model_type": "aria_moe_lm"},
+                                 projector_patch_to_query_dict=P2Q, image_token_index=IMG_TOKEN, attn_implementation=attn, pad_token_id=0)
+        m = ns.mdl.AriaForConditionalGeneration(acfg).to(bf16)
+        _init(m, std=0.05)
+        return m.train()
+
+    eager, ours = build("eager"), build(name)
+    ours.load_state_dict(eager.state_dict())
+    assert ours.config.text_config._attn_implementation == name and ours.config.vision_config._attn_implementation == name
+    g = torch.Generator().manual_seed(0)
+    pv = torch.randn(2, 3, 56, 56, generator=g).clamp(-1, 1).to(bf16)
+    pm = torch.ones(2, 56, 56, dtype=torch.bool)
+    pm[1, 42:, :] = False  # 3 x 2 valid patches of 4 x 4: the ViT's key mask is not a prefix
+    pm[1, :, 28:] = False
+    S = 20
+    ids = torch.randint(10, 128, (2, S), generator=g)
+    ids[0, 2:6] = IMG_TOKEN
+    ids[1, 5:9] = IMG_TOKEN
+    am = torch.ones(2, S, dtype=torch.long)
+    am[1, 17:] = 0
+    labels = ids.clone()
+    labels[:, :8] = -100
+
+    def run(m):
+        m.zero_grad()
+        o = m(input_ids=ids, pixel_values=pv, pixel_mask=pm, attention_mask=am, labels=labels)
+        o.loss.backward()
+        return o
+
+    want = run(eager)
+    original = ns.moe.experts_gemm
+    try:
+        seams.install_experts_gemm(ns.moe)
+        got = run(ours)
+    finally:
+        ns.moe.experts_gemm = original
+    with torch.no_grad():
+        va, _ = eager.vision_tower(pv, pixel_mask=pm)
+        vb, _ = ours.vision_tower(pv, pixel_mask=pm)
+    rel_close(vb.last_hidden_state, va.last_hidden_state, 3e-2, "ViT output (padded patches masked)")
+    keep = am.bool()
+    err = (got.logits.float() - want.logits.float()).abs().amax(-1)[keep]
+    scale = want.logits.float().abs().max()
+    assert (err <= 3e-2 * scale).float().mean() >= 0.9 and err.max() <= 2e-1 * scale, (err.topk(4).values, scale)
+    assert abs(float(got.loss.detach()) - float(want.loss.detach())) <= 2e-2 * abs(float(want.loss.detach()))
+    pe, po = dict(eager.named_parameters()), dict(ours.named_parameters())
+    for n in ("language_model.model.layers.0.self_attn.q_proj.weight", "language_model.model.embed_tokens.weight",
+              "language_model.lm_head.weight", "multi_modal_projector.query", "language_model.model.layers.1.mlp.experts.fc2.weight",
+              "vision_tower.vision_model.encoder.layers.0.self_attn.q_proj.weight"):
+        a, b = pe[n].grad.float().flatten(), po[n].grad.float().flatten()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp(min=1e-30))
+        assert cos >= 0.97, (n, cos)
