@@ -51,11 +51,16 @@ class _SdpaFn(torch.autograd.Function):
 
 def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, Sq: int, Skv: int, H: int, hd: int, scale: float, causal: bool,
          key_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Differentiable flash attention on token-major bf16 operands; head dims other than 64/128 are zero-padded on the host."""
-    hdp = _pad_hd(hd)
+    """Differentiable flash attention on token-major bf16 operands.  Head dims the kernels do not implement natively are zero-padded on
+    the host: the backward has 64 / 128, the forward also 72 (the frozen ViT under no_grad runs unpadded)."""
+    need_bwd = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
+    hdp = _pad_hd(hd, need_bwd)
     if hdp != hd:
         q, k, v = (_pad_heads(t, H, hd, hdp) for t in (q, k, v))
-    o = _SdpaFn.apply(_c(q), _c(k), _c(v), key_mask, B, Sq, Skv, H, hdp, float(scale), bool(causal))
+    if need_bwd:
+        o = _SdpaFn.apply(_c(q), _c(k), _c(v), key_mask, B, Sq, Skv, H, hdp, float(scale), bool(causal))
+    else:
+        o = ops.attention_fwd(_c(q), _c(k), _c(v), B, Sq, H, hdp, float(scale), bool(causal), key_mask=key_mask, Skv=Skv)[0]
     return _unpad_heads(o, H, hd, hdp) if hdp != hd else o
 
 

@@ -60,3 +60,25 @@ def test_hf_to_gptfast_bridge(golden):
 
 def test_decode_engine_reference_golden(golden):
     M.case_decode_engine_reference_golden(DEV, golden)
+
+
+def test_seam_attention_interface_native_hd72_without_grad():
+    """aria_amd.seams.attention_interface as the (frozen) ViT calls it: non-causal, head_dim 72, a key mask that is not a prefix, no grad ->
+    the native hd-72 forward kernel (no padding to 128); against fp32 torch on the same bf16 operands."""
+    import types
+
+    from aria_amd import seams
+
+    B, H, S, hd = 2, 2, 70, 72
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(B, H, S, hd, generator=g).to(torch.bfloat16) for _ in range(3))
+    mask = torch.ones(B, S, dtype=torch.bool)
+    mask[1, 5:9] = False
+    mask[1, 60:] = False
+    with torch.no_grad():
+        out, w = seams.attention_interface(types.SimpleNamespace(is_causal=False), q, k, v, mask, scaling=hd ** -0.5)
+    assert w is None and out.shape == (B, S, H, hd)
+    sc = torch.einsum("bhqd,bhkd->bhqk", q.float(), k.float()) * hd ** -0.5
+    sc = sc.masked_fill(~mask[:, None, None, :], float("-inf"))
+    want = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc, -1), v.float())
+    M.rel_close(out, want, 2e-2, "hd 72 attention through the seam")
