@@ -1,5 +1,6 @@
 """Module-level parity through the SIMT emulator (CPU): aria_amd modules vs the oracle on the golden fixtures."""
 import pytest
+import torch
 
 from tests import model_cases as M
 
