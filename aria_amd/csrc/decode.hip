@@ -319,21 +319,20 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(bf16_t* qkv, const bf16
 }
 
 // Attention of ONE new token over the static cache, fused with RoPE and the cache write (gptfast/model.py:413-447, KVCache.update
-// :67-93): grid = heads, 4 waves.  HD/8 lanes share a key (8 features each, one 16-byte load per lane and key), so a wave works on
+// :67-93): 4 waves per workgroup.  HD/8 lanes share a key (8 features each, one 16-byte load per lane and key), so a wave works on
 // 64/(HD/8) keys at a time, 4 deep (all K and V loads of an iteration are issued before the first use); every lane group keeps an online
 // softmax state (m, l, o[8]) which is merged across groups and waves at the end (flash-decoding).  Softmax in the log2 domain, P rounded
 // to bf16 before it multiplies V (what the flash kernel feeds its MFMA), fp32 accumulation.  The generic flash kernel spends ~19 us per
-// layer on this (20 workgroups built for 256 queries); this one ~5.
+// layer on this (20 workgroups built for 256 queries); decode_attn_kernel ~5.
+//
+// DecodeAttn<HD>::run is the body shared by the two kernels below: keys [kbeg, kend) of one head, `writes_new` (block-uniform) = this
+// workgroup owns the new position and puts the rotated key / value into the cache before reading it back.  On return the lanes with
+// w == 0 && grp == 0 hold the UNNORMALISED state (m, lsum, o[8] for features sub*8 ..) of the whole range.
 template <int HD>
-__global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, const bf16_t* fc, const int32_t* pos, bf16_t* k_cache,
-                                                          bf16_t* v_cache, bf16_t* out, int D, float scale) {
-    constexpr int LPK = HD / 8, KPW = 64 / LPK, U = 4;
-    ARIA_SMEM_STATIC float red[4][LPK][10];
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, sub = l % LPK, grp = l / LPK, head = blockIdx.x;
-    const int ps = pos[0], nkeys = ps + 1;
-    const long long col = (long long)head * HD + sub * 8;
-    const u32x4 f = ld16(fc + (long long)ps * HD + sub * 8);
-    auto rope = [&](const u32x4& a) {
+struct DecodeAttn {
+    static constexpr int LPK = HD / 8, KPW = 64 / LPK, U = 4, PER_ITER = 4 * KPW * U;
+
+    static __device__ __forceinline__ u32x4 rope(const u32x4& a, const u32x4& f) {
         u32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -341,84 +340,106 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, con
             o[q] = pack2bf(x0 * cs - x1 * sn, x1 * cs + x0 * sn);
         }
         return o;
-    };
-    const u32x4 qr = rope(ld16(qkv + col));
-    if (w == 0 && grp == 0) {  // this head's slice of the new key / value goes into the cache first; it is read back below
-        st16(k_cache + (long long)ps * D + col, rope(ld16(qkv + D + col)));
-        st16(v_cache + (long long)ps * D + col, ld16(qkv + 2 * D + col));
     }
-    sync();
-    const float scale2 = scale * 1.4426950408889634f;
-    float m = -INFINITY, lsum = 0.f, o[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    const int per_iter = 4 * KPW * U;
-    for (int j0 = 0; j0 < nkeys; j0 += per_iter) {  // block-uniform trip count
-        u32x4 kx[U], vx[U];
-        int key[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            key[u] = j0 + (w * U + u) * KPW + grp;
-            const long long row = (long long)min(key[u], nkeys - 1) * D + col;
-            kx[u] = ld16(k_cache + row);
-            vx[u] = ld16(v_cache + row);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float sc = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sc = dot2bf(kx[u][q], qr[q], sc);
-#pragma unroll
-            for (int d = 1; d < LPK; d <<= 1) sc += shfl_xor(sc, d);
-            const float s2 = key[u] < nkeys ? sc * scale2 : -INFINITY;
-            const float m_new = fmaxf(m, s2);
-            if (m_new == -INFINITY) continue;  // nothing seen yet by this lane group (uniform within the group)
-            const float alpha = exp2_fast(m - m_new), p = exp2_fast(s2 - m_new), pb = rbf(p);
-            lsum = lsum * alpha + p;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                o[2 * q] = o[2 * q] * alpha + pb * bflo(vx[u][q]);
-                o[2 * q + 1] = o[2 * q + 1] * alpha + pb * bfhi(vx[u][q]);
-            }
-            m = m_new;
-        }
-    }
-    // merge the lane groups of a wave (lanes with equal `sub`), then the four waves through LDS
-    auto merge = [&](float m2, float l2, const float (&o2)[8]) {
+
+    static __device__ __forceinline__ void merge(float& m, float& lsum, float (&o)[8], float m2, float l2, const float (&o2)[8]) {
         const float mm = fmaxf(m, m2);
         const float a = mm == -INFINITY ? 0.f : exp2_fast(m - mm), b = mm == -INFINITY ? 0.f : exp2_fast(m2 - mm);
         lsum = lsum * a + l2 * b;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = o[e] * a + o2[e] * b;
         m = mm;
-    };
-#pragma unroll
-    for (int d = LPK; d < 64; d <<= 1) {
-        float o2[8];
-        const float m2 = shfl_xor(m, d), l2 = shfl_xor(lsum, d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o2[e] = shfl_xor(o[e], d);
-        merge(m2, l2, o2);
     }
-    if (grp == 0) {
-        red[w][sub][0] = m;
-        red[w][sub][1] = lsum;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[w][sub][2 + e] = o[e];
-    }
-    sync();
-    if (w == 0 && grp == 0) {
-        for (int ww = 1; ww < 4; ++ww) {
-            float o2[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o2[e] = red[ww][sub][2 + e];
-            merge(red[ww][sub][0], red[ww][sub][1], o2);
+
+    static __device__ __forceinline__ void run(const bf16_t* qkv, const bf16_t* fc, int ps, bf16_t* k_cache, bf16_t* v_cache, int D,
+                                               float scale, int head, int kbeg, int kend, bool writes_new, float (&red)[4][LPK][10],
+                                               float& m, float& lsum, float (&o)[8]) {
+        const int l = threadIdx.x & 63, w = threadIdx.x >> 6, sub = l % LPK, grp = l / LPK;
+        const long long col = (long long)head * HD + sub * 8;
+        const u32x4 f = ld16(fc + (long long)ps * HD + sub * 8);
+        const u32x4 qr = rope(ld16(qkv + col), f);
+        if (writes_new && w == 0 && grp == 0) {  // this head's slice of the new key / value goes into the cache first; it is read back below
+            st16(k_cache + (long long)ps * D + col, rope(ld16(qkv + D + col), f));
+            st16(v_cache + (long long)ps * D + col, ld16(qkv + 2 * D + col));
         }
+        sync();
+        const float scale2 = scale * 1.4426950408889634f;
+        m = -INFINITY, lsum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+        for (int j0 = kbeg; j0 < kend; j0 += PER_ITER) {  // block-uniform trip count (zero for an empty range)
+            u32x4 kx[U], vx[U];
+            int key[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                key[u] = j0 + (w * U + u) * KPW + grp;
+                const long long row = (long long)min(key[u], kend - 1) * D + col;
+                kx[u] = ld16(k_cache + row);
+                vx[u] = ld16(v_cache + row);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float sc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sc = dot2bf(kx[u][q], qr[q], sc);
+#pragma unroll
+                for (int d = 1; d < LPK; d <<= 1) sc += shfl_xor(sc, d);
+                const float s2 = key[u] < kend ? sc * scale2 : -INFINITY;
+                const float m_new = fmaxf(m, s2);
+                if (m_new == -INFINITY) continue;  // nothing seen yet by this lane group (uniform within the group)
+                const float alpha = exp2_fast(m - m_new), p = exp2_fast(s2 - m_new), pb = rbf(p);
+                lsum = lsum * alpha + p;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o[2 * q] = o[2 * q] * alpha + pb * bflo(vx[u][q]);
+                    o[2 * q + 1] = o[2 * q + 1] * alpha + pb * bfhi(vx[u][q]);
+                }
+                m = m_new;
+            }
+        }
+        // merge the lane groups of a wave (lanes with equal `sub`), then the four waves through LDS
+#pragma unroll
+        for (int d = LPK; d < 64; d <<= 1) {
+            float o2[8];
+            const float m2 = shfl_xor(m, d), l2 = shfl_xor(lsum, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o2[e] = shfl_xor(o[e], d);
+            merge(m, lsum, o, m2, l2, o2);
+        }
+        if (grp == 0) {
+            red[w][sub][0] = m;
+            red[w][sub][1] = lsum;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[w][sub][2 + e] = o[e];
+        }
+        sync();
+        if (w == 0 && grp == 0) {
+            for (int ww = 1; ww < 4; ++ww) {
+                float o2[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o2[e] = red[ww][sub][2 + e];
+                merge(m, lsum, o, red[ww][sub][0], red[ww][sub][1], o2);
+            }
+        }
+    }
+};
+
+// grid = heads: one workgroup walks the whole context of its head and normalises
+template <int HD>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, const bf16_t* fc, const int32_t* pos, bf16_t* k_cache,
+                                                          bf16_t* v_cache, bf16_t* out, int D, float scale) {
+    using A = DecodeAttn<HD>;
+    ARIA_SMEM_STATIC float red[4][A::LPK][10];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, sub = l % A::LPK, grp = l / A::LPK, head = blockIdx.x;
+    const int ps = pos[0];
+    float m, lsum, o[8];
+    A::run(qkv, fc, ps, k_cache, v_cache, D, scale, head, 0, ps + 1, true, red, m, lsum, o);
+    if (w == 0 && grp == 0) {
         const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
         u32x4 r;
 #pragma unroll
         for (int q = 0; q < 4; ++q) r[q] = pack2bf(o[2 * q] * inv, o[2 * q + 1] * inv);
-        st16(out + col, r);
+        st16(out + (long long)head * HD + sub * 8, r);
     }
 }
 
@@ -433,95 +454,16 @@ constexpr int DECODE_MAX_SPLITS = 32;
 template <int HD>
 __global__ __launch_bounds__(256) void decode_attn_split_kernel(const bf16_t* qkv, const bf16_t* fc, const int32_t* pos, bf16_t* k_cache,
                                                                 bf16_t* v_cache, float* part, int D, float scale) {
-    constexpr int LPK = HD / 8, KPW = 64 / LPK, U = 4, PER_ITER = 4 * KPW * U;
-    ARIA_SMEM_STATIC float red[4][LPK][10];
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, sub = l % LPK, grp = l / LPK, head = blockIdx.x, split = blockIdx.y;
+    using A = DecodeAttn<HD>;
+    ARIA_SMEM_STATIC float red[4][A::LPK][10];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, sub = l % A::LPK, grp = l / A::LPK, head = blockIdx.x, split = blockIdx.y;
     const int NS = gridDim.y;
     const int ps = pos[0], nkeys = ps + 1;
-    const int chunk = ((nkeys + NS - 1) / NS + PER_ITER - 1) / PER_ITER * PER_ITER;
+    const int chunk = ((nkeys + NS - 1) / NS + A::PER_ITER - 1) / A::PER_ITER * A::PER_ITER;
     const int kbeg = split * chunk, kend = min(nkeys, kbeg + chunk);
-    const long long col = (long long)head * HD + sub * 8;
-    const u32x4 f = ld16(fc + (long long)ps * HD + sub * 8);
-    auto rope = [&](const u32x4& a) {
-        u32x4 o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float x0 = bflo(a[q]), x1 = bfhi(a[q]), cs = bflo(f[q]), sn = bfhi(f[q]);
-            o[q] = pack2bf(x0 * cs - x1 * sn, x1 * cs + x0 * sn);
-        }
-        return o;
-    };
-    const u32x4 qr = rope(ld16(qkv + col));
-    const bool owner = ps >= kbeg && ps < kend;  // block-uniform
-    if (owner && w == 0 && grp == 0) {
-        st16(k_cache + (long long)ps * D + col, rope(ld16(qkv + D + col)));
-        st16(v_cache + (long long)ps * D + col, ld16(qkv + 2 * D + col));
-    }
-    sync();
-    const float scale2 = scale * 1.4426950408889634f;
-    float m = -INFINITY, lsum = 0.f, o[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    for (int j0 = kbeg; j0 < kend; j0 += PER_ITER) {  // block-uniform trip count (zero for an empty range)
-        u32x4 kx[U], vx[U];
-        int key[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            key[u] = j0 + (w * U + u) * KPW + grp;
-            const long long row = (long long)min(key[u], kend - 1) * D + col;
-            kx[u] = ld16(k_cache + row);
-            vx[u] = ld16(v_cache + row);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float sc = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sc = dot2bf(kx[u][q], qr[q], sc);
-#pragma unroll
-            for (int d = 1; d < LPK; d <<= 1) sc += shfl_xor(sc, d);
-            const float s2 = key[u] < kend ? sc * scale2 : -INFINITY;
-            const float m_new = fmaxf(m, s2);
-            if (m_new == -INFINITY) continue;
-            const float alpha = exp2_fast(m - m_new), p = exp2_fast(s2 - m_new), pb = rbf(p);
-            lsum = lsum * alpha + p;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                o[2 * q] = o[2 * q] * alpha + pb * bflo(vx[u][q]);
-                o[2 * q + 1] = o[2 * q + 1] * alpha + pb * bfhi(vx[u][q]);
-            }
-            m = m_new;
-        }
-    }
-    auto merge = [&](float m2, float l2, const float (&o2)[8]) {
-        const float mm = fmaxf(m, m2);
-        const float a = mm == -INFINITY ? 0.f : exp2_fast(m - mm), b = mm == -INFINITY ? 0.f : exp2_fast(m2 - mm);
-        lsum = lsum * a + l2 * b;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = o[e] * a + o2[e] * b;
-        m = mm;
-    };
-#pragma unroll
-    for (int d = LPK; d < 64; d <<= 1) {
-        float o2[8];
-        const float m2 = shfl_xor(m, d), l2 = shfl_xor(lsum, d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o2[e] = shfl_xor(o[e], d);
-        merge(m2, l2, o2);
-    }
-    if (grp == 0) {
-        red[w][sub][0] = m;
-        red[w][sub][1] = lsum;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[w][sub][2 + e] = o[e];
-    }
-    sync();
+    float m, lsum, o[8];
+    A::run(qkv, fc, ps, k_cache, v_cache, D, scale, head, kbeg, kend, ps >= kbeg && ps < kend, red, m, lsum, o);
     if (w == 0 && grp == 0) {
-        for (int ww = 1; ww < 4; ++ww) {
-            float o2[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o2[e] = red[ww][sub][2 + e];
-            merge(red[ww][sub][0], red[ww][sub][1], o2);
-        }
         float* dst = part + ((long long)head * NS + split) * (HD + 2);
         if (sub == 0) {
             dst[0] = m;
