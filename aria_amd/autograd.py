@@ -203,3 +203,72 @@ class EmbeddingFn(torch.autograd.Function):
         dw = torch.zeros(ctx.shape, dtype=bf16, device=dy.device)
         ops.embedding_bwd(_c(dy), ids32, dw)
         return None, dw
+
+
+class RopeFn(torch.autograd.Function):
+    """Half-split RoPE (modeling_llama.py:130-160) on the first n_heads*hd columns of token-major x [B*S, >= n_heads*hd] as its own
+    node (the fused attention block applies it in place); the backward of a rotation is the inverse rotation."""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin, S, n_heads, hd):
+        ctx.save_for_backward(cos, sin)
+        ctx.dims = (S, n_heads, hd)
+        return ops.rope_(x.clone(), cos, sin, S, n_heads, hd)
+
+    @staticmethod
+    def backward(ctx, dy):
+        cos, sin = ctx.saved_tensors
+        S, n_heads, hd = ctx.dims
+        return ops.rope_(dy.contiguous().clone(), cos, sin, S, n_heads, hd, inverse=True), None, None, None, None, None
+
+
+class SdpaFn(torch.autograd.Function):
+    """softmax(q k^T * scale + mask) v over token-major [B*S, H*hd] operands (aria_attn_fwd / aria_attn_bwd): causal and / or
+    kv_len int32 [B] (right padding) and / or key_mask uint8 [B, Skv]; head dims 64 / 128."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_mask, kv_len, B, Sq, Skv, H, hd, scale, causal):
+        o, lse = ops.attention_fwd(q, k, v, B, Sq, H, hd, scale, causal, kv_len=kv_len, key_mask=key_mask, Skv=Skv)
+        ctx.save_for_backward(q, k, v, o, lse, key_mask, kv_len)
+        ctx.dims = (B, Sq, Skv, H, hd, scale, causal)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse, key_mask, kv_len = ctx.saved_tensors
+        B, Sq, Skv, H, hd, scale, causal = ctx.dims
+        dq, dk, dv = ops.attention_bwd(q, k, v, o, _c(do), lse, B, Sq, H, hd, scale, causal, kv_len=kv_len, key_mask=key_mask, Skv=Skv)
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None
+
+
+def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, Sq: int, Skv: int, H: int, hd: int, scale: float, causal: bool,
+         key_mask: Optional[torch.Tensor] = None, kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable flash attention on token-major bf16 operands.  Head dims the kernels do not implement natively are zero-padded on
+    the host: the backward has 64 / 128, the forward also 72 (the frozen ViT under no_grad runs unpadded)."""
+    need_bwd = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
+    hdp = Fn._pad_hd(hd, need_bwd)
+    if hdp != hd:
+        q, k, v = (Fn._pad_heads(t, H, hd, hdp) for t in (q, k, v))
+    if need_bwd:
+        o = SdpaFn.apply(_c(q), _c(k), _c(v), key_mask, kv_len, B, Sq, Skv, H, hdp, float(scale), bool(causal))
+    else:
+        o = ops.attention_fwd(_c(q), _c(k), _c(v), B, Sq, H, hdp, float(scale), bool(causal), kv_len=kv_len, key_mask=key_mask, Skv=Skv)[0]
+    return Fn._unpad_heads(o, H, hd, hdp) if hdp != hd else o
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """Masked-mean CE over logits [T, V] (labels already shifted, -100 = ignore; modeling_aria.py:301-323) for heads whose logits come
+    out of a module (an adapted lm_head): the CE kernel leaves d(loss)/d(logits) in a copy during the forward."""
+
+    @staticmethod
+    def forward(ctx, logits, labels_shifted):
+        count_in = (labels_shifted >= 0).sum(dtype=torch.int32).reshape(1)
+        dlogits = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        loss_sum, _, _ = ops.cross_entropy(logits, labels_shifted, grad_scale=1.0, dlogits=dlogits, count_in=count_in)
+        ctx.dlogits = dlogits
+        return (loss_sum / count_in.clamp(min=1).to(torch.float32)).reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        d, ctx.dlogits = ctx.dlogits, None
+        return (d.mul_(dloss) if d is not None else None), None

@@ -1,5 +1,6 @@
-"""LoRA on the grouped expert GEMM: the reference's cheapest fine-tune recipe
-(recipes/config_lora.yaml:44-59) adapts ``experts.fc1`` / ``experts.fc2`` with per-expert rank-r factors through the same
+"""LoRA for the reference's cheapest fine-tune recipe (recipes/config_lora.yaml:44-59).
+
+Grouped expert GEMMs: ``experts.fc1`` / ``experts.fc2`` get per-expert rank-r factors through the same
 ``experts_gemm`` seam (aria/lora/layers.py:30-224):
 
     y = base(x, tpe) + lora_B(lora_A(dropout(x), tpe), tpe) * (lora_alpha / r)        (layers.py:129-139)
@@ -9,6 +10,14 @@ plain calls of the MI355X grouped GEMM (N = r for A, K = r for B; r must be a mu
 not in this image, so the layer is a stand-alone module with peft's surface for this class: ``merge`` / ``unmerge`` /
 ``get_delta_weight`` / ``scaling`` / ``disable_adapters``; ``apply_lora_to_experts`` is the part of ``get_peft_model`` the recipe uses
 (wrap the target modules, freeze everything else).
+
+The recipe's other targets (q/k/v/o_proj, gate/up/down_proj of the shared experts, lm_head) are plain ``nn.Linear``-shaped modules; in the
+reference they get peft's stock Linear adapter (peft/tuners/lora/layer.py, ``Linear.forward``):
+
+    y = base(x) + lora_B(lora_A(dropout(x))) * (lora_alpha / r)          lora_A: Linear(in, r), lora_B: Linear(r, out), no bias
+
+``LinearLoraLayer`` is that adapter on this package's ``Linear`` (three MFMA GEMMs, N = r for A, K = r for B); the decoder blocks notice a
+wrapped projection and run module by module instead of through their fused autograd nodes (``moe_lm._plain_linears``).
 """
 from __future__ import annotations
 
@@ -18,7 +27,7 @@ from typing import Dict, Iterable
 import torch
 from torch import nn
 
-from .moe_lm import GroupedGEMM
+from .moe_lm import GroupedGEMM, Linear
 
 
 class GroupedGemmLoraLayer(nn.Module):
@@ -83,6 +92,68 @@ class GroupedGemmLoraLayer(nn.Module):
             self.merged = False
 
 
+class LinearLoraLayer(nn.Module):
+    """peft's LoRA ``Linear`` on ``aria_amd.moe_lm.Linear`` (weight [out, in]): ``lora_A.weight`` [r, in] ~ kaiming_uniform(a = sqrt(5)),
+    ``lora_B.weight`` [out, r] = 0, delta weight = B @ A * scaling."""
+
+    def __init__(self, base_layer: Linear, r: int = 8, lora_alpha: int = 16, lora_dropout: float = 0.0, init_lora_weights: bool = True):
+        super().__init__()
+        if r <= 0:
+            raise ValueError(f"`r` should be a positive integer value but the value passed is {r}")
+        if r % 8:
+            raise ValueError("r must be a multiple of 8 (16-byte bf16 granules of the GEMM operands)")
+        self.base_layer = base_layer
+        self.in_features, self.out_features = base_layer.in_features, base_layer.out_features
+        self.r, self.lora_alpha, self.scaling = r, lora_alpha, lora_alpha / r
+        self.lora_dropout = nn.Dropout(p=lora_dropout) if lora_dropout > 0.0 else nn.Identity()
+        self.lora_A = Linear(self.in_features, r).to(base_layer.weight.device)
+        self.lora_B = Linear(r, self.out_features).to(base_layer.weight.device)
+        self.merged = False
+        self.disable_adapters = False
+        if init_lora_weights:
+            self.reset_lora_parameters()
+        for p in base_layer.parameters():
+            p.requires_grad_(False)
+
+    @property
+    def weight(self):
+        return self.base_layer.weight
+
+    @property
+    def bias(self):
+        return self.base_layer.bias
+
+    def reset_lora_parameters(self):
+        with torch.no_grad():
+            a = torch.empty(self.lora_A.weight.shape, dtype=torch.float32)
+            nn.init.kaiming_uniform_(a, a=math.sqrt(5))
+            self.lora_A.weight.copy_(a.to(self.lora_A.weight.dtype))
+            self.lora_B.weight.zero_()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.disable_adapters:
+            if self.merged:
+                self.unmerge()
+            return self.base_layer(x)
+        result = self.base_layer(x)
+        if self.merged:
+            return result
+        return result + self.lora_B(self.lora_A(self.lora_dropout(x))) * self.scaling
+
+    def get_delta_weight(self) -> torch.Tensor:
+        return torch.matmul(self.lora_B.weight, self.lora_A.weight) * self.scaling
+
+    def merge(self) -> None:
+        if not self.merged:
+            self.base_layer.weight.data += self.get_delta_weight()
+            self.merged = True
+
+    def unmerge(self) -> None:
+        if self.merged:
+            self.base_layer.weight.data -= self.get_delta_weight()
+            self.merged = False
+
+
 def apply_lora_to_experts(model: nn.Module, r: int = 8, lora_alpha: int = 16, lora_dropout: float = 0.0,
                           target_suffixes: Iterable[str] = ("experts.fc1", "experts.fc2")) -> nn.Module:
     """Freeze every parameter, wrap each ``GroupedGEMM`` whose qualified name ends with one of ``target_suffixes`` (the recipe's
@@ -120,17 +191,21 @@ def get_lora_target_modules(model_named_modules, cfg) -> list:
 
 
 def apply_lora_from_config(model: nn.Module, cfg) -> list:
-    """``use_peft: true`` of recipes/config_lora.yaml for the part this package covers: the grouped expert GEMMs among the selected
-    target modules get a ``GroupedGemmLoraLayer``; plain ``nn.Linear``-shaped targets (q/k/v/o_proj, shared experts, lm_head) are
-    reported back as skipped (their LoRA is peft's stock Linear adapter, outside the grouped-GEMM seam)."""
+    """``use_peft: true`` of recipes/config_lora.yaml (aria/train.py:100-112): among the selected target modules the grouped expert GEMMs
+    get a ``GroupedGemmLoraLayer`` and the ``Linear`` projections of the language model (q/k/v/o_proj, shared experts, lm_head) a
+    ``LinearLoraLayer``; everything else is frozen.  Returned: the selected names that were NOT adapted (``nn.Linear`` modules of the
+    projector / vision tower when the recipe does not freeze them: their blocks have no module-by-module path here)."""
     names = [n for n, _ in model.named_modules()]
     targets = get_lora_target_modules(names, cfg)
+    r, alpha, drop = int(cfg.get("lora_r", 8)), int(cfg.get("lora_alpha", 32)), float(cfg.get("lora_dropout", 0.0))
     grouped = [n for n in targets if isinstance(model.get_submodule(n), GroupedGEMM)]
+    linear = [n for n in targets if type(model.get_submodule(n)) is Linear and ("language_model." in n or n.startswith(("model.", "lm_head")))]
     for p in model.parameters():
         p.requires_grad_(False)
-    for name in grouped:
-        parent = model.get_submodule(name.rsplit(".", 1)[0])
-        setattr(parent, name.rsplit(".", 1)[-1],
-                GroupedGemmLoraLayer(model.get_submodule(name), int(cfg.get("lora_r", 8)), int(cfg.get("lora_alpha", 32)),
-                                     float(cfg.get("lora_dropout", 0.0))))
-    return [n for n in targets if n not in grouped and not any(n.startswith(g + ".") for g in grouped)]
+    for name in grouped + linear:
+        parent = model.get_submodule(name.rsplit(".", 1)[0]) if "." in name else model
+        base = model.get_submodule(name)
+        layer = GroupedGemmLoraLayer(base, r, alpha, drop) if name in grouped else LinearLoraLayer(base, r, alpha, drop)
+        setattr(parent, name.rsplit(".", 1)[-1], layer)
+    adapted = grouped + linear
+    return [n for n in targets if n not in adapted and not any(n.startswith(g + ".") for g in adapted)]

@@ -86,6 +86,12 @@ class Linear(nn.Module):
         return AG.linear(x, self.weight, self.bias)
 
 
+def _plain_linears(*mods) -> bool:
+    """True when every module is the stock ``Linear`` (the fused blocks read ``.weight`` directly); False as soon as an adapter
+    (aria_amd/lora.py) wraps one of them -- the block then runs module by module so the adapter's forward is what executes."""
+    return all(type(m) is Linear for m in mods)
+
+
 class RMSNorm(nn.Module):
     """LlamaRMSNorm (transformers/models/llama/modeling_llama.py:62-67)."""
 
@@ -213,11 +219,16 @@ class MoELayer(nn.Module):
         x = hidden_states.reshape(-1, shp[-1])
         x = x if x.is_contiguous() else x.contiguous()
         se = self.shared_experts
-        if type(self.experts.fc1) is not GroupedGEMM or type(self.experts.fc2) is not GroupedGEMM:
-            return self.forward_modular(x).view(shp)  # an adapter (LoRA) sits on the expert GEMMs: go through the modules
+        if self.has_adapter():
+            return self.forward_modular(x).view(shp)  # an adapter (LoRA) sits on an expert GEMM or a shared-expert projection
         out = AG.MoELayerFn.apply(x, self.router.weight, self.experts.fc1.weight, self.experts.fc2.weight,
                                   se.gate_proj.weight, se.up_proj.weight, se.down_proj.weight, self.moe_config())
         return out.view(shp)
+
+    def has_adapter(self) -> bool:
+        e, se = self.experts, self.shared_experts
+        return (type(e.fc1) is not GroupedGEMM or type(e.fc2) is not GroupedGEMM
+                or not _plain_linears(se.gate_proj, se.up_proj, se.down_proj))
 
     def forward_modular(self, x: torch.Tensor) -> torch.Tensor:
         """The same layer (moe_lm.py:548-577) built from its differentiable pieces, calling ``self.experts`` / ``self.shared_experts``
@@ -252,10 +263,27 @@ class AriaAttention(nn.Module):
     def forward(self, hidden_states: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
                 kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, S, D = hidden_states.shape
+        if not _plain_linears(self.q_proj, self.k_proj, self.v_proj, self.o_proj):
+            return self.forward_modular(hidden_states, cos, sin, kv_len)
         x = hidden_states.reshape(B * S, D)
         out = AG.AttnBlockFn.apply(x if x.is_contiguous() else x.contiguous(), self.q_proj.weight, self.k_proj.weight,
                                    self.v_proj.weight, self.o_proj.weight, cos, sin, B, S, self.attn_config(), kv_len)
         return out.view(B, S, D)
+
+    def forward_modular(self, hidden_states: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                        kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """LlamaAttention.forward (modeling_llama.py:243-281) from its differentiable pieces, calling the four projections as MODULES --
+        what an adapter on q/k/v/o_proj (recipes/config_lora.yaml:47-59) needs; same kernels as the fused node."""
+        c = self.config
+        H, Hkv, hd = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        if Hkv != H:
+            raise NotImplementedError("GQA (num_key_value_heads != num_attention_heads): Aria is MHA (gptfast/model.py:56-58)")
+        B, S, D = hidden_states.shape
+        x = hidden_states.reshape(B * S, D)
+        q = AG.RopeFn.apply(self.q_proj(x), cos, sin, S, H, hd)
+        k = AG.RopeFn.apply(self.k_proj(x), cos, sin, S, H, hd)
+        o = AG.sdpa(q, k, self.v_proj(x), B, S, S, H, hd, hd ** -0.5, True, kv_len=kv_len)
+        return self.o_proj(o).view(B, S, D)
 
 
 class MoEDecoderLayer(nn.Module):
@@ -279,9 +307,9 @@ class MoEDecoderLayer(nn.Module):
     def forward(self, hidden_states: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
                 kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, S, D = hidden_states.shape
-        m = self.mlp.experts
-        if type(m.fc1) is not GroupedGEMM or type(m.fc2) is not GroupedGEMM:
-            # an adapter (aria_amd/lora.py) wraps an expert GEMM: LlamaDecoderLayer.forward module by module (modeling_llama.py:295-325)
+        a = self.self_attn
+        if self.mlp.has_adapter() or not _plain_linears(a.q_proj, a.k_proj, a.v_proj, a.o_proj):
+            # an adapter (aria_amd/lora.py) wraps a GEMM of this layer: LlamaDecoderLayer.forward module by module (modeling_llama.py:295-325)
             h = hidden_states + self.self_attn(self.input_layernorm(hidden_states), cos, sin, kv_len)
             return h + self.mlp(self.post_attention_layernorm(h))
         x = hidden_states.reshape(B * S, D)
@@ -370,7 +398,10 @@ class AriaMoELMForCausalLM(nn.Module):
         loss = logits = None
         if labels is not None:
             ls = labels.reshape(-1).to(torch.int32) if labels_are_shifted else Fn.shift_labels(labels, attention_mask)
-            loss = AG.LMHeadLossFn.apply(hn.reshape(B * S, D), self.lm_head.weight, ls.contiguous())
+            if _plain_linears(self.lm_head):
+                loss = AG.LMHeadLossFn.apply(hn.reshape(B * S, D), self.lm_head.weight, ls.contiguous())
+            else:  # an adapted lm_head: its own forward produces the logits, then the CE kernel
+                loss = AG.CrossEntropyFn.apply(self.lm_head(hn.reshape(B * S, D)), ls.contiguous())
         if return_logits or (labels is None and return_logits is None):
             hl = hn[:, -num_logits_to_keep:, :] if num_logits_to_keep else hn
             logits = self.lm_head(hl)

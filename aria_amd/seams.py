@@ -19,8 +19,7 @@ from typing import Optional
 import torch
 
 from . import ops
-from .autograd import _c, experts_gemm
-from .functional import _pad_hd, _pad_heads, _unpad_heads
+from .autograd import _c, experts_gemm, sdpa
 
 bf16 = torch.bfloat16
 
@@ -29,39 +28,6 @@ def install_experts_gemm(moe_lm_module) -> None:
     """``moe_lm.experts_gemm = <HIP grouped GEMM>`` (same call contract: input [M,K] grouped by expert, weight [E,K,N], tokens_per_expert [E]
     on any device; differentiable in input and weight)."""
     moe_lm_module.experts_gemm = experts_gemm
-
-
-class _SdpaFn(torch.autograd.Function):
-    """softmax(q k^T * scale + mask) v over token-major [B*S, H*hd] operands (aria_attn_fwd / aria_attn_bwd)."""
-
-    @staticmethod
-    def forward(ctx, q, k, v, key_mask, B, Sq, Skv, H, hd, scale, causal):
-        o, lse = ops.attention_fwd(q, k, v, B, Sq, H, hd, scale, causal, key_mask=key_mask, Skv=Skv)
-        ctx.save_for_backward(q, k, v, o, lse, key_mask)
-        ctx.dims = (B, Sq, Skv, H, hd, scale, causal)
-        return o
-
-    @staticmethod
-    def backward(ctx, do):
-        q, k, v, o, lse, key_mask = ctx.saved_tensors
-        B, Sq, Skv, H, hd, scale, causal = ctx.dims
-        dq, dk, dv = ops.attention_bwd(q, k, v, o, _c(do), lse, B, Sq, H, hd, scale, causal, key_mask=key_mask, Skv=Skv)
-        return dq, dk, dv, None, None, None, None, None, None, None, None
-
-
-def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, Sq: int, Skv: int, H: int, hd: int, scale: float, causal: bool,
-         key_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Differentiable flash attention on token-major bf16 operands.  Head dims the kernels do not implement natively are zero-padded on
-    the host: the backward has 64 / 128, the forward also 72 (the frozen ViT under no_grad runs unpadded)."""
-    need_bwd = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
-    hdp = _pad_hd(hd, need_bwd)
-    if hdp != hd:
-        q, k, v = (_pad_heads(t, H, hd, hdp) for t in (q, k, v))
-    if need_bwd:
-        o = _SdpaFn.apply(_c(q), _c(k), _c(v), key_mask, B, Sq, Skv, H, hdp, float(scale), bool(causal))
-    else:
-        o = ops.attention_fwd(_c(q), _c(k), _c(v), B, Sq, H, hdp, float(scale), bool(causal), key_mask=key_mask, Skv=Skv)[0]
-    return _unpad_heads(o, H, hd, hdp) if hdp != hd else o
 
 
 def attention_interface(module, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attention_mask: Optional[torch.Tensor],

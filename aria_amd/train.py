@@ -101,13 +101,35 @@ def build_model(cfg, device):
     for i in (cfg.get("freeze_llm_layers") or []):
         for p in model.language_model.model.layers[int(i)].parameters():
             p.requires_grad = False
-    if cfg.get("use_peft"):  # recipes/config_lora.yaml: adapters on the grouped expert GEMMs (aria_amd/lora.py)
+    if cfg.get("use_peft"):  # recipes/config_lora.yaml: adapters on the expert GEMMs and the LM's Linear projections (aria_amd/lora.py)
         from .lora import apply_lora_from_config
 
         skipped = apply_lora_from_config(model, cfg)
         if skipped and int(os.environ.get("RANK", "0")) == 0:
-            print(f"[aria_amd.train] LoRA: {len(skipped)} Linear-shaped target modules left without adapter (grouped expert GEMMs only)")
+            print(f"[aria_amd.train] LoRA: {len(skipped)} target modules outside the language model left without adapter: {skipped[:4]}")
     return model.train(), acfg
+
+
+def save_output(model, cfg) -> str:
+    """``trainer.save_model(output_dir)`` (aria/train.py:247-249): full fine-tunes write the HF checkpoint directory (config.json + sharded
+    safetensors, reference key names); ``use_peft`` runs write only the adapter, like peft's ``save_pretrained``: ``adapter_model.safetensors``
+    (``...lora_A.weight`` / ``...lora_B.weight`` keyed by this package's module names) + ``adapter_config.json`` (r, alpha, dropout, targets)."""
+    out = str(cfg["output_dir"])
+    os.makedirs(out, exist_ok=True)
+    if cfg.get("use_peft"):
+        from safetensors.torch import save_file
+
+        from .lora import lora_state_dict
+
+        save_file({k: v.detach().cpu().contiguous() for k, v in lora_state_dict(model).items()}, os.path.join(out, "adapter_model.safetensors"),
+                  metadata={"format": "pt"})
+        with open(os.path.join(out, "adapter_config.json"), "w") as f:
+            json.dump({"peft_type": "LORA", "r": int(cfg.get("lora_r", 8)), "lora_alpha": int(cfg.get("lora_alpha", 32)),
+                       "lora_dropout": float(cfg.get("lora_dropout", 0.0)), "target_modules": list(cfg.get("lora_target_modules") or []),
+                       "base_model_name_or_path": cfg.get("model_name_or_path")}, f, indent=2)
+    else:
+        model.save_pretrained(out)
+    return out
 
 
 def synthetic_batch(cfg, acfg, device, gen):
@@ -174,9 +196,12 @@ def main(argv=None):
             toks = world * accum * cfg["per_device_train_batch_size"] * cfg["max_seq_length"]
             print(json.dumps({"step": step, "loss": round(loss_acc, 4), "lr": opt.lr, "step_s": round(dt, 3), "tokens_per_s": round(toks / dt, 1)}),
                   flush=True)
+    if rank == 0 and cfg.get("save_final", not cfg["tiny"]):  # every rank holds the full updated bf16 weights (ShardedAdamW all-gathers)
+        save_output(model, cfg)
     if world > 1:
         import torch.distributed as dist
 
+        dist.barrier()
         dist.destroy_process_group()
     return history
 

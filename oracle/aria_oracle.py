@@ -199,6 +199,19 @@ def lora_delta_weight(lora_a: Tensor, lora_b: Tensor, scaling: float) -> Tensor:
     return torch.matmul(lora_a, lora_b) * scaling
 
 
+def lora_linear(x: Tensor, base_w: Tensor, lora_a: Tensor, lora_b: Tensor, scaling: float) -> Tensor:
+    """peft's stock LoRA ``Linear.forward`` (peft 0.x ``tuners/lora/layer.py``: ``result = base(x) + lora_B(lora_A(dropout(x))) * scaling``;
+    the adapter the reference's recipe puts on q/k/v/o_proj, the shared experts and lm_head -- recipes/config_lora.yaml:47-59 through
+    ``get_peft_model``, aria/train.py:100-112).  peft is absent from this image: restated from the published algorithm, dropout = 0.
+    base_w [out, in], lora_a [r, in], lora_b [out, r]."""
+    return x @ base_w.t() + (x @ lora_a.t()) @ lora_b.t() * scaling
+
+
+def lora_linear_delta_weight(lora_a: Tensor, lora_b: Tensor, scaling: float) -> Tensor:
+    """peft ``Linear.get_delta_weight``: B @ A * scaling, [out, in]."""
+    return lora_b @ lora_a * scaling
+
+
 def grouped_mlp(permuted: Tensor, fc1: Tensor, fc2: Tensor, tpe: Tensor) -> Tensor:
     """GroupedMLP.forward moe_lm.py:511-525."""
     return sequential_gemm(glu(sequential_gemm(permuted, fc1, tpe)), fc2, tpe)

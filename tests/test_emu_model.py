@@ -43,6 +43,10 @@ def test_lora_grouped_gemm():
     M.case_lora_grouped_gemm(DEV)
 
 
+def test_lora_linear_lm():
+    M.case_lora_linear_lm(DEV)
+
+
 @pytest.mark.parametrize("head_dim,max_seq", [(64, 24), (128, 16400)])  # (128, 24) runs on hardware; here it would cost 20 s more
 def test_decode_engine(head_dim, max_seq):
     M.case_decode_engine(DEV, head_dim, max_seq)

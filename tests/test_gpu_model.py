@@ -49,3 +49,7 @@ def test_hf_to_gptfast_bridge(golden):
 
 def test_decode_engine_reference_golden(golden):
     M.case_decode_engine_reference_golden(DEV, golden)
+
+
+def test_lora_linear_lm():  # last on purpose: newest composition of already-covered kernels
+    M.case_lora_linear_lm(DEV)

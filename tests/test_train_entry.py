@@ -48,22 +48,40 @@ def test_recipe_yaml_is_honoured():
     assert cfg["max_steps"] == 3 and cfg["learning_rate"] == 1e-4 and cfg["adam_beta2"] == 0.95
 
 
-def test_toy_finetune_reduces_loss():
+def test_toy_finetune_reduces_loss(tmp_path):
     from aria_amd.train import main
 
     hist = main(["--tiny", "per_device_train_batch_size=2", "gradient_accumulation_steps=1", "max_seq_length=24", "max_steps=6",
                  "learning_rate=1e-2", "weight_decay=0.0", "warmup_ratio=0.0", "images_per_sample=1", "logging_steps=100",
-                 "synthetic_fixed=true"])
+                 "synthetic_fixed=true", "save_final=true", f"output_dir={tmp_path}"])
     assert len(hist) == 6 and hist[-1] < hist[0] - 0.3, hist
+    # trainer.save_model(output_dir) (aria/train.py:247-249): an HF checkpoint directory the model class loads back
+    from aria_amd.modeling_aria import AriaForConditionalGeneration
+
+    assert (tmp_path / "config.json").exists() and (tmp_path / "model.safetensors.index.json").exists()
+    again = AriaForConditionalGeneration.from_pretrained(str(tmp_path))
+    assert sum(p.numel() for p in again.parameters()) > 0
 
 
-def test_lora_recipe_trains_only_the_expert_adapters():
-    """recipes/config_lora.yaml keys (use_peft, lora_r, lora_alpha, lora_target_modules): adapters on experts.fc1 / fc2, everything
-    else frozen, and a few steps still reduce the loss of a fixed batch."""
+def test_lora_recipe_trains_only_the_adapters(tmp_path):
+    """recipes/config_lora.yaml keys (use_peft, lora_r, lora_alpha, lora_dropout, the recipe's full lora_target_modules list): adapters on
+    experts.fc1 / fc2 (grouped) and on the LM's Linear projections + lm_head, everything else frozen, and a few steps still reduce the
+    loss of a fixed batch."""
     from aria_amd.train import main
 
     hist = main(["--tiny", "per_device_train_batch_size=2", "gradient_accumulation_steps=1", "max_seq_length=24", "max_steps=4",
                  "learning_rate=3e-2", "weight_decay=0.0", "warmup_ratio=0.0", "images_per_sample=1", "logging_steps=100",
-                 "synthetic_fixed=true", "use_peft=true", "lora_r=8", "lora_alpha=32", "freeze_projector=true",
-                 'lora_target_modules=["fc1","fc2","q_proj"]'])
+                 "synthetic_fixed=true", "use_peft=true", "lora_r=8", "lora_alpha=32", "lora_dropout=0.05", "freeze_projector=true",
+                 'lora_target_modules=["fc1","fc2","q_proj","k_proj","v_proj","linear","o_proj","up_proj","down_proj","out_proj",'
+                 '"gate_proj","lm_head"]', "save_final=true", f"output_dir={tmp_path}"])
     assert len(hist) == 4 and hist[-1] < hist[0], hist
+    import json
+
+    from safetensors.torch import load_file
+
+    adapter = load_file(str(tmp_path / "adapter_model.safetensors"))
+    acfg = json.load(open(tmp_path / "adapter_config.json"))
+    assert acfg["r"] == 8 and acfg["lora_alpha"] == 32 and "lm_head" in acfg["target_modules"]
+    assert adapter and all(".lora_A." in k or ".lora_B." in k for k in adapter)
+    assert any(k.endswith("lm_head.lora_B.weight") for k in adapter) and any("experts.fc1.lora_A" in k for k in adapter)
+    assert float(max(v.float().abs().max() for k, v in adapter.items() if ".lora_B." in k)) > 0.0  # B left its zero init: it trained
