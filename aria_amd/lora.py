@@ -209,3 +209,28 @@ def apply_lora_from_config(model: nn.Module, cfg) -> list:
         setattr(parent, name.rsplit(".", 1)[-1], layer)
     adapted = grouped + linear
     return [n for n in targets if n not in adapted and not any(n.startswith(g + ".") for g in adapted)]
+
+
+def load_lora_adapter(model: nn.Module, path: str, **freeze) -> list:
+    """Re-create the adapters a ``use_peft`` run of ``aria_amd.train`` saved (``adapter_config.json`` + ``adapter_model.safetensors``) on a
+    freshly loaded base model: wraps the same target modules (``freeze`` = the run's freeze_vit / freeze_projector / freeze_llm /
+    freeze_llm_layers selection, default: the recipe's freeze_vit + freeze_projector) and copies the factors in.  Returns the adapted names."""
+    import json
+    import os
+
+    from safetensors.torch import load_file
+
+    with open(os.path.join(path, "adapter_config.json")) as f:
+        ac = json.load(f)
+    cfg = dict(lora_r=ac["r"], lora_alpha=ac["lora_alpha"], lora_dropout=ac.get("lora_dropout", 0.0),
+               lora_target_modules=ac["target_modules"], freeze_vit=True, freeze_projector=True)
+    cfg.update(freeze)
+    apply_lora_from_config(model, cfg)
+    factors = load_file(os.path.join(path, "adapter_model.safetensors"))
+    own = lora_state_dict(model)
+    if set(own) != set(factors):
+        raise KeyError(f"adapter / model mismatch: {sorted(set(own) ^ set(factors))[:4]}")
+    with torch.no_grad():
+        for k, v in own.items():
+            v.copy_(factors[k].to(v.dtype))
+    return sorted({k.rsplit(".lora_", 1)[0] for k in own})

@@ -85,3 +85,12 @@ def test_lora_recipe_trains_only_the_adapters(tmp_path):
     assert adapter and all(".lora_A." in k or ".lora_B." in k for k in adapter)
     assert any(k.endswith("lm_head.lora_B.weight") for k in adapter) and any("experts.fc1.lora_A" in k for k in adapter)
     assert float(max(v.float().abs().max() for k, v in adapter.items() if ".lora_B." in k)) > 0.0  # B left its zero init: it trained
+    # the adapter goes back onto a fresh base model
+    from aria_amd.lora import load_lora_adapter, lora_state_dict
+    from aria_amd.train import build_model, load_config
+
+    fresh, _ = build_model(load_config(["--tiny"]), torch.device("cpu"))
+    names = load_lora_adapter(fresh, str(tmp_path))
+    assert any(n.endswith("lm_head") for n in names) and len(names) == len(adapter) // 2
+    got = lora_state_dict(fresh)
+    assert all(torch.equal(got[k].cpu(), adapter[k]) for k in adapter)
