@@ -211,6 +211,17 @@ def apply_lora_from_config(model: nn.Module, cfg) -> list:
     return [n for n in targets if n not in adapted and not any(n.startswith(g + ".") for g in adapted)]
 
 
+def merge_and_unload(model: nn.Module) -> nn.Module:
+    """peft's ``merge_and_unload``: fold every adapter into its base weight (W += delta) and put the plain base module back, so the
+    fused blocks, ``save_pretrained`` and ``to_gptfast()`` / the decode engine see ordinary reference-layout weights again."""
+    wrapped = [(n, m) for n, m in model.named_modules() if isinstance(m, (GroupedGemmLoraLayer, LinearLoraLayer))]
+    for name, layer in wrapped:
+        layer.merge()
+        parent = model.get_submodule(name.rsplit(".", 1)[0]) if "." in name else model
+        setattr(parent, name.rsplit(".", 1)[-1], layer.base_layer)
+    return model
+
+
 def load_lora_adapter(model: nn.Module, path: str, **freeze) -> list:
     """Re-create the adapters a ``use_peft`` run of ``aria_amd.train`` saved (``adapter_config.json`` + ``adapter_model.safetensors``) on a
     freshly loaded base model: wraps the same target modules (``freeze`` = the run's freeze_vit / freeze_projector / freeze_llm /
