@@ -397,12 +397,17 @@ def _dbg(msg):
 @torch.no_grad()
 def generate(model: Aria, input_ids: torch.Tensor, max_new_tokens: int, *, pixel_values=None, pixel_mask=None,
              temperature: float = 0.8, top_k: Optional[int] = 200, decoder: Optional[DecodeGraph] = None,
-             stop_token: Optional[int] = None, use_graph: bool = False) -> Tuple[torch.Tensor, Optional[DecodeGraph]]:
-    """gptfast/generate.py:112-177: prefill (ViT + projector + full prompt) then token-by-token decode."""
+             stop_token: Optional[int] = None, use_graph: bool = False, callback=None,
+             cache_size: Optional[int] = None) -> Tuple[torch.Tensor, Optional[DecodeGraph]]:
+    """gptfast/generate.py:112-177: prefill (ViT + projector + full prompt) then token-by-token decode.  ``callback(new_tokens)`` is the
+    reference's early-stop hook (decode_n_tokens :80-105: called after every token with the list of new token tensors, ``True`` stops);
+    ``stop_token`` is the cheap form of the same for single-token stop strings.  ``cache_size`` pre-sizes the static KV cache (:139-150)."""
     T = input_ids.size(1)
     dev = input_ids.device
-    if model.llm.max_seq_length < T + max_new_tokens:
-        model.setup_caches(1, T + max_new_tokens)
+    if cache_size is not None and cache_size < T + max_new_tokens:
+        raise ValueError("need cache_size to be greater than max_new_tokens + size-of-prompt")
+    if model.llm.max_seq_length < max(T + max_new_tokens, cache_size or 0):
+        model.setup_caches(1, max(T + max_new_tokens, cache_size or 0))
         decoder = None
     _dbg("start")
     emb = model.prepare_embeddings(input_ids, pixel_values, pixel_mask)
@@ -427,6 +432,8 @@ def generate(model: Aria, input_ids: torch.Tensor, max_new_tokens: int, *, pixel
         toks.append(nxt.view(1))
         pos += 1
         if stop_token is not None and int(nxt) == stop_token:
+            break
+        if callback is not None and callback(toks) is True:
             break
     return torch.cat([input_ids.view(-1), torch.cat(toks).long()]), decoder
 
