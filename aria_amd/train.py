@@ -8,9 +8,10 @@ gradient_checkpointing, moe_z_loss_coeff, moe_aux_loss_coeff, freeze_vit, freeze
 logging_steps, output_dir.  trl / peft / accelerate / DeepSpeed are replaced by: GradSync (RCCL all-reduce overlapped with backward),
 ShardedAdamW (ZeRO-2-style sharded state, fused HIP AdamW), MoEAuxLossAutoScaler.set_loss_scale(1/grad_accum) (train.py:229).
 
-Out of scope: dataset mixing / chat templating / image decoding (aria/data.py, processing_aria.py) -- without
-network access there is neither a dataset nor a checkpoint, so ``--synthetic`` (default) draws random samples of the configured
-shape; ``model_name_or_path`` may point to a local HF checkpoint directory (``aria_amd.checkpoint``) or a ``torch.save``d state dict.
+Data: ``dataset_mixer`` (aria/data.py format and mixing rule: ``aria_amd.data``) through the reference's collate (chat template, label
+masking, image processor: ``aria_amd.processing.collate_fn``), sharded by rank; ``synthetic_data=true`` (or no ``dataset_mixer``) draws
+random samples of the configured shape instead (throughput runs, tests).  ``model_name_or_path`` may point to a local HF checkpoint
+directory (``aria_amd.checkpoint``) or a ``torch.save``d state dict; the run ends with ``save_output`` (checkpoint directory or adapter).
 """
 from __future__ import annotations
 
@@ -62,12 +63,14 @@ def build_model(cfg, device):
         text = AriaMoELMConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, vocab_size=512, moe_intermediate_size=64,
                                moe_num_experts=8, moe_topk=2, moe_z_loss_coeff=cfg["moe_z_loss_coeff"],
                                moe_aux_loss_coeff=cfg["moe_aux_loss_coeff"], gradient_checkpointing=cfg["gradient_checkpointing"])
-        vis = AriaVisionConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, image_size=56)
-        acfg = AriaConfig(vision_config=vis, text_config=text, projector_patch_to_query_dict={16: 4}, image_token_index=9)
+        side = int(cfg.get("tiny_image_size", 56))   # 56 -> 16 patches -> 4 tokens (synthetic); 490 -> 1225 -> 128 (what the processor emits)
+        vis = AriaVisionConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, image_size=side)
+        acfg = AriaConfig(vision_config=vis, text_config=text, projector_patch_to_query_dict={16: 4, 1225: 128, 4900: 256},
+                          image_token_index=int(cfg.get("image_token_index", 9)))
     else:
         text = AriaMoELMConfig(moe_z_loss_coeff=cfg["moe_z_loss_coeff"], moe_aux_loss_coeff=cfg["moe_aux_loss_coeff"],
                                gradient_checkpointing=cfg["gradient_checkpointing"])
-        acfg = AriaConfig(vision_config=AriaVisionConfig(), text_config=text, image_token_index=9)
+        acfg = AriaConfig(vision_config=AriaVisionConfig(), text_config=text, image_token_index=int(cfg.get("image_token_index", 9)))
     torch.set_default_device(device)
     model = AriaForConditionalGeneration(acfg)
     torch.set_default_device("cpu")
@@ -149,7 +152,40 @@ def synthetic_batch(cfg, acfg, device, gen):
     return dict(input_ids=ids, pixel_values=pv, pixel_mask=pm, attention_mask=torch.ones_like(ids), labels=labels)
 
 
-def main(argv=None):
+def real_batches(cfg, acfg, device, rank, world, tokenizer=None):
+    """``dataset_mixer`` of the recipe -> device batches: aria/train.py:117-209 (collate: chat template + label masking + image processor)
+    over the rows ``aria_amd.data.mix_datasets`` selects, sharded by rank."""
+    import copy
+
+    from .data import batches, mix_datasets
+    from .processing import AriaVisionProcessor, collate_fn
+
+    if tokenizer is None:
+        from transformers import AutoTokenizer
+
+        tokenizer = AutoTokenizer.from_pretrained(str(cfg.get("tokenizer_path") or cfg["model_name_or_path"]), use_fast=False)
+    if getattr(tokenizer, "pad_token", None) is None:
+        tokenizer.pad_token = tokenizer.unk_token
+    rows = mix_datasets(cfg["dataset_mixer"])["train"]
+
+    class SizedProcessor(AriaVisionProcessor):
+        """collate_fn calls ``processor(images, split_image=...)`` like aria/train.py:192, and ``__call__``'s own default (980,
+        vision_processor.py:208) would override the configured size while the chat template expands ``processor.max_image_size``: with the
+        recipe's 980 the two agree, with 490 the reference trips its token / feature count check.  Here the configured size is the default."""
+
+        def __call__(self, images, max_image_size=None, **kw):
+            return super().__call__(images, max_image_size=max_image_size, **kw)
+
+    image_processor = SizedProcessor(max_image_size=int(cfg["max_image_size"]))
+    max_steps = int(cfg.get("max_steps") or 0)
+    epochs = 10 ** 9 if max_steps > 0 else float(cfg["num_train_epochs"])  # max_steps wins over num_train_epochs like in the HF Trainer
+    for examples in batches(rows, int(cfg["per_device_train_batch_size"]), rank, world, epochs):
+        batch = collate_fn(copy.deepcopy(examples), tokenizer, image_processor, split_image=bool(cfg.get("split_image", False)),
+                           max_seq_length=int(cfg["max_seq_length"]))
+        yield {k: v.to(device) for k, v in batch.items() if k != "num_crops"}
+
+
+def main(argv=None, tokenizer=None):
     cfg = load_config(sys.argv[1:] if argv is None else argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -172,17 +208,28 @@ def main(argv=None):
     sync = GradSync(model) if world > 1 else None
     opt = ShardedAdamW(model.parameters(), lr=cfg["learning_rate"], betas=(0.9, cfg["adam_beta2"]), weight_decay=cfg["weight_decay"])
     gen = torch.Generator(device=device).manual_seed(cfg["seed"] + rank)
-    total = int(cfg["max_steps"])
+    # data: the recipe's dataset_mixer (aria/data.py format) unless synthetic_data=true / no dataset is configured (throughput runs, tests)
+    use_real = bool(cfg.get("dataset_mixer")) and not cfg.get("synthetic_data", False)
+    stream = real_batches(cfg, acfg, device, rank, world, tokenizer) if use_real else None
+    total = int(cfg.get("max_steps") or 0)
+    if use_real and total <= 0:  # epochs: optimizer steps = batches per rank // accumulation
+        from .data import mix_datasets
+
+        n_rows = len(mix_datasets(cfg["dataset_mixer"])["train"])
+        total = int(float(cfg["num_train_epochs"]) * (n_rows // world // int(cfg["per_device_train_batch_size"]))) // accum
     history = []
     for step in range(1, total + 1):
         t0 = time.perf_counter()
         opt.zero_grad()
         loss_acc = 0.0
         for micro in range(accum):
-            if cfg.get("synthetic_fixed"):  # overfit one batch (tests): random labels are irreducible otherwise
-                gen.manual_seed(cfg["seed"] + rank + micro)
-            batch = synthetic_batch(cfg, acfg, device, gen)
-            out = model(**batch, return_logits=False, validate_image_tokens=False)
+            if use_real:
+                batch = next(stream)
+            else:
+                if cfg.get("synthetic_fixed"):  # overfit one batch (tests): random labels are irreducible otherwise
+                    gen.manual_seed(cfg["seed"] + rank + micro)
+                batch = synthetic_batch(cfg, acfg, device, gen)
+            out = model(**batch, return_logits=False, validate_image_tokens=use_real)
             (out.loss / accum).backward()
             loss_acc += float(out.loss.detach()) / accum
         if sync is not None:
