@@ -126,6 +126,24 @@ class ShardedAdamW:
         for p in self.params:
             p.grad = None
 
+    def state_dict(self) -> dict:
+        """This rank's shard of the optimizer state (fp32 master / m / v slices + the shard bounds they belong to) and the step counter:
+        what a resumed run needs next to the bf16 weights (one file per rank, like ZeRO's per-rank optimizer shards)."""
+        return {"step_count": self.step_count, "world": self.world, "rank": self.rank,
+                "shards": [{"lo": st["lo"], "hi": st["hi"], "master": st["master"].detach().cpu(), "m": st["m"].detach().cpu(),
+                            "v": st["v"].detach().cpu()} for st in self.state]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        if sd["world"] != self.world or sd["rank"] != self.rank or len(sd["shards"]) != len(self.state):
+            raise ValueError(f"optimizer shard of rank {sd['rank']}/{sd['world']} with {len(sd['shards'])} tensors does not fit "
+                             f"rank {self.rank}/{self.world} with {len(self.state)}")
+        self.step_count = int(sd["step_count"])
+        for st, src in zip(self.state, sd["shards"]):
+            if (st["lo"], st["hi"]) != (src["lo"], src["hi"]):
+                raise ValueError("optimizer shard bounds changed (different parameter set or world size)")
+            for k in ("master", "m", "v"):
+                st[k].copy_(src[k].to(st[k].device))
+
     @torch.no_grad()
     def step(self, lr: Optional[float] = None, grad_scale: float = 1.0):
         from . import ops

@@ -5,7 +5,7 @@ recipes/config_full.yaml`` (+ ``key=value`` / ``--key value`` overrides), launch
 Honoured recipe keys (recipes/config_full.yaml): per_device_train_batch_size, gradient_accumulation_steps, learning_rate,
 weight_decay, adam_beta2, warmup_ratio, lr_scheduler_type (cosine), max_seq_length, max_image_size, num_train_epochs / max_steps,
 gradient_checkpointing, moe_z_loss_coeff, moe_aux_loss_coeff, freeze_vit, freeze_projector, freeze_llm, freeze_llm_layers, seed,
-logging_steps, output_dir.  trl / peft / accelerate / DeepSpeed are replaced by: GradSync (RCCL all-reduce overlapped with backward),
+logging_steps, output_dir, dataset_mixer, save_strategy (epoch | steps | no) / save_steps, resume_from_checkpoint, use_peft + lora_*.  trl / peft / accelerate / DeepSpeed are replaced by: GradSync (RCCL all-reduce overlapped with backward),
 ShardedAdamW (ZeRO-2-style sharded state, fused HIP AdamW), MoEAuxLossAutoScaler.set_loss_scale(1/grad_accum) (train.py:229).
 
 Data: ``dataset_mixer`` (aria/data.py format and mixing rule: ``aria_amd.data``) through the reference's collate (chat template, label
@@ -135,6 +135,57 @@ def save_output(model, cfg) -> str:
     return out
 
 
+def save_checkpoint(model, opt, cfg, step: int, history, rank: int, world: int) -> str:
+    """``save_strategy`` checkpoints (recipes/config_full.yaml:20-21; HF Trainer layout ``output_dir/checkpoint-<step>``): the weights
+    (rank 0; HF directory or adapter, as ``save_output``), every rank's optimizer shard, and ``trainer_state.json``."""
+    path = os.path.join(str(cfg["output_dir"]), f"checkpoint-{step}")
+    os.makedirs(path, exist_ok=True)
+    if rank == 0:
+        save_output(model, {**cfg, "output_dir": path})
+        with open(os.path.join(path, "trainer_state.json"), "w") as f:
+            json.dump({"global_step": step, "world_size": world, "log_history": [float(x) for x in history]}, f)
+    torch.save(opt.state_dict(), os.path.join(path, f"optimizer_rank{rank}.pt"))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()  # the checkpoint is complete (all shards written) before any rank moves on
+    return path
+
+
+def latest_checkpoint(output_dir: str):
+    """The ``checkpoint-<step>`` directory with the highest step that is complete (has trainer_state.json), or None."""
+    best = None
+    if os.path.isdir(output_dir):
+        for name in os.listdir(output_dir):
+            if name.startswith("checkpoint-") and name[11:].isdigit() and os.path.exists(os.path.join(output_dir, name, "trainer_state.json")):
+                if best is None or int(name[11:]) > int(best[11:]):
+                    best = name
+    return os.path.join(output_dir, best) if best else None
+
+
+def load_checkpoint(model, opt, path: str, cfg, rank: int, world: int):
+    """-> (step, history).  Weights first (they are what ShardedAdamW's bf16 side holds), then this rank's optimizer shard."""
+    with open(os.path.join(path, "trainer_state.json")) as f:
+        state = json.load(f)
+    if state["world_size"] != world:
+        raise ValueError(f"checkpoint written by {state['world_size']} ranks, resumed on {world}")
+    if cfg.get("use_peft"):
+        from safetensors.torch import load_file
+
+        from .lora import lora_state_dict
+
+        factors = load_file(os.path.join(path, "adapter_model.safetensors"))
+        with torch.no_grad():
+            for k, v in lora_state_dict(model).items():
+                v.copy_(factors[k].to(v.dtype))
+    else:
+        from .checkpoint import load_checkpoint_dir, load_hf_into
+
+        load_hf_into(model, load_checkpoint_dir(path), strict=True)
+    opt.load_state_dict(torch.load(os.path.join(path, f"optimizer_rank{rank}.pt"), map_location="cpu"))
+    return int(state["global_step"]), list(state["log_history"])
+
+
 def synthetic_batch(cfg, acfg, device, gen):
     B, S = cfg["per_device_train_batch_size"], cfg["max_seq_length"]
     V = acfg.text_config.vocab_size
@@ -152,7 +203,7 @@ def synthetic_batch(cfg, acfg, device, gen):
     return dict(input_ids=ids, pixel_values=pv, pixel_mask=pm, attention_mask=torch.ones_like(ids), labels=labels)
 
 
-def real_batches(cfg, acfg, device, rank, world, tokenizer=None):
+def real_batches(cfg, acfg, device, rank, world, tokenizer=None, rows=None, skip: int = 0):
     """``dataset_mixer`` of the recipe -> device batches: aria/train.py:117-209 (collate: chat template + label masking + image processor)
     over the rows ``aria_amd.data.mix_datasets`` selects, sharded by rank."""
     import copy
@@ -166,7 +217,7 @@ def real_batches(cfg, acfg, device, rank, world, tokenizer=None):
         tokenizer = AutoTokenizer.from_pretrained(str(cfg.get("tokenizer_path") or cfg["model_name_or_path"]), use_fast=False)
     if getattr(tokenizer, "pad_token", None) is None:
         tokenizer.pad_token = tokenizer.unk_token
-    rows = mix_datasets(cfg["dataset_mixer"])["train"]
+    rows = mix_datasets(cfg["dataset_mixer"])["train"] if rows is None else rows
 
     class SizedProcessor(AriaVisionProcessor):
         """collate_fn calls ``processor(images, split_image=...)`` like aria/train.py:192, and ``__call__``'s own default (980,
@@ -179,7 +230,9 @@ def real_batches(cfg, acfg, device, rank, world, tokenizer=None):
     image_processor = SizedProcessor(max_image_size=int(cfg["max_image_size"]))
     max_steps = int(cfg.get("max_steps") or 0)
     epochs = 10 ** 9 if max_steps > 0 else float(cfg["num_train_epochs"])  # max_steps wins over num_train_epochs like in the HF Trainer
-    for examples in batches(rows, int(cfg["per_device_train_batch_size"]), rank, world, epochs):
+    for n, examples in enumerate(batches(rows, int(cfg["per_device_train_batch_size"]), rank, world, epochs)):
+        if n < skip:  # resumed run: what the interrupted run consumed (the order is deterministic), skipped before any image is opened
+            continue
         batch = collate_fn(copy.deepcopy(examples), tokenizer, image_processor, split_image=bool(cfg.get("split_image", False)),
                            max_seq_length=int(cfg["max_seq_length"]))
         yield {k: v.to(device) for k, v in batch.items() if k != "num_crops"}
@@ -210,15 +263,29 @@ def main(argv=None, tokenizer=None):
     gen = torch.Generator(device=device).manual_seed(cfg["seed"] + rank)
     # data: the recipe's dataset_mixer (aria/data.py format) unless synthetic_data=true / no dataset is configured (throughput runs, tests)
     use_real = bool(cfg.get("dataset_mixer")) and not cfg.get("synthetic_data", False)
-    stream = real_batches(cfg, acfg, device, rank, world, tokenizer) if use_real else None
     total = int(cfg.get("max_steps") or 0)
-    if use_real and total <= 0:  # epochs: optimizer steps = batches per rank // accumulation
+    rows, steps_per_epoch = None, None
+    if use_real:
         from .data import mix_datasets
 
-        n_rows = len(mix_datasets(cfg["dataset_mixer"])["train"])
-        total = int(float(cfg["num_train_epochs"]) * (n_rows // world // int(cfg["per_device_train_batch_size"]))) // accum
-    history = []
-    for step in range(1, total + 1):
+        rows = mix_datasets(cfg["dataset_mixer"])["train"]
+        steps_per_epoch = max(1, len(rows) // world // int(cfg["per_device_train_batch_size"]) // accum)
+        if total <= 0:  # epochs: optimizer steps = batches per rank // accumulation
+            total = int(float(cfg["num_train_epochs"]) * (len(rows) // world // int(cfg["per_device_train_batch_size"]))) // accum
+    history, first = [], 1
+    strategy = str(cfg.get("save_strategy", "no"))
+    save_every = steps_per_epoch if strategy == "epoch" else int(cfg.get("save_steps", 500)) if strategy == "steps" else None
+    if cfg.get("resume_from_checkpoint"):  # true: the latest checkpoint in output_dir (config_full.yaml:21); a path: that one
+        ck = cfg["resume_from_checkpoint"]
+        ck = latest_checkpoint(str(cfg["output_dir"])) if ck is True else str(ck)
+        if ck:
+            done, history = load_checkpoint(model, opt, ck, cfg, rank, world)
+            first = done + 1
+            if not use_real and not cfg.get("synthetic_fixed"):
+                for _ in range(done * accum):  # replay the generator draws of the steps already taken
+                    synthetic_batch(cfg, acfg, device, gen)
+    stream = real_batches(cfg, acfg, device, rank, world, tokenizer, rows, skip=(first - 1) * accum) if use_real else None
+    for step in range(first, total + 1):
         t0 = time.perf_counter()
         opt.zero_grad()
         loss_acc = 0.0
@@ -239,6 +306,8 @@ def main(argv=None, tokenizer=None):
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         history.append(loss_acc)
+        if save_every and step % save_every == 0 and step < total:
+            save_checkpoint(model, opt, cfg, step, history, rank, world)
         if rank == 0 and step % int(cfg["logging_steps"]) == 0:
             toks = world * accum * cfg["per_device_train_batch_size"] * cfg["max_seq_length"]
             print(json.dumps({"step": step, "loss": round(loss_acc, 4), "lr": opt.lr, "step_s": round(dt, 3), "tokens_per_s": round(toks / dt, 1)}),

@@ -94,3 +94,20 @@ def test_lora_recipe_trains_only_the_adapters(tmp_path):
     assert any(n.endswith("lm_head") for n in names) and len(names) == len(adapter) // 2
     got = lora_state_dict(fresh)
     assert all(torch.equal(got[k].cpu(), adapter[k]) for k in adapter)
+
+
+def test_checkpoint_resume_continues_the_same_run(tmp_path):
+    """save_strategy / resume_from_checkpoint (recipes/config_full.yaml:20-21): weights + sharded optimizer state + step + data position --
+    an interrupted run resumed from its checkpoint reproduces the uninterrupted loss history exactly."""
+    import json
+
+    from aria_amd.train import latest_checkpoint, main
+
+    common = ["--tiny", "per_device_train_batch_size=1", "gradient_accumulation_steps=2", "max_seq_length=24", "learning_rate=1e-2",
+              "weight_decay=0.1", "warmup_ratio=0.25", "images_per_sample=1", "logging_steps=100"]
+    straight = main(common + ["max_steps=3", "save_strategy=steps", "save_steps=2", f"output_dir={tmp_path / 'b'}"])
+    ck = latest_checkpoint(str(tmp_path / "b"))
+    assert ck.endswith("checkpoint-2") and json.load(open(f"{ck}/trainer_state.json"))["global_step"] == 2
+    assert {"config.json", "model.safetensors.index.json", "optimizer_rank0.pt", "trainer_state.json"} <= set(__import__("os").listdir(ck))
+    resumed = main(common + ["max_steps=3", "resume_from_checkpoint=true", f"output_dir={tmp_path / 'b'}"])   # runs step 3 only
+    assert len(straight) == 3 and resumed == straight, (resumed, straight)
