@@ -257,7 +257,8 @@ def main(argv=None, tokenizer=None):
 
     model, acfg = build_model(cfg, device)
     accum = int(cfg["gradient_accumulation_steps"])
-    MoEAuxLossAutoScaler.set_loss_scale(1.0 / accum)                     # aria/train.py:229
+    aux_scale_before = MoEAuxLossAutoScaler.main_loss_backward_scale
+    MoEAuxLossAutoScaler.set_loss_scale(1.0 / accum)                     # aria/train.py:229 (a process-wide setting, restored on return)
     sync = GradSync(model) if world > 1 else None
     opt = ShardedAdamW(model.parameters(), lr=cfg["learning_rate"], betas=(0.9, cfg["adam_beta2"]), weight_decay=cfg["weight_decay"])
     gen = torch.Generator(device=device).manual_seed(cfg["seed"] + rank)
@@ -319,6 +320,7 @@ def main(argv=None, tokenizer=None):
 
         dist.barrier()
         dist.destroy_process_group()
+    MoEAuxLossAutoScaler.set_loss_scale(aux_scale_before)
     return history
 
 
