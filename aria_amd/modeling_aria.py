@@ -70,6 +70,32 @@ class AriaForConditionalGeneration(nn.Module):
         for p in self.language_model.parameters():
             p.requires_grad = False
 
+    # ---- expert parallelism (BASELINE config #5)
+    def enable_expert_parallel(self, group=None) -> None:
+        """Shard the routed experts of every decoder layer over ``group`` (default: all ranks); everything else stays replicated."""
+        for layer in self.language_model.model.layers:
+            layer.mlp.enable_expert_parallel(group)
+
+    def expert_parallel_group(self):
+        mlp = self.language_model.model.layers[0].mlp
+        return (mlp.ep_group, True) if mlp.ep_enabled else (None, False)
+
+    def full_state_dict(self) -> dict:
+        """``state_dict()`` in the reference layout on EVERY rank: the expert shards of an expert-parallel model are all-gathered back
+        into ``[E, ...]`` tensors (a collective: call it on all ranks); identical to ``state_dict()`` otherwise."""
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        group, ep = self.expert_parallel_group()
+        if not ep:
+            return sd
+        import torch.distributed as dist
+
+        W = dist.get_world_size(group)
+        for k in [k for k in sd if k.endswith(("mlp.experts.fc1.weight", "mlp.experts.fc2.weight"))]:
+            parts = [torch.empty_like(sd[k]) for _ in range(W)]
+            dist.all_gather(parts, sd[k].contiguous(), group=group)
+            sd[k] = torch.cat(parts, dim=0)
+        return sd
+
     def get_input_embeddings(self):
         return self.language_model.get_input_embeddings()
 
@@ -102,7 +128,7 @@ class AriaForConditionalGeneration(nn.Module):
         load_hf_into(model, load_checkpoint_dir(path), strict=strict)
         return model.eval()
 
-    def save_pretrained(self, path: str, max_shard_bytes: int = 5 << 30) -> None:
+    def save_pretrained(self, path: str, max_shard_bytes: int = 5 << 30, state_dict: Optional[dict] = None) -> None:
         import json
         import os
 
@@ -124,7 +150,7 @@ class AriaForConditionalGeneration(nn.Module):
                    ignore_index=self.config.ignore_index, image_token_index=self.config.image_token_index, torch_dtype="bfloat16")
         with open(os.path.join(path, "config.json"), "w") as f:
             json.dump(cfg, f, indent=2)
-        save_checkpoint_dir(self.state_dict(), path, max_shard_bytes=max_shard_bytes)
+        save_checkpoint_dir(self.state_dict() if state_dict is None else state_dict, path, max_shard_bytes=max_shard_bytes)
 
     # ---- inference bridge: HF surface (training layout) -> gptfast surface (inference layout)
     def to_gptfast(self):

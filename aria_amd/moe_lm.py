@@ -205,6 +205,27 @@ class MoELayer(nn.Module):
         self.token_dispatcher = TokenDispatcher(config)
         self.experts = GroupedMLP(config)
         self.shared_experts = SharedExpertMLP(config)
+        self.ep_group = None     # set by enable_expert_parallel: the process group the routed experts are sharded over
+        self.ep_enabled = False
+
+    def enable_expert_parallel(self, group=None) -> None:
+        """Config #5: keep only this rank's E/W routed experts (rank g owns experts [g*E/W, (g+1)*E/W)); from now on forward() dispatches
+        rows to their owners with an all-to-all (``aria_amd.expert_parallel.ep_moe_forward``).  The local shards are marked ``_ep_local``:
+        their gradients are complete on the owner, so ``GradSync`` does not all-reduce them and ``ShardedAdamW`` keeps their state whole."""
+        import torch.distributed as dist
+
+        W, r = dist.get_world_size(group), dist.get_rank(group)
+        E = self.config.moe_num_experts
+        if E % W:
+            raise ValueError(f"{E} experts do not shard over {W} ranks")
+        per = E // W
+        for fc in (self.experts.fc1, self.experts.fc2):
+            if type(fc) is not GroupedGEMM:
+                raise NotImplementedError("expert parallelism with an adapter on the expert GEMMs")
+            local = nn.Parameter(fc.weight.detach()[r * per:(r + 1) * per].clone(), requires_grad=fc.weight.requires_grad)
+            local._ep_local = True
+            fc.weight, fc.groups = local, per
+        self.ep_group, self.ep_enabled = group, True
 
     def moe_config(self) -> Fn.MoEConfig:
         c = self.config
@@ -219,6 +240,11 @@ class MoELayer(nn.Module):
         x = hidden_states.reshape(-1, shp[-1])
         x = x if x.is_contiguous() else x.contiguous()
         se = self.shared_experts
+        if self.ep_enabled:
+            from .expert_parallel import ep_moe_forward
+
+            return ep_moe_forward(x, self.router.weight, self.experts.fc1.weight, self.experts.fc2.weight, se.gate_proj.weight,
+                                  se.up_proj.weight, se.down_proj.weight, self.moe_config(), self.ep_group).view(shp)
         if self.has_adapter():
             return self.forward_modular(x).view(shp)  # an adapter (LoRA) sits on an expert GEMM or a shared-expert projection
         out = AG.MoELayerFn.apply(x, self.router.weight, self.experts.fc1.weight, self.experts.fc2.weight,
@@ -308,8 +334,9 @@ class MoEDecoderLayer(nn.Module):
                 kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, S, D = hidden_states.shape
         a = self.self_attn
-        if self.mlp.has_adapter() or not _plain_linears(a.q_proj, a.k_proj, a.v_proj, a.o_proj):
-            # an adapter (aria_amd/lora.py) wraps a GEMM of this layer: LlamaDecoderLayer.forward module by module (modeling_llama.py:295-325)
+        if self.mlp.ep_enabled or self.mlp.has_adapter() or not _plain_linears(a.q_proj, a.k_proj, a.v_proj, a.o_proj):
+            # an adapter (aria_amd/lora.py) wraps a GEMM of this layer, or the experts are sharded over ranks (an all-to-all sits inside
+            # the MoE block): LlamaDecoderLayer.forward module by module (modeling_llama.py:295-325)
             h = hidden_states + self.self_attn(self.input_layernorm(hidden_states), cos, sin, kv_len)
             return h + self.mlp(self.post_attention_layernorm(h))
         x = hidden_states.reshape(B * S, D)

@@ -32,6 +32,7 @@ class GradSync:
         self.overlap = overlap
         self.handles: List = []
         self.small: List[torch.nn.Parameter] = []
+        self.ep_local: List[torch.nn.Parameter] = []   # expert shards of an expert-parallel model: complete on their owner, never all-reduced
         self.large_pending: List[torch.nn.Parameter] = []
         self._hooks = []
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
@@ -39,6 +40,9 @@ class GradSync:
         if self.world > 1:
             for p in module.parameters():
                 if not p.requires_grad:
+                    continue
+                if getattr(p, "_ep_local", False):
+                    self.ep_local.append(p)
                     continue
                 if p.numel() <= SMALL_NUMEL:
                     self.small.append(p)
@@ -60,6 +64,9 @@ class GradSync:
         """Call after backward(): completes every exchange; afterwards .grad holds the rank-average."""
         if self.world <= 1:
             return
+        for p in self.ep_local:  # the owner accumulated the contributions of EVERY rank's tokens (sum): same 1/W as the averaged replicas
+            if p.grad is not None:
+                p.grad.div_(self.world)
         for p in self.large_pending:
             self.handles.append((self._reduce(p.grad, True), p))
         self.large_pending = []
@@ -114,11 +121,12 @@ class ShardedAdamW:
         self.state = []
         for p in self.params:
             n = p.numel()
-            per = (n + self.world - 1) // self.world
+            local = bool(getattr(p, "_ep_local", False))      # an expert-parallel shard: every rank holds DIFFERENT experts -> whole state here
+            per = n if local else (n + self.world - 1) // self.world
             per += per & 1                                    # even shard length (kernel works on bf16 pairs)
-            lo, hi = min(n, self.rank * per), min(n, (self.rank + 1) * per)
+            lo, hi = (0, n) if local else (min(n, self.rank * per), min(n, (self.rank + 1) * per))
             flat = p.detach().view(-1)
-            self.state.append(dict(lo=lo, hi=hi, per=per, master=flat[lo:hi].float().clone(),
+            self.state.append(dict(lo=lo, hi=hi, per=per, local=local, master=flat[lo:hi].float().clone(),
                                    m=torch.zeros(hi - lo, dtype=torch.float32, device=p.device),
                                    v=torch.zeros(hi - lo, dtype=torch.float32, device=p.device)))
 
@@ -163,7 +171,7 @@ class ShardedAdamW:
                     ops.adamw_step_(pf[:n], gf[:n].contiguous(), st["master"][:n], st["m"][:n], st["v"][:n], lr=lr, beta1=self.betas[0],
                                     beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, step=self.step_count,
                                     grad_scale=grad_scale)
-            if self.world > 1:
+            if self.world > 1 and not st["local"]:
                 flat = p.view(-1)
                 n_all, per = flat.numel(), st["per"]
                 if n_all == per * self.world:

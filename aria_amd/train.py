@@ -118,6 +118,9 @@ def save_output(model, cfg) -> str:
     safetensors, reference key names); ``use_peft`` runs write only the adapter, like peft's ``save_pretrained``: ``adapter_model.safetensors``
     (``...lora_A.weight`` / ``...lora_B.weight`` keyed by this package's module names) + ``adapter_config.json`` (r, alpha, dropout, targets)."""
     out = str(cfg["output_dir"])
+    full = model.full_state_dict() if cfg.get("expert_parallel") else None   # a collective: every rank calls save_output in that case
+    if int(os.environ.get("RANK", "0")) != 0:
+        return out
     os.makedirs(out, exist_ok=True)
     if cfg.get("use_peft"):
         from safetensors.torch import save_file
@@ -131,7 +134,7 @@ def save_output(model, cfg) -> str:
                        "lora_dropout": float(cfg.get("lora_dropout", 0.0)), "target_modules": list(cfg.get("lora_target_modules") or []),
                        "base_model_name_or_path": cfg.get("model_name_or_path")}, f, indent=2)
     else:
-        model.save_pretrained(out)
+        model.save_pretrained(out, state_dict=full)
     return out
 
 
@@ -140,8 +143,8 @@ def save_checkpoint(model, opt, cfg, step: int, history, rank: int, world: int) 
     (rank 0; HF directory or adapter, as ``save_output``), every rank's optimizer shard, and ``trainer_state.json``."""
     path = os.path.join(str(cfg["output_dir"]), f"checkpoint-{step}")
     os.makedirs(path, exist_ok=True)
+    save_output(model, {**cfg, "output_dir": path})          # writes on rank 0 (gathers expert shards from all ranks first if sharded)
     if rank == 0:
-        save_output(model, {**cfg, "output_dir": path})
         with open(os.path.join(path, "trainer_state.json"), "w") as f:
             json.dump({"global_step": step, "world_size": world, "log_history": [float(x) for x in history]}, f)
     torch.save(opt.state_dict(), os.path.join(path, f"optimizer_rank{rank}.pt"))
@@ -181,7 +184,12 @@ def load_checkpoint(model, opt, path: str, cfg, rank: int, world: int):
     else:
         from .checkpoint import load_checkpoint_dir, load_hf_into
 
-        load_hf_into(model, load_checkpoint_dir(path), strict=True)
+        sd = load_checkpoint_dir(path)
+        if cfg.get("expert_parallel"):  # the checkpoint holds all experts: keep this rank's
+            for k in [k for k in sd if k.endswith(("mlp.experts.fc1.weight", "mlp.experts.fc2.weight"))]:
+                per = sd[k].shape[0] // world
+                sd[k] = sd[k][rank * per:(rank + 1) * per]
+        load_hf_into(model, sd, strict=True)
     opt.load_state_dict(torch.load(os.path.join(path, f"optimizer_rank{rank}.pt"), map_location="cpu"))
     return int(state["global_step"]), list(state["log_history"])
 
@@ -256,6 +264,10 @@ def main(argv=None, tokenizer=None):
     from .parallel import GradSync, ShardedAdamW, cosine_lr
 
     model, acfg = build_model(cfg, device)
+    if cfg.get("expert_parallel") and world > 1:  # BASELINE config #5: routed experts sharded over all ranks (EP = world), the rest data-parallel
+        if cfg.get("use_peft"):
+            raise NotImplementedError("expert_parallel with use_peft")
+        model.enable_expert_parallel()
     accum = int(cfg["gradient_accumulation_steps"])
     aux_scale_before = MoEAuxLossAutoScaler.main_loss_backward_scale
     MoEAuxLossAutoScaler.set_loss_scale(1.0 / accum)                     # aria/train.py:229 (a process-wide setting, restored on return)
@@ -313,7 +325,7 @@ def main(argv=None, tokenizer=None):
             toks = world * accum * cfg["per_device_train_batch_size"] * cfg["max_seq_length"]
             print(json.dumps({"step": step, "loss": round(loss_acc, 4), "lr": opt.lr, "step_s": round(dt, 3), "tokens_per_s": round(toks / dt, 1)}),
                   flush=True)
-    if rank == 0 and cfg.get("save_final", not cfg["tiny"]):  # every rank holds the full updated bf16 weights (ShardedAdamW all-gathers)
+    if cfg.get("save_final", not cfg["tiny"]):  # written by rank 0: every rank holds the full updated bf16 weights (ShardedAdamW all-gathers)
         save_output(model, cfg)
     if world > 1:
         import torch.distributed as dist

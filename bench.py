@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--images", type=int, default=2, help="980px images per sample (NLVR2-style: 2); 0 = text only")
     ap.add_argument("--vit-layers", type=int, default=27, help="debug only")
     ap.add_argument("--no-overlap", action="store_true", help="exchange gradients after backward instead of under it")
+    ap.add_argument("--ep", action="store_true", help="BASELINE config #5 instead of #3: routed experts sharded over the N ranks (all-to-all "
+                                                      "dispatch over xGMI), everything else data-parallel; not what the driver runs")
     return ap.parse_args()
 
 
@@ -151,6 +153,8 @@ def main():
     init_params(model, seed=0)  # same weights on every rank (DP replicas)
     model.train()
     model.freeze_vit()          # recipes/config_full.yaml:39-42: ViT frozen, projector + LLM trainable
+    if args.ep and world > 1:
+        model.enable_expert_parallel()  # every rank built the same 64 experts (same seed) and keeps its 64 / N
     sync = GradSync(model, overlap=not args.no_overlap) if world > 1 else None
 
     B, S, V = args.batch, args.seq, cfg.vocab_size
@@ -273,7 +277,7 @@ def main():
                                    "trainable projector (256 tok/img) -> 28-layer MoE decoder (64 experts top-6, D=2560, V=100352) "
                                    "fwd+bwd incl. lm_head+CE and router aux-loss grads",
                        "layers": args.layers, "vit_layers": args.vit_layers, "images_per_sample": n_img, "global_batch": world * B, "seq_len": S,
-                       "parallelism": f"dp{world}" if world > 1 else "single", "grad_checkpointing": bool(args.recompute),
+                       "parallelism": (f"dp{world}+ep{world}" if args.ep else f"dp{world}") if world > 1 else "single", "grad_checkpointing": bool(args.recompute),
                        "optimizer_in_step": False,  # metric = fwd+bwd; AdamW state (299 GB fp32) only exists sharded over >= 2 GPUs
                        "loss": round(float(loss), 4)},
             "roofline": {"kernel": {1: "gemm_kernel", 2: "gemm2_kernel", 3: "gemm3_kernel"}.get(timed_grouped_gemm.variant, "gemm?_kernel")
