@@ -71,12 +71,9 @@ def inference(image_path: str, prompt: str, model, processor, max_image_size: in
 
 def main(argv=None):
     args = parse_arguments(argv)
-    from transformers import AutoTokenizer
+    from .processing import AriaProcessor
 
-    from .processing import AriaProcessor, AriaVisionProcessor
-
-    tokenizer = AutoTokenizer.from_pretrained(args.tokenizer_path, use_fast=False)
-    processor = AriaProcessor(tokenizer=tokenizer, image_processor=AriaVisionProcessor(max_image_size=args.max_image_size))
+    processor = AriaProcessor.from_pretrained(args.base_model_path, tokenizer_path=args.tokenizer_path)   # aria/inference.py:137-139
     model = load_model(args.base_model_path, args.peft_model_path)
     print(inference(args.image_path, args.prompt, model, processor, args.max_image_size, args.split_image, args.max_new_tokens, args.temperature))
 

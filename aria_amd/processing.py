@@ -83,6 +83,36 @@ class AriaVisionProcessor:
         self.image_std = list(image_std)
         self.model_input_names = ["pixel_values"]
 
+    # ---- preprocessor_config.json (BaseImageProcessor.save_pretrained / from_pretrained layout: a flat JSON of the constructor fields)
+    def to_dict(self) -> Dict:
+        return {"image_processor_type": "AriaVisionProcessor", "max_image_size": self.max_image_size, "min_image_size": self.min_image_size,
+                "image_mean": list(self.image_mean), "image_std": list(self.image_std)}
+
+    def save_pretrained(self, save_directory: str) -> str:
+        import json
+        import os
+
+        os.makedirs(save_directory, exist_ok=True)
+        path = os.path.join(save_directory, "preprocessor_config.json")
+        with open(path, "w") as f:
+            json.dump(self.to_dict(), f, indent=2)
+        return path
+
+    @classmethod
+    def from_pretrained(cls, path: str) -> "AriaVisionProcessor":
+        """``path``: a checkpoint directory (or the JSON file itself); a directory without the file gives the defaults, like the hub
+        checkpoint whose config only names the class."""
+        import json
+        import os
+
+        file = os.path.join(path, "preprocessor_config.json") if os.path.isdir(path) else path
+        raw = {}
+        if os.path.exists(file):
+            with open(file) as f:
+                raw = json.load(f)
+        keys = ("max_image_size", "min_image_size", "image_mean", "image_std")
+        return cls(**{k: raw[k] for k in keys if k in raw})
+
     def _to_normalized_tensor(self, img: Image.Image) -> torch.Tensor:
         # torchvision ToTensor (uint8 HWC -> float CHW / 255) followed by Normalize ((x - mean) / std), both in fp32
         x = torch.from_numpy(np.array(img, dtype=np.uint8, copy=True)).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
@@ -180,6 +210,31 @@ class AriaProcessor:
                                      max_length=max_length)
         batch = {**text_inputs, **image_inputs}
         return (batch, prompts) if return_final_prompts else batch
+
+    def save_pretrained(self, save_directory: str, **kwargs) -> None:
+        """processing_aria.py:216-229: the image processor's config and the tokenizer files side by side."""
+        if self.image_processor is not None:
+            self.image_processor.save_pretrained(save_directory)
+        if self.tokenizer is not None and hasattr(self.tokenizer, "save_pretrained"):
+            self.tokenizer.save_pretrained(save_directory)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, tokenizer_path: Optional[str] = None,
+                        image_processor_path: Optional[str] = None, **kwargs) -> "AriaProcessor":
+        """processing_aria.py:231-275 for LOCAL directories (no hub access): image processor from ``preprocessor_config.json``, tokenizer
+        through ``AutoTokenizer`` (slow tokenizer, like the reference); a tokenizer that fails to load leaves ``tokenizer = None``."""
+        image_processor = AriaVisionProcessor.from_pretrained(image_processor_path or pretrained_model_name_or_path)
+        tokenizer = chat_template = None
+        try:
+            from transformers import AutoTokenizer
+
+            tokenizer = AutoTokenizer.from_pretrained(tokenizer_path or pretrained_model_name_or_path, use_fast=False)
+            chat_template = getattr(tokenizer, "chat_template", None)
+        except Exception as e:  # same behaviour as the reference: warn and go on without a tokenizer
+            import warnings
+
+            warnings.warn(f"Failed to load tokenizer from {tokenizer_path or pretrained_model_name_or_path}: {e}")
+        return cls(image_processor=image_processor, tokenizer=tokenizer, chat_template=chat_template)
 
     def batch_decode(self, *args, **kwargs):
         if self.tokenizer is None:

@@ -219,12 +219,6 @@ def real_batches(cfg, acfg, device, rank, world, tokenizer=None, rows=None, skip
     from .data import batches, mix_datasets
     from .processing import AriaVisionProcessor, collate_fn
 
-    if tokenizer is None:
-        from transformers import AutoTokenizer
-
-        tokenizer = AutoTokenizer.from_pretrained(str(cfg.get("tokenizer_path") or cfg["model_name_or_path"]), use_fast=False)
-    if getattr(tokenizer, "pad_token", None) is None:
-        tokenizer.pad_token = tokenizer.unk_token
     rows = mix_datasets(cfg["dataset_mixer"])["train"] if rows is None else rows
 
     class SizedProcessor(AriaVisionProcessor):
@@ -281,6 +275,13 @@ def main(argv=None, tokenizer=None):
     if use_real:
         from .data import mix_datasets
 
+        if tokenizer is None:
+            from transformers import AutoTokenizer
+
+            tokenizer = AutoTokenizer.from_pretrained(str(cfg.get("tokenizer_path") or cfg["model_name_or_path"]), use_fast=False)
+        if getattr(tokenizer, "pad_token", None) is None:
+            tokenizer.pad_token = tokenizer.unk_token        # aria/train.py:226-227
+
         rows = mix_datasets(cfg["dataset_mixer"])["train"]
         steps_per_epoch = max(1, len(rows) // world // int(cfg["per_device_train_batch_size"]) // accum)
         if total <= 0:  # epochs: optimizer steps = batches per rank // accumulation
@@ -327,6 +328,11 @@ def main(argv=None, tokenizer=None):
                   flush=True)
     if cfg.get("save_final", not cfg["tiny"]):  # written by rank 0: every rank holds the full updated bf16 weights (ShardedAdamW all-gathers)
         save_output(model, cfg)
+        if rank == 0 and use_real:  # processor.save_pretrained(output_dir), aria/train.py:247: image-processor config + tokenizer files
+            from .processing import AriaProcessor, AriaVisionProcessor
+
+            AriaProcessor(image_processor=AriaVisionProcessor(max_image_size=int(cfg["max_image_size"])), tokenizer=tokenizer).save_pretrained(
+                str(cfg["output_dir"]))
     if world > 1:
         import torch.distributed as dist
 

@@ -85,7 +85,8 @@ def test_finetune_on_a_local_dataset(tmp_path):
     try:
         hist = main(["--tiny", "per_device_train_batch_size=1", "gradient_accumulation_steps=1", "max_seq_length=400", "max_image_size=490",
                      "num_train_epochs=1", "max_steps=0", "learning_rate=1e-2", "weight_decay=0.0", "warmup_ratio=0.0", "logging_steps=100",
-                     "tiny_image_size=490", f"image_token_index={StubTokenizer.SPECIAL.index('<|img|>')}", f'dataset_mixer={{"{root}": 1}}'], tokenizer=tok)
+                     "tiny_image_size=490", "save_final=true", f"output_dir={tmp_path / 'out'}", f"image_token_index={StubTokenizer.SPECIAL.index('<|img|>')}", f'dataset_mixer={{"{root}": 1}}'], tokenizer=tok)
     finally:
         emu_lib.uninstall()
+    assert (tmp_path / "out" / "config.json").exists() and json.load(open(tmp_path / "out" / "preprocessor_config.json"))["max_image_size"] == 490
     assert len(hist) == 2 and all(np.isfinite(hist))        # 2 rows / batch 1 = 2 optimizer steps in one epoch

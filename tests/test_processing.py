@@ -201,3 +201,26 @@ def test_processor_output_feeds_the_model_end_to_end():
         assert out.logits.shape == (1, inputs["input_ids"].shape[1], 512) and bool(torch.isfinite(out.logits.float()).all())
     finally:
         emu_lib.uninstall()
+
+
+def test_processor_save_and_load_round_trip(tmp_path):
+    """processing_aria.py:216-275: preprocessor_config.json next to the tokenizer files; a directory without either gives the default
+    image processor and (like the reference) no tokenizer."""
+    vp = P.AriaVisionProcessor(max_image_size=490, min_image_size=300, image_mean=(0.4, 0.5, 0.6), image_std=(0.2, 0.3, 0.4))
+    saved = []
+
+    class Tk(StubTokenizer):
+        def save_pretrained(self, d):
+            saved.append(d)
+
+    P.AriaProcessor(image_processor=vp, tokenizer=Tk()).save_pretrained(str(tmp_path))
+    assert saved == [str(tmp_path)] and (tmp_path / "preprocessor_config.json").exists()
+    back = P.AriaVisionProcessor.from_pretrained(str(tmp_path))
+    assert back.to_dict() == vp.to_dict()
+    img = make_images()[3]
+    a, b = vp([img]), back([img], max_image_size=None)
+    assert torch.equal(a["pixel_values"], vp([img], max_image_size=980)["pixel_values"]) and b["pixel_values"].shape[-1] == 490
+    with pytest.warns(UserWarning):
+        proc = P.AriaProcessor.from_pretrained(str(tmp_path))          # no tokenizer files there
+    assert proc.tokenizer is None and proc.image_processor.max_image_size == 490
+    assert P.AriaVisionProcessor.from_pretrained(str(tmp_path / "empty")).to_dict() == P.AriaVisionProcessor().to_dict()
