@@ -144,6 +144,52 @@ def load_checkpoint_dir(path: str) -> Dict[str, torch.Tensor]:
     raise FileNotFoundError(f"no checkpoint index or weight file under {path}")
 
 
+def iter_checkpoint_shards(path: str):
+    """The same files as :func:`load_checkpoint_dir`, one state-dict shard at a time (a 25 B-parameter checkpoint is ~50 GB: the loader
+    below never holds more than one shard on the host)."""
+    def read(file):
+        if file.endswith(".safetensors"):
+            from safetensors.torch import load_file
+
+            return load_file(file, device="cpu")
+        return torch.load(file, map_location="cpu", mmap=True, weights_only=True)
+
+    for index in ("model.safetensors.index.json", "pytorch_model.bin.index.json"):
+        ipath = os.path.join(path, index)
+        if os.path.exists(ipath):
+            with open(ipath) as f:
+                files = sorted(set(json.load(f)["weight_map"].values()))
+            for name in files:
+                yield read(os.path.join(path, name))
+            return
+    for single in ("model.safetensors", "pytorch_model.bin", "model.pth"):
+        if os.path.exists(os.path.join(path, single)):
+            yield read(os.path.join(path, single))
+            return
+    raise FileNotFoundError(f"no checkpoint index or weight file under {path}")
+
+
+def load_hf_dir_into(model: torch.nn.Module, path: str, strict: bool = True):
+    """:func:`load_hf_into` shard by shard.  Returns (missing, unexpected)."""
+    own = model.state_dict()
+    seen, unexpected = set(), []
+    with torch.no_grad():
+        for shard in iter_checkpoint_shards(path):
+            for k, v in shard.items():
+                if k in own:
+                    if own[k].shape != v.shape:
+                        raise ValueError(f"{k}: checkpoint {tuple(v.shape)} vs module {tuple(own[k].shape)}")
+                    own[k].copy_(v.to(own[k].dtype))
+                    seen.add(k)
+                elif not k.endswith("rotary_emb.inv_freq"):
+                    unexpected.append(k)
+            del shard
+    missing = [k for k in own if k not in seen]
+    if strict and (missing or unexpected):
+        raise KeyError(f"load_hf_dir_into: missing {missing[:4]} unexpected {unexpected[:4]}")
+    return missing, unexpected
+
+
 def save_checkpoint_dir(sd: Dict[str, torch.Tensor], path: str, max_shard_bytes: int = 5 << 30) -> None:
     """Sharded safetensors + index in the HF convention (``model-0000k-of-0000n.safetensors``, ``metadata.total_size``)."""
     from safetensors.torch import save_file

@@ -113,7 +113,7 @@ class AriaForConditionalGeneration(nn.Module):
         import json
         import os
 
-        from .checkpoint import load_checkpoint_dir, load_hf_into
+        from .checkpoint import load_hf_dir_into
 
         with open(os.path.join(path, "config.json")) as f:
             raw = json.load(f)
@@ -125,7 +125,7 @@ class AriaForConditionalGeneration(nn.Module):
             model = cls(config)
         finally:
             torch.set_default_device(prev if prev is not None else "cpu")
-        load_hf_into(model, load_checkpoint_dir(path), strict=strict)
+        load_hf_dir_into(model, path, strict=strict)  # shard by shard: the host never holds the whole checkpoint
         return model.eval()
 
     def save_pretrained(self, path: str, max_shard_bytes: int = 5 << 30, state_dict: Optional[dict] = None) -> None:

@@ -85,9 +85,9 @@ def build_model(cfg, device):
                 p.normal_(0.0, 0.02, generator=g)
     path = cfg.get("model_name_or_path")
     if path and os.path.isdir(str(path)):  # HF checkpoint directory (sharded safetensors / bin + index), reference key names
-        from .checkpoint import load_checkpoint_dir, load_hf_into
+        from .checkpoint import load_hf_dir_into
 
-        load_hf_into(model, load_checkpoint_dir(str(path)), strict=False)
+        load_hf_dir_into(model, str(path), strict=False)
     elif path and os.path.isfile(str(path)):
         sd = torch.load(path, map_location="cpu")
         own = model.state_dict()

@@ -94,3 +94,28 @@ def test_save_and_from_pretrained_round_trip(tmp_path):
     assert again.config.image_token_index == 7 and again.config.projector_patch_to_query_dict == {4: 2}
     assert again.config.text_config.moe_num_experts == 4 and again.config.vision_config.image_size == 28
     assert again.config.text_config.max_position_embeddings == 128
+
+
+def test_sharded_directory_streams_shard_by_shard(tmp_path):
+    """load_hf_dir_into = load_hf_into over iter_checkpoint_shards: same result as loading the whole directory, shape / strictness checks
+    included (from_pretrained of a ~50 GB checkpoint never holds more than one shard on the host)."""
+    import torch
+    from torch import nn
+
+    from aria_amd import checkpoint as C
+
+    torch.manual_seed(0)
+    src = nn.Sequential(nn.Linear(8, 16), nn.Linear(16, 4))
+    sd = {k: v.detach().clone() for k, v in src.state_dict().items()}
+    C.save_checkpoint_dir(sd, str(tmp_path), max_shard_bytes=300)          # forces several shards
+    shards = list(C.iter_checkpoint_shards(str(tmp_path)))
+    assert len(shards) >= 3 and sorted(k for s in shards for k in s) == sorted(sd)
+    dst = nn.Sequential(nn.Linear(8, 16), nn.Linear(16, 4))
+    assert C.load_hf_dir_into(dst, str(tmp_path)) == ([], [])
+    assert all(torch.equal(a, b) for a, b in zip(dst.state_dict().values(), src.state_dict().values()))
+    import pytest
+
+    with pytest.raises(KeyError):
+        C.load_hf_dir_into(nn.Sequential(nn.Linear(8, 16)), str(tmp_path))             # unexpected keys, strict
+    with pytest.raises(ValueError):
+        C.load_hf_dir_into(nn.Sequential(nn.Linear(8, 16), nn.Linear(16, 5)), str(tmp_path))   # shape mismatch
