@@ -176,6 +176,10 @@ class AriaForConditionalGeneration(nn.Module):
         finally:
             torch.set_default_device(prev if prev is not None else "cpu")
         sd = {k: p.detach() for k, p in self.state_dict().items()}
+        if any(".lora_" in k or ".base_layer." in k for k in sd):
+            raise RuntimeError("to_gptfast()/generate(): LoRA adapters are still attached -- fold them in first (aria_amd.lora.merge_and_unload)")
+        if self.expert_parallel_group()[1]:
+            raise RuntimeError("to_gptfast()/generate(): the experts are sharded over ranks -- generate from a checkpoint (full_state_dict / save_pretrained)")
         conv = hf_to_gptfast(sd, t.num_attention_heads, t.head_dim, t.num_key_value_heads)
         G.load_model_pth(twin, conv, strict=True)
         twin.vision_tower, twin.multi_modal_projector = self.vision_tower, self.multi_modal_projector  # share, do not copy
