@@ -1,0 +1,41 @@
+"""Property-based sweeps (hypothesis, bounded and derandomized: the same examples every run) of the index-heavy kernels through the SIMT
+emulator: shapes the fixed parametrisations do not hit -- T = 1, k = E, experts without rows, ragged widths -- for the router (bit-exact
+indices under the tie protocol), the dispatcher (stable order, permute / unpermute bit-exact) and the grouped GEMM family."""
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from tests import kernel_cases as C
+
+DEV = "cpu"
+COMMON = dict(deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emu():
+    from tests.emu import emu_lib
+
+    emu_lib.install()
+    yield
+    emu_lib.uninstall()
+
+
+@settings(max_examples=25, **COMMON)
+@given(T=st.integers(1, 300), E=st.sampled_from([2, 4, 8, 16, 64, 96, 200]), kfrac=st.floats(0.0, 1.0), f32=st.booleans())
+def test_route_any_shape(T, E, kfrac, f32):
+    k = max(1, min(8, E, int(round(kfrac * min(8, E)))))
+    C.case_route(DEV, T, max(E, 4), k, torch.float32 if f32 else torch.bfloat16, exact=True)   # (the case forces ties through columns 1 and 3)
+
+
+@settings(max_examples=20, **COMMON)
+@given(T=st.integers(1, 260), E=st.sampled_from([2, 4, 8, 64]), k=st.integers(1, 6), D8=st.integers(1, 20))
+def test_dispatch_any_shape(T, E, k, D8):
+    C.case_dispatch(DEV, T, E, min(k, E), exact=True, D=8 * D8)
+
+
+@settings(max_examples=12, **COMMON)
+@given(counts=st.lists(st.one_of(st.just(0), st.integers(0, 70), st.integers(120, 300)), min_size=1, max_size=9),
+       K8=st.integers(1, 12), N8=st.integers(1, 20))
+def test_grouped_gemm_any_counts(counts, K8, N8):
+    C.case_grouped_gemm(DEV, counts, K=8 * K8, N=8 * N8)
