@@ -337,8 +337,17 @@ class MoEDecoderLayer(nn.Module):
         if self.mlp.ep_enabled or self.mlp.has_adapter() or not _plain_linears(a.q_proj, a.k_proj, a.v_proj, a.o_proj):
             # an adapter (aria_amd/lora.py) wraps a GEMM of this layer, or the experts are sharded over ranks (an all-to-all sits inside
             # the MoE block): LlamaDecoderLayer.forward module by module (modeling_llama.py:295-325)
-            h = hidden_states + self.self_attn(self.input_layernorm(hidden_states), cos, sin, kv_len)
-            return h + self.mlp(self.post_attention_layernorm(h))
+            def block(x):
+                h = x + self.self_attn(self.input_layernorm(x), cos, sin, kv_len)
+                return h + self.mlp(self.post_attention_layernorm(h))
+
+            if self.config.gradient_checkpointing and self.training and torch.is_grad_enabled() and not self.mlp.ep_enabled:
+                # the recipe's gradient_checkpointing for the module-by-module form (the fused node has its own recompute flag); not with
+                # sharded experts: a recomputed forward would issue its all-to-alls a second time, out of step with the other ranks' backward
+                from torch.utils.checkpoint import checkpoint
+
+                return checkpoint(block, hidden_states, use_reentrant=False)
+            return block(hidden_states)
         x = hidden_states.reshape(B * S, D)
         x = x if x.is_contiguous() else x.contiguous()
         recompute = bool(self.config.gradient_checkpointing and self.training and torch.is_grad_enabled())

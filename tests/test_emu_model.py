@@ -87,3 +87,33 @@ def test_seam_attention_interface_native_hd72_without_grad():
     sc = sc.masked_fill(~mask[:, None, None, :], float("-inf"))
     want = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc, -1), v.float())
     M.rel_close(out, want, 2e-2, "hd 72 attention through the seam")
+
+
+def test_adapted_decoder_layer_with_gradient_checkpointing():
+    """recipes/config_lora.yaml runs with gradient_checkpointing: the module-by-module decoder layer recomputed in backward gives the same
+    loss and the same LoRA gradients as the stored-activation run (dropout off: bit-identical)."""
+    from aria_amd.lora import apply_lora_from_config
+    from aria_amd.moe_lm import AriaMoELMForCausalLM
+
+    d = dict(hidden_size=64, num_attention_heads=1, num_key_value_heads=1, num_hidden_layers=2, vocab_size=96, moe_intermediate_size=32,
+             moe_num_experts=8, moe_topk=2, moe_num_shared_experts=2)
+    results = []
+    for ckpt in (False, True):
+        torch.manual_seed(3)
+        lm = AriaMoELMForCausalLM(M.make_cfg(d, gradient_checkpointing=ckpt))
+        with torch.no_grad():
+            for n, p in lm.named_parameters():
+                p.copy_(torch.ones(p.shape) if "norm" in n else (torch.randn(p.shape) * 0.08).to(torch.bfloat16))
+        apply_lora_from_config(lm, dict(lora_r=8, lora_alpha=16, lora_target_modules=["fc1", "q_proj", "down_proj"]))
+        with torch.no_grad():
+            for n, p in lm.named_parameters():
+                if "lora_B" in n:
+                    p.copy_((torch.randn(p.shape) * 0.05).to(torch.bfloat16))
+        lm.train()
+        ids = torch.randint(1, 96, (2, 17), generator=torch.Generator().manual_seed(1))
+        out = lm(input_ids=ids, labels=ids)
+        out.loss.backward()
+        results.append((out.loss.detach().clone(), {n: p.grad.clone() for n, p in lm.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = results
+    assert torch.equal(l0, l1) and set(g0) == set(g1) and len(g0) >= 10
+    assert all(torch.equal(g0[n], g1[n]) for n in g0)
