@@ -23,7 +23,8 @@ def close(got, want, rtol=2e-2, atol=2e-2):
     assert got.shape == want.shape, (got.shape, want.shape)
     err = (got - want).abs()
     tol = atol + rtol * want.abs()
-    assert bool((err <= tol).all()), f"max err {err.max().item():.4g} (tol there {tol.flatten()[err.argmax()].item():.3g})"
+    worst = (err - tol).flatten().argmax()  # the element that exceeds its own tolerance the most (not simply the largest error)
+    assert bool((err <= tol).all()), f"err {err.flatten()[worst].item():.4g} > tol {tol.flatten()[worst].item():.3g} (max err {err.max().item():.4g})"
 
 
 def same(got, want, exact):
