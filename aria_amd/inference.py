@@ -45,28 +45,16 @@ def prepare_input(image_path: str, prompt: str, processor, max_image_size: int, 
     return processor(text=text, images=image, return_tensors="pt", max_image_size=max_image_size, split_image=split_image)
 
 
-def stop_token_id(tokenizer, text: str = "<|im_end|>"):
-    """the id ``stop_strings=["<|im_end|>"]`` (aria/inference.py:118) amounts to: <|im_end|> is one token in Aria's vocabulary"""
-    if hasattr(tokenizer, "convert_tokens_to_ids"):
-        i = tokenizer.convert_tokens_to_ids(text)
-        if isinstance(i, int) and i >= 0 and i != getattr(tokenizer, "unk_token_id", None):
-            return i
-    try:
-        ids = tokenizer.encode(text, add_special_tokens=False)
-    except TypeError:
-        ids = tokenizer.encode(text)
-    return int(ids[0]) if len(ids) == 1 else None
-
-
 def inference(image_path: str, prompt: str, model, processor, max_image_size: int = 980, split_image: bool = False, max_new_tokens: int = 500,
               temperature: float = 0.9) -> str:
+    """aria/inference.py:101-131, call for call (the README quick start's generate arguments)."""
     inputs = prepare_input(image_path, prompt, processor, max_image_size, split_image)
-    dev = model.language_model.lm_head.weight.device
-    ids = inputs["input_ids"].to(dev)
-    out = model.generate(ids, inputs["pixel_values"].to(dev).to(torch.bfloat16), inputs["pixel_mask"].to(dev), max_new_tokens=max_new_tokens,
-                         temperature=temperature, stop_token=stop_token_id(processor.tokenizer))
-    new = out[ids.shape[1]:]
-    return processor.tokenizer.decode(new.tolist(), skip_special_tokens=True).replace("<|im_end|>", "")
+    inputs["pixel_values"] = inputs["pixel_values"].to(model.dtype)
+    inputs = {k: v.to(model.device) for k, v in inputs.items()}
+    output = model.generate(**inputs, max_new_tokens=max_new_tokens, stop_strings=["<|im_end|>"], tokenizer=processor.tokenizer, do_sample=True,
+                            temperature=temperature)
+    prompt_len = inputs["input_ids"].shape[1]
+    return processor.tokenizer.decode(output[0][prompt_len:].tolist(), skip_special_tokens=True).replace("<|im_end|>", "")
 
 
 def main(argv=None):

@@ -185,21 +185,59 @@ class AriaForConditionalGeneration(nn.Module):
         twin.vision_tower, twin.multi_modal_projector = self.vision_tower, self.multi_modal_projector  # share, do not copy
         return twin.eval()
 
+    @property
+    def device(self) -> torch.device:
+        return self.language_model.lm_head.weight.device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.language_model.lm_head.weight.dtype
+
     @torch.no_grad()
-    def generate(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor] = None, pixel_mask: Optional[torch.Tensor] = None,
-                 max_new_tokens: int = 128, temperature: float = 0.8, top_k: Optional[int] = 200, stop_token: Optional[int] = None,
-                 refresh: bool = False) -> torch.Tensor:
-        """Sampling loop of gptfast/generate.py:112-177 on the gptfast twin (built on first use; ``refresh=True`` rebuilds it after
-        the weights changed).  input_ids [1, T] -> 1-D tensor prompt + new tokens."""
+    def generate(self, input_ids: torch.Tensor = None, pixel_values: Optional[torch.Tensor] = None, pixel_mask: Optional[torch.Tensor] = None,
+                 attention_mask: Optional[torch.Tensor] = None, max_new_tokens: int = 128, do_sample: bool = True, temperature: float = 0.8,
+                 top_k: Optional[int] = 200, stop_strings=None, tokenizer=None, stop_token: Optional[int] = None, refresh: bool = False,
+                 **unused) -> torch.Tensor:
+        """The README quick start's call (README.md:45-88: ``model.generate(**inputs, max_new_tokens=..., stop_strings=["<|im_end|>"],
+        tokenizer=processor.tokenizer, do_sample=True, temperature=0.9)``) for batch 1, served by the sampling loop of
+        gptfast/generate.py:112-177 on the gptfast twin (built on first use; ``refresh=True`` rebuilds it after the weights changed).
+        input_ids [1, T] -> [1, T + new] like HF (prompt included).  ``do_sample=False`` is greedy; a stop string that is a single token of
+        ``tokenizer`` is compared on the device, longer ones through the reference's decode-and-compare hook; ``attention_mask`` of a single
+        unpadded sequence carries no information and is ignored."""
         from . import gptfast as G
 
+        if input_ids is None or input_ids.dim() != 2 or input_ids.shape[0] != 1:
+            raise NotImplementedError("generate(): batch 1 (the gptfast decode path); input_ids [1, T]")
+        if attention_mask is not None and not bool(attention_mask.ne(0).all()):
+            raise NotImplementedError("generate(): padded prompts are not supported (batch 1 has nothing to pad)")
         if refresh or getattr(self, "_gptfast_twin", None) is None:
             object.__setattr__(self, "_gptfast_twin", self.to_gptfast())
             object.__setattr__(self, "_gptfast_decoder", None)
+        if not do_sample:
+            temperature, top_k = 1.0, 1
+        callback = None
+        if stop_strings:
+            if tokenizer is None:
+                raise ValueError("generate(stop_strings=...) needs tokenizer=... (like HF's)")
+            multi = []
+            for text in stop_strings:
+                ids = tokenizer.encode(text, add_special_tokens=False) if hasattr(tokenizer, "convert_tokens_to_ids") else tokenizer.encode(text)
+                if len(ids) == 1 and stop_token is None:
+                    stop_token = int(ids[0])
+                else:
+                    multi.append(text)
+            if multi:
+                def callback(tokens):
+                    decoded = tokenizer.decode(torch.cat(tokens).tolist())
+                    return any(decoded.endswith(t) for t in multi)
+        key = (float(temperature), top_k)
+        if getattr(self, "_gptfast_sampling", key) != key:  # the cached decoder closes over its sampling parameters
+            object.__setattr__(self, "_gptfast_decoder", None)
+        object.__setattr__(self, "_gptfast_sampling", key)
         out, dec = G.generate(self._gptfast_twin, input_ids, max_new_tokens, pixel_values=pixel_values, pixel_mask=pixel_mask,
-                              temperature=temperature, top_k=top_k, decoder=self._gptfast_decoder, stop_token=stop_token)
+                              temperature=temperature, top_k=top_k, decoder=self._gptfast_decoder, stop_token=stop_token, callback=callback)
         object.__setattr__(self, "_gptfast_decoder", dec)
-        return out
+        return out.view(1, -1)
 
     def image_features(self, pixel_values: torch.Tensor, pixel_mask: Optional[torch.Tensor]) -> torch.Tensor:
         feat, atts = self.vision_tower(pixel_values, pixel_mask)

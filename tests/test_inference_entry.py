@@ -43,7 +43,6 @@ def test_inference_script_pieces(tmp_path):
     assert args.max_image_size == 980 and args.split_image and args.peft_model_path is None   # aria/inference.py:30-52 flags / defaults
     tok = Tok()
     img_id, end_id = Tok.SPECIAL.index("<|img|>"), Tok.SPECIAL.index("<|im_end|>")
-    assert I.stop_token_id(tok) == end_id
     cfg = AriaConfig(vision_config=dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=64, image_size=490),
                      text_config=dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=1, vocab_size=512, moe_intermediate_size=16,
                                       moe_num_experts=8, moe_topk=2, max_position_embeddings=512),
