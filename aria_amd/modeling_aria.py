@@ -96,6 +96,16 @@ class AriaForConditionalGeneration(nn.Module):
             sd[k] = torch.cat(parts, dim=0)
         return sd
 
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None) -> None:
+        """HF's switch (the Trainer calls it for ``gradient_checkpointing: true``): per-layer recompute in the decoder."""
+        self.config.text_config.gradient_checkpointing = True
+
+    def gradient_checkpointing_disable(self) -> None:
+        self.config.text_config.gradient_checkpointing = False
+
+    def num_parameters(self, only_trainable: bool = False) -> int:
+        return sum(p.numel() for p in self.parameters() if p.requires_grad or not only_trainable)
+
     def get_input_embeddings(self):
         return self.language_model.get_input_embeddings()
 
