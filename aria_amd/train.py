@@ -147,7 +147,8 @@ def save_checkpoint(model, opt, cfg, step: int, history, rank: int, world: int) 
     if rank == 0:
         with open(os.path.join(path, "trainer_state.json"), "w") as f:
             json.dump({"global_step": step, "world_size": world, "log_history": [float(x) for x in history]}, f)
-    torch.save(opt.state_dict(), os.path.join(path, f"optimizer_rank{rank}.pt"))
+    torch.save({**opt.state_dict(), "log_history": [float(x) for x in history]},   # (each rank logs the loss of ITS micro-batches)
+               os.path.join(path, f"optimizer_rank{rank}.pt"))
     if world > 1:
         import torch.distributed as dist
 
@@ -190,8 +191,9 @@ def load_checkpoint(model, opt, path: str, cfg, rank: int, world: int):
                 per = sd[k].shape[0] // world
                 sd[k] = sd[k][rank * per:(rank + 1) * per]
         load_hf_into(model, sd, strict=True)
-    opt.load_state_dict(torch.load(os.path.join(path, f"optimizer_rank{rank}.pt"), map_location="cpu"))
-    return int(state["global_step"]), list(state["log_history"])
+    shard = torch.load(os.path.join(path, f"optimizer_rank{rank}.pt"), map_location="cpu")
+    opt.load_state_dict(shard)
+    return int(state["global_step"]), list(shard.get("log_history", state["log_history"]))
 
 
 def synthetic_batch(cfg, acfg, device, gen):
