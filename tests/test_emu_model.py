@@ -117,3 +117,9 @@ def test_adapted_decoder_layer_with_gradient_checkpointing():
     (l0, g0), (l1, g1) = results
     assert torch.equal(l0, l1) and set(g0) == set(g1) and len(g0) >= 10
     assert all(torch.equal(g0[n], g1[n]) for n in g0)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("ARIA_SLOW_TESTS") != "1", reason="~3 min through the emulator (130 M multiply-adds per token "
+                    "at Aria's widths); runs on hardware in tests/test_gpu_model.py, and here with ARIA_SLOW_TESTS=1")
+def test_decode_engine_aria_width():
+    M.case_decode_engine_aria_width(DEV, n_tokens=3)

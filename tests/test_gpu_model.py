@@ -51,5 +51,9 @@ def test_decode_engine_reference_golden(golden):
     M.case_decode_engine_reference_golden(DEV, golden)
 
 
+def test_decode_engine_aria_width():  # the decode kernels' Aria-width instantiations against the fp32 oracle (passes through the emulator too)
+    M.case_decode_engine_aria_width(DEV, n_tokens=6)
+
+
 def test_lora_linear_lm():  # last on purpose: newest composition of already-covered kernels
     M.case_lora_linear_lm(DEV)
