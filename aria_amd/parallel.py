@@ -37,6 +37,15 @@ class GradSync:
         self._hooks = []
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         self._avg = dist.ReduceOp.AVG if backend == "nccl" else None
+        if self._avg is not None and self.world > 1:
+            # probe once (every rank alike): a collective library without an averaging reduction for bf16 falls back to SUM + scale
+            try:
+                probe = torch.ones(2, dtype=torch.bfloat16, device=next(module.parameters()).device)
+                dist.all_reduce(probe, op=self._avg, group=process_group)
+                if abs(float(probe[0]) - 1.0) > 1e-3:
+                    raise RuntimeError("averaging all-reduce returned a wrong value")
+            except Exception:
+                self._avg = None
         if self.world > 1:
             for p in module.parameters():
                 if not p.requires_grad:
