@@ -21,7 +21,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver); before the HIP runtime starts
+
+import torch  # noqa: E402
 
 
 def load_config(argv):
