@@ -19,7 +19,6 @@ import torch.nn as nn
 
 from . import functional as Fn
 from . import hip, ops
-from .modeling_aria import AriaConfig
 from .vision import AriaProjector, AriaVisionConfig, AriaVisionModel
 
 bf16 = torch.bfloat16

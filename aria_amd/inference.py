@@ -7,8 +7,6 @@ from __future__ import annotations
 
 import argparse
 
-import torch
-
 
 def parse_arguments(argv=None):
     parser = argparse.ArgumentParser(description="Aria inference on MI355X")

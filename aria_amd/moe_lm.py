@@ -9,7 +9,7 @@ This is host-side glue only.  There is no PyTorch fallback: on a machine without
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 import torch.nn as nn

@@ -18,7 +18,6 @@ from typing import Optional
 
 import torch
 
-from . import ops
 from .autograd import _c, experts_gemm, sdpa
 
 bf16 = torch.bfloat16
