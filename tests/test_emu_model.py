@@ -36,6 +36,15 @@ def test_aria_full_golden(golden):
     M.case_aria_full_golden(DEV, golden)
 
 
+def test_lm_head_over_labelled_rows_only(golden, monkeypatch):
+    """ARIA_LMHEAD_SKIP_MASKED=1: the lm_head GEMMs and the CE run over the positions that carry a label only (row gather / scatter, row
+    count padded to 8) -- the full model's loss and gradients against the reference fixture are unchanged (labels of the fixture mask the
+    prompt and the padding)."""
+    monkeypatch.setenv("ARIA_LMHEAD_SKIP_MASKED", "1")
+    M.case_aria_full_golden(DEV, golden)
+    M.case_lm_golden(DEV, golden)
+
+
 def test_gptfast_golden(golden):
     M.case_gptfast_golden(DEV, golden)
 

@@ -6,6 +6,9 @@ next GPU session; flip defaults only for what passes and wins:
 1. parity: tests/kernel_cases.case_decode_attention (aria_decode_attn, split-KV flash-decoding form) on the device;
 2. timing: aria_decode_attn alone, one workgroup per head vs heads x splits, at cache fills 1 K .. 64 K (Aria head shape 20 x 128);
 3. timing: full decode step (random-init Aria-25.3B LLM) at long contexts with ARIA_DECODE_SPLIT_KV unset / 1.
+
+Separately (each is one bench line, ~2.5 min):  python bench.py --steps 3   vs   ARIA_LMHEAD_SKIP_MASKED=1 python bench.py --steps 3
+(lm_head GEMMs + CE over the labelled 25 % of the positions only; expected ~-15 ms per step, loss identical).
 """
 import json
 import os
