@@ -172,7 +172,7 @@ class LMHeadLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hn, lm_w, labels_shifted):
         need = hn.requires_grad or lm_w.requires_grad
-        loss, d_hn, g_w = Fn.lm_head_loss_fwd_bwd(hn, lm_w, labels_shifted, need_grads=need)
+        loss, d_hn, g_w = Fn.lm_head_loss_fwd_bwd(hn, lm_w, labels_shifted, need_grads=need, need_w=ctx.needs_input_grad[1])
         ctx.d_hn, ctx.g_w = d_hn, g_w
         return loss
 

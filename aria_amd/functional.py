@@ -237,7 +237,7 @@ def rope_tables(S: int, head_dim: int, theta: float, device) -> tuple:
 
 
 # ----------------------------------------------------------------------------------------------- LM head + loss
-def lm_head_loss_fwd_bwd(hn, lm_w, labels_shifted, need_grads: bool = True):
+def lm_head_loss_fwd_bwd(hn, lm_w, labels_shifted, need_grads: bool = True, need_w: bool = True):
     """logits = hn @ lm_w^T; masked-mean CE (labels already shifted, -100 = ignore).  The CE kernel overwrites the logits
     with d(loss)/d(logits) (scaled by 1/n_valid on the device: no host sync), so the backward GEMMs can run immediately.
     -> (loss fp32 scalar tensor, d_hn | None, g_lm_w | None)
@@ -246,7 +246,7 @@ def lm_head_loss_fwd_bwd(hn, lm_w, labels_shifted, need_grads: bool = True):
     any gradient, so only the rows with a label go through the [rows, V] GEMMs (an SFT batch masks its prompts: 75 % of the positions
     in the benchmark's batch) -- one host sync for the row count, a row gather before and a row scatter after."""
     if os.environ.get("ARIA_LMHEAD_SKIP_MASKED") == "1":
-        return _lm_head_loss_valid_rows(hn, lm_w, labels_shifted, need_grads)
+        return _lm_head_loss_valid_rows(hn, lm_w, labels_shifted, need_grads, need_w)
     logits = ops.gemm(hn, lm_w)
     count_in = (labels_shifted >= 0).sum(dtype=torch.int32).reshape(1)
     loss_sum, count, _ = ops.cross_entropy(logits, labels_shifted, grad_scale=1.0, dlogits=logits if need_grads else None,
@@ -255,16 +255,16 @@ def lm_head_loss_fwd_bwd(hn, lm_w, labels_shifted, need_grads: bool = True):
     if not need_grads:
         return loss, None, None
     d_hn = ops.gemm(logits, lm_w, b_oc=True)
-    g_w = ops.gemm(logits, hn, a_oc=True, b_oc=True)
+    g_w = ops.gemm(logits, hn, a_oc=True, b_oc=True) if need_w else None   # (a frozen lm_head needs no [V, D] weight gradient)
     return loss, d_hn, g_w
 
 
-def _lm_head_loss_valid_rows(hn, lm_w, labels_shifted, need_grads: bool):
+def _lm_head_loss_valid_rows(hn, lm_w, labels_shifted, need_grads: bool, need_w: bool = True):
     rows = torch.nonzero(labels_shifted >= 0).flatten().to(torch.int32)          # (host sync: the GEMMs' M)
     n = int(rows.numel())
     if n == 0:
         zero = torch.zeros((), dtype=torch.float32, device=hn.device)
-        return zero, (torch.zeros_like(hn) if need_grads else None), (torch.zeros_like(lm_w) if need_grads else None)
+        return zero, (torch.zeros_like(hn) if need_grads else None), (torch.zeros_like(lm_w) if need_grads and need_w else None)
     pad = (-n) % 8                                                                 # the wgrad reads dlogits [rows, V] output-contiguous: rows % 8
     if pad:
         rows = torch.cat([rows, rows[-1:].expand(pad)])
@@ -279,7 +279,7 @@ def _lm_head_loss_valid_rows(hn, lm_w, labels_shifted, need_grads: bool):
     if not need_grads:
         return loss, None, None
     d_hv = ops.gemm(logits, lm_w, b_oc=True)
-    g_w = ops.gemm(logits, hv, a_oc=True, b_oc=True)
+    g_w = ops.gemm(logits, hv, a_oc=True, b_oc=True) if need_w else None
     d_hn = torch.zeros_like(hn)
     d_hn.index_copy_(0, rows[:n].long(), d_hv[:n])                                 # distinct rows: a plain scatter
     return loss, d_hn, g_w

@@ -132,3 +132,29 @@ def test_adapted_decoder_layer_with_gradient_checkpointing():
                     "at Aria's widths); runs on hardware in tests/test_gpu_model.py, and here with ARIA_SLOW_TESTS=1")
 def test_decode_engine_aria_width():
     M.case_decode_engine_aria_width(DEV, n_tokens=3)
+
+
+def test_frozen_lm_head_skips_its_weight_gradient(golden):
+    """freeze_llm-style runs: with lm_head frozen the fused lm_head + CE node still returns the hidden-state gradient but no [V, D] GEMM."""
+    from aria_amd import autograd as AG
+    from aria_amd import ops
+
+    g = golden("lm")
+    V, D = g["weights"]["lm_head.weight"].shape
+    torch.manual_seed(0)
+    hn = (torch.randn(12, D) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    w = g["weights"]["lm_head.weight"].to(torch.bfloat16)
+    labels = torch.randint(0, V, (12,), dtype=torch.int32)
+    calls, inner = [], ops.gemm
+    ops.gemm = lambda a, b, **k: (calls.append((bool(k.get("a_oc")), bool(k.get("b_oc")))), inner(a, b, **k))[1]
+    try:
+        AG.LMHeadLossFn.apply(hn, w.clone().requires_grad_(False), labels).backward()
+        frozen_calls, d_frozen = list(calls), hn.grad.clone()
+        calls.clear()
+        hn.grad = None
+        wt = w.clone().requires_grad_(True)
+        AG.LMHeadLossFn.apply(hn, wt, labels).backward()
+    finally:
+        ops.gemm = inner
+    assert (True, True) not in frozen_calls and (True, True) in calls           # the [V, D] weight-gradient GEMM only when it is wanted
+    assert torch.equal(d_frozen, hn.grad) and wt.grad is not None
