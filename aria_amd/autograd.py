@@ -160,9 +160,10 @@ class DecoderLayerFn(torch.autograd.Function):
         c = ctx.c
         if recompute:
             _, c = Fn.decoder_layer_fwd(x, p, cos, sin, B, S, acfg, mcfg, eps, kv_len, save=True)
-        dx, g = Fn.decoder_layer_bwd(_c(dout), c, p, cos, sin)
+        wanted = {k for k, w in zip(_LAYER_KEYS, ctx.needs_input_grad[10:]) if w}   # frozen parameters: no weight-gradient GEMM
+        dx, g = Fn.decoder_layer_bwd(_c(dout), c, p, cos, sin, None if len(wanted) == len(_LAYER_KEYS) else wanted)
         ctx.c = None
-        return (dx, None, None, None, None, None, None, None, None, None) + tuple(g[k] for k in _LAYER_KEYS)
+        return (dx, None, None, None, None, None, None, None, None, None) + tuple(g[k] if k in wanted else None for k in _LAYER_KEYS)
 
 
 class LMHeadLossFn(torch.autograd.Function):

@@ -81,8 +81,13 @@ def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save: b
     return out, ctx
 
 
-def moe_bwd(dout, ctx, router_w, fc1, fc2, gate_w, up_w, down_w):
-    """-> dx, dict(grads)."""
+def _want(need, *keys) -> bool:
+    """need = None: every weight gradient; else the set of parameter keys whose gradient is wanted (frozen ones are skipped)."""
+    return need is None or any(k in need for k in keys)
+
+
+def moe_bwd(dout, ctx, router_w, fc1, fc2, gate_w, up_w, down_w, need=None):
+    """-> dx, dict(grads); weight gradients of frozen parameters (keys missing from ``need``) are not computed (None)."""
     cfg: MoEConfig = ctx["cfg"]
     k, E = cfg.topk, cfg.num_experts
     x, inv, offsets = ctx["x"], ctx["inv"], ctx["offsets"]
@@ -90,24 +95,26 @@ def moe_bwd(dout, ctx, router_w, fc1, fc2, gate_w, up_w, down_w):
     # routed experts
     d_eo, dscores = ops.moe_unpermute_bwd(dout, ctx["eo"], inv, ctx["scores"], k)
     d_act = ops.grouped_gemm(d_eo, fc2, offsets, w_is_kn=False)
-    g_fc2 = ops.grouped_gemm_wgrad(ctx["act"], d_eo, offsets, E)
+    g_fc2 = ops.grouped_gemm_wgrad(ctx["act"], d_eo, offsets, E) if _want(need, "fc2") else None
     d_h1 = ops.swiglu_bwd(ctx["h1"], d_act)
     d_perm = ops.grouped_gemm(d_h1, fc1, offsets, w_is_kn=False)
-    g_fc1 = ops.grouped_gemm_wgrad(ctx["perm"], d_h1, offsets, E)
+    g_fc1 = ops.grouped_gemm_wgrad(ctx["perm"], d_h1, offsets, E) if _want(need, "fc1") else None
     dx = ops.moe_unpermute(d_perm, inv, None, k)                     # backward of the row gather
     # shared expert
     d_sact = ops.gemm(dout, down_w, b_oc=True)
-    g_down = ops.gemm(dout, ctx["sact"], a_oc=True, b_oc=True)
+    g_down = ops.gemm(dout, ctx["sact"], a_oc=True, b_oc=True) if _want(need, "down") else None
     d_gu = ops.swiglu_bwd(ctx["gu"], d_sact)
     ops.gemm(d_gu, ctx["wgu"], b_oc=True, out=dx, accumulate=True)
     # gate and up weight gradients as ONE wide GEMM ([2*I2, D] = d_gu^T x): 260 tiles of 256x256 instead of 2 x 130
-    g_gu = ops.gemm(d_gu, x, a_oc=True, b_oc=True)
-    g_gate, g_up = g_gu[:I2], g_gu[I2:]
+    g_gate = g_up = None
+    if _want(need, "gate", "up"):
+        g_gu = ops.gemm(d_gu, x, a_oc=True, b_oc=True)
+        g_gate, g_up = g_gu[:I2], g_gu[I2:]
     # router (top-k softmax + z-loss + load-balancing loss gradients)
     dlogits = ops.moe_route_bwd(ctx["logits"], ctx["idx"], ctx["scores"], dscores, ctx["counts"], cfg.z_loss_coeff,
                                 cfg.aux_loss_coeff, cfg.aux_scale)
     ops.gemm(dlogits, router_w, b_oc=True, out=dx, accumulate=True)
-    g_router = ops.gemm(dlogits, x, a_oc=True, b_oc=True)
+    g_router = ops.gemm(dlogits, x, a_oc=True, b_oc=True) if _want(need, "router") else None
     return dx, dict(router=g_router, fc1=g_fc1, fc2=g_fc2, gate=g_gate, up=g_up, down=g_down)
 
 
@@ -185,21 +192,23 @@ def attn_block_fwd(x, wq, wk, wv, wo, cos, sin, B: int, S: int, cfg: AttnConfig,
     return out, ctx
 
 
-def attn_block_bwd(dout, ctx, wq, wk, wv, wo, cos, sin):
+def attn_block_bwd(dout, ctx, wq, wk, wv, wo, cos, sin, need=None):
     cfg: AttnConfig = ctx["cfg"]
     H, hd = cfg.num_heads, cfg.head_dim
     B, S, x, o = ctx["B"], ctx["S"], ctx["x"], ctx["o"]
     T, Dq = x.shape[0], H * hd
     d_o = ops.gemm(dout, wo, b_oc=True)
-    g_wo = ops.gemm(dout, o if o.is_contiguous() else o.contiguous(), a_oc=True, b_oc=True)
+    g_wo = ops.gemm(dout, o if o.is_contiguous() else o.contiguous(), a_oc=True, b_oc=True) if _want(need, "wo") else None
     dqkv = torch.empty((T, 3 * Dq), dtype=bf16, device=x.device)
     sdpa_bwd(d_o, ctx["actx"], B, S, H, hd, hd ** -0.5, cfg.causal, ctx["kv_len"], dq=dqkv[:, :Dq], dk=dqkv[:, Dq:2 * Dq],
              dv=dqkv[:, 2 * Dq:])
     ops.rope_(dqkv[:, :2 * Dq], cos, sin, S, 2 * H, hd, inverse=True)
     dx = ops.gemm(dqkv, ctx["wqkv"], b_oc=True)
     # q, k, v weight gradients as ONE wide GEMM ([3*Dq, D] = dqkv^T x)
-    g_qkv = ops.gemm(dqkv, x, a_oc=True, b_oc=True)
-    g_wq, g_wk, g_wv = g_qkv[:Dq], g_qkv[Dq:2 * Dq], g_qkv[2 * Dq:]
+    g_wq = g_wk = g_wv = None
+    if _want(need, "wq", "wk", "wv"):
+        g_qkv = ops.gemm(dqkv, x, a_oc=True, b_oc=True)
+        g_wq, g_wk, g_wv = g_qkv[:Dq], g_qkv[Dq:2 * Dq], g_qkv[2 * Dq:]
     return dx, dict(q=g_wq, k=g_wk, v=g_wv, o=g_wo)
 
 
@@ -216,10 +225,10 @@ def decoder_layer_fwd(x, p: dict, cos, sin, B: int, S: int, acfg: AttnConfig, mc
     return out, ctx
 
 
-def decoder_layer_bwd(dout, ctx, p: dict, cos, sin):
-    dhn, gm = moe_bwd(dout, ctx["mctx"], p["router"], p["fc1"], p["fc2"], p["gate"], p["up"], p["down"])
+def decoder_layer_bwd(dout, ctx, p: dict, cos, sin, need=None):
+    dhn, gm = moe_bwd(dout, ctx["mctx"], p["router"], p["fc1"], p["fc2"], p["gate"], p["up"], p["down"], need)
     dh, g_ln2 = ops.rmsnorm_bwd(dhn, ctx["h"], p["ln2"], ctx["rstd2"], dres=dout)       # + gradient of the residual stream
-    dxn, ga = attn_block_bwd(dh, ctx["actx"], p["wq"], p["wk"], p["wv"], p["wo"], cos, sin)
+    dxn, ga = attn_block_bwd(dh, ctx["actx"], p["wq"], p["wk"], p["wv"], p["wo"], cos, sin, need)
     dx, g_ln1 = ops.rmsnorm_bwd(dxn, ctx["x"], p["ln1"], ctx["rstd1"], dres=dh)
     grads = dict(ln1=g_ln1, ln2=g_ln2, wq=ga["q"], wk=ga["k"], wv=ga["v"], wo=ga["o"], router=gm["router"], fc1=gm["fc1"],
                  fc2=gm["fc2"], gate=gm["gate"], up=gm["up"], down=gm["down"])

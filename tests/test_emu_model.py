@@ -158,3 +158,49 @@ def test_frozen_lm_head_skips_its_weight_gradient(golden):
         ops.gemm = inner
     assert (True, True) not in frozen_calls and (True, True) in calls           # the [V, D] weight-gradient GEMM only when it is wanted
     assert torch.equal(d_frozen, hn.grad) and wt.grad is not None
+
+
+def test_frozen_parameters_skip_their_weight_gradient_gemms(golden):
+    """freeze_llm_layers / partially frozen runs: the fused decoder-layer backward computes no weight gradient for a frozen parameter, and
+    what it does compute is bit-identical to the all-trainable run."""
+    from aria_amd import ops
+    from aria_amd.moe_lm import AriaMoELMForCausalLM, load_reference_state_dict
+
+    g = golden("lm")
+    ids = g["input_ids"]
+
+    def run(freeze):
+        lm = AriaMoELMForCausalLM(M.make_cfg(g["cfg"]))
+        load_reference_state_dict(lm, g["weights"])
+        lm.train()
+        for n, p in lm.named_parameters():
+            if freeze(n):
+                p.requires_grad_(False)
+        counts = {"wgrad": 0, "gwgrad": 0}
+        inner, ginner = ops.gemm, ops.grouped_gemm_wgrad
+
+        def gemm(a, b, **k):
+            counts["wgrad"] += bool(k.get("a_oc")) and bool(k.get("b_oc"))
+            return inner(a, b, **k)
+
+        def gw(*a, **k):
+            counts["gwgrad"] += 1
+            return ginner(*a, **k)
+
+        ops.gemm, ops.grouped_gemm_wgrad = gemm, gw
+        try:
+            lm(input_ids=ids, labels=ids).loss.backward()
+        finally:
+            ops.gemm, ops.grouped_gemm_wgrad = inner, ginner
+        return {n: (None if p.grad is None else p.grad.clone()) for n, p in lm.named_parameters()}, counts
+
+    full, c_full = run(lambda n: False)
+    frozen = lambda n: n.startswith("model.layers.0.") or n.endswith("layers.1.mlp.experts.fc1.weight") or "layers.1.self_attn.o_proj" in n  # noqa: E731
+    part, c_part = run(frozen)
+    assert c_full["gwgrad"] == 4 and c_part["gwgrad"] == 1                # fc1 + fc2 of two layers  ->  fc2 of layer 1 only
+    assert c_part["wgrad"] <= c_full["wgrad"] - 6                         # layer 0: qkv, o, down, gate/up, router; layer 1: o
+    for n in full:
+        if frozen(n):
+            assert part[n] is None, n
+        else:
+            assert torch.equal(part[n], full[n]), n
