@@ -29,7 +29,7 @@ def _worker(rank, world, port, outdir, ep):
     emu_lib.install()
     from aria_amd.train import main
 
-    hist = main(["--tiny", "per_device_train_batch_size=2", "gradient_accumulation_steps=1", "max_seq_length=24", "max_steps=3",
+    hist = main(["--tiny", "per_device_train_batch_size=2", "gradient_accumulation_steps=1", "max_seq_length=24", "max_steps=2",
                  "learning_rate=1e-2", "weight_decay=0.0", "warmup_ratio=0.0", "images_per_sample=1", "logging_steps=100", "synthetic_fixed=true",
                  f"expert_parallel={'true' if ep else 'false'}", "save_final=true", f"output_dir={outdir}/{'ep' if ep else 'dp'}"])
     torch.save(hist, os.path.join(outdir, f"hist_{'ep' if ep else 'dp'}_{rank}.pt"))
@@ -46,7 +46,7 @@ def test_expert_parallel_training_matches_data_parallel():
         eph = [torch.load(os.path.join(d, f"hist_ep_{r}.pt")) for r in range(world)]
         w_dp, w_ep = load_file(os.path.join(d, "dp", "model.safetensors")), load_file(os.path.join(d, "ep", "model.safetensors"))
     for r in range(world):
-        assert len(eph[r]) == 3 and eph[r][-1] < eph[r][0]                                 # it trains
+        assert len(eph[r]) == 2 and eph[r][-1] < eph[r][0]                                 # it trains
         for a, b in zip(eph[r], dp[r]):
             assert abs(a - b) <= 2e-2 * abs(b), (r, eph[r], dp[r])                          # like data parallelism does
     assert set(w_dp) == set(w_ep)
@@ -54,7 +54,7 @@ def test_expert_parallel_training_matches_data_parallel():
         assert w_dp[k].shape == w_ep[k].shape, k                                           # full [E, ...] expert tensors were gathered back
     for k in ("language_model.model.layers.0.mlp.experts.fc1.weight", "language_model.model.layers.1.mlp.experts.fc2.weight",
               "language_model.model.layers.0.self_attn.q_proj.weight", "language_model.lm_head.weight"):
-        # three Adam steps of 1e-2 each: an element whose tiny gradient changes sign under bf16 noise lands one or two steps apart, so
-        # compare in the mean (<= a sixth of one step) and bound the worst element by the three steps taken
+        # two Adam steps of 1e-2 each: an element whose tiny gradient changes sign under bf16 noise lands one or two steps apart, so
+        # compare in the mean (<= a sixth of one step) and bound the worst element by three steps
         diff = (w_ep[k].float() - w_dp[k].float()).abs()
         assert float(diff.mean()) <= 1.7e-3 and float(diff.max()) <= 6.1e-2, (k, float(diff.mean()), float(diff.max()))

@@ -51,10 +51,10 @@ def test_recipe_yaml_is_honoured():
 def test_toy_finetune_reduces_loss(tmp_path):
     from aria_amd.train import main
 
-    hist = main(["--tiny", "per_device_train_batch_size=2", "gradient_accumulation_steps=1", "max_seq_length=24", "max_steps=6",
+    hist = main(["--tiny", "per_device_train_batch_size=2", "gradient_accumulation_steps=1", "max_seq_length=24", "max_steps=4",
                  "learning_rate=1e-2", "weight_decay=0.0", "warmup_ratio=0.0", "images_per_sample=1", "logging_steps=100",
                  "synthetic_fixed=true", "save_final=true", f"output_dir={tmp_path}"])
-    assert len(hist) == 6 and hist[-1] < hist[0] - 0.3, hist
+    assert len(hist) == 4 and hist[-1] < hist[0] - 0.2, hist
     # trainer.save_model(output_dir) (aria/train.py:247-249): an HF checkpoint directory the model class loads back
     from aria_amd.modeling_aria import AriaForConditionalGeneration
 
