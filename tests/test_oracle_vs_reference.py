@@ -60,3 +60,30 @@ def test_lora_restatement_matches_the_reference_grouped_gemm_modules():
         merged = ns.moe.GroupedGEMM(K, N, E)
         merged.weight.copy_(base.weight + O.lora_delta_weight(a.weight, b.weight, scaling))
         assert torch.allclose(merged(x, tpe), want, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_lm_matches_live_reference_over_random_shapes(case):
+    """heads x head_dim, experts / top-k / shared experts, depth, vocabulary, eps, RoPE base, batch and length drawn per case (a 60-case sweep
+    of the same generator was run once offline: no mismatch)."""
+    import random
+
+    ns = load_reference()
+    rnd = random.Random(100 + case)
+    H, hd = rnd.choice([1, 2, 3, 4]), rnd.choice([8, 16, 32])
+    E = rnd.choice([2, 3, 6, 8, 16])
+    k, inter, shared = rnd.randint(1, min(4, E)), rnd.choice([8, 16, 24]), rnd.choice([1, 2, 3])
+    text = dict(hidden_size=H * hd, num_attention_heads=H, num_key_value_heads=H, num_hidden_layers=rnd.choice([1, 2, 3]),
+                vocab_size=rnd.choice([32, 64, 101]), intermediate_size=inter * shared, moe_intermediate_size=inter, moe_num_experts=E,
+                moe_topk=k, moe_num_shared_experts=shared, rms_norm_eps=rnd.choice([1e-5, 1e-6]), rope_theta=rnd.choice([1e4, 5e6]),
+                max_position_embeddings=128, pad_token_id=0)
+    torch.manual_seed(case)
+    lm = ns.moe.AriaMoELMForCausalLM(ns.moe.AriaMoELMConfig(**text, attn_implementation="eager")).eval()
+    with torch.no_grad():
+        for p in lm.parameters():
+            p.normal_(0, 0.1)
+    ids = torch.randint(1, text["vocab_size"], (rnd.randint(1, 3), rnd.randint(1, 24)))
+    w = {n: v.detach() for n, v in lm.state_dict().items()}
+    ocfg = O.LMConfig(**{n: v for n, v in text.items() if n in O.LMConfig.__dataclass_fields__})
+    with torch.no_grad():
+        assert torch.allclose(O.lm_forward(w["model.embed_tokens.weight"][ids], w, ocfg), lm(input_ids=ids).logits, atol=5e-5, rtol=2e-4)
