@@ -42,7 +42,6 @@ def test_lm_head_over_labelled_rows_only(golden, monkeypatch):
     prompt and the padding)."""
     monkeypatch.setenv("ARIA_LMHEAD_SKIP_MASKED", "1")
     M.case_aria_full_golden(DEV, golden)
-    M.case_lm_golden(DEV, golden)
 
 
 def test_gptfast_golden(golden):

@@ -117,7 +117,7 @@ def test_gptfast_generator_chat_and_benchmark(tmp_path):
     assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), twin.state_dict().values()))
 
     mc = GG.ModelConfig(checkpoint_path=tmp_path / "model.pth", device="cpu", compile=True)      # compile flags: accepted, ignored
-    gc = GG.GenerationConfig(max_new_tokens=3, top_k=5, temperature=0.8, cache_size=600, stop_strings=["<|im_end|>", "\n\n"])
+    gc = GG.GenerationConfig(max_new_tokens=2, top_k=5, temperature=0.8, cache_size=600, stop_strings=["<|im_end|>", "\n\n"])
     gen = GG.Generator(mc, gc, model=twin.eval(), processor=proc)
     assert gen._stops() == ([end_id], ["\n\n"])
     rng = np.random.default_rng(2)
@@ -127,7 +127,7 @@ def test_gptfast_generator_chat_and_benchmark(tmp_path):
     torch.manual_seed(5)
     text_only = [{"role": "user", "content": [{"text": "count to three", "type": "text"}]}]
     new = gen.generate(text_only, None, detokenize=False)               # (the image path runs once, in the chat turn below: 7 s of emulated ViT)
-    assert new.dim() == 1 and 1 <= new.numel() <= 3                      # generated part only, like generate.py:174
+    assert new.dim() == 1 and 1 <= new.numel() <= 2                      # generated part only, like generate.py:174
     assert twin.llm.max_seq_length >= 600                               # cache_size pre-sized the static KV cache
     with pytest.raises(ValueError):
         GG.Generator(mc, GG.GenerationConfig(max_new_tokens=600, cache_size=100), model=twin, processor=proc).generate(messages, Image.open(path))
@@ -142,5 +142,5 @@ def test_gptfast_generator_chat_and_benchmark(tmp_path):
     chat.reset()
     assert chat.history == []
 
-    res = GG.run_benchmark(gen, text_only, None, num_runs=2, warmup=0)
+    res = GG.run_benchmark(gen, text_only, None, num_runs=1, warmup=0)
     assert set(res) == {"mean_latency", "std_latency", "mean_tokens", "std_tokens", "tokens_per_second"} and res["tokens_per_second"] > 0
