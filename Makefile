@@ -18,7 +18,7 @@ aria_amd/libaria_hip.so: $(OBJ)
 # test infrastructure: same sources, SIMT emulator instead of a GPU
 emu: tests/emu/libaria_emu.so
 tests/emu/libaria_emu.so: $(SRC) $(HDR) tests/emu/hip_emu.cpp tests/emu/hip_emu.h
-	$(HOSTCXX) -x c++ -std=c++17 -O2 -g -fPIC -shared -DARIA_EMU -Wno-unknown-attributes -Wno-unused-value -Wno-psabi \
+	$(HOSTCXX) -x c++ -std=c++17 -O3 -g -fPIC -shared -DARIA_EMU -Wno-unknown-attributes -Wno-unused-value -Wno-psabi \
 	    -Iinclude -Iaria_amd/csrc -Itests/emu $(SRC) tests/emu/hip_emu.cpp -o $@
 
 oracle_c:
