@@ -1,0 +1,74 @@
+"""Exercise bench.py's OWN code path (argument handling, timing hooks, roofline / JSON assembly) on CPU through the emulator, without
+touching bench.py: this harness hands bench.py a torch proxy whose "cuda" is the CPU (fake events, no-op synchronisation) and shrinks the
+model dimensions.  Prints bench.py's JSON line; the numbers mean nothing -- it only has to run and carry every contract field.
+
+    python tools/bench_dry_run.py
+"""
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from tests.emu import emu_lib  # noqa: E402
+
+emu_lib.install()
+
+
+class FakeEvent:
+    def __init__(self, enable_timing=False):
+        self.t = None
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+class TorchProxy(types.ModuleType):
+    """torch as bench.py sees it: device("cuda", i) and Generator(device="cuda") land on the CPU, torch.cuda is a stub"""
+
+    def __init__(self):
+        super().__init__("torch")
+        self.cuda = types.SimpleNamespace(is_available=lambda: True, set_device=lambda i: None, synchronize=lambda *a: None, Event=FakeEvent)
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    def device(self, *a, **k):
+        return torch.device("cpu")
+
+    def Generator(self, device=None):
+        return torch.Generator(device="cpu")
+
+
+import aria_amd.moe_lm as moe_lm  # noqa: E402
+import aria_amd.vision as vision  # noqa: E402
+import bench  # noqa: E402
+
+bench.torch = TorchProxy()
+RealLM, RealVis = moe_lm.AriaMoELMConfig, vision.AriaVisionConfig
+
+
+def tiny_lm(**kw):
+    kw.update(hidden_size=64, num_attention_heads=1, vocab_size=512, moe_intermediate_size=16, moe_num_experts=8, moe_topk=2)
+    return RealLM(**kw)
+
+
+def tiny_vis(**kw):
+    return RealVis(hidden_size=64, num_attention_heads=1, intermediate_size=64, image_size=56, **kw)
+
+
+moe_lm.AriaMoELMConfig, vision.AriaVisionConfig = tiny_lm, tiny_vis
+sys.argv = ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--layers", "2", "--vit-layers", "1", "--images", "0", "--batch", "2",
+            "--seq", "64", "--no-cpu-baseline", "--time-grouped"]
+try:
+    bench.main()
+finally:
+    moe_lm.AriaMoELMConfig, vision.AriaVisionConfig = RealLM, RealVis
