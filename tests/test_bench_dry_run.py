@@ -1,0 +1,30 @@
+"""bench.py's own code path (argument handling, timing hooks on the dominant kernel, barrier / max-over-ranks timing, roofline and JSON
+assembly) exercised on CPU: tools/bench_dry_run.py hands bench.py a torch proxy whose "cuda" is the CPU, shrinks the model and routes
+"nccl" to "gloo".  The numbers mean nothing; the line must carry every field of the driver's contract, for N = 1 and for two ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "config", "roofline"}
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_line_carries_the_contract(world):
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_dry_run.py")] + (["--world", str(world)] if world > 1 else [])
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                      # ONE JSON line, from rank 0
+    res = json.loads(lines[0])
+    assert CONTRACT <= set(res)
+    assert res["n_gpus"] == world and res["steps"] == 2 and res["warmup"] == 1 and res["higher_is_better"] is True and res["scaling"] == "weak"
+    assert res["value"] > 0 and res["ms_per_step"] > 0 and res["unit"] == "tokens/s" and res["dtype"] == "bf16"
+    assert res["config"]["parallelism"] == ("single" if world == 1 else "dp2") and res["config"]["global_batch"] == 2 * world
+    roof = res["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof) and roof["bound"] == "mfma" and roof["launches_timed"] == 4
+    assert roof["kernel"].startswith("gemm") and "experts.fc1" in roof["kernel"]

@@ -2,7 +2,9 @@
 touching bench.py: this harness hands bench.py a torch proxy whose "cuda" is the CPU (fake events, no-op synchronisation) and shrinks the
 model dimensions.  Prints bench.py's JSON line; the numbers mean nothing -- it only has to run and carry every contract field.
 
-    python tools/bench_dry_run.py
+    python tools/bench_dry_run.py            # N = 1
+    python tools/bench_dry_run.py --world 2  # the N > 1 branch: two gloo ranks (init_process_group is redirected from "nccl" to "gloo")
+    python tools/bench_dry_run.py --world 2 --ep
 """
 import json
 import os
@@ -48,27 +50,52 @@ class TorchProxy(types.ModuleType):
         return torch.Generator(device="cpu")
 
 
-import aria_amd.moe_lm as moe_lm  # noqa: E402
-import aria_amd.vision as vision  # noqa: E402
-import bench  # noqa: E402
+def run(world: int, rank: int, ep: bool):
+    import aria_amd.moe_lm as moe_lm
+    import aria_amd.vision as vision
+    import bench
 
-bench.torch = TorchProxy()
-RealLM, RealVis = moe_lm.AriaMoELMConfig, vision.AriaVisionConfig
+    bench.torch = TorchProxy()
+    if world > 1:
+        import torch.distributed as dist
+
+        real_init = dist.init_process_group
+        dist.init_process_group = lambda backend=None, **kw: real_init("gloo", rank=rank, world_size=world)
+    RealLM, RealVis = moe_lm.AriaMoELMConfig, vision.AriaVisionConfig
+
+    def tiny_lm(**kw):
+        kw.update(hidden_size=64, num_attention_heads=1, vocab_size=512, moe_intermediate_size=16, moe_num_experts=8, moe_topk=2)
+        return RealLM(**kw)
+
+    def tiny_vis(**kw):
+        return RealVis(hidden_size=64, num_attention_heads=1, intermediate_size=64, image_size=56, **kw)
+
+    moe_lm.AriaMoELMConfig, vision.AriaVisionConfig = tiny_lm, tiny_vis
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--layers", "2", "--vit-layers", "1", "--images", "0",
+                "--batch", "2", "--seq", "64", "--no-cpu-baseline"] + (["--ep"] if ep else []) + (["--time-grouped"] if world == 1 else [])
+    try:
+        bench.main()
+    finally:
+        moe_lm.AriaMoELMConfig, vision.AriaVisionConfig = RealLM, RealVis
 
 
-def tiny_lm(**kw):
-    kw.update(hidden_size=64, num_attention_heads=1, vocab_size=512, moe_intermediate_size=16, moe_num_experts=8, moe_topk=2)
-    return RealLM(**kw)
+def _worker(rank, world, port, ep):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    run(world, rank, ep)
 
 
-def tiny_vis(**kw):
-    return RealVis(hidden_size=64, num_attention_heads=1, intermediate_size=64, image_size=56, **kw)
+if __name__ == "__main__":
+    world = int(sys.argv[sys.argv.index("--world") + 1]) if "--world" in sys.argv else 1
+    ep = "--ep" in sys.argv
+    if world == 1:
+        run(1, 0, False)
+    else:
+        import socket
 
+        import torch.multiprocessing as mp
 
-moe_lm.AriaMoELMConfig, vision.AriaVisionConfig = tiny_lm, tiny_vis
-sys.argv = ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--layers", "2", "--vit-layers", "1", "--images", "0", "--batch", "2",
-            "--seq", "64", "--no-cpu-baseline", "--time-grouped"]
-try:
-    bench.main()
-finally:
-    moe_lm.AriaMoELMConfig, vision.AriaVisionConfig = RealLM, RealVis
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        mp.spawn(_worker, args=(world, port, ep), nprocs=world, join=True)
