@@ -261,6 +261,7 @@ def main(argv=None, tokenizer=None):
     from .moe_lm import MoEAuxLossAutoScaler
     from .parallel import GradSync, ShardedAdamW, cosine_lr
 
+    torch.manual_seed(int(cfg["seed"]))   # set_seed(training_args.seed): adapter init and dropout draw from the global generator -- the same on every rank
     model, acfg = build_model(cfg, device)
     if cfg.get("expert_parallel") and world > 1:  # BASELINE config #5: routed experts sharded over all ranks (EP = world), the rest data-parallel
         if cfg.get("use_peft"):

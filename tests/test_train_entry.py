@@ -70,7 +70,7 @@ def test_lora_recipe_trains_only_the_adapters(tmp_path):
     from aria_amd.train import main
 
     hist = main(["--tiny", "per_device_train_batch_size=2", "gradient_accumulation_steps=1", "max_seq_length=24", "max_steps=3",
-                 "learning_rate=3e-2", "weight_decay=0.0", "warmup_ratio=0.0", "images_per_sample=1", "logging_steps=100",
+                 "learning_rate=1e-2", "weight_decay=0.0", "warmup_ratio=0.0", "images_per_sample=1", "logging_steps=100",
                  "synthetic_fixed=true", "use_peft=true", "lora_r=8", "lora_alpha=32", "lora_dropout=0.05", "freeze_projector=true",
                  'lora_target_modules=["fc1","fc2","q_proj","k_proj","v_proj","linear","o_proj","up_proj","down_proj","out_proj",'
                  '"gate_proj","lm_head"]', "save_final=true", f"output_dir={tmp_path}"])
