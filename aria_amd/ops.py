@@ -308,6 +308,9 @@ def adamw_step_(param: torch.Tensor, grad: torch.Tensor, master: torch.Tensor, m
     assert all(t.is_contiguous() and t.numel() == n for t in (param, grad, master, m, v))
     hip.get_lib().call("aria_adamw_step", _p(param), _p(grad), _p(master), _p(m), _p(v), n, float(lr), float(beta1), float(beta2),
                        float(eps), float(weight_decay), int(step), float(grad_scale), _stream(param))
+    # the kernel wrote param / master / m / v behind autograd's back: bump the version counters so that anything keyed on them
+    # (the ViT's cached fused q/k/v weight, saved-tensor checks) sees the update
+    torch.autograd.graph.increment_version(param)
 
 
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -16,6 +16,7 @@ directory (``aria_amd.checkpoint``) or a ``torch.save``d state dict; the run end
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -61,41 +62,56 @@ def build_model(cfg, device):
     from .moe_lm import AriaMoELMConfig
     from .vision import AriaVisionConfig
 
-    if cfg["tiny"]:
-        text = AriaMoELMConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, vocab_size=512, moe_intermediate_size=64,
-                               moe_num_experts=8, moe_topk=2, moe_z_loss_coeff=cfg["moe_z_loss_coeff"],
-                               moe_aux_loss_coeff=cfg["moe_aux_loss_coeff"], gradient_checkpointing=cfg["gradient_checkpointing"])
-        side = int(cfg.get("tiny_image_size", 56))   # 56 -> 16 patches -> 4 tokens (synthetic); 490 -> 1225 -> 128 (what the processor emits)
-        vis = AriaVisionConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, image_size=side)
-        acfg = AriaConfig(vision_config=vis, text_config=text, projector_patch_to_query_dict={16: 4, 1225: 128, 4900: 256},
-                          image_token_index=int(cfg.get("image_token_index", 9)))
-    else:
-        text = AriaMoELMConfig(moe_z_loss_coeff=cfg["moe_z_loss_coeff"], moe_aux_loss_coeff=cfg["moe_aux_loss_coeff"],
-                               gradient_checkpointing=cfg["gradient_checkpointing"])
-        acfg = AriaConfig(vision_config=AriaVisionConfig(), text_config=text, image_token_index=int(cfg.get("image_token_index", 9)))
-    torch.set_default_device(device)
-    model = AriaForConditionalGeneration(acfg)
-    torch.set_default_device("cpu")
-    g = torch.Generator(device=device).manual_seed(cfg["seed"])
-    with torch.no_grad():
-        for n, p in model.named_parameters():
-            if "norm" in n and n.endswith("weight") or "ln_" in n and n.endswith("weight"):
-                p.fill_(1.0)
-            elif n.endswith("bias"):
-                p.zero_()
-            else:
-                p.normal_(0.0, 0.02, generator=g)
     path = cfg.get("model_name_or_path")
-    if path and os.path.isdir(str(path)):  # HF checkpoint directory (sharded safetensors / bin + index), reference key names
-        from .checkpoint import load_hf_dir_into
-
-        load_hf_dir_into(model, str(path), strict=False)
-    elif path and os.path.isfile(str(path)):
-        sd = torch.load(path, map_location="cpu")
-        own = model.state_dict()
+    from_dir = bool(path) and os.path.isdir(str(path)) and os.path.isfile(os.path.join(str(path), "config.json"))
+    if from_dir:
+        # HF checkpoint directory (config.json + sharded safetensors, reference key names): dimensions come from ITS config.json, like
+        # AriaForConditionalGeneration.from_pretrained (aria/train.py:53-58), and every key must match -- a silently skipped tensor
+        # would fine-tune from random weights
+        model = AriaForConditionalGeneration.from_pretrained(str(path), device=device, strict=True)
+        acfg = model.config
+        t = acfg.text_config
+        t.moe_z_loss_coeff, t.moe_aux_loss_coeff = cfg["moe_z_loss_coeff"], cfg["moe_aux_loss_coeff"]      # aria/train.py:67-68
+        t.gradient_checkpointing = cfg["gradient_checkpointing"]
+    else:
+        if cfg["tiny"]:
+            text = AriaMoELMConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, vocab_size=512, moe_intermediate_size=64,
+                                   moe_num_experts=8, moe_topk=2, moe_z_loss_coeff=cfg["moe_z_loss_coeff"],
+                                   moe_aux_loss_coeff=cfg["moe_aux_loss_coeff"], gradient_checkpointing=cfg["gradient_checkpointing"])
+            side = int(cfg.get("tiny_image_size", 56))   # 56 -> 16 patches -> 4 tokens (synthetic); 490 -> 1225 -> 128 (what the processor emits)
+            vis = AriaVisionConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, image_size=side)
+            acfg = AriaConfig(vision_config=vis, text_config=text, projector_patch_to_query_dict={16: 4, 1225: 128, 4900: 256},
+                              image_token_index=int(cfg.get("image_token_index", 9)))
+        else:
+            text = AriaMoELMConfig(moe_z_loss_coeff=cfg["moe_z_loss_coeff"], moe_aux_loss_coeff=cfg["moe_aux_loss_coeff"],
+                                   gradient_checkpointing=cfg["gradient_checkpointing"])
+            acfg = AriaConfig(vision_config=AriaVisionConfig(), text_config=text, image_token_index=int(cfg.get("image_token_index", 9)))
+        torch.set_default_device(device)
+        model = AriaForConditionalGeneration(acfg)
+        torch.set_default_device("cpu")
+        g = torch.Generator(device=device).manual_seed(cfg["seed"])
         with torch.no_grad():
-            for k, v in own.items():
-                if k in sd:
+            for n, p in model.named_parameters():
+                if "norm" in n and n.endswith("weight") or "ln_" in n and n.endswith("weight"):
+                    p.fill_(1.0)
+                elif n.endswith("bias"):
+                    p.zero_()
+                else:
+                    p.normal_(0.0, 0.02, generator=g)
+        if path and os.path.isdir(str(path)):  # weight shards without a config.json: the configured dimensions, every key must match
+            from .checkpoint import load_hf_dir_into
+
+            load_hf_dir_into(model, str(path), strict=True)
+        elif path and os.path.isfile(str(path)):  # a plain state-dict file
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+            own = model.state_dict()
+            missing = [k for k in own if k not in sd]
+            if missing:
+                raise KeyError(f"{path}: {len(missing)} parameters of the model are not in the file (first: {missing[:4]})")
+            with torch.no_grad():
+                for k, v in own.items():
+                    if v.shape != sd[k].shape:
+                        raise ValueError(f"{k}: file {tuple(sd[k].shape)} vs module {tuple(v.shape)}")
                     v.copy_(sd[k].to(v.dtype))
     if cfg["freeze_vit"]:
         model.freeze_vit()
@@ -270,8 +286,9 @@ def main(argv=None, tokenizer=None):
     accum = int(cfg["gradient_accumulation_steps"])
     aux_scale_before = MoEAuxLossAutoScaler.main_loss_backward_scale
     MoEAuxLossAutoScaler.set_loss_scale(1.0 / accum)                     # aria/train.py:229 (a process-wide setting, restored on return)
-    sync = GradSync(model) if world > 1 else None
-    opt = ShardedAdamW(model.parameters(), lr=cfg["learning_rate"], betas=(0.9, cfg["adam_beta2"]), weight_decay=cfg["weight_decay"])
+    # ZeRO-2 (recipes/accelerate_configs/zero2.yaml): gradients reduce-scattered onto the rank that owns their optimizer shard
+    sync = GradSync(model, mode=str(cfg.get("grad_exchange", "reduce_scatter"))) if world > 1 else None
+    opt = ShardedAdamW(model.named_parameters(), lr=cfg["learning_rate"], betas=(0.9, cfg["adam_beta2"]), weight_decay=cfg["weight_decay"])
     gen = torch.Generator(device=device).manual_seed(cfg["seed"] + rank)
     # data: the recipe's dataset_mixer (aria/data.py format) unless synthetic_data=true / no dataset is configured (throughput runs, tests)
     use_real = bool(cfg.get("dataset_mixer")) and not cfg.get("synthetic_data", False)
@@ -315,8 +332,10 @@ def main(argv=None, tokenizer=None):
                 if cfg.get("synthetic_fixed"):  # overfit one batch (tests): random labels are irreducible otherwise
                     gen.manual_seed(cfg["seed"] + rank + micro)
                 batch = synthetic_batch(cfg, acfg, device, gen)
-            out = model(**batch, return_logits=False, validate_image_tokens=use_real)
-            (out.loss / accum).backward()
+            # only the last micro-step of the accumulation window exchanges gradients (DeepSpeed's gradient-accumulation boundary)
+            with (sync.no_sync() if sync is not None and micro < accum - 1 else contextlib.nullcontext()):
+                out = model(**batch, return_logits=False, validate_image_tokens=use_real)
+                (out.loss / accum).backward()
             loss_acc += float(out.loss.detach()) / accum
         if sync is not None:
             sync.finish()

@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--images", type=int, default=2, help="980px images per sample (NLVR2-style: 2); 0 = text only")
     ap.add_argument("--vit-layers", type=int, default=27, help="debug only")
     ap.add_argument("--no-overlap", action="store_true", help="exchange gradients after backward instead of under it")
+    ap.add_argument("--allreduce", action="store_true", help="all-reduce every gradient (each replica keeps the full average) instead of the "
+                    "ZeRO-2 reduce-scatter onto the owner of the optimizer shard (recipes/accelerate_configs/zero2.yaml)")
     ap.add_argument("--ep", action="store_true", help="BASELINE config #5 instead of #3: routed experts sharded over the N ranks (all-to-all "
                                                       "dispatch over xGMI), everything else data-parallel; not what the driver runs")
     return ap.parse_args()
@@ -120,8 +122,26 @@ def cpu_baseline(cfg_kwargs, seconds_budget=40.0):
                       f"at B=1,S={S}; value = S/(28*t_layer+t_head); os.cpu_count()={os.cpu_count()}"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (no torchrun around it): re-exec this script under torch.distributed.run with N ranks on
+    127.0.0.1, one per GPU, so that the plain form measures N GPUs instead of silently measuring one."""
+    import socket
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {args.gpus} without a launcher -> re-exec under torch.distributed.run ({args.gpus} ranks, port {port})",
+          file=sys.stderr, flush=True)
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,7 +154,14 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line would not measure what it names")
+    if world > 1:
+        n_seen = dist.get_world_size()
+        if rank == 0:
+            print(f"bench.py: RCCL process group up, {n_seen} ranks, device {torch.cuda.get_device_name(local)}", file=sys.stderr, flush=True)
+        if n_seen != args.gpus:
+            raise SystemExit(f"bench.py: process group has {n_seen} ranks, --gpus {args.gpus}")
 
     from aria_amd import hip, ops
     from aria_amd.modeling_aria import AriaConfig, AriaForConditionalGeneration
@@ -144,7 +171,7 @@ def main():
 
     cfg_kwargs = dict(hidden_size=2560, num_hidden_layers=args.layers, num_attention_heads=20, vocab_size=100352,
                       moe_intermediate_size=1664, moe_num_experts=64, moe_topk=6, moe_num_shared_experts=2,
-                      rms_norm_eps=1e-6, rope_theta=5_000_000.0, moe_z_loss_coeff=1e-5, moe_aux_loss_coeff=1e-4)
+                      rms_norm_eps=1e-6, rope_theta=5_000_000.0, moe_z_loss_coeff=1e-5, moe_aux_loss_coeff=1e-3)  # aria/model/moe_lm.py:57-58 defaults
     cfg = AriaMoELMConfig(**cfg_kwargs, gradient_checkpointing=args.recompute)
     IMG_TOKEN, QTOK = 9, 256                       # gptfast/model.py:54; 980px image -> 4900 patches -> 256 query tokens
     acfg = AriaConfig(vision_config=AriaVisionConfig(num_hidden_layers=args.vit_layers), text_config=cfg,
@@ -157,7 +184,7 @@ def main():
     model.freeze_vit()          # recipes/config_full.yaml:39-42: ViT frozen, projector + LLM trainable
     if args.ep and world > 1:
         model.enable_expert_parallel()  # every rank built the same 64 experts (same seed) and keeps its 64 / N
-    sync = GradSync(model, overlap=not args.no_overlap) if world > 1 else None
+    sync = GradSync(model, overlap=not args.no_overlap, mode="all_reduce" if args.allreduce else "reduce_scatter") if world > 1 else None
 
     B, S, V = args.batch, args.seq, cfg.vocab_size
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
@@ -279,7 +306,8 @@ def main():
                                    "trainable projector (256 tok/img) -> 28-layer MoE decoder (64 experts top-6, D=2560, V=100352) "
                                    "fwd+bwd incl. lm_head+CE and router aux-loss grads",
                        "layers": args.layers, "vit_layers": args.vit_layers, "images_per_sample": n_img, "global_batch": world * B, "seq_len": S,
-                       "parallelism": (f"dp{world}+ep{world}" if args.ep else f"dp{world}") if world > 1 else "single", "grad_checkpointing": bool(args.recompute),
+                       "parallelism": (f"dp{world}+ep{world}" if args.ep else f"dp{world}") if world > 1 else "single",
+                       "grad_exchange": None if world == 1 else ("all_reduce" if args.allreduce else "reduce_scatter (ZeRO-2)"), "grad_checkpointing": bool(args.recompute),
                        "optimizer_in_step": False,  # metric = fwd+bwd; AdamW state (299 GB fp32) only exists sharded over >= 2 GPUs
                        "loss": round(float(loss), 4)},
             "roofline": {"kernel": {1: "gemm_kernel", 2: "gemm2_kernel", 3: "gemm3_kernel"}.get(timed_grouped_gemm.variant, "gemm?_kernel")

@@ -38,7 +38,8 @@ class TorchProxy(types.ModuleType):
 
     def __init__(self):
         super().__init__("torch")
-        self.cuda = types.SimpleNamespace(is_available=lambda: True, set_device=lambda i: None, synchronize=lambda *a: None, Event=FakeEvent)
+        self.cuda = types.SimpleNamespace(is_available=lambda: True, set_device=lambda i: None, synchronize=lambda *a: None, Event=FakeEvent,
+                                          get_device_name=lambda *a: "cpu (dry run)")
 
     def __getattr__(self, name):
         return getattr(torch, name)
