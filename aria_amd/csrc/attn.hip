@@ -13,9 +13,8 @@
 //    per-query rescale stays lane-local.
 //  * dK/dV compute S = Q K^T untransposed, so a lane owns one KEY column and P^T / dS^T are lane-local A operands.
 //  * Operands that are needed "k-strided" (V^T, K^T, dO, Q as B/A operands along the token axis) are read from the
-//    row-major LDS tile with eight ds_read_b32 per lane (two adjacent feature columns per dword): the lane builds the
-//    fragments of feature columns 2c and 2c+1, which belong to two different MFMA tiles.  Any permutation of the
-//    reduction index is legal as long as both operands agree, so the k order follows the accumulator layout.
+//    row-major LDS tile through ds_read_b64_tr_b16 (hardware 4x16 transpose).  Any permutation of the reduction index is
+//    legal as long as both operands agree, so the k order follows the accumulator layout.
 //  * tensors are [B, S, H, hd] views of token-major activations (row stride ld*): no head transposes in HBM.
 #include "aria_device.h"
 #include "aria_hip.h"
@@ -61,27 +60,6 @@ __device__ __forceinline__ s16x8 frag_rc(const bf16_t* s, int row, int kk, int l
     return *reinterpret_cast<const s16x8*>(s + row * Cfg<HD>::PITCH + kk * 16 + (l >> 5) * 8);
 }
 
-// "pair" fragments along the token axis: 8 token rows {rb + 4h + e (e<4), rb + 8 + 4h + (e-4) (e>=4)} at feature
-// columns col, col+1 (one dword).  Matches the accumulator-register order of a 32x32 tile (regs 8u..8u+7).
-template <int HD>
-__device__ __forceinline__ void frag_pair(s16x8& even, s16x8& odd, const bf16_t* s, int rb, int col, int l) {
-    const int h = l >> 5;
-    uint32_t d[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int row = rb + 4 * h + (e & 3) + (e >> 2) * 8;
-        d[e] = *reinterpret_cast<const uint32_t*>(s + row * Cfg<HD>::PITCH + col);
-    }
-    u32x4 lo, hi;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        lo[j] = (d[2 * j] & 0xffffu) | (d[2 * j + 1] << 16);
-        hi[j] = (d[2 * j] >> 16) | (d[2 * j + 1] & 0xffff0000u);
-    }
-    even = __builtin_bit_cast(s16x8, lo);
-    odd = __builtin_bit_cast(s16x8, hi);
-}
-
 // accumulator regs 8u..8u+7 of a 32x32 tile -> bf16 fragment (lane-local)
 __device__ __forceinline__ s16x8 pack_frag(const f32x16& p, int u) {
     u32x4 v;
@@ -97,130 +75,6 @@ __device__ __forceinline__ f32x16 zero_acc() {
 #pragma unroll
     for (int r = 0; r < 16; ++r) z[r] = 0.f;
     return z;
-}
-
-// =========================================================================================== forward
-// grid (ceil(S/128), H, B); wave w owns queries q0 + 32w + (l&31)
-template <int HD>
-__global__ __launch_bounds__(NT) void attn_fwd_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE,
-                                                      const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
-                                                      long long ldq, long long ldk, long long ldv, long long ldo, float scale,
-                                                      int causal) {
-    using C = Cfg<HD>;
-    ARIA_DYN_SMEM(smem);
-    bf16_t* sK = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* sV = sK + 64 * C::PITCH;
-    uint8_t* sM = reinterpret_cast<uint8_t*>(sV + 64 * C::PITCH);
-    const int t = threadIdx.x, l = t & 63, w = t >> 6, h2 = l >> 5;
-    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
-    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
-    const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
-    const bf16_t* Kb = K + tok0 * ldk + head * HD;
-    const bf16_t* Vb = V + tok0 * ldv + head * HD;
-    const uint8_t* kmb = key_mask ? key_mask + tok0 : nullptr;
-    const int q_abs = q0 + 32 * w + (l & 31);
-    const int klen = kv_len ? min(S, kv_len[b]) : S;
-
-    // Q fragments (B operand of S^T = K Q^T): Q[q][16kk + 8h2 ..]
-    s16x8 qf[C::KS];
-#pragma unroll
-    for (int kk = 0; kk < C::KS; ++kk) {
-        u32x4 v = zero16();
-        if (q_abs < Sq) v = ld16(Qb + (long long)q_abs * ldq + kk * 16 + h2 * 8);
-        qf[kk] = __builtin_bit_cast(s16x8, v);
-    }
-    f32x16 o[2 * C::DB];
-#pragma unroll
-    for (int i = 0; i < 2 * C::DB; ++i) o[i] = zero_acc();
-    float m = -INFINITY, lsum = 0.f;
-
-    int kv_end = klen;
-    if (causal) kv_end = min(kv_end, q0 + 128);
-    const int ntiles = (kv_end + 63) / 64;
-    u32x4 rk[C::NCH64], rv[C::NCH64];
-    if (ntiles > 0) {
-        tile_load<HD>(rk, Kb, ldk, 0, S, t);
-        tile_load<HD>(rv, Vb, ldv, 0, S, t);
-    }
-    for (int it = 0; it < ntiles; ++it) {
-        const int kv0 = it * 64;
-        tile_store<HD>(rk, sK, t);
-        tile_store<HD>(rv, sV, t);
-        if (kmb && t < 64) sM[t] = (kv0 + t < S) ? kmb[kv0 + t] : 0;
-        sync();
-        if (it + 1 < ntiles) {
-            tile_load<HD>(rk, Kb, ldk, kv0 + 64, S, t);
-            tile_load<HD>(rv, Vb, ldv, kv0 + 64, S, t);
-        }
-        // S^T tile: rows = keys (2 x 32), cols = this wave's 32 queries
-        f32x16 st[2];
-        st[0] = zero_acc();
-        st[1] = zero_acc();
-#pragma unroll
-        for (int kk = 0; kk < C::KS; ++kk) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) st[i] = mfma32(frag_rc<HD>(sK, i * 32 + (l & 31), kk, l), qf[kk], st[i]);
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kvl = i * 32 + acc_row(r, l);
-                const int kv = kv0 + kvl;
-                float v = st[i][r] * scale;
-                if (kv >= klen || (causal && kv > q_abs) || (kmb && !sM[kvl])) v = -INFINITY;
-                st[i][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, shfl_xor(mx, 32));
-        const float m_new = fmaxf(m, mx);
-        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = __expf(m - m_safe);
-        float ps = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __expf(st[i][r] - m_safe);
-                st[i][r] = p;
-                ps += p;
-            }
-        lsum = lsum * alpha + ps;
-        m = m_new;
-#pragma unroll
-        for (int i = 0; i < 2 * C::DB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        // O^T += V^T P^T
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const s16x8 pf = pack_frag(st[i], u);
-#pragma unroll
-                for (int db = 0; db < C::DB; ++db) {
-                    s16x8 ve, vo;
-                    frag_pair<HD>(ve, vo, sV, i * 32 + 16 * u, 64 * db + 2 * (l & 31), l);
-                    o[2 * db] = mfma32(ve, pf, o[2 * db]);
-                    o[2 * db + 1] = mfma32(vo, pf, o[2 * db + 1]);
-                }
-            }
-        sync();
-    }
-    const float ltot = lsum + shfl_xor(lsum, 32);
-    const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
-    if (q_abs < Sq) {
-        if (h2 == 0 && LSE) LSE[((long long)b * H + head) * Sq + q_abs] = (ltot > 0.f) ? m + logf(ltot) : -INFINITY;
-        bf16_t* orow = O + (tokq0 + q_abs) * ldo + head * HD;
-#pragma unroll
-        for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = 64 * db + 2 * acc_row(r, l);
-                *reinterpret_cast<uint32_t*>(orow + d) = pack2bf(o[2 * db][r] * inv, o[2 * db + 1][r] * inv);
-            }
-    }
 }
 
 // 1-D grid -> (block along the sequence, head, batch) for the 512-thread kernels.  Workgroup n runs on XCD n % 8 (own L2).
@@ -502,244 +356,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* O, const 
     }
 }
 
-// =========================================================================================== dK, dV
-// grid (ceil(S/128), H, B): block owns 128 keys, wave w owns keys kv0 + 32w + (l&31); loop over 64-query tiles.
-template <int HD>
-__global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
-                                                           const float* LSE, const float* DELTA, bf16_t* dK, bf16_t* dV,
-                                                           const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
-                                                           long long ldq, long long ldk, long long ldv, long long lddo,
-                                                           long long lddk, long long lddv, float scale, int causal) {
-    using C = Cfg<HD>;
-    ARIA_DYN_SMEM(smem);
-    bf16_t* sQ = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* sdO = sQ + 64 * C::PITCH;
-    float* sLse = reinterpret_cast<float*>(sdO + 64 * C::PITCH);
-    float* sDel = sLse + 64;
-    const int t = threadIdx.x, l = t & 63, w = t >> 6, h2 = l >> 5;
-    const int b = blockIdx.z, head = blockIdx.y, kv0 = blockIdx.x * 128;
-    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
-    const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
-    const bf16_t* Kb = K + tok0 * ldk + head * HD;
-    const bf16_t* Vb = V + tok0 * ldv + head * HD;
-    const bf16_t* dOb = dO + tokq0 * lddo + head * HD;
-    const float* lseb = LSE + ((long long)b * H + head) * Sq;
-    const float* delb = DELTA + ((long long)b * H + head) * Sq;
-    const int kv_abs = kv0 + 32 * w + (l & 31);
-    const int klen = kv_len ? min(S, kv_len[b]) : S;
-    const bool key_ok = kv_abs < klen && (!key_mask || key_mask[tok0 + kv_abs] != 0);
-
-    // K and V fragments of this lane's key (B operands of S = Q K^T and dP = dO V^T)
-    s16x8 kf[C::KS], vf[C::KS];
-#pragma unroll
-    for (int kk = 0; kk < C::KS; ++kk) {
-        u32x4 a = zero16(), c = zero16();
-        if (kv_abs < S) {
-            a = ld16(Kb + (long long)kv_abs * ldk + kk * 16 + h2 * 8);
-            c = ld16(Vb + (long long)kv_abs * ldv + kk * 16 + h2 * 8);
-        }
-        kf[kk] = __builtin_bit_cast(s16x8, a);
-        vf[kk] = __builtin_bit_cast(s16x8, c);
-    }
-    f32x16 dk[2 * C::DB], dv[2 * C::DB];
-#pragma unroll
-    for (int i = 0; i < 2 * C::DB; ++i) {
-        dk[i] = zero_acc();
-        dv[i] = zero_acc();
-    }
-    // queries that can see any of this block's keys
-    const int q_begin = causal ? (kv0 / 64) * 64 : 0;
-    const int ntiles = kv0 < klen ? (Sq - q_begin + 63) / 64 : 0;
-    u32x4 rq[C::NCH64], rdo[C::NCH64];
-    if (ntiles > 0) {
-        tile_load<HD>(rq, Qb, ldq, q_begin, Sq, t);
-        tile_load<HD>(rdo, dOb, lddo, q_begin, Sq, t);
-    }
-    for (int it = 0; it < ntiles; ++it) {
-        const int qt0 = q_begin + it * 64;
-        tile_store<HD>(rq, sQ, t);
-        tile_store<HD>(rdo, sdO, t);
-        if (t < 64) {
-            const int q = qt0 + t;
-            sLse[t] = q < Sq ? lseb[q] : 0.f;
-            sDel[t] = q < Sq ? delb[q] : 0.f;
-        }
-        sync();
-        if (it + 1 < ntiles) {
-            tile_load<HD>(rq, Qb, ldq, qt0 + 64, Sq, t);
-            tile_load<HD>(rdo, dOb, lddo, qt0 + 64, Sq, t);
-        }
-        // S and dP tiles: rows = queries (2 x 32), cols = this wave's 32 keys
-        f32x16 s[2], dp[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            s[i] = zero_acc();
-            dp[i] = zero_acc();
-        }
-#pragma unroll
-        for (int kk = 0; kk < C::KS; ++kk)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                s[i] = mfma32(frag_rc<HD>(sQ, i * 32 + (l & 31), kk, l), kf[kk], s[i]);
-                dp[i] = mfma32(frag_rc<HD>(sdO, i * 32 + (l & 31), kk, l), vf[kk], dp[i]);
-            }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = i * 32 + acc_row(r, l);
-                const int q = qt0 + ql;
-                float p = 0.f;
-                if (q < Sq && key_ok && !(causal && kv_abs > q)) p = __expf(s[i][r] * scale - sLse[ql]);
-                s[i][r] = p;                                       // P
-                dp[i][r] = p * (dp[i][r] - sDel[ql]) * scale;      // dS * scale
-            }
-        // dV^T... accumulate dV[kv][d] += P^T dO and dK[kv][d] += dS^T Q  (A = lane-local P^T / dS^T fragments)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const s16x8 pf = pack_frag(s[i], u);
-                const s16x8 dsf = pack_frag(dp[i], u);
-#pragma unroll
-                for (int db = 0; db < C::DB; ++db) {
-                    s16x8 e0, e1;
-                    frag_pair<HD>(e0, e1, sdO, i * 32 + 16 * u, 64 * db + 2 * (l & 31), l);
-                    dv[2 * db] = mfma32(pf, e0, dv[2 * db]);
-                    dv[2 * db + 1] = mfma32(pf, e1, dv[2 * db + 1]);
-                    frag_pair<HD>(e0, e1, sQ, i * 32 + 16 * u, 64 * db + 2 * (l & 31), l);
-                    dk[2 * db] = mfma32(dsf, e0, dk[2 * db]);
-                    dk[2 * db + 1] = mfma32(dsf, e1, dk[2 * db + 1]);
-                }
-            }
-        sync();
-    }
-    // accumulator: rows = keys kv0 + 32w + acc_row, cols = features 64db + 2(l&31) + parity
-#pragma unroll
-    for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kv = kv0 + 32 * w + acc_row(r, l);
-            if (kv >= S) continue;
-            const int d = 64 * db + 2 * (l & 31);
-            *reinterpret_cast<uint32_t*>(dK + (tok0 + kv) * lddk + head * HD + d) = pack2bf(dk[2 * db][r], dk[2 * db + 1][r]);
-            *reinterpret_cast<uint32_t*>(dV + (tok0 + kv) * lddv + head * HD + d) = pack2bf(dv[2 * db][r], dv[2 * db + 1][r]);
-        }
-}
-
-// =========================================================================================== dQ
-// grid (ceil(S/128), H, B): wave w owns queries q0 + 32w + (l&31); loop over 64-key tiles (transposed layout, as fwd)
-template <int HD>
-__global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
-                                                         const float* LSE, const float* DELTA, bf16_t* dQ, const int32_t* kv_len,
-                                                         const uint8_t* key_mask, int Sq, int S, int H, long long ldq,
-                                                         long long ldk, long long ldv, long long lddo, long long lddq,
-                                                         float scale, int causal) {
-    using C = Cfg<HD>;
-    ARIA_DYN_SMEM(smem);
-    bf16_t* sK = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* sV = sK + 64 * C::PITCH;
-    uint8_t* sM = reinterpret_cast<uint8_t*>(sV + 64 * C::PITCH);
-    const int t = threadIdx.x, l = t & 63, w = t >> 6, h2 = l >> 5;
-    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
-    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
-    const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
-    const bf16_t* Kb = K + tok0 * ldk + head * HD;
-    const bf16_t* Vb = V + tok0 * ldv + head * HD;
-    const bf16_t* dOb = dO + tokq0 * lddo + head * HD;
-    const uint8_t* kmb = key_mask ? key_mask + tok0 : nullptr;
-    const int q_abs = q0 + 32 * w + (l & 31);
-    const int klen = kv_len ? min(S, kv_len[b]) : S;
-    s16x8 qf[C::KS], dof[C::KS];
-#pragma unroll
-    for (int kk = 0; kk < C::KS; ++kk) {
-        u32x4 a = zero16(), c = zero16();
-        if (q_abs < Sq) {
-            a = ld16(Qb + (long long)q_abs * ldq + kk * 16 + h2 * 8);
-            c = ld16(dOb + (long long)q_abs * lddo + kk * 16 + h2 * 8);
-        }
-        qf[kk] = __builtin_bit_cast(s16x8, a);
-        dof[kk] = __builtin_bit_cast(s16x8, c);
-    }
-    float lse = 0.f, del = 0.f;
-    if (q_abs < Sq) {
-        lse = LSE[((long long)b * H + head) * Sq + q_abs];
-        del = DELTA[((long long)b * H + head) * Sq + q_abs];
-    }
-    f32x16 dq[2 * C::DB];
-#pragma unroll
-    for (int i = 0; i < 2 * C::DB; ++i) dq[i] = zero_acc();
-    int kv_end = klen;
-    if (causal) kv_end = min(kv_end, q0 + 128);
-    const int ntiles = (kv_end + 63) / 64;
-    u32x4 rk[C::NCH64], rv[C::NCH64];
-    if (ntiles > 0) {
-        tile_load<HD>(rk, Kb, ldk, 0, S, t);
-        tile_load<HD>(rv, Vb, ldv, 0, S, t);
-    }
-    for (int it = 0; it < ntiles; ++it) {
-        const int kv0 = it * 64;
-        tile_store<HD>(rk, sK, t);
-        tile_store<HD>(rv, sV, t);
-        if (kmb && t < 64) sM[t] = (kv0 + t < S) ? kmb[kv0 + t] : 0;
-        sync();
-        if (it + 1 < ntiles) {
-            tile_load<HD>(rk, Kb, ldk, kv0 + 64, S, t);
-            tile_load<HD>(rv, Vb, ldv, kv0 + 64, S, t);
-        }
-        f32x16 st[2], dpt[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            st[i] = zero_acc();
-            dpt[i] = zero_acc();
-        }
-#pragma unroll
-        for (int kk = 0; kk < C::KS; ++kk)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                st[i] = mfma32(frag_rc<HD>(sK, i * 32 + (l & 31), kk, l), qf[kk], st[i]);
-                dpt[i] = mfma32(frag_rc<HD>(sV, i * 32 + (l & 31), kk, l), dof[kk], dpt[i]);
-            }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kvl = i * 32 + acc_row(r, l);
-                const int kv = kv0 + kvl;
-                float p = 0.f;
-                if (q_abs < Sq && kv < klen && !(causal && kv > q_abs) && !(kmb && !sM[kvl])) p = __expf(st[i][r] * scale - lse);
-                dpt[i][r] = p * (dpt[i][r] - del) * scale;  // dS^T * scale
-            }
-        // dQ^T += K^T dS^T
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const s16x8 dsf = pack_frag(dpt[i], u);
-#pragma unroll
-                for (int db = 0; db < C::DB; ++db) {
-                    s16x8 e0, e1;
-                    frag_pair<HD>(e0, e1, sK, i * 32 + 16 * u, 64 * db + 2 * (l & 31), l);
-                    dq[2 * db] = mfma32(e0, dsf, dq[2 * db]);
-                    dq[2 * db + 1] = mfma32(e1, dsf, dq[2 * db + 1]);
-                }
-            }
-        sync();
-    }
-    if (q_abs < Sq) {
-        bf16_t* row = dQ + (tokq0 + q_abs) * lddq + head * HD;
-#pragma unroll
-        for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = 64 * db + 2 * acc_row(r, l);
-                *reinterpret_cast<uint32_t*>(row + d) = pack2bf(dq[2 * db][r], dq[2 * db + 1][r]);
-            }
-    }
-}
-
 // =========================================================================================== backward v2
-// Same two-kernel split as v1, cheaper inner loops: K/V (dQ kernel) or Q/dO (dK/dV kernel) tiles double-buffered in LDS with
+// Two kernels (dK/dV per key tile, dQ per query tile): K/V (dQ kernel) or Q/dO (dK/dV kernel) tiles double-buffered in LDS with
 // one barrier per tile, token-strided operands through ds_read_b64_tr_b16 (natural feature order, no VALU repacking), mask
 // arithmetic only on edge / diagonal / padded tiles, probabilities as exp2(s * scale*log2e - lse*log2e).
 
