@@ -101,9 +101,38 @@ def topk_lowest_index(logits: Tensor, k: int) -> Tuple[Tensor, Tensor]:
     return torch.gather(logits, 1, order), order
 
 
+_FORCED_ROUTING: Optional[list] = None  # see forced_routing()
+
+
+class forced_routing:
+    """Test protocol, NOT reference behaviour: inside ``with forced_routing([idx_layer0, idx_layer1, ...])`` the
+    i-th router call takes its top-k expert ids from the list (the ids the device kernel chose) instead of from its own top-k; scores,
+    tokens_per_expert and every gradient follow from the oracle's OWN logits at those ids.  Used at Aria width, where ~2 % of the
+    tokens have a k-th / (k+1)-th logit gap below the bf16 rounding of the logits: the router is checked separately
+    (ids equal wherever the gap is resolvable), and the arithmetic downstream of it is compared on identical routing so that one
+    flipped token does not masquerade as a 10 % error of an expert's weight gradient."""
+
+    def __init__(self, indices):
+        self.indices = list(indices)
+
+    def __enter__(self):
+        global _FORCED_ROUTING
+        self._prev, _FORCED_ROUTING = _FORCED_ROUTING, list(self.indices)
+        return self
+
+    def __exit__(self, *exc):
+        global _FORCED_ROUTING
+        _FORCED_ROUTING = self._prev
+        return False
+
+
 def router_routing(logits: Tensor, topk: int, num_experts: int) -> Tuple[Tensor, Tensor, Tensor]:
     """scores, top_indices, tokens_per_expert.  moe_lm.py:243-293 (eval branch)."""
-    top_logits, top_indices = topk_lowest_index(logits, topk)
+    if _FORCED_ROUTING:
+        top_indices = _FORCED_ROUTING.pop(0).to(torch.int64).reshape(logits.shape[0], topk)
+        top_logits = torch.gather(logits, 1, top_indices)
+    else:
+        top_logits, top_indices = topk_lowest_index(logits, topk)
     scores = torch.softmax(top_logits, dim=-1, dtype=torch.float32).type_as(logits)  # :262
     tokens_per_expert = torch.bincount(top_indices.flatten(), minlength=num_experts)  # histc :264-269
     return scores, top_indices, tokens_per_expert
@@ -168,9 +197,7 @@ def token_unpermutation(expert_out: Tensor, scores: Tensor, sorted_indices: Tens
     return buf.sum(dim=1).type_as(expert_out).view(out_shape)
 
 
-def sequential_gemm(inp: Tensor, weight: Tensor, tokens_per_expert: Tensor) -> Tensor:
-    """moe_lm.py:398-428 -- the semantics of seam B1 ``experts_gemm(input, weight, tokens_per_expert)``:
-    out[s_e:s_e+n_e] = inp[s_e:s_e+n_e] @ weight[e]."""
+def _sequential_gemm_loop(inp: Tensor, weight: Tensor, tokens_per_expert: Tensor) -> Tensor:
     out = torch.zeros(inp.shape[0], weight.shape[-1], dtype=inp.dtype)
     start = 0
     for e in range(weight.shape[0]):
@@ -179,6 +206,41 @@ def sequential_gemm(inp: Tensor, weight: Tensor, tokens_per_expert: Tensor) -> T
             out[start : start + n] = inp[start : start + n] @ weight[e]
         start += n
     return out
+
+
+class _SequentialGemm(torch.autograd.Function):
+    """The loop above with its derivative written out (d inp[rows of e] = d out[rows of e] @ weight[e]^T, d weight[e] =
+    inp[rows of e]^T @ d out[rows of e]) -- what autograd computes for the loop, without the full-size zero tensor it allocates per
+    ``weight[e]`` select (64 x 3.5 GB at Aria width: 50 s per layer).  tests/test_oracle_golden.py checks it against plain autograd."""
+
+    @staticmethod
+    def forward(ctx, inp, weight, tokens_per_expert):
+        ctx.save_for_backward(inp, weight)
+        ctx.tpe = [int(n) for n in tokens_per_expert]
+        return _sequential_gemm_loop(inp, weight, tokens_per_expert)
+
+    @staticmethod
+    def backward(ctx, gout):
+        inp, weight = ctx.saved_tensors
+        ginp = torch.zeros_like(inp) if ctx.needs_input_grad[0] else None
+        gw = torch.zeros_like(weight) if ctx.needs_input_grad[1] else None
+        start = 0
+        for e, n in enumerate(ctx.tpe):
+            if n:
+                if ginp is not None:
+                    ginp[start : start + n] = gout[start : start + n] @ weight[e].t()
+                if gw is not None:
+                    torch.mm(inp[start : start + n].t(), gout[start : start + n], out=gw[e])
+            start += n
+        return ginp, gw, None
+
+
+def sequential_gemm(inp: Tensor, weight: Tensor, tokens_per_expert: Tensor) -> Tensor:
+    """moe_lm.py:398-428 -- the semantics of seam B1 ``experts_gemm(input, weight, tokens_per_expert)``:
+    out[s_e:s_e+n_e] = inp[s_e:s_e+n_e] @ weight[e]."""
+    if torch.is_grad_enabled() and (inp.requires_grad or weight.requires_grad):
+        return _SequentialGemm.apply(inp, weight, tokens_per_expert)
+    return _sequential_gemm_loop(inp, weight, tokens_per_expert)
 
 
 def glu(x: Tensor) -> Tensor:

@@ -1,0 +1,370 @@
+"""Module-level parity AT THE CONFIG WIDTHS OF BASELINE.json (VERDICT r1 "missing" #1): the golden fixtures are toy-sized (D 64, 8
+experts), so at those sizes every GEMM dispatches to the 128x128 v1 kernel and the benchmarked 256x256 kernels (gemm2 / gemm3, the
+expert-major XCD tile list) are only reached by kernel-level cases.  Here whole blocks run at D 2560 / 20 x 128 / 64 experts top-6 /
+I 1664 (decoder), 1152 / 16 x 72 / 4304 on 4900 patches (ViT) and config #1 end to end, against ``oracle/aria_oracle.py`` in fp32 on
+the same bf16-rounded weights and inputs (reference: aria/model/moe_lm.py:548-602, modeling_aria.py:194-335).
+
+Every case takes its dimensions as arguments: the hardware suite (-m gpu, tests/test_gpu_fullwidth.py) passes the real ones, the CPU
+suite runs the SAME code at reduced width through the SIMT emulator (tests/test_emu_fullwidth.py) so that the comparison logic
+itself is exercised without a GPU.
+
+Protocol.
+  * Router: ids equal wherever the oracle's logit gaps around the k-th place exceed 2 bf16 ulps of the logit scale (the
+    kernel sees bf16-rounded logits); the fraction of tokens with the same expert SET is reported and bounded.
+  * Everything downstream of the router is compared on IDENTICAL routing (``O.forced_routing`` with the ids the device chose): a
+    flipped token would otherwise show up as a ~10 % error of one expert's weight gradient although no arithmetic is wrong.
+  * Metrics per tensor: relative L2 error, cosine, and max-abs error over max-abs of the reference -- all three bounded, so a wrong
+    small-magnitude block cannot hide behind a large one (VERDICT r1 weak #1b).  The measured values are collected in ``REPORT`` and
+    written to gpurun_out/fullwidth_parity.json by the hardware suite (copied to profiles/ as evidence).
+"""
+import json
+import os
+
+import torch
+
+from oracle import aria_oracle as O
+
+bf16 = torch.bfloat16
+REPORT = {}
+
+
+def metrics(got, want):
+    got, want = got.detach().double().cpu().flatten(), want.detach().double().cpu().flatten()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    diff = got - want
+    wn = want.norm().clamp(min=1e-30)
+    return {"rel_l2": float(diff.norm() / wn), "cos": float(torch.dot(got, want) / (got.norm().clamp(min=1e-30) * wn)),
+            "max_rel": float(diff.abs().max() / want.abs().max().clamp(min=1e-30))}
+
+
+def check(case, name, got, want, rel_l2, max_rel, cos=None):
+    m = metrics(got, want)
+    REPORT.setdefault(case, {})[name] = {k: round(v, 6) for k, v in m.items()}
+    cos = 1.0 - 0.5 * rel_l2 * rel_l2 * 4 if cos is None else cos  # |a-b| <= e|b| implies cos >= ~1 - e^2/2; allow 4x
+    assert m["rel_l2"] <= rel_l2 and m["max_rel"] <= max_rel and m["cos"] >= cos, (case, name, m, (rel_l2, max_rel, cos))
+
+
+def dump_report(path):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    prev = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            prev = json.load(f)
+    prev.update(REPORT)
+    with open(path, "w") as f:
+        json.dump(prev, f, indent=1, sort_keys=True)
+
+
+def randw(shape, gen, std=0.02):
+    return (torch.randn(shape, generator=gen) * std).to(bf16)
+
+
+def lm_weights(cfg: O.LMConfig, seed: int):
+    """Reference state-dict keys (moe_lm.py: LlamaForCausalLM layout), N(0, 0.02) like the benchmark, norm weights 1 +- 0.1."""
+    g = torch.Generator().manual_seed(seed)
+    D, E, I, V = cfg.hidden_size, cfg.moe_num_experts, cfg.moe_intermediate_size, cfg.vocab_size
+    I2 = I * cfg.moe_num_shared_experts
+    Dq = cfg.num_attention_heads * cfg.head_dim
+    w = {"model.embed_tokens.weight": randw((V, D), g), "lm_head.weight": randw((V, D), g),
+         "model.norm.weight": (1 + 0.1 * torch.randn(D, generator=g)).to(bf16)}
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        w[p + "input_layernorm.weight"] = (1 + 0.1 * torch.randn(D, generator=g)).to(bf16)
+        w[p + "post_attention_layernorm.weight"] = (1 + 0.1 * torch.randn(D, generator=g)).to(bf16)
+        for n in "qkv":
+            w[p + f"self_attn.{n}_proj.weight"] = randw((Dq, D), g)
+        w[p + "self_attn.o_proj.weight"] = randw((D, Dq), g)
+        w[p + "mlp.router.weight"] = randw((E, D), g)
+        w[p + "mlp.experts.fc1.weight"] = randw((E, D, 2 * I), g)
+        w[p + "mlp.experts.fc2.weight"] = randw((E, I, D), g)
+        w[p + "mlp.shared_experts.gate_proj.weight"] = randw((I2, D), g)
+        w[p + "mlp.shared_experts.up_proj.weight"] = randw((I2, D), g)
+        w[p + "mlp.shared_experts.down_proj.weight"] = randw((D, I2), g)
+    return w
+
+
+class _Recorder:
+    """Records what the device router chose (ops.moe_route) and which GEMM kernel family every grouped GEMM dispatched to."""
+
+    def __init__(self):
+        from aria_amd import hip, ops
+
+        self.ops, self.hip = ops, hip
+        self.idx, self.variants = [], []
+
+    def __enter__(self):
+        ops = self.ops
+        self._route, self._gg = ops.moe_route, ops.grouped_gemm
+
+        def route(logits, k):
+            r = self._route(logits, k)
+            self.idx.append(r[1].detach().cpu().long())
+            return r
+
+        def gg(*a, **kw):
+            r = self._gg(*a, **kw)
+            self.variants.append(int(self.hip.get_lib().cdll.aria_last_gemm_variant()))
+            return r
+
+        ops.moe_route, ops.grouped_gemm = route, gg
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.moe_route, self.ops.grouped_gemm = self._route, self._gg
+        return False
+
+
+class _OracleLogits:
+    """Records the oracle's router logits per router call (to judge which tokens have a resolvable top-k)."""
+
+    def __enter__(self):
+        self.logits = []
+        self._orig = O.router_routing
+
+        def rr(logits, topk, num_experts):
+            self.logits.append(logits.detach().clone())
+            return self._orig(logits, topk, num_experts)
+
+        O.router_routing = rr
+        return self
+
+    def __exit__(self, *exc):
+        O.router_routing = self._orig
+        return False
+
+
+def router_parity(case, layer, dev_idx, logits, k, min_same=0.93):
+    """dev_idx [T,k] (device order) vs the oracle's own top-k on its fp32 logits."""
+    _, own = O.topk_lowest_index(logits, k)
+    srt = torch.sort(logits, dim=1, descending=True).values
+    ulp2 = 2.0 ** -6 * logits.abs().max()     # 2 bf16 ulps at the logit scale
+    gaps = (srt[:, :k] - srt[:, 1:k + 1]).min(dim=1).values   # every gap down to the k / k+1 boundary
+    safe = gaps > ulp2
+    same_set = (torch.sort(dev_idx, 1).values == torch.sort(own, 1).values).all(1)
+    REPORT.setdefault(case, {})[f"router.layer{layer}"] = {"tokens": int(logits.shape[0]), "safe_frac": round(float(safe.float().mean()), 4),
+                                                            "same_set_frac": round(float(same_set.float().mean()), 4)}
+    assert bool(safe.any())
+    assert torch.equal(dev_idx[safe], own[safe]), f"{case}: router ids differ on a token with resolvable gaps (layer {layer})"
+    assert float(same_set.float().mean()) >= min_same, (case, layer, float(same_set.float().mean()))
+
+
+def case_lm(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, B, S, expect_big_gemm, seed=5,
+            act_tol=(2e-2, 4e-2), grad_tol=(3e-2, 6e-2)):
+    """L-layer AriaMoELMForCausalLM at the given width: eval logits, training loss and EVERY gradient (aux losses on)."""
+    from aria_amd.moe_lm import AriaMoELMConfig, AriaMoELMForCausalLM, load_reference_state_dict
+
+    ocfg = O.LMConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, num_key_value_heads=heads, vocab_size=vocab,
+                      moe_intermediate_size=inter, moe_num_experts=experts, moe_topk=topk)
+    w = lm_weights(ocfg, seed)
+    cfg = AriaMoELMConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, vocab_size=vocab,
+                          moe_intermediate_size=inter, moe_num_experts=experts, moe_topk=topk, moe_num_shared_experts=2,
+                          rms_norm_eps=ocfg.rms_norm_eps, rope_theta=ocfg.rope_theta, moe_z_loss_coeff=ocfg.moe_z_loss_coeff,
+                          moe_aux_loss_coeff=ocfg.moe_aux_loss_coeff)
+    lm = AriaMoELMForCausalLM(cfg)
+    load_reference_state_dict(lm, w)
+    lm = lm.to(dev)
+    ids = torch.randint(0, vocab, (B, S), generator=torch.Generator().manual_seed(seed + 1))
+    wf = {k: v.float().requires_grad_(True) for k, v in w.items()}
+
+    # ---- eval: logits
+    lm.eval()
+    with _Recorder() as rec, torch.no_grad():
+        got = lm(input_ids=ids.to(dev)).logits.float().cpu()
+    assert len(rec.idx) == layers
+    if expect_big_gemm:  # the 256x256 kernel families (v2 / v3) are what runs at this size -- the point of the case
+        assert rec.variants and min(rec.variants) >= 2, rec.variants
+    REPORT.setdefault(case, {})["grouped_gemm_variants"] = sorted(set(rec.variants))
+    with _OracleLogits() as ol, O.forced_routing(rec.idx), torch.no_grad():
+        want = O.lm_forward(wf["model.embed_tokens.weight"][ids], wf, ocfg)
+    for i in range(layers):
+        router_parity(case, i, rec.idx[i], ol.logits[i], topk)
+    check(case, "logits", got, want, *act_tol)
+
+    # ---- training: loss and gradients with the router's aux losses
+    lm.train()
+    with _Recorder() as rec:
+        out = lm(input_ids=ids.to(dev), labels=ids.to(dev), return_logits=False)
+        out.loss.backward()
+    with O.forced_routing(rec.idx):
+        lgo = O.lm_forward(wf["model.embed_tokens.weight"][ids], wf, ocfg, training=True)
+    loss_o = torch.nn.functional.cross_entropy(lgo[:, :-1].reshape(-1, vocab), ids[:, 1:].reshape(-1))
+    loss_o.backward()
+    rel = abs(float(out.loss.detach()) - float(loss_o.detach())) / abs(float(loss_o.detach()))
+    REPORT[case]["loss"] = {"got": float(out.loss.detach()), "want": float(loss_o.detach()), "rel": round(rel, 6)}
+    assert rel <= 5e-3, REPORT[case]["loss"]
+    n = 0
+    for name, p in lm.named_parameters():
+        assert p.grad is not None and wf[name].grad is not None, name
+        check(case, "grad " + name, p.grad, wf[name].grad, *grad_tol)
+        n += 1
+    assert n == 3 + 12 * layers
+
+
+# ------------------------------------------------------------------------------------------------------------ ViT + projector
+def vit_weights(vc: O.VisionConfig, n_queries: int, out_dim: int, ff_dim: int, seed: int):
+    g = torch.Generator().manual_seed(seed)
+    D, I, P = vc.hidden_size, vc.intermediate_size, (vc.image_size // vc.patch_size) ** 2
+    w = {}
+    v = "vision_tower.vision_model."
+    w[v + "embeddings.patch_embedding.weight"] = randw((D, vc.num_channels, vc.patch_size, vc.patch_size), g)
+    w[v + "embeddings.patch_embedding.bias"] = randw((D,), g)
+    w[v + "embeddings.position_embedding.weight"] = randw((P, D), g)
+    for i in range(vc.num_hidden_layers):
+        p = v + f"encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            w[p + f"self_attn.{n}.weight"] = randw((D, D), g)
+            w[p + f"self_attn.{n}.bias"] = randw((D,), g)
+        for n in ("layer_norm1", "layer_norm2"):
+            w[p + n + ".weight"] = (1 + 0.1 * torch.randn(D, generator=g)).to(bf16)
+            w[p + n + ".bias"] = randw((D,), g)
+        w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"] = randw((I, D), g), randw((I,), g)
+        w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"] = randw((D, I), g), randw((D,), g)
+    m = "multi_modal_projector."
+    w[m + "query"] = randw((n_queries, D), g, 1.0)
+    for n in ("q_proj", "k_proj", "v_proj"):
+        w[m + f"cross_attn.{n}.weight"] = randw((D, D), g)
+    w[m + "cross_attn.multihead_attn.in_proj_weight"] = randw((3 * D, D), g)
+    w[m + "cross_attn.multihead_attn.in_proj_bias"] = randw((3 * D,), g)
+    w[m + "cross_attn.multihead_attn.out_proj.weight"], w[m + "cross_attn.multihead_attn.out_proj.bias"] = randw((D, D), g), randw((D,), g)
+    w[m + "cross_attn.linear.weight"], w[m + "cross_attn.linear.bias"] = randw((D, D), g), randw((D,), g)
+    for n in ("cross_attn.layer_norm", "cross_attn.ln_kv", "ln_ffn"):
+        w[m + n + ".weight"] = (1 + 0.1 * torch.randn(D, generator=g)).to(bf16)
+        w[m + n + ".bias"] = randw((D,), g)
+    w[m + "ffn.linear_in.weight"] = randw((ff_dim, D), g)
+    w[m + "ffn.linear_out.weight"] = randw((out_dim, ff_dim), g)
+    return w
+
+
+def _load(module, sd, prefix):
+    own = module.state_dict()
+    missing = [k for k in own if prefix + k not in sd]
+    assert not missing, missing[:5]
+    with torch.no_grad():
+        for k, v in own.items():
+            v.copy_(sd[prefix + k].to(v.dtype))
+
+
+def case_vit_projector(dev, case, *, hidden, heads, inter, image, layers, queries, out_dim, n_images, valid_rows, seed=9,
+                       tol=(2e-2, 5e-2)):
+    """AriaVisionModel (frozen fast path AND module path) + AriaProjector on images whose bottom rows are padding (pixel_mask)."""
+    from aria_amd.vision import AriaProjector, AriaVisionConfig, AriaVisionModel
+
+    vc = O.VisionConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=inter, image_size=image)
+    P = (image // vc.patch_size) ** 2
+    p2q = {P: queries}
+    w = vit_weights(vc, queries, out_dim, out_dim, seed)
+    cfg = AriaVisionConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=inter, image_size=image)
+    vit = AriaVisionModel(cfg)
+    _load(vit, w, "vision_tower.")
+    proj = AriaProjector(p2q, hidden, heads, hidden, out_dim, out_dim)
+    _load(proj, w, "multi_modal_projector.")
+    vit, proj = vit.to(dev).eval(), proj.to(dev).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    pv = torch.randn((n_images, 3, image, image), generator=g).clamp_(-1, 1).to(bf16)
+    pm = torch.ones((n_images, image, image), dtype=torch.bool)
+    pm[0, valid_rows:, :] = False                      # image 0: bottom rows padded (not a multiple of the patch size on purpose)
+    pm[0, :, image - 3 * vc.patch_size:] = False       # ... and three patch columns on the right
+    wf = {k: v.float() for k, v in w.items()}
+    ocfg = O.AriaOracleConfig(vision=vc, patch_to_query=p2q, projector_heads=heads)
+    with torch.no_grad():
+        want_feat, want_atts = O.vit_forward(pv.float(), pm, wf, "vision_tower.", vc)
+        want_proj = O.projector_forward(want_feat, want_atts, wf, "multi_modal_projector.", ocfg)
+        feat, atts = vit(pv.to(dev), pm.to(dev))
+        pj = proj(feat, attn_mask=atts)
+    assert torch.equal(atts.cpu(), want_atts)
+    valid = ~want_atts
+    check(case, "vit features (valid patches, frozen fast path)", feat.cpu()[valid], want_feat[valid], *tol)
+    check(case, "projector", pj, want_proj, *tol)
+    feat_m, _ = vit(pv.to(dev).requires_grad_(True), pm.to(dev))     # module-by-module path (a trainable tower)
+    check(case, "vit features (module path)", feat_m.detach().cpu()[valid], want_feat[valid], *tol)
+
+
+# ------------------------------------------------------------------------------------------------------------ config #1 end to end
+def case_aria_config1(dev, case, *, text, vision, queries, n_text, seed=13, act_tol=(2e-2, 5e-2), grad_tol=(4e-2, 8e-2)):
+    """BASELINE.json config #1: one image + text through AriaForConditionalGeneration (ViT -> projector -> masked_scatter -> MoE LM ->
+    shifted masked CE), logits + loss + gradients of projector and LM (ViT frozen), vs O.aria_forward (modeling_aria.py:194-335)."""
+    from aria_amd.modeling_aria import AriaConfig, AriaForConditionalGeneration
+
+    tc = O.LMConfig(**text)
+    vc = O.VisionConfig(**vision)
+    P = (vc.image_size // vc.patch_size) ** 2
+    p2q = {P: queries}
+    IMG = 9
+    w = {("language_model." + k): v for k, v in lm_weights(tc, seed).items()}
+    w.update(vit_weights(vc, queries, tc.hidden_size, tc.hidden_size, seed + 1))
+    cfg = AriaConfig(vision_config=dict(vision), text_config=dict(text, moe_num_shared_experts=2), projector_patch_to_query_dict=p2q,
+                     image_token_index=IMG)
+    model = AriaForConditionalGeneration(cfg)
+    _load(model.vision_tower, w, "vision_tower.")
+    _load(model.multi_modal_projector, w, "multi_modal_projector.")
+    _load(model.language_model, w, "language_model.")
+    model = model.to(dev)
+    model.freeze_vit()
+    g = torch.Generator().manual_seed(seed + 2)
+    S = 14 + queries + n_text
+    ids = torch.randint(10, tc.vocab_size, (1, S), generator=g)
+    ids[0, 7:7 + queries] = IMG
+    am = torch.ones((1, S), dtype=torch.long)
+    labels = ids.clone()
+    labels[0, :7 + queries + 4] = -100
+    pv = torch.randn((1, 3, vc.image_size, vc.image_size), generator=g).clamp_(-1, 1).to(bf16)
+    pm = torch.ones((1, vc.image_size, vc.image_size), dtype=torch.bool)
+    pm[0, int(0.75 * vc.image_size):, :] = False
+    wf = {k: (v.float().requires_grad_(not k.startswith("vision_tower."))) for k, v in w.items()}
+    ocfg = O.AriaOracleConfig(text=tc, vision=vc, patch_to_query=p2q, projector_heads=vc.num_attention_heads, image_token_index=IMG)
+    model.eval()
+    with _Recorder() as rec, torch.no_grad():
+        out = model(input_ids=ids.to(dev), pixel_values=pv.to(dev), pixel_mask=pm.to(dev), attention_mask=am.to(dev), labels=labels.to(dev),
+                    return_logits=True)
+    with _OracleLogits() as ol, O.forced_routing(rec.idx), torch.no_grad():
+        want_logits, want_loss = O.aria_forward(ids, pv.float(), pm, am, labels, wf, ocfg)
+    for i in range(tc.num_hidden_layers):
+        router_parity(case, i, rec.idx[i], ol.logits[i], tc.moe_topk, min_same=0.9)
+    check(case, "logits", out.logits, want_logits, *act_tol)
+    assert abs(float(out.loss) - float(want_loss)) <= 5e-3 * abs(float(want_loss)), (float(out.loss), float(want_loss))
+    model.train()
+    with _Recorder() as rec:
+        out = model(input_ids=ids.to(dev), pixel_values=pv.to(dev), pixel_mask=pm.to(dev), attention_mask=am.to(dev), labels=labels.to(dev))
+        out.loss.backward()
+    with O.forced_routing(rec.idx):
+        _, lo = O.aria_forward(ids, pv.float(), pm, am, labels, wf, ocfg, training=True)
+    lo.backward()
+    assert abs(float(out.loss.detach()) - float(lo.detach())) <= 5e-3 * abs(float(lo.detach()))
+    n = 0
+    for name, p in model.named_parameters():
+        if name.startswith("vision_tower."):
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None and wf[name].grad is not None, name
+        check(case, "grad " + name, p.grad, wf[name].grad, *grad_tol)
+        n += 1
+    assert n >= 3 + 12 * tc.num_hidden_layers + 10
+
+
+# ------------------------------------------------------------------------------------------------------------ long causal attention
+def case_long_attention(dev, case, *, S, H, hd, B=1, seed=21, tol=(6e-3, 2e-2), gtol=(8e-3, 3e-2)):
+    """Causal flash attention forward + backward at config #4's sequence scale (gptfast/model.py:137-149, 413-447), fp32 eager oracle."""
+    from aria_amd import ops
+
+    D = H * hd
+    g = torch.Generator().manual_seed(seed)
+    qkv = torch.randn((B * S, 3 * D), generator=g).to(bf16)
+    do = torch.randn((B * S, D), generator=g).to(bf16)
+    scale = hd ** -0.5
+    qd = qkv.to(dev)
+    o, lse = ops.attention_fwd(qd[:, :D], qd[:, D:2 * D], qd[:, 2 * D:], B, S, H, hd, scale, True, None)
+    dq, dk, dv = ops.attention_bwd(qd[:, :D], qd[:, D:2 * D], qd[:, 2 * D:], o, do.to(dev), lse, B, S, H, hd, scale, True, None)
+    got = [t.float().cpu() for t in (o, dq, dk, dv)]
+    want_o = torch.empty(B * S, D)
+    grads = [torch.empty(B * S, D) for _ in range(3)]
+    for h in range(H):   # head by head: one S x S fp32 score matrix at a time
+        sl = slice(h * hd, (h + 1) * hd)
+        q, k, v = (qkv[:, i * D:(i + 1) * D][:, sl].float().view(B, S, 1, hd).transpose(1, 2).clone().requires_grad_(True) for i in range(3))
+        oh = O.attention_eager(q, k, v, scale, True)                     # [B,1,S,hd]
+        oh.backward(do[:, sl].float().view(B, S, 1, hd).transpose(1, 2))
+        want_o[:, sl] = oh.detach().transpose(1, 2).reshape(B * S, hd)
+        for dst, t in zip(grads, (q, k, v)):
+            dst[:, sl] = t.grad.transpose(1, 2).reshape(B * S, hd)
+    check(case, "o", got[0], want_o, *tol)
+    for name, gt, wt in zip(("dq", "dk", "dv"), got[1:], grads):
+        check(case, name, gt, wt, *gtol)

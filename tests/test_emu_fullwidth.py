@@ -1,0 +1,37 @@
+"""The full-width parity cases (tests/fullwidth_cases.py) at REDUCED width through the SIMT emulator: exercises the comparison logic
+(forced routing, router protocol, per-tensor metrics, every parameter's gradient) on CPU.  The real widths run on hardware
+(tests/test_gpu_fullwidth.py, -m gpu)."""
+import pytest
+
+from tests import fullwidth_cases as F
+from tests.emu import emu_lib
+
+
+@pytest.fixture(autouse=True)
+def _emu():
+    emu_lib.install()
+    yield
+    emu_lib.uninstall()
+
+
+def test_lm_case_small():
+    F.case_lm("cpu", "emu_lm", hidden=128, heads=2, experts=8, topk=2, inter=32, vocab=160, layers=2, B=2, S=24, expect_big_gemm=False,
+              act_tol=(3e-2, 8e-2), grad_tol=(8e-2, 2e-1))
+    assert "grad model.layers.1.mlp.experts.fc1.weight" in F.REPORT["emu_lm"] and "router.layer1" in F.REPORT["emu_lm"]
+
+
+def test_vit_projector_case_small():
+    F.case_vit_projector("cpu", "emu_vit", hidden=144, heads=2, inter=96, image=70, layers=1, queries=4, out_dim=64, n_images=2, valid_rows=40,
+                         tol=(4e-2, 1e-1))
+
+
+def test_aria_config1_case_small():
+    F.case_aria_config1("cpu", "emu_cfg1",
+                        text=dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2, vocab_size=160,
+                                  moe_intermediate_size=32, moe_num_experts=8, moe_topk=2),
+                        vision=dict(hidden_size=144, num_hidden_layers=1, num_attention_heads=2, intermediate_size=96, image_size=70),
+                        queries=4, n_text=20, act_tol=(4e-2, 1e-1), grad_tol=(1e-1, 2.5e-1))
+
+
+def test_long_attention_case_small():
+    F.case_long_attention("cpu", "emu_attn", S=320, H=1, hd=128)

@@ -1,0 +1,49 @@
+"""Module-level parity at BASELINE.json's config widths on the MI355X: the 256x256 GEMM kernels and the
+expert-major XCD tile list are the kernels under test here (asserted through aria_last_gemm_variant).  Measured per-tensor metrics go
+to gpurun_out/fullwidth_parity.json."""
+import os
+
+import pytest
+
+from tests import fullwidth_cases as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARIA_TEXT = dict(hidden_size=2560, num_attention_heads=20, num_key_value_heads=20, moe_intermediate_size=1664, moe_num_experts=64, moe_topk=6)
+ARIA_VIT = dict(hidden_size=1152, num_attention_heads=16, intermediate_size=4304)
+
+
+@pytest.fixture(autouse=True)
+def _report():
+    yield
+    F.dump_report(os.path.join(ROOT, "gpurun_out", "fullwidth_parity.json"))
+
+
+def test_decoder_layer_aria_width_T4096():
+    """ONE decoder layer fwd+bwd at D 2560 / 20 x 128 / E 64 top-6 / I 1664, T = 2 x 2048 = 4096 (24 576 expert rows: 1664 tiles of the
+    256 x 256 grouped GEMM) inside a 1-layer LM with a small vocabulary: logits, loss, all 15 gradients."""
+    F.case_lm(DEV, "decoder_layer_T4096", hidden=2560, heads=20, experts=64, topk=6, inter=1664, vocab=4096, layers=1, B=2, S=2048,
+              expect_big_gemm=True)
+
+
+def test_two_decoder_layers_aria_width_ragged():
+    """Two layers, T = 3 x 1000 (ragged row tiles, S not a multiple of any tile)."""
+    F.case_lm(DEV, "decoder_2layers_T3000", hidden=2560, heads=20, experts=64, topk=6, inter=1664, vocab=2048, layers=2, B=3, S=1000,
+              expect_big_gemm=True, seed=6)
+
+
+def test_vit_layer_980px_padded_and_projector_256():
+    """ONE ViT layer at 1152 / 16 x 72 / 4304 on 980-px images (4900 patches) with a padded pixel_mask + the projector with 256 queries."""
+    F.case_vit_projector(DEV, "vit_980_layer", hidden=1152, heads=16, inter=4304, image=980, layers=1, queries=256, out_dim=2560, n_images=2,
+                         valid_rows=735)
+
+
+def test_config1_end_to_end():
+    """BASELINE config #1: 490-px image (1225 patches -> 128 tokens) + 128 text tokens, full widths, full vocabulary, 2 + 2 layers."""
+    F.case_aria_config1(DEV, "config1_490px_128text", text=dict(ARIA_TEXT, num_hidden_layers=2, vocab_size=100352),
+                        vision=dict(ARIA_VIT, num_hidden_layers=2, image_size=490), queries=128, n_text=128)
+
+
+def test_causal_attention_S16384_fwd_bwd():
+    F.case_long_attention(DEV, "attention_causal_S16384", S=16384, H=2, hd=128)
