@@ -90,7 +90,7 @@ class _Recorder:
         from aria_amd import hip, ops
 
         self.ops, self.hip = ops, hip
-        self.idx, self.variants = [], []
+        self.idx, self.logits, self.variants = [], [], []
 
     def __enter__(self):
         ops = self.ops
@@ -99,6 +99,7 @@ class _Recorder:
         def route(logits, k):
             r = self._route(logits, k)
             self.idx.append(r[1].detach().cpu().long())
+            self.logits.append(logits.detach().float().cpu())
             return r
 
         def gg(*a, **kw):
@@ -133,17 +134,21 @@ class _OracleLogits:
         return False
 
 
-def router_parity(case, layer, dev_idx, logits, k, min_same=0.93):
-    """dev_idx [T,k] (device order) vs the oracle's own top-k on its fp32 logits."""
+def router_parity(case, layer, dev_idx, dev_logits, logits, k, min_same=0.9):
+    """Device router vs the oracle's own top-k on its fp32 logits.  The device sees ITS logits (bf16 GEMM output on bf16 activations
+    that carry the rounding of everything upstream); with delta_t = max_e |device logit - oracle logit| of token t, the two top-k
+    ORDERS are provably the same whenever every oracle gap down to the k / k+1 boundary exceeds 2 delta_t -- there the ids must be
+    bit-equal.  Also bounds the logit error itself and reports how many tokens end up with the same expert set."""
+    check(case, f"router logits layer{layer}", dev_logits, logits, 2e-2, 6e-2)
     _, own = O.topk_lowest_index(logits, k)
     srt = torch.sort(logits, dim=1, descending=True).values
-    ulp2 = 2.0 ** -6 * logits.abs().max()     # 2 bf16 ulps at the logit scale
     gaps = (srt[:, :k] - srt[:, 1:k + 1]).min(dim=1).values   # every gap down to the k / k+1 boundary
-    safe = gaps > ulp2
+    delta = (dev_logits - logits).abs().max(dim=1).values
+    safe = gaps > 2 * delta + 1e-12
     same_set = (torch.sort(dev_idx, 1).values == torch.sort(own, 1).values).all(1)
     REPORT.setdefault(case, {})[f"router.layer{layer}"] = {"tokens": int(logits.shape[0]), "safe_frac": round(float(safe.float().mean()), 4),
                                                             "same_set_frac": round(float(same_set.float().mean()), 4)}
-    assert bool(safe.any())
+    assert float(safe.float().mean()) >= 0.5, REPORT[case][f"router.layer{layer}"]
     assert torch.equal(dev_idx[safe], own[safe]), f"{case}: router ids differ on a token with resolvable gaps (layer {layer})"
     assert float(same_set.float().mean()) >= min_same, (case, layer, float(same_set.float().mean()))
 
@@ -177,7 +182,7 @@ def case_lm(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, B,
     with _OracleLogits() as ol, O.forced_routing(rec.idx), torch.no_grad():
         want = O.lm_forward(wf["model.embed_tokens.weight"][ids], wf, ocfg)
     for i in range(layers):
-        router_parity(case, i, rec.idx[i], ol.logits[i], topk)
+        router_parity(case, i, rec.idx[i], rec.logits[i], ol.logits[i], topk)
     check(case, "logits", got, want, *act_tol)
 
     # ---- training: loss and gradients with the router's aux losses
@@ -319,7 +324,7 @@ def case_aria_config1(dev, case, *, text, vision, queries, n_text, seed=13, act_
     with _OracleLogits() as ol, O.forced_routing(rec.idx), torch.no_grad():
         want_logits, want_loss = O.aria_forward(ids, pv.float(), pm, am, labels, wf, ocfg)
     for i in range(tc.num_hidden_layers):
-        router_parity(case, i, rec.idx[i], ol.logits[i], tc.moe_topk, min_same=0.9)
+        router_parity(case, i, rec.idx[i], rec.logits[i], ol.logits[i], tc.moe_topk)
     check(case, "logits", out.logits, want_logits, *act_tol)
     assert abs(float(out.loss) - float(want_loss)) <= 5e-3 * abs(float(want_loss)), (float(out.loss), float(want_loss))
     model.train()
