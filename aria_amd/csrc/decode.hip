@@ -514,11 +514,13 @@ int launch_decode_attn(void* stream, const bf16_t* qkv, const bf16_t* freqs, con
     return aria_check_launch();
 }
 
-// ARIA_DECODE_SPLIT_KV: unset / "0" = off (contexts > 16 K take the generic flash kernel); "1" = one split per 1024 cache slots
-// (2..32); N > 1 = exactly N splits.  Opt-in until it has been timed on hardware.
+// ARIA_DECODE_SPLIT_KV: unset / "1" = one split per 1024 cache slots (2..32) for caches beyond 2048 slots; "0" = off (one workgroup
+// per head; contexts > 16 K take the generic flash kernel); N > 1 = exactly N splits.  Measured on MI355X (profiles/r02_decode_split_kv.json):
+// whole decode step 6.04 -> 3.19 ms at S_max 4096, 15.2 -> 3.70 ms at 16 K, 39.3 -> 4.37 ms at 32 K; the attention launch alone
+// 384 -> 42 us at a 16 K fill.  Parity: tests/kernel_cases.py::case_decode_attention on hardware, 7 shapes.
 int decode_splits_for(int64_t Smax) {
     const char* e = std::getenv("ARIA_DECODE_SPLIT_KV");  // read per call (a few ns against ~7 launches): tests flip it in-process
-    const int mode = e ? atoi(e) : 0;
+    const int mode = e ? atoi(e) : 1;
     if (mode <= 0 || Smax <= 2048) return 1;
     const int64_t n = mode == 1 ? (Smax + 1023) / 1024 : mode;
     return int(n < 2 ? 2 : n > DECODE_MAX_SPLITS ? DECODE_MAX_SPLITS : n);
