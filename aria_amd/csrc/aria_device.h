@@ -184,6 +184,15 @@ __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) {
 #endif
 }
 
+// low 32 bits of the product of two values below 2^24 (v_mul_u32_u24: full rate; v_mul_lo_u32 is quarter rate)
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
+#ifdef ARIA_EMU
+    return a * b;
+#else
+    return __umul24(a, b);
+#endif
+}
+
 // ---- 16-byte global / LDS access helpers ----
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }

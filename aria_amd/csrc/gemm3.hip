@@ -44,6 +44,7 @@
 #include "aria_hip.h"
 #include "gemm_params.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 using namespace ad;
@@ -51,22 +52,37 @@ using namespace ad;
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int LDS_OPERAND = 65536, LDS_HALF = 32768, LDS_BUF = 16384;  // byte strides: operand (A,B) / half / buffer
 
-// byte offset (from the operand base pointer, at k = 0) of the 16 bytes lane l of wave w fetches for piece s of a half-tile
+// The 16 bytes lane l of wave w fetches for piece s (0 / 1) of a half-tile, as a byte offset from the operand base pointer at k = 0.
+// Only two per-lane values are kept (they do not depend on the tile); the offset itself is put together from them and the tile's
+// wave-uniform origin at the point of use (5 VALU operations per piece against ~250 cycles of matrix work): 2-4 VGPRs instead of 8
+// precomputed offsets, and a change of tile (persistent form) touches scalar registers only.
+//   rc ([rows][k]):  piece q = 2 w + s holds rows r = 8 q + (l >> 3); the 16-byte chunk is (l & 7) ^ ((r >> 1) & 7) = c0 ^ 4 s
+//   oc ([k][rows]):  piece q holds k-rows k = 4 q + (l >> 4); the lane's 8 columns are chunk * 32 + (l & 3) * 8, chunk = ((l & 15) >> 2) ^ (k & 3)
 template <bool OC>
-__device__ __forceinline__ uint32_t piece_offset(int s, int w, int l, int first, int limit, long long ld) {
-    const int q = 2 * w + s;  // 1-KiB piece index inside the half-tile
-    if (!OC) {
-        const int r = q * 8 + (l >> 3);
-        const int row = min(first + r, limit - 1);
-        const int chunk = (l & 7) ^ ((r >> 1) & 7);
-        return uint32_t((row * ld + chunk * 8) * 2);
-    } else {
-        const int k = q * 4 + (l >> 4);
-        const int chunk = ((l & 15) >> 2) ^ (k & 3);
-        const int col = min(first + chunk * 32 + (l & 3) * 8, limit - 8);
-        return uint32_t((k * ld + col) * 2);
+struct LaneSrc {
+    int a, b;  // rc: row of piece 0 inside the half (piece 1: + 8), chunk byte offset of piece 0 (piece 1: ^ 64); oc: k-row of piece 0
+               // (piece 1: + 4), first column inside the half
+    __device__ __forceinline__ void init(int w, int l) {
+        if (!OC) {
+            a = 16 * w + (l >> 3);
+            b = ((l & 7) ^ (l >> 4)) * 16;
+        } else {
+            a = 8 * w + (l >> 4);
+            b = (((l & 15) >> 2) ^ ((l >> 4) & 3)) * 32 + (l & 3) * 8;
+        }
     }
-}
+    // first: first row / column of the half in the operand; limit: rows / columns of the operand (clamped: see "Edges" above);
+    // ld2 = leading dimension in BYTES (< 2^24, checked by the launcher: one full-rate 24-bit multiply)
+    __device__ __forceinline__ uint32_t offset(int s, int first, int limit, uint32_t ld2) const {
+        if (!OC) {
+            const int row = min(first + a + 8 * s, limit - 1);
+            return mul24(uint32_t(row), ld2) + uint32_t(b ^ (64 * s));
+        } else {
+            const int col = min(first + b, limit - 8);
+            return mul24(uint32_t(a + 4 * s), ld2) + 2u * uint32_t(col);
+        }
+    }
+};
 
 // lane-dependent part of the fragment addresses inside a half-tile image (bytes)
 template <bool OC>
@@ -74,8 +90,10 @@ struct FragAddr {
     uint32_t v[4];
     __device__ __forceinline__ void init(int tile_base, int l) {  // tile_base: first row of the wave's rows inside the half
         if (!OC) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) v[kk] = uint32_t((tile_base + (l & 31)) * 128 + (((2 * kk + (l >> 5)) ^ ((l >> 1) & 7)) << 4));
+            // chunk (2 kk + (l >> 5)) ^ ((l >> 1) & 7) = (2 kk) ^ x with x = (l >> 5) ^ ((l >> 1) & 7) (2 kk is even), and the row part is a
+            // multiple of 128: the address for kk is v[0] ^ (kk << 5) -- one register instead of four
+            v[0] = uint32_t((tile_base + (l & 31)) * 128 + ((((l >> 5) ^ ((l >> 1) & 7)) & 7) << 4));
+            v[1] = v[2] = v[3] = 0;
         } else {
             const int k = 8 * (l >> 5) + ((l & 15) >> 2), within = 32 * ((l >> 4) & 1) + 8 * (l & 3);
 #pragma unroll
@@ -86,7 +104,7 @@ struct FragAddr {
     // fragment of rows tile_base + 32 i + (l & 31), k = 16 kk + 8 (l >> 5) + 0..7
     __device__ __forceinline__ s16x8 read(const char* half, int i, int kk) const {
         if (!OC) {
-            return *reinterpret_cast<const s16x8*>(half + v[kk] + i * 4096);
+            return *reinterpret_cast<const s16x8*>(half + (v[0] ^ uint32_t(kk << 5)) + i * 4096);
         } else {
             const bf16_t* p = reinterpret_cast<const bf16_t*>(half + v[i] + kk * 4096);
             const s16x4 a0 = ds_read_tr16(p);
@@ -106,38 +124,62 @@ struct FragAddr {
 __device__ const uint32_t aria_zero_page[64] = {};
 
 struct Stage {  // everything a wave needs to issue its two DMA pieces of any half-tile
-    int w, nk, tail_k;  // wave id, K-tiles of this workgroup, valid reduction indices in the last one (64 = it is full)
-    int late;           // DMA pieces are issued inside the MFMA section instead of before the barrier
-    const char* gA;
-    const char* gB;
+    // per launch (wave-uniform)
+    int w, late;               // wave id; DMA pieces are issued inside the MFMA section instead of before the barrier
+    int limA, limB;            // rows of the A operand (M) / of the B operand (N): sources are clamped to the last one
+    uint32_t ldA2, ldB2;       // leading dimensions in bytes
     long long kstepA, kstepB;  // bytes per K-tile along k
-    uint32_t offA[2][2], offB[2][2];  // [half][piece]
-    char* lds;                        // smem + 2048 * w  (wave-uniform)
+    char* lds;                 // smem + 2048 * w
+    // per tile (wave-uniform)
+    int nk, tail_k;  // K-tiles of this tile, valid reduction indices in the last one (64 = it is full)
+    int g0;          // persistent form: index, in the workgroup's running K-tile count, of this tile's K-tile 0 (else 0)
+    int m0, n0;      // first row of the tile in A / in B
+    const char* gA;  // operand bases at the tile's first reduction index
+    const char* gB;
+    // per lane, tile-independent
+    int la_a, la_b, lb_a, lb_b;
 };
 
 template <bool A_OC, bool B_OC, int OPERAND, int HALF, int BUF>
-__device__ __forceinline__ void stage_half(const Stage& st, int tile) {
+__device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
+    constexpr bool OC = OPERAND == 0 ? A_OC : B_OC;
+    const int tile = gtile - st.g0;
     const char* g = (OPERAND == 0 ? st.gA + tile * st.kstepA : st.gB + tile * st.kstepB);
     char* d = st.lds + OPERAND * LDS_OPERAND + HALF * LDS_HALF + BUF * LDS_BUF;
-    const char* s0 = g + (OPERAND == 0 ? st.offA[HALF][0] : st.offB[HALF][0]);
-    const char* s1 = g + (OPERAND == 0 ? st.offA[HALF][1] : st.offB[HALF][1]);
+    LaneSrc<OC> ls;
+    ls.a = OPERAND == 0 ? st.la_a : st.lb_a;
+    ls.b = OPERAND == 0 ? st.la_b : st.lb_b;
+    const int first = (OPERAND == 0 ? st.m0 : st.n0) + HALF * 128, limit = OPERAND == 0 ? st.limA : st.limB;
+    const uint32_t ld2 = OPERAND == 0 ? st.ldA2 : st.ldB2;
+    const char* s0 = g + ls.offset(0, first, limit, ld2);
+    const char* s1 = g + ls.offset(1, first, limit, ld2);
     if (st.tail_k < BK && tile == st.nk - 1) {  // wave-uniform: the ragged end of the reduction -> granules past it read zeros
-        constexpr bool OC = OPERAND == 0 ? A_OC : B_OC;
+        // first reduction index (inside the tile) of this lane's 16 bytes, pieces 0 and 1
+        const int k0 = OC ? ls.a : ls.b >> 1, k1 = OC ? ls.a + 4 : (ls.b ^ 64) >> 1;
         const int l = lane_id();
-        int k0, k1;  // first reduction index (inside the tile) of this lane's 16 bytes, pieces 0 and 1
-        if (!OC) {
-            const int r0 = (2 * st.w) * 8 + (l >> 3), r1 = r0 + 8;
-            k0 = ((l & 7) ^ ((r0 >> 1) & 7)) * 8;
-            k1 = ((l & 7) ^ ((r1 >> 1) & 7)) * 8;
-        } else {
-            k0 = (2 * st.w) * 4 + (l >> 4);
-            k1 = k0 + 4;
-        }
         if (k0 >= st.tail_k) s0 = reinterpret_cast<const char*>(aria_zero_page) + 16 * (l & 15);
         if (k1 >= st.tail_k) s1 = reinterpret_cast<const char*>(aria_zero_page) + 16 * (l & 15);
     }
     glds16(s0, d);
     glds16(s1, d + 1024);
+}
+
+template <bool A_OC, bool B_OC, class P>
+__device__ __forceinline__ void stage_init(Stage& st, const P& p, int w, int l, char* smem) {
+    st.w = w;
+    st.late = (p.order >> 8) & 1;
+    st.limA = p.M;
+    st.limB = p.N;
+    st.ldA2 = uint32_t(2 * p.lda);
+    st.ldB2 = uint32_t(2 * p.ldb);
+    st.kstepA = A_OC ? 2 * BK * p.lda : 2 * BK;
+    st.kstepB = B_OC ? 2 * BK * p.ldb : 2 * BK;
+    st.lds = smem + 2048 * w;
+    LaneSrc<A_OC> la;
+    LaneSrc<B_OC> lb;
+    la.init(w, l);
+    lb.init(w, l);
+    st.la_a = la.a, st.la_b = la.b, st.lb_a = lb.a, st.lb_b = lb.b;
 }
 
 // One phase: quadrant (QA, QB) of the K-tile in buffer BUF.  SO/SH/SB: operand, half, buffer of the DMA issued here.
@@ -235,6 +277,50 @@ __device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4
     if (kt < nk) k_tile<A_OC, B_OC, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
 }
 
+// ---- epilogue of one 256x256 tile: bias, pair exchange so every lane owns two adjacent columns of one row, (accumulate), round, store
+template <class P>
+__device__ __forceinline__ void store_tile3(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l,
+                                            int wm, int wn) {
+    const int c = l & 31, h = l >> 5, odd = l & 1;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + b * 128 + wn * 32 + c;
+        const float bv = (p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f;
+        const int npair = n & ~1;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {  // register pair (2rp, 2rp+1) = two consecutive rows
+                    const float v0 = aria_epilogue_act(p, acc[a][i][b][2 * rp] + bv), v1 = aria_epilogue_act(p, acc[a][i][b][2 * rp + 1] + bv);
+                    const int r = 2 * rp;
+                    const int mrow = m0 + a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (p.c_f32) {
+                        if (n < p.N) {
+                            float* d0 = reinterpret_cast<float*>(C) + (long long)mrow * p.ldc + n;
+                            if (mrow < m_end) *d0 = p.accumulate ? *d0 + v0 : v0;
+                            if (mrow + 1 < m_end) d0[p.ldc] = p.accumulate ? d0[p.ldc] + v1 : v1;
+                        }
+                    } else {
+                        const float got = shfl_xor(odd ? v0 : v1, 1);   // wave-uniform control flow: every lane exchanges
+                        const int m = mrow + odd;
+                        float lo = odd ? got : v0, hi = odd ? v1 : got;  // columns npair, npair+1 of row m
+                        if (m < m_end && npair < p.N) {
+                            uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + npair);
+                            if (p.accumulate) {
+                                const uint32_t old = *dst;
+                                lo += bflo(old);
+                                hi += bfhi(old);
+                            }
+                            *dst = pack2bf(lo, hi);
+                        }
+                    }
+                }
+            }
+    }
+}
+
 template <bool A_OC, bool B_OC>
 __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     ARIA_DYN_SMEM(smem);
@@ -282,22 +368,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     }
 
     Stage st;
-    st.kstepA = A_OC ? 2 * BK * p.lda : 2 * BK;
-    st.kstepB = B_OC ? 2 * BK * p.ldb : 2 * BK;
+    stage_init<A_OC, B_OC>(st, p, w, l, smem);
     st.gA = reinterpret_cast<const char*>(p.A) + (A_OC ? 2 * k_begin * p.lda : 2 * (long long)k_begin) + kt_first * st.kstepA;
     st.gB = reinterpret_cast<const char*>(p.B + b_off) + (B_OC ? 2 * k_begin * p.ldb : 2 * (long long)k_begin) + kt_first * st.kstepB;
-    st.w = w;
-    st.late = (p.order >> 8) & 1;
+    st.g0 = 0;
     st.nk = nk;
     st.tail_k = (kt_first + nk == nk_all && nk_all > 0) ? k_len - (nk_all - 1) * BK : BK;  // only the overall last K-tile is ragged
-    st.lds = smem + 2048 * w;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            st.offA[h][s] = piece_offset<A_OC>(s, w, l, m0 + h * 128, p.M, p.lda);
-            st.offB[h][s] = piece_offset<B_OC>(s, w, l, n0 + h * 128, p.N, p.ldb);
-        }
+    st.m0 = m0;
+    st.n0 = n0;
     FragAddr<A_OC> aa;
     FragAddr<B_OC> ab;
     aa.init(wm * 64, l);
@@ -354,43 +432,258 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
                         dst[(a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + b * 128 + wn * 32 + c] = acc[a][i][b][r];
         return;
     }
-    // ---- epilogue: bias, pair exchange so every lane owns two adjacent columns of one row, (accumulate), round, store
+    store_tile3(p, acc, C, m0, m_end, n0, l, wm, wn);
+}
+
+// ================================================================================================ persistent form (gemm3p)
+// The shapes of this model have SHORT reductions (K = 1152 .. 3328: 18-52 K-tiles; an expert's ~1536 tokens in the weight gradients:
+// 24), so with one tile per workgroup the pipeline fill (96 KiB per CU at ~11 B/clk/CU while every CU of the chip is in its prologue:
+// ~9k cycles) and the drain cost 7-18 % of a tile's ~50-100k cycles, and workgroups that share operand panels drift apart in time so
+// their L2 sees each panel several times (PMC, fc1 forward: 6.4 GB fetched for 1.6 GB of operands).  Here the launch is 256
+// workgroups (one per CU) and workgroup (xcd, j) walks tiles j, j + 32, j + 64, ... of its XCD's chunk of the tile list:
+//   * the K-tile stream simply CONTINUES across the tile boundary: the last two K-tiles of a tile already stage the first two of the
+//     next one (same phase schedule, same buffers by running K-tile parity), the accumulators are stored and zeroed between two
+//     barriers' worth of nothing else, and the first counted wait of the next tile also covers the stores;
+//   * the 32 workgroups of an XCD start together and run tiles of (nearly) equal length, so they stay in step and the panels they
+//     share are fetched into that XCD's L2 once.
+// Tiles whose reduction is shorter than two K-tiles (or whose successor's is) fall back to a drained boundary + fresh prologue.
+// Register budget: the K loop already sits at the 256-VGPR / 104-SGPR limit of two waves per SIMD, so everything that is only needed at
+// a tile boundary is kept OUT of registers on purpose: the parameter block is re-read from the kernarg segment through a laundered
+// pointer (params3), and the descriptors of the current and the next tile live in a wave-private 128-byte LDS slot (tile3_put / _get).
+struct Tile3 {  // wave-uniform description of one output tile
+    int m0, m_end, n0, k_begin, k_len, e;  // e: expert (mode 1: selects the weight matrix, mode 2: the output matrix), else 0
+};
+
+#if defined(ARIA_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+typedef const GemmParams KParams3;
+__device__ __forceinline__ KParams3& params3(const GemmParams& p) { return p; }
+#else
+// the block is the kernel's only argument: offset 0 of the kernarg segment (constant address space -> scalar loads of just the fields
+// the caller goes on to use)
+typedef const __attribute__((address_space(4))) GemmParams KParams3;
+__device__ __forceinline__ KParams3& params3(const GemmParams&) {
+    KParams3* pp = (KParams3*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pp));  // opaque: the loads are issued here, not hoisted to the kernel entry and kept live across the K loop
+    return *pp;
+}
+#endif
+
+__device__ __forceinline__ void tile3_put(char* slot, const Tile3& d) {
+    int* s = reinterpret_cast<int*>(slot);
+    s[0] = d.m0, s[1] = d.m_end, s[2] = d.n0, s[3] = d.k_begin, s[4] = d.k_len, s[5] = d.e;
+}
+__device__ __forceinline__ Tile3 tile3_get(const char* slot) {
+    const int* s = reinterpret_cast<const int*>(slot);
+    Tile3 d;
+    d.m0 = first_lane(s[0]), d.m_end = first_lane(s[1]), d.n0 = first_lane(s[2]);
+    d.k_begin = first_lane(s[3]), d.k_len = first_lane(s[4]), d.e = first_lane(s[5]);
+    return d;
+}
+
+// the i-th tile of this workgroup: workgroup b = (xcd b & 7, slot b >> 3) takes positions slot + (gridDim.x / 8) * i of its XCD's
+// contiguous chunk of the tile list (mode 0: XCD-contiguous order of aria_tile_coords; mode 1: aria_grouped_tile's expert-major
+// list; mode 2: the E x (ntn x ntm) weight-gradient tiles, expert-major).  Every lane of the wave must take part.
+template <class P>
+__device__ __forceinline__ bool tile3_at(const P& p, int i, int l, Tile3& d) {
+    const int xcd = blockIdx.x & 7, idx = int(blockIdx.x >> 3) + int(gridDim.x >> 3) * i;
+    d.k_begin = 0;
+    d.k_len = p.K;
+    d.m_end = p.M;
+    d.e = 0;
+    int tmi = 0, tn = 0;
+    if (p.mode == 1) {
+        int expert = 0, m0 = 0, m_end = 0;
+        if (!aria_grouped_tile(p, xcd + 8 * idx, l, expert, m0, m_end, tn)) return false;
+        d.m0 = first_lane(m0);
+        d.m_end = first_lane(m_end);
+        d.n0 = first_lane(tn) * BN;
+        d.e = first_lane(expert);
+        return true;
+    }
+    const int per_e = p.ntn * p.ntm, T = p.mode == 2 ? per_e * p.E : per_e;
+    const int q = T >> 3, r = T & 7;
+    const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, size = q + (xcd < r ? 1 : 0);
+    if (idx >= size) return false;
+    int v = lo + idx;
+    if (p.mode == 2) {
+        d.e = v / per_e;
+        v -= d.e * per_e;
+    }
+    if (!aria_tile_from_pos(p, v, tmi, tn)) return false;
+    d.m0 = tmi * BM;
+    d.n0 = tn * BN;
+    if (p.mode == 2) {
+        d.k_begin = p.offsets[d.e];
+        d.k_len = p.offsets[d.e + 1] - d.k_begin;
+    }
+    return d.m0 < d.m_end;
+}
+
+// per-tile (wave-uniform) part of the stage descriptor.  baseA / baseB / strideB are kept in the descriptor's scalars so that the switch
+// to the next tile inside the K loop needs nothing but its 6-int descriptor.
+struct Bases3 {
+    const char* A;
+    const char* B;
+    long long lda2, ldb2, strideB2;  // bytes
+    int mode;
+};
+template <bool A_OC, bool B_OC>
+__device__ __forceinline__ void stage_setup(Stage& st, const Bases3& bs, const Tile3& d, int g0) {
+    st.gA = bs.A + (A_OC ? d.k_begin * bs.lda2 : 2 * (long long)d.k_begin);
+    st.gB = bs.B + (bs.mode == 1 ? d.e * bs.strideB2 : 0) + (B_OC ? d.k_begin * bs.ldb2 : 2 * (long long)d.k_begin);
+    st.nk = (d.k_len + BK - 1) / BK;
+    st.tail_k = st.nk > 0 ? d.k_len - (st.nk - 1) * BK : BK;
+    st.g0 = g0;
+    st.m0 = d.m0;
+    st.n0 = d.n0;
+}
+
+// one K-tile of the running stream: g = its index in the workgroup's K-tile count (buffer g & 1 = BUF); n1 / n2: K-tiles g + 1 / g + 2
+// exist (in this tile or, chained, in the next one).  `between` runs after phase 2: the place where the stage descriptor may switch to
+// the next tile (K-tile g + 1 has been issued completely, K-tile g + 2 not yet).
+template <bool A_OC, bool B_OC, int BUF, bool EDGE, class F>
+__device__ __forceinline__ void k_tile_p(f32x16 (&acc)[2][2][2], const FragAddr<A_OC>& aa, const FragAddr<B_OC>& ab, const char* smem,
+                                         Stage& st, int g, bool n1, bool n2, int rl, int cl, F between) {
+    // the fragments live inside ONE K-tile (B0 from phase 1 to phase 4): declared here so that no path of the surrounding tile loop
+    // (edge tiles assign them conditionally) can stretch their live ranges over the epilogue
+    s16x8 fa[2][4], fb[2][4];
+    phase<A_OC, B_OC, 0, 0, true, true, BUF, 0, 1, BUF ^ 1, 1, EDGE>(acc, fa, fb, aa, ab, smem, st, g + 1, n1, n1, rl, cl);
+    phase<A_OC, B_OC, 0, 1, false, true, BUF, 1, 1, BUF ^ 1, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, g + 1, n1, false, rl, cl);
+    between();
+    phase<A_OC, B_OC, 1, 1, true, false, BUF, 0, 0, BUF, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, g + 2, n2, false, rl, cl);
+    phase<A_OC, B_OC, 1, 0, false, false, BUF, 1, 0, BUF, 4, EDGE>(acc, fa, fb, aa, ab, smem, st, g + 2, n2, n2, rl, cl);
+}
+
+// LDS behind the operand images: per wave 2 x 64 bytes of tile descriptors (tile i at parity i & 1)
+constexpr int LDS_TILES3 = 2 * LDS_OPERAND;
+constexpr int LDS_TOTAL3 = LDS_TILES3 + 8 * 128;
+
+// the K-tiles of one output tile, continuing the workgroup's running count g (buffer parity): same shape as k_loop3 -- straight-line
+// pairs of K-tiles -- so that the register allocation of the hot loop is the one of the one-tile kernel
+template <bool A_OC, bool B_OC, bool EDGE>
+__device__ __forceinline__ void k_loop3p(f32x16 (&acc)[2][2][2], const FragAddr<A_OC>& aa, const FragAddr<B_OC>& ab, const char* smem,
+                                         Stage& st, const Bases3& bs, int& g, int nk, bool chain, int rl, int cl, const char* next_slot) {
+    int tl = 0;
+    auto one = [&](auto buf) {
+        constexpr int BUF = decltype(buf)::value;
+        const bool n1 = tl + 1 < nk || chain, n2 = tl + 2 < nk || chain;
+        const bool sw = chain && tl == nk - 2;
+        k_tile_p<A_OC, B_OC, BUF, EDGE>(acc, aa, ab, smem, st, g, n1, n2, rl, cl, [&]() {
+            if (sw) stage_setup<A_OC, B_OC>(st, bs, tile3_get(next_slot), g + 2);  // from here on the staging belongs to the next tile
+        });
+        ++tl, ++g;
+    };
+    if ((g & 1) && nk > 0) one(std::integral_constant<int, 1>{});
+    while (tl + 1 < nk) {
+        one(std::integral_constant<int, 0>{});
+        one(std::integral_constant<int, 1>{});
+    }
+    if (tl < nk) one(std::integral_constant<int, 0>{});
+}
+
+template <bool A_OC, bool B_OC>
+__global__ __launch_bounds__(512) void gemm3p_kernel(GemmParams p_arg) {
+    ARIA_DYN_SMEM(smem);
+    const int t = threadIdx.x, l = t & 63, w = first_lane(t >> 6), wm = w >> 2, wn = w & 3;
+    char* slots = smem + LDS_TILES3 + 128 * w;  // [2][64 bytes], wave-private: descriptor of tile i at slots + 64 * (i & 1)
+    Stage st;
+    Bases3 bs;
+    int nk, N;
+    bool have_next, chain;
+    {
+        KParams3& p = params3(p_arg);
+        Tile3 cur, nxt;
+        if (!tile3_at(p, 0, l, cur)) return;
+        have_next = tile3_at(p, 1, l, nxt);
+        tile3_put(slots, cur);
+        tile3_put(slots + 64, nxt);
+        stage_init<A_OC, B_OC>(st, p, w, l, smem);
+        bs.A = reinterpret_cast<const char*>(p.A);
+        bs.B = reinterpret_cast<const char*>(p.B);
+        bs.lda2 = 2 * p.lda, bs.ldb2 = 2 * p.ldb, bs.strideB2 = 2 * p.strideB, bs.mode = p.mode;
+        stage_setup<A_OC, B_OC>(st, bs, cur, 0);
+        nk = st.nk;
+        chain = have_next && nk >= 2 && (nxt.k_len + BK - 1) / BK >= 2;
+        N = p.N;
+    }
+    FragAddr<A_OC> aa;
+    FragAddr<B_OC> ab;
+    aa.init(wm * 64, l);
+    ab.init(wn * 32, l);
+
+    f32x16 acc[2][2][2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + b * 128 + wn * 32 + c;
-        const float bv = (p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f;
-        const int npair = n & ~1;
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
+
+    int g = 0;          // K-tiles this workgroup has run since the last fresh prologue (parity = LDS buffer)
+    bool fresh = true;  // the pipeline is empty: the tile starts with a prologue
+    for (int i = 0;; ++i) {
+        if (fresh) {
+            // tile 0 completely, A0 and B0 of tile 1 (phases 1 and 2 of tile 0 issue its A1 and B1) -- the steady-state queue shape
+            g = 0;
+            if (nk > 0) {
+                stage_half<A_OC, B_OC, 0, 0, 0>(st, 0);
+                stage_half<A_OC, B_OC, 1, 0, 0>(st, 0);
+                stage_half<A_OC, B_OC, 1, 1, 0>(st, 0);
+                stage_half<A_OC, B_OC, 0, 1, 0>(st, 0);
+            }
+            if (nk > 1) {
+                stage_half<A_OC, B_OC, 0, 0, 1>(st, 1);
+                stage_half<A_OC, B_OC, 1, 0, 1>(st, 1);
+                wait_vm<4>();
+            } else {
+                wait_vm<0>();
+            }
+            raw_barrier();
+            if (wm == 1) raw_barrier();  // waves 4-7 run one barrier behind waves 0-3
+            fresh = false;
+        }
+        int rl, cl;
+        bool edge;
+        {
+            const Tile3 cur = tile3_get(slots + 64 * (i & 1));
+            rl = cur.m_end - cur.m0 - wm * 64, cl = N - cur.n0 - wn * 32;
+            edge = !(cur.m0 + BM <= cur.m_end && cur.n0 + BN <= N);
+        }
+        if (edge)
+            k_loop3p<A_OC, B_OC, true>(acc, aa, ab, smem, st, bs, g, nk, chain, rl, cl, slots + 64 * ((i + 1) & 1));
+        else
+            k_loop3p<A_OC, B_OC, false>(acc, aa, ab, smem, st, bs, g, nk, chain, rl, cl, slots + 64 * ((i + 1) & 1));
+        if (!chain && wm == 0) raw_barrier();  // drained boundary / end of the list: balance the barrier count of the two groups
+        {
+            KParams3& p = params3(p_arg);
+            const Tile3 cur = tile3_get(slots + 64 * (i & 1));
+            const long long c_off = p.mode == 2 ? (long long)cur.e * p.strideC : 0;
+            store_tile3(p, acc, static_cast<char*>(p.C) + c_off * (p.c_f32 ? 4 : 2), cur.m0, cur.m_end, cur.n0, l, wm, wn);
+        }
+        if (!have_next) break;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {  // register pair (2rp, 2rp+1) = two consecutive rows
-                    const float v0 = aria_epilogue_act(p, acc[a][i][b][2 * rp] + bv), v1 = aria_epilogue_act(p, acc[a][i][b][2 * rp + 1] + bv);
-                    const int r = 2 * rp;
-                    const int mrow = m0 + a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (p.c_f32) {
-                        if (n < p.N) {
-                            float* d0 = reinterpret_cast<float*>(C) + (long long)mrow * p.ldc + n;
-                            if (mrow < m_end) *d0 = p.accumulate ? *d0 + v0 : v0;
-                            if (mrow + 1 < m_end) d0[p.ldc] = p.accumulate ? d0[p.ldc] + v1 : v1;
-                        }
-                    } else {
-                        const float got = shfl_xor(odd ? v0 : v1, 1);   // wave-uniform control flow: every lane exchanges
-                        const int m = mrow + odd;
-                        float lo = odd ? got : v0, hi = odd ? v1 : got;  // columns npair, npair+1 of row m
-                        if (m < m_end && npair < p.N) {
-                            uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + npair);
-                            if (p.accumulate) {
-                                const uint32_t old = *dst;
-                                lo += bflo(old);
-                                hi += bfhi(old);
-                            }
-                            *dst = pack2bf(lo, hi);
-                        }
-                    }
-                }
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][i2][b][r] = 0.f;
+        {   // tile i + 1 becomes the current one; look one further ahead
+            KParams3& p = params3(p_arg);
+            const Tile3 cur = tile3_get(slots + 64 * ((i + 1) & 1));
+            if (!chain) {  // (the K loop left nothing in flight: its last waits were vmcnt(0))
+                stage_setup<A_OC, B_OC>(st, bs, cur, 0);
+                fresh = true;
             }
+            nk = (cur.k_len + BK - 1) / BK;
+            Tile3 nxt;
+            have_next = tile3_at(p, i + 2, l, nxt);
+            tile3_put(slots + 64 * (i & 1), nxt);
+            chain = have_next && nk >= 2 && (nxt.k_len + BK - 1) / BK >= 2;
+        }
     }
 }
 
@@ -465,6 +758,7 @@ long long aria_gemm3_workspace_bytes(long long M, long long N, long long K) {
 int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* stream, void* workspace, long long workspace_bytes) {
     const unsigned grid_y = p.mode == 2 ? unsigned(p.E) : 1u;
     const size_t shmem = size_t(2) * LDS_OPERAND;
+    const size_t shmem_p = size_t(LDS_TOTAL3);  // + the persistent form's tile / stage descriptors
     const int ntn = (p.N + BN - 1) / BN;
     GemmParams q = p;
     q.ntn = ntn;
@@ -482,11 +776,32 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
         }
     }
     const char* ord = std::getenv("ARIA_GEMM_ORDER");
+    // persistent form (gemm3p): 256 workgroups walk the tile list.  OPT-IN (ARIA_GEMM_PERSIST=1; =2 forces it whatever the tile count,
+    // ARIA_GEMM_PERSIST_GRID=<multiple of 8> sets the workgroup count -- tests).  Measured on MI355X (profiles/r02_gemm_persistent.md): a
+    // workgroup chains tiles at 4.3 TF/s per CU against 4.2 for one tile per workgroup (the pipeline fill it hides is ~2 %, not the 8 %
+    // the K sweep had suggested -- most of that was the partly filled last round, which the remainder split-K already covers), and the
+    // static round-robin loses more to imbalance (edge tiles, 2.5 rounds) than chaining wins: dense K = 2560 820 vs 899 TF/s, grouped fc1
+    // forward 716 vs 872.  Kept for a dynamic tile queue; not the default.
+    const char* pe = std::getenv("ARIA_GEMM_PERSIST");
+    const char* pg = std::getenv("ARIA_GEMM_PERSIST_GRID");
+    const int pgrid_n = pg ? (std::atoi(pg) + 7) / 8 * 8 : 256;
+    const long long tiles_bound = (long long)ntn * ntm * (p.mode == 2 ? p.E : 1);
+    const bool persist = pe && pe[0] != '0' && q.split == 1 && pgrid_n >= 8 && (tiles_bound > pgrid_n || pe[0] == '2');
     // bit 8 = DMA pieces inside the MFMA section: measured +4..6 % with two k-contiguous operands, -5 % when an operand goes through
     // the transposing reads (profiles/r01_gemm_tuning.md)
     q.order = ord ? std::atoi(ord) : (!a_oc && !b_oc ? 256 + 4 : 4);
     if (ntn * ntm <= 0) return ARIA_OK;
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
+    if (persist) {
+        dim3 pgrid{unsigned(pgrid_n)}, pblock(512);
+        if (!a_oc && !b_oc)
+            ARIA_LAUNCH((gemm3p_kernel<false, false>), pgrid, pblock, shmem_p, stream, q);
+        else if (!a_oc && b_oc)
+            ARIA_LAUNCH((gemm3p_kernel<false, true>), pgrid, pblock, shmem_p, stream, q);
+        else
+            ARIA_LAUNCH((gemm3p_kernel<true, true>), pgrid, pblock, shmem_p, stream, q);
+        return aria_check_launch();
+    }
     dim3 grid(unsigned(aria_tile_grid(q)), grid_y), block(512);
     if (!a_oc && !b_oc)
         ARIA_LAUNCH((gemm3_kernel<false, false>), grid, block, shmem, stream, q);

@@ -22,9 +22,12 @@ struct GemmParams {
     float* ws;
     int order;     // tile-order variant (tuning knob): 0 = XCD-contiguous row-major, 1 = plain, >= 2 = groups of `order` row tiles
 };
+// (the device helpers below are templates on the block's type so that a kernel may also hand them the block where it lies in the
+// kernarg segment -- a reference into the constant address space: scalar loads at the point of use instead of registers held live)
 
 // position in the (mode 0 / 2) tile list -> (row tile, column tile)
-__device__ __forceinline__ bool aria_tile_from_pos(const GemmParams& p, int tile, int& tmi, int& tn) {
+template <class P>
+__device__ __forceinline__ bool aria_tile_from_pos(const P& p, int tile, int& tmi, int& tn) {
     tn = tile % p.ntn;
     tmi = tile / p.ntn;
     if ((p.order & 255) >= 2) {
@@ -42,7 +45,8 @@ __device__ __forceinline__ bool aria_tile_from_pos(const GemmParams& p, int tile
 // ~32 tiles an XCD works on at a time form a GM x (32/GM) patch that shares A row panels and B column panels.
 // Each XCD gets one contiguous chunk of the tile list (modes 0 and 2; mode 1 uses aria_grouped_tile below).
 // Returns false when the workgroup has no tile.
-__device__ __forceinline__ bool aria_tile_coords(const GemmParams& p, int bid, int nwg, int& tmi, int& tn) {
+template <class P>
+__device__ __forceinline__ bool aria_tile_coords(const P& p, int bid, int nwg, int& tmi, int& tn) {
     int tile = bid;
     if ((p.order & 255) != 1) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -56,7 +60,8 @@ __device__ __forceinline__ bool aria_tile_coords(const GemmParams& p, int bid, i
 // a time belong to one expert and share its weight column panels (each fetched from HBM once instead of once per pair of row
 // tiles) and its row panels, and every XCD gets the same number of REAL tiles however uneven the routing is.
 // Every lane of the calling wave must take part (wave collectives).  Returns false when the workgroup has no tile.
-__device__ __forceinline__ bool aria_grouped_tile(const GemmParams& p, int bid, int l, int& expert, int& m0, int& m_end, int& tn) {
+template <class P>
+__device__ __forceinline__ bool aria_grouped_tile(const P& p, int bid, int l, int& expert, int& m0, int& m_end, int& tn) {
     int T = 0;
     for (int e0 = 0; e0 < p.E; e0 += 64) {
         const int e = e0 + l;
@@ -108,7 +113,8 @@ inline int aria_tile_grid(const GemmParams& p) {
 }
 
 // the epilogue value of every GEMM kernel: bias added by the caller; activation exactly as a separate elementwise kernel would see it
-__device__ __forceinline__ float aria_epilogue_act(const GemmParams& p, float v) {
+template <class P>
+__device__ __forceinline__ float aria_epilogue_act(const P& p, float v) {
     return p.act == 1 ? ad::gelu_tanh(ad::rbf(v)) : v;
 }
 

@@ -155,6 +155,32 @@ def test_grouped_gemm_v3_ragged_everything(force_gemm_v3):
     C.case_grouped_gemm(DEV, [3, 0, 130, 5, 0, 0, 300, 1])  # K = 72, N = 136: no dimension is a multiple of the tile
 
 
+# v3 persistent form (gemm3p): 8 workgroups walk the tile list, the K-tile stream continues across tile boundaries (chained) or is
+# drained where a reduction is shorter than two K-tiles.  Forced on with a tiny grid so that every workgroup runs several tiles.
+@pytest.fixture(params=["0", "1"], ids=["dma-early", "dma-late"])
+def force_gemm_v3p(monkeypatch, request):
+    monkeypatch.setenv("ARIA_GEMM_FORCE", "3")
+    monkeypatch.setenv("ARIA_GEMM_PERSIST", "2")
+    monkeypatch.setenv("ARIA_GEMM_PERSIST_GRID", "8")
+    monkeypatch.setenv("ARIA_EMU_GLDS_DEFER", request.param)
+
+
+@pytest.mark.parametrize("M,N,K", [(1296, 1032, 192), (2100, 520, 136), (520, 2304, 64), (1300, 600, 320)])
+@pytest.mark.parametrize("a_oc,b_oc", [(False, False), (False, True), (True, True)])
+def test_gemm_v3_persistent_layouts(force_gemm_v3p, M, N, K, a_oc, b_oc):
+    """24-30 tiles on 8 workgroups: 3-4 tiles each, odd and even K-tile counts (buffer parity carries over), K = 64 -> drained
+    boundaries (one K-tile per tile), ragged K = 136, edge tiles in both directions."""
+    C.case_gemm_layouts(DEV, M, N, K, a_oc, b_oc)
+
+
+@pytest.mark.parametrize("counts,K,N", [([300, 0, 700, 5, 0, 0, 900, 1, 260, 515], 128, 520), ([3, 0, 130, 5, 0, 0, 300, 1], 72, 136),
+                                        ([600, 50, 70, 130, 1, 0, 0, 1200], 192, 264)])
+def test_grouped_gemm_v3_persistent(force_gemm_v3p, counts, K, N):
+    """grouped-M forward / dgrad (expert-major tile list) and the grouped-K weight gradient (reduction length = an expert's token
+    count: 0, 1, 5, 50, 70, 130, ... -> chained and drained boundaries mixed, ragged last K-tiles)."""
+    C.case_grouped_gemm(DEV, counts, K=K, N=N)
+
+
 @pytest.mark.parametrize("H,hd,pos,splits", [(2, 128, 0, 4), (2, 128, 63, 2), (3, 128, 64, 2), (2, 128, 777, 3), (2, 128, 2999, 16),
                                              (2, 128, 1500, 32), (3, 64, 127, 2), (2, 64, 128, 2), (2, 64, 1000, 5)])
 def test_decode_attention_split_kv(H, hd, pos, splits):
