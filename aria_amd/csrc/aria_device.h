@@ -233,6 +233,15 @@ __device__ __forceinline__ void raw_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
+// all lanes of the wave have executed what precedes (hardware: a wave runs in lockstep and its LDS operations complete in order, so this
+// is only a compiler scheduling barrier; the emulator runs lanes as fibers and really synchronises them)
+__device__ __forceinline__ void wave_barrier() {
+#ifdef ARIA_EMU
+    emu::wave_sync();
+#else
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
 template <int P>
 __device__ __forceinline__ void wave_prio() {
 #ifndef ARIA_EMU

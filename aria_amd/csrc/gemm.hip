@@ -262,7 +262,7 @@ int launch_gemm(const GemmParams& p, int a_oc, int b_oc, int grid_x, int grid_y,
 }
 
 thread_local int g_last_variant = 0;
-constexpr int GROUPED_V3_DEFAULT = 1;  // in-bench A/B: v3 wins the [N,K]-weight form by 17 %, loses the [K,N] form (fc1 forward) by 7 %
+constexpr int GROUPED_V3_DEFAULT = 3;  // r02 in-bench A/B with the wide epilogue: v3 for both weight forms 702 ms/step, v2 for the [K,N] form 710
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // v1 (128x128 tiles, 3 blocks/CU) wins when the 256x256 grid would not fill the chip; v2 otherwise.
@@ -410,7 +410,9 @@ int aria_grouped_gemm_wgrad_bf16(const void* A, const void* dY, void* dW, const 
     // Measured on MI355X (98304 routed rows, 64 experts): v3 749 TF/s vs v2 800-830 on these short (~24 K-tile) reductions with two
     // transposed operands -- v3's longer prologue and its 24-read first phase do not pay here, so v2 stays the default.
     const char* force3 = std::getenv("ARIA_GEMM_FORCE");
-    if (force3 && force3[0] == '3' && use_v3(((K + 255) / 256) * ((N + 255) / 256) * E, 64, 0, 0, K, N))
+    // r02: with the wide epilogue v3 is level with v2 here too (in-bench 710.3 vs 714.6 ms/step); ARIA_GEMM_WGRAD_V3=0 goes back to v2
+    const char* wg3 = std::getenv("ARIA_GEMM_WGRAD_V3");
+    if (((force3 && force3[0] == '3') || !(wg3 && wg3[0] == '0')) && !(force3 && (force3[0] == '1' || force3[0] == '2')) && use_v3(((K + 255) / 256) * ((N + 255) / 256) * E, 64, 0, 0, K, N))
         return g_last_variant = 3, aria_launch_gemm3(p, 1, 1, int((K + 255) / 256), stream);
     if (use_v2(((K + 255) / 256) * ((N + 255) / 256) * E)) return g_last_variant = 2, aria_launch_gemm2(p, 1, 1, int((K + 255) / 256), int(E), stream);
     return g_last_variant = 1, launch_gemm(p, 1, 1, p.ntn * ntm, int(E), stream);

@@ -277,6 +277,175 @@ __device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4
     if (kt < nk) k_tile<A_OC, B_OC, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
 }
 
+// ================================================================================================ v4 K loop
+// v3's ablation (profiles/r01_gemm_tuning.md) shows the matrix pipe paced by what sits BETWEEN the MFMA sections: a slot (one group's 8
+// MFMAs = 256 cycles) takes ~584 cycles because the other group's fragment reads are issued just before a barrier and needed right
+// after it -- the LDS service time of up to 48 KiB per group is exposed, and the read / DMA section (~360 cycles) is longer than the
+// MFMA section it should hide under.  v4 removes the read section: a wave prefetches the fragments of its NEXT phase between the MFMAs
+// of the current one (registers are recycled k-substep by k-substep: a fragment's registers are reloaded right after the two MFMAs that
+// read them), issues its two DMA pieces there too, and the two wave groups simply hand the matrix pipe to each other:
+//
+//     barrier | 8 MFMA interleaved with { next-phase fragment reads, 2 DMA pieces } | counted vmcnt | barrier
+//
+// with waves 4-7 one barrier behind waves 0-3, so exactly one group is inside its MFMA section at any time and a fragment read has a
+// whole slot of the OTHER group to land in.  Same quadrant walk as v3 -- (A0,B0) (A0,B1) (A1,B1) (A1,B0) -- same accumulation order
+// (bit-identical results).  Fragment traffic of K-tile t (buffer t & 1; P = t & 1 selects the B register halves):
+//
+//   phase 1  MFMA A0 x B0(fb[P])     reads B1(t) -> fb[P^1]                         DMA A1(t+1) -> other buffer   wait: A1(t) landed
+//   phase 2  MFMA A0 x B1(fb[P^1])   reads A1(t) -> fa (rolling)                    DMA A0(t+2) -> this buffer
+//   phase 3  MFMA A1 x B1(fb[P^1])   --                                             DMA B0(t+2) -> this buffer    wait: A0, B0(t+1) landed
+//   phase 4  MFMA A1 x B0(fb[P])     reads A0(t+1) -> fa (rolling), B0(t+1) -> fb[P^1]   DMA B1(t+2) -> this buffer    wait: B1(t+1) landed
+//
+// Hazards.  WAR: every slot is refilled at least two phases after the phase that reads it last (both groups have consumed -- waited
+// for -- those fragments by then): A1 read in phase 2, refilled in phase 1 of the next tile; A0 and B0 read in phase 4 of the previous
+// tile, refilled in phases 2 and 3; B1 read in phase 1, refilled in phase 4.  RAW: a half-tile is read in the phase AFTER the one whose
+// closing barrier follows the wait that retires it (each wave waits for its own pieces; the other group is one barrier behind, so the
+// wait sits before the closing barrier of the phase before the reading one).  Each wait leaves the 8 newer pieces in flight
+// (80 KiB per CU); every piece has 4-5 phases to land.
+// ARIA_ABL (timing experiments only, never defined in the product build): bit 0 no MFMAs, bit 1 no fragment reads, bit 2 no DMA / vmcnt
+// waits, bit 3 no barriers
+#ifndef ARIA_ABL
+#define ARIA_ABL 0
+#endif
+__device__ __forceinline__ void keep_alive(const s16x8& f) {
+#if !defined(ARIA_EMU) && ARIA_ABL
+    asm volatile("" ::"v"(f));
+#endif
+}
+__device__ __forceinline__ void bar4() {
+    if (!(ARIA_ABL & 8)) raw_barrier();
+}
+template <int N>
+__device__ __forceinline__ void wait4() {
+    if (!(ARIA_ABL & 32)) wait_vm<N>();
+}
+#define ARIA_MFMA4(dst, a, b)                       \
+    do {                                            \
+        if (ARIA_ABL & 1) {                         \
+            keep_alive(a);                          \
+            keep_alive(b);                          \
+        } else {                                    \
+            dst = mfma32(a, b, dst);                \
+        }                                           \
+    } while (0)
+
+template <bool A_OC, bool B_OC, int BUF, bool EDGE>
+__device__ __forceinline__ void k_tile4(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
+                                        const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int t, int nk, int rl, int cl) {
+    constexpr int P = BUF;  // B0(t) lives in fb[P], B1(t) in fb[P ^ 1]
+    constexpr bool RD = !(ARIA_ABL & 2), DMA = !(ARIA_ABL & 4);
+    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+    const char* a0n = smem + 0 * LDS_HALF + (BUF ^ 1) * LDS_BUF;                  // A0 of tile t + 1
+    const char* a1c = smem + 1 * LDS_HALF + BUF * LDS_BUF;                        // A1 of tile t
+    const char* b0n = smem + LDS_OPERAND + 0 * LDS_HALF + (BUF ^ 1) * LDS_BUF;    // B0 of tile t + 1
+    const char* b1c = smem + LDS_OPERAND + 1 * LDS_HALF + BUF * LDS_BUF;          // B1 of tile t
+    // which 32-row / 32-column MFMA tiles of the wave lie inside the output (edge tiles only)
+    const bool rowA0[2] = {!EDGE || 0 < rl, !EDGE || 32 < rl}, rowA1[2] = {!EDGE || 128 < rl, !EDGE || 160 < rl};
+    const bool colB0 = !EDGE || 0 < cl, colB1 = !EDGE || 128 < cl;
+
+    // DMA placement.  IDLE (default): a wave issues its two pieces -- and waits for older ones -- between the barrier that closes its MFMA
+    // section and the one that opens the next, i.e. while the OTHER group owns the matrix pipe (a piece costs ~100 cycles of issue that
+    // nothing hides when the wave is alone on its SIMD; measured: profiles/r02_gemm_v4.md).  ARIA_ABL bit 4: inside the MFMA section.
+    constexpr bool IDLE = !(ARIA_ABL & 16);
+
+    // ---- phase 1: (A0, B0)
+    bar4();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (rowA0[i] && colB0) ARIA_MFMA4(acc[0][i][0], fa[i][kk], fb[P][kk]);
+        if (RD) fb[P ^ 1][kk] = ab.read(b1c, 0, kk);
+        if (!IDLE && DMA && kk == 1 && n1) stage_half<A_OC, B_OC, 0, 1, BUF ^ 1>(st, t + 1);
+        sched_fence();
+    }
+    if (!IDLE && DMA) {
+        if (n1) wait4<8>(); else wait4<0>();   // A1 of this tile
+    }
+    bar4();
+    if (IDLE && DMA && n1) stage_half<A_OC, B_OC, 0, 1, BUF ^ 1>(st, t + 1);   // A1(t+1); nothing to wait for here
+
+    // ---- phase 2: (A0, B1); A1 takes over the A registers k-substep by k-substep
+    bar4();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (rowA0[i] && colB1) ARIA_MFMA4(acc[0][i][1], fa[i][kk], fb[P ^ 1][kk]);
+        if (RD) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i][kk] = aa.read(a1c, i, kk);
+        }
+        if (!IDLE && DMA && kk == 1 && n2) stage_half<A_OC, B_OC, 0, 0, BUF>(st, t + 2);
+        sched_fence();
+    }
+    bar4();
+    if (IDLE && DMA) {
+        if (n2) stage_half<A_OC, B_OC, 0, 0, BUF>(st, t + 2);   // A0(t+2)
+        if (n1) {                                                 // A0 and B0 of the next tile (read in phase 4)
+            if (n2) wait4<6>(); else wait4<4>();
+        }
+    }
+
+    // ---- phase 3: (A1, B1)
+    bar4();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (rowA1[i] && colB1) ARIA_MFMA4(acc[1][i][1], fa[i][kk], fb[P ^ 1][kk]);
+        if (!IDLE && DMA && kk == 1 && n2) stage_half<A_OC, B_OC, 1, 0, BUF>(st, t + 2);
+        sched_fence();
+    }
+    if (!IDLE && DMA && n1) {   // A0 and B0 of the next tile
+        if (n2) wait4<8>(); else wait4<4>();
+    }
+    bar4();
+    if (IDLE && DMA) {
+        if (n2) stage_half<A_OC, B_OC, 1, 0, BUF>(st, t + 2);   // B0(t+2)
+        if (n1) {                                                 // B1 of the next tile (read in its phase 1)
+            if (n2) wait4<6>(); else wait4<2>();
+        }
+    }
+
+    // ---- phase 4: (A1, B0); the next tile's A0 / B0 take over the A registers and the free B half
+    bar4();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (rowA1[i] && colB0) ARIA_MFMA4(acc[1][i][0], fa[i][kk], fb[P][kk]);
+        if (RD && n1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i][kk] = aa.read(a0n, i, kk);
+            fb[P ^ 1][kk] = ab.read(b0n, 0, kk);
+        }
+        if (!IDLE && DMA && kk == 1 && n2) stage_half<A_OC, B_OC, 1, 1, BUF>(st, t + 2);
+        sched_fence();
+    }
+    if (!IDLE && DMA && n1) {   // B1 of the next tile
+        if (n2) wait4<8>(); else wait4<2>();
+    }
+    bar4();
+    if (IDLE && DMA) {
+        if (n2) stage_half<A_OC, B_OC, 1, 1, BUF>(st, t + 2);   // B1(t+2)
+        if (n1) {                                                 // A1 of the next tile (read in its phase 2)
+            if (n2) wait4<6>(); else wait4<0>();
+        }
+    }
+}
+
+template <bool A_OC, bool B_OC, bool EDGE>
+__device__ __forceinline__ void k_loop4(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
+                                        const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int nk, int rl, int cl) {
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        k_tile4<A_OC, B_OC, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
+        k_tile4<A_OC, B_OC, 1, EDGE>(acc, fa, fb, aa, ab, smem, st, kt + 1, nk, rl, cl);
+    }
+    if (kt < nk) k_tile4<A_OC, B_OC, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
+}
+
 // ---- epilogue of one 256x256 tile: bias, pair exchange so every lane owns two adjacent columns of one row, (accumulate), round, store
 template <class P>
 __device__ __forceinline__ void store_tile3(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l,
@@ -321,7 +490,53 @@ __device__ __forceinline__ void store_tile3(const P& p, const f32x16 (&acc)[2][2
     }
 }
 
-template <bool A_OC, bool B_OC>
+// Wide form of the epilogue for bf16 outputs (no accumulate): the 4-byte-per-lane stores above are 512 store instructions per tile and
+// CU, and the texture-address unit retires one wave-instruction per ~31 cycles whatever its width (measured: an LDS-DMA-only loop runs at
+// 1 KiB per 31 cycles per CU) -- 8 us per tile, 10 % of a K = 2560 tile, with no MFMA running.  Here every wave parks its 128 x 64 block
+// of the tile in its own 16 KiB of the (now idle) operand images as bf16 rows of 64 bytes and writes it out in 16-byte pieces: 16
+// global_store_dwordx4 per wave instead of 64 dword stores, each covering 16 rows x 64 contiguous bytes.
+// Only for column tiles that lie wholly inside N with 16-byte aligned rows (the caller checks); rows past m_end are predicated off.
+template <class P>
+__device__ __forceinline__ void store_tile3_wide(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
+                                                 int wm, int wn, char* smem) {
+    const int c = l & 31, h = l >> 5, odd = l & 1;
+    char* mine = smem + 16384 * w;  // [a][b][64 rows][64 bytes]
+    wave_barrier();
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + b * 128 + wn * 32 + c;
+        const float bv = p.bias ? bf2f(p.bias[n]) : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {  // register pair (2rp, 2rp+1) = two consecutive rows
+                    const float v0 = aria_epilogue_act(p, acc[a][i][b][2 * rp] + bv), v1 = aria_epilogue_act(p, acc[a][i][b][2 * rp + 1] + bv);
+                    const int r = 2 * rp;
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;  // inside the 64-row block
+                    const float got = shfl_xor(odd ? v0 : v1, 1);
+                    const float lo = odd ? got : v0, hi = odd ? v1 : got;  // columns (c & ~1), (c | 1) of that row
+                    *reinterpret_cast<uint32_t*>(mine + (a * 2 + b) * 4096 + row * 64 + (c & ~1) * 2) = pack2bf(lo, hi);
+                }
+    }
+    wave_barrier();
+    const int rr = l >> 2, cc = (l & 3) * 8;  // this lane's row inside a 16-row slab / first of its 8 columns
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s16 = 0; s16 < 4; ++s16) {
+                const int row = s16 * 16 + rr;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(mine + (a * 2 + b) * 4096 + row * 64 + cc * 2);
+                const int m = m0 + a * 128 + wm * 64 + row;
+                if (m < m_end)
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + n0 + b * 128 + wn * 32 + cc) = v;
+            }
+}
+
+template <bool A_OC, bool B_OC, int VER>
 __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     ARIA_DYN_SMEM(smem);
     const int t = threadIdx.x, l = t & 63, w = first_lane(t >> 6), wm = w >> 2, wn = w & 3;
@@ -392,30 +607,65 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
                 for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
     s16x8 fa[2][4], fb[2][4];  // A fragments of the current A half; B fragments of BOTH halves (B0 is used by phases 1 and 4)
 
-    // ---- prologue: tile 0 completely, A0 and B0 of tile 1 (phases 1 and 2 of tile 0 issue its A1 and B1) -- the steady-state
-    // queue shape
-    if (nk > 0) {
-        stage_half<A_OC, B_OC, 0, 0, 0>(st, 0);
-        stage_half<A_OC, B_OC, 1, 0, 0>(st, 0);
-        stage_half<A_OC, B_OC, 1, 1, 0>(st, 0);
-        stage_half<A_OC, B_OC, 0, 1, 0>(st, 0);
-    }
-    if (nk > 1) {
-        stage_half<A_OC, B_OC, 0, 0, 1>(st, 1);
-        stage_half<A_OC, B_OC, 1, 0, 1>(st, 1);
-        wait_vm<4>();
-    } else {
-        wait_vm<0>();
-    }
-    raw_barrier();
-    if (wm == 1) raw_barrier();  // waves 4-7 run one barrier behind waves 0-3
-
     // rows / columns of this wave's part of half 0 that are in range (half 1 lies 128 further)
     const int rows_left = m_end - m0 - wm * 64, cols_left = p.N - n0 - wn * 32;
-    if (m0 + BM <= m_end && n0 + BN <= p.N)
-        k_loop3<A_OC, B_OC, false>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
-    else
-        k_loop3<A_OC, B_OC, true>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
+    const bool interior = m0 + BM <= m_end && n0 + BN <= p.N;
+    if (VER == 3) {
+        // ---- prologue: tile 0 completely, A0 and B0 of tile 1 (phases 1 and 2 of tile 0 issue its A1 and B1) -- the steady-state
+        // queue shape
+        if (nk > 0) {
+            stage_half<A_OC, B_OC, 0, 0, 0>(st, 0);
+            stage_half<A_OC, B_OC, 1, 0, 0>(st, 0);
+            stage_half<A_OC, B_OC, 1, 1, 0>(st, 0);
+            stage_half<A_OC, B_OC, 0, 1, 0>(st, 0);
+        }
+        if (nk > 1) {
+            stage_half<A_OC, B_OC, 0, 0, 1>(st, 1);
+            stage_half<A_OC, B_OC, 1, 0, 1>(st, 1);
+            wait_vm<4>();
+        } else {
+            wait_vm<0>();
+        }
+        raw_barrier();
+        if (wm == 1) raw_barrier();  // waves 4-7 run one barrier behind waves 0-3
+        if (interior)
+            k_loop3<A_OC, B_OC, false>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
+        else
+            k_loop3<A_OC, B_OC, true>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
+    } else {
+        // ---- v4 prologue: tile 0 completely and A0, B0, B1 of tile 1 in flight (the queue shape phase 1 of tile 0 expects); A0 and B0 of
+        // tile 0 go to registers ("phase 4 of tile -1")
+        if (nk > 0) {
+            stage_half<A_OC, B_OC, 0, 0, 0>(st, 0);
+            stage_half<A_OC, B_OC, 1, 0, 0>(st, 0);
+            stage_half<A_OC, B_OC, 1, 1, 0>(st, 0);
+            stage_half<A_OC, B_OC, 0, 1, 0>(st, 0);
+        }
+        if (nk > 1) {
+            stage_half<A_OC, B_OC, 0, 0, 1>(st, 1);
+            stage_half<A_OC, B_OC, 1, 0, 1>(st, 1);
+            stage_half<A_OC, B_OC, 1, 1, 1>(st, 1);
+            wait_vm<10>();  // A0 and B0 of tile 0
+        } else {
+            wait_vm<4>();
+        }
+        raw_barrier();
+        if (nk > 0) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i][kk] = aa.read(smem, i, kk);
+                fb[0][kk] = ab.read(smem + LDS_OPERAND, 0, kk);
+            }
+        }
+        if (nk > 1) wait_vm<6>(); else wait_vm<0>();   // B1 of tile 0 (read in phase 1) -- its A1 is waited for at the end of phase 1
+        raw_barrier();
+        if (wm == 1) raw_barrier();  // waves 4-7 run one barrier behind waves 0-3
+        if (interior)
+            k_loop4<A_OC, B_OC, false>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
+        else
+            k_loop4<A_OC, B_OC, true>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
+    }
     if (wm == 0) raw_barrier();  // balance the barrier count of the two groups
 
     const int c = l & 31, h = l >> 5, odd = l & 1;
@@ -432,7 +682,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
                         dst[(a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + b * 128 + wn * 32 + c] = acc[a][i][b][r];
         return;
     }
-    store_tile3(p, acc, C, m0, m_end, n0, l, wm, wn);
+    if (!p.c_f32 && !p.accumulate && n0 + BN <= p.N && p.wide_store)
+        store_tile3_wide(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
+    else
+        store_tile3(p, acc, C, m0, m_end, n0, l, wm, wn);
 }
 
 // ================================================================================================ persistent form (gemm3p)
@@ -790,6 +1043,9 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     // bit 8 = DMA pieces inside the MFMA section: measured +4..6 % with two k-contiguous operands, -5 % when an operand goes through
     // the transposing reads (profiles/r01_gemm_tuning.md)
     q.order = ord ? std::atoi(ord) : (!a_oc && !b_oc ? 256 + 4 : 4);
+    // wide epilogue: every 8-column piece of a C row must be 16-byte aligned.  ARIA_GEMM_WIDE_STORE=0 switches it off (A/B measurements).
+    const char* wsd = std::getenv("ARIA_GEMM_WIDE_STORE");
+    q.wide_store = !(wsd && wsd[0] == '0') && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.ldc & 7) == 0 && (p.strideC & 7) == 0;
     if (ntn * ntm <= 0) return ARIA_OK;
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
     if (persist) {
@@ -803,12 +1059,25 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
         return aria_check_launch();
     }
     dim3 grid(unsigned(aria_tile_grid(q)), grid_y), block(512);
-    if (!a_oc && !b_oc)
-        ARIA_LAUNCH((gemm3_kernel<false, false>), grid, block, shmem, stream, q);
-    else if (!a_oc && b_oc)
-        ARIA_LAUNCH((gemm3_kernel<false, true>), grid, block, shmem, stream, q);
-    else
-        ARIA_LAUNCH((gemm3_kernel<true, true>), grid, block, shmem, stream, q);
+    // K-loop generation: v3's phase schedule; ARIA_GEMM_V4=1 selects v4 (fragment prefetch inside the MFMA sections, DMA from the idle
+    // group): +9 % at 8192^3, -2..-4 % on this model's short reductions (profiles/r02_gemm_v4.md) -- opt-in
+    const char* v4 = std::getenv("ARIA_GEMM_V4");
+    const bool use4 = v4 && v4[0] == '1';
+    if (use4) {
+        if (!a_oc && !b_oc)
+            ARIA_LAUNCH((gemm3_kernel<false, false, 4>), grid, block, shmem, stream, q);
+        else if (!a_oc && b_oc)
+            ARIA_LAUNCH((gemm3_kernel<false, true, 4>), grid, block, shmem, stream, q);
+        else
+            ARIA_LAUNCH((gemm3_kernel<true, true, 4>), grid, block, shmem, stream, q);
+    } else {
+        if (!a_oc && !b_oc)
+            ARIA_LAUNCH((gemm3_kernel<false, false, 3>), grid, block, shmem, stream, q);
+        else if (!a_oc && b_oc)
+            ARIA_LAUNCH((gemm3_kernel<false, true, 3>), grid, block, shmem, stream, q);
+        else
+            ARIA_LAUNCH((gemm3_kernel<true, true, 3>), grid, block, shmem, stream, q);
+    }
     if (q.split > 1) ARIA_LAUNCH(gemm3_reduce_kernel, dim3(unsigned(R), 16), dim3(256), 0, stream, q);
     return aria_check_launch();
 }

@@ -20,6 +20,7 @@ struct GemmParams {
     // ranges into fp32 slabs (ws), which a second kernel sums in a fixed order.  split <= 1: off.
     int split, split_first;
     float* ws;
+    int wide_store;  // v3: C rows are 16-byte aligned at every 8th column (pointer, ldc, strideC): full-width column tiles take the wide epilogue
     int order;     // tile-order variant (tuning knob): 0 = XCD-contiguous row-major, 1 = plain, >= 2 = groups of `order` row tiles
 };
 // (the device helpers below are templates on the block's type so that a kernel may also hand them the block where it lies in the

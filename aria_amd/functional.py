@@ -251,10 +251,11 @@ def lm_head_loss_fwd_bwd(hn, lm_w, labels_shifted, need_grads: bool = True, need
     with d(loss)/d(logits) (scaled by 1/n_valid on the device: no host sync), so the backward GEMMs can run immediately.
     -> (loss fp32 scalar tensor, d_hn | None, g_lm_w | None)
 
-    ARIA_LMHEAD_SKIP_MASKED=1 (opt-in until timed on hardware): positions whose label is ignored contribute neither to the loss nor to
-    any gradient, so only the rows with a label go through the [rows, V] GEMMs (an SFT batch masks its prompts: 75 % of the positions
-    in the benchmark's batch) -- one host sync for the row count, a row gather before and a row scatter after."""
-    if os.environ.get("ARIA_LMHEAD_SKIP_MASKED") == "1":
+    Positions whose label is ignored contribute neither to the loss nor to any gradient, so only the rows with a label go through the
+    [rows, V] GEMMs (an SFT batch masks its prompts: 75 % of the positions in the benchmark's batch) -- one host sync for the row count,
+    a row gather before and a row scatter after.  Measured on MI355X: 714.6 -> 701.7 ms per config #3 step, identical loss
+    (ARIA_LMHEAD_SKIP_MASKED=0 switches it off)."""
+    if os.environ.get("ARIA_LMHEAD_SKIP_MASKED", "1") != "0":
         return _lm_head_loss_valid_rows(hn, lm_w, labels_shifted, need_grads, need_w)
     logits = ops.gemm(hn, lm_w)
     count_in = (labels_shifted >= 0).sum(dtype=torch.int32).reshape(1)

@@ -89,7 +89,7 @@ def test_attention_hd72_forward(B, Sq, Skv, H, masked):
 
 
 @pytest.mark.parametrize("force", ["1", "2", "3", None])
-@pytest.mark.parametrize("M,N,K", [(40, 72, 64), (264, 136, 192)])
+@pytest.mark.parametrize("M,N,K", [(40, 72, 64), (264, 136, 192), (72, 520, 128)])
 def test_gemm_fused_gelu(monkeypatch, force, M, N, K):
     if force:
         monkeypatch.setenv("ARIA_GEMM_FORCE", force)
