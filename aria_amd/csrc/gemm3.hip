@@ -536,6 +536,44 @@ __device__ __forceinline__ void store_tile3_wide(const P& p, const f32x16 (&acc)
             }
 }
 
+// The same with a 2 KiB staging buffer per wave (one 32 x 32 accumulator tile pair at a time): for the persistent form, whose operand
+// images are already being refilled for the next tile when a tile's accumulators are written out.
+template <class P>
+__device__ __forceinline__ void store_tile3_wide_small(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l,
+                                                       int wm, int wn, char* stage) {
+    const int c = l & 31, h = l >> 5, odd = l & 1;
+    const int rr = l >> 2, cc = (l & 3) * 8;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + b * 128 + wn * 32 + c;
+        const float bv = p.bias ? bf2f(p.bias[n]) : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wave_barrier();
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    const float v0 = aria_epilogue_act(p, acc[a][i][b][2 * rp] + bv), v1 = aria_epilogue_act(p, acc[a][i][b][2 * rp + 1] + bv);
+                    const int r = 2 * rp;
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h + odd;  // inside the 32-row tile
+                    const float got = shfl_xor(odd ? v0 : v1, 1);
+                    const float lo = odd ? got : v0, hi = odd ? v1 : got;
+                    *reinterpret_cast<uint32_t*>(stage + row * 64 + (c & ~1) * 2) = pack2bf(lo, hi);
+                }
+                wave_barrier();
+#pragma unroll
+                for (int s16 = 0; s16 < 2; ++s16) {
+                    const int row = s16 * 16 + rr;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * 64 + cc * 2);
+                    const int m = m0 + a * 128 + wm * 64 + i * 32 + row;
+                    if (m < m_end)
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + n0 + b * 128 + wn * 32 + cc) = v;
+                }
+            }
+    }
+}
+
 template <bool A_OC, bool B_OC, int VER>
 __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     ARIA_DYN_SMEM(smem);
@@ -809,7 +847,8 @@ __device__ __forceinline__ void k_tile_p(f32x16 (&acc)[2][2][2], const FragAddr<
 
 // LDS behind the operand images: per wave 2 x 64 bytes of tile descriptors (tile i at parity i & 1)
 constexpr int LDS_TILES3 = 2 * LDS_OPERAND;
-constexpr int LDS_TOTAL3 = LDS_TILES3 + 8 * 128;
+constexpr int LDS_STAGE3 = LDS_TILES3 + 8 * 128;      // 8 waves x 2 KiB: staging of the wide epilogue
+constexpr int LDS_TOTAL3 = LDS_STAGE3 + 8 * 2048;
 
 // the K-tiles of one output tile, continuing the workgroup's running count g (buffer parity): same shape as k_loop3 -- straight-line
 // pairs of K-tiles -- so that the register allocation of the hot loop is the one of the one-tile kernel
@@ -913,7 +952,11 @@ __global__ __launch_bounds__(512) void gemm3p_kernel(GemmParams p_arg) {
             KParams3& p = params3(p_arg);
             const Tile3 cur = tile3_get(slots + 64 * (i & 1));
             const long long c_off = p.mode == 2 ? (long long)cur.e * p.strideC : 0;
-            store_tile3(p, acc, static_cast<char*>(p.C) + c_off * (p.c_f32 ? 4 : 2), cur.m0, cur.m_end, cur.n0, l, wm, wn);
+            char* C = static_cast<char*>(p.C) + c_off * (p.c_f32 ? 4 : 2);
+            if (!p.c_f32 && !p.accumulate && cur.n0 + BN <= N && p.wide_store)
+                store_tile3_wide_small(p, acc, C, cur.m0, cur.m_end, cur.n0, l, wm, wn, smem + LDS_STAGE3 + 2048 * w);
+            else
+                store_tile3(p, acc, C, cur.m0, cur.m_end, cur.n0, l, wm, wn);
         }
         if (!have_next) break;
 #pragma unroll
