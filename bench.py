@@ -72,20 +72,35 @@ def init_params(model, seed):
                     flat[o:o + chunk].normal_(0.0, 0.02, generator=g)
 
 
-def pmc_traffic(variant=2):
-    """HBM bytes per fc1 launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
-    tools/gemm_pmc_target.py = the same shape; gfx950 FETCH_SIZE x2 correction applied), for the kernel family the run dispatched
-    to -- counters cannot be read inside the timed run.  None if there is no pass for that kernel."""
+PMC_KERNEL_TAG = "gemm3_kernel<rc,oc,3>+wide_store+expert_major"   # the fc1 launch the committed PMC pass profiled
+
+
+def fc1_kernel_tag(variant):
+    """What the default path launched for experts.fc1 in THIS run, spelled like profiles/r02_pmc_fc1.json's kernel_tag."""
+    if variant != 3:
+        return f"gemm{variant}_kernel<rc,oc>"
+    v4 = os.environ.get("ARIA_GEMM_V4") == "1"
+    wide = os.environ.get("ARIA_GEMM_WIDE_STORE", "1") != "0"
+    persist = os.environ.get("ARIA_GEMM_PERSIST", "0") not in ("0", "")
+    return f"gemm3{'p' if persist else ''}_kernel<rc,oc,{4 if v4 else 3}>" + ("+wide_store" if wide else "") + "+expert_major"
+
+
+def pmc_traffic(variant=3):
+    """Bytes beyond the L2s per fc1 launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    tools/gemm_pmc_target.py = the same shape; gfx950 FETCH_SIZE x2 correction applied) -- counters cannot be read inside the timed run.
+    None unless the pass profiled exactly the kernel / epilogue / tile order this run launched."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_fc1.json")) as f:
-            return round(json.load(f)["kernels"][f"gemm{variant}_kernel<rc,oc>"]["hbm_bytes_per_launch"])
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_fc1.json")) as f:
+            d = json.load(f)
+        return round(d["hbm_bytes_per_launch"]) if d["kernel_tag"] == fc1_kernel_tag(variant) else None
     except Exception:
         return None
 
 
 def cpu_baseline(cfg_kwargs, seconds_budget=40.0):
-    """The CPU oracle (oracle/aria_oracle.py, 'port' of the reference algorithm) timed on this host: one full-width decoder
-    layer + lm_head/CE, fwd+bwd, fp32, B=1 S=256; extrapolated to 28 layers."""
+    """The CPU oracle (oracle/aria_oracle.py, 'port' of the reference algorithm: the reference itself cannot travel to the GPU box) timed on
+    this host at the benchmark's sequence shape: one full-width decoder layer + lm_head/CE, fwd+bwd, fp32, B=1 S=2048 (one of the 8
+    samples of the micro-batch); extrapolated to 28 layers."""
     from oracle import aria_oracle as O
 
     torch.manual_seed(0)
@@ -104,7 +119,7 @@ def cpu_baseline(cfg_kwargs, seconds_budget=40.0):
     w = {k: (torch.randn(*s) * 0.02).requires_grad_(True) for k, s in shapes.items()}
     w["model.layers.0.input_layernorm.weight"] = torch.ones(D, requires_grad=True)
     w["model.layers.0.post_attention_layernorm.weight"] = torch.ones(D, requires_grad=True)
-    S = 256
+    S = 2048
     pos = torch.arange(S)[None]
 
     def layer_step(s):
@@ -317,8 +332,7 @@ def main():
                        "grad_exchange": None if world == 1 else ("all_reduce" if args.allreduce else "reduce_scatter (ZeRO-2)"), "grad_checkpointing": bool(args.recompute),
                        "optimizer_in_step": False,  # metric = fwd+bwd; AdamW state (299 GB fp32) only exists sharded over >= 2 GPUs
                        "loss": round(float(loss), 4)},
-            "roofline": {"kernel": {1: "gemm_kernel", 2: "gemm2_kernel", 3: "gemm3_kernel"}.get(timed_grouped_gemm.variant, "gemm?_kernel")
-                                   + "<rc,oc> grouped-M (experts.fc1 forward)", "bound": "mfma",
+            "roofline": {"kernel": fc1_kernel_tag(timed_grouped_gemm.variant) + " grouped-M (experts.fc1 forward)", "bound": "mfma",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / peak, 4),
                          "traffic": pmc_traffic(timed_grouped_gemm.variant),
