@@ -1,0 +1,246 @@
+"""Hugging Face surface of the native modules (SURVEY 8b seam B3): ``PreTrainedConfig`` / ``PreTrainedModel`` + ``GenerationMixin``
+subclasses registered with ``AutoConfig`` / ``AutoModelForCausalLM`` under the reference's model types, so that
+``AutoModelForCausalLM.from_pretrained(dir)``, ``save_pretrained``, HF ``generate()``, ``Trainer`` and peft's module walk accept them.
+
+Mirrors aria/model/modeling_aria.py:38-58 (``AriaPretrainedModel``: ``config_class``, ``base_model_prefix = "model"``,
+``_no_split_modules``, ``supports_gradient_checkpointing``, ``_supports_flash_attn_2 / _supports_sdpa / _supports_cache_class``),
+``:125-192`` (the model class and its freeze_* / set_moe_* helpers) and ``:337-365`` (``prepare_inputs_for_generation``), and
+aria/model/configuration_aria.py:31-114 / moe_lm.py:43-80 / vision_encoder.py:31-40 (the three configs).
+
+The arithmetic is the native path's (``aria_amd.modeling_aria.AriaForConditionalGeneration``: HIP kernels behind the C ABI); this file
+only adds the HF plumbing.  State-dict keys are the reference's (``vision_tower.*``, ``multi_modal_projector.*``, ``language_model.*``),
+so checkpoints written by either class load into the other and into the reference.
+
+KV cache: the hot path's fast decode engine lives behind the gptfast surface (``.generate_fast`` = the native ``generate``).  The HF
+``generate()`` loop is supported for compatibility without a cache (every step re-runs the prefix: ``use_cache`` is forced off) -- correct,
+quadratic; it is what lets recipes that call ``model.generate(**inputs)`` with arbitrary ``GenerationConfig`` options run unchanged.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from transformers import AutoConfig, AutoModelForCausalLM, GenerationMixin, PreTrainedModel
+from transformers.configuration_utils import PreTrainedConfig
+from transformers.modeling_outputs import CausalLMOutputWithPast
+
+from . import modeling_aria as native
+from .moe_lm import AriaMoELMConfig as NativeTextConfig
+from .vision import AriaVisionConfig as NativeVisionConfig
+
+_TEXT_KEYS = ("moe_intermediate_size", "moe_num_experts", "moe_topk", "moe_z_loss_coeff", "moe_aux_loss_coeff", "moe_num_shared_experts",
+              "hidden_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads", "vocab_size", "rms_norm_eps", "rope_theta",
+              "max_position_embeddings", "pad_token_id")
+_VISION_KEYS = ("hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "patch_size", "image_size", "num_channels",
+                "layer_norm_eps")
+
+
+class AriaMoELMHFConfig(PreTrainedConfig):
+    """aria/model/moe_lm.py:43-80 (``AriaMoELMConfig(LlamaConfig)``), Aria-25.3B defaults."""
+
+    model_type = "aria_moe_lm"
+
+    def __init__(self, **kwargs):
+        n = NativeTextConfig(**{k: kwargs[k] for k in _TEXT_KEYS if k in kwargs})
+        for k in _TEXT_KEYS:
+            kwargs[k] = getattr(n, k)
+        pad = kwargs.pop("pad_token_id")
+        for k, v in kwargs.items():
+            if k in _TEXT_KEYS:
+                setattr(self, k, v)
+        super().__init__(**{k: v for k, v in kwargs.items() if k not in _TEXT_KEYS})
+        self.pad_token_id = pad
+
+
+class AriaVisionHFConfig(PreTrainedConfig):
+    """aria/model/vision_encoder.py:31-40 (``AriaVisionConfig(SiglipVisionConfig)``)."""
+
+    model_type = "aria_vision_model"
+
+    def __init__(self, **kwargs):
+        n = NativeVisionConfig(**{k: kwargs[k] for k in _VISION_KEYS if k in kwargs})
+        for k in _VISION_KEYS:
+            setattr(self, k, getattr(n, k))
+        super().__init__(**{k: v for k, v in kwargs.items() if k not in _VISION_KEYS})
+
+
+class AriaHFConfig(PreTrainedConfig):
+    """aria/model/configuration_aria.py:31-114: ``vision_config`` / ``text_config`` sub-configs (dicts in config.json),
+    ``projector_patch_to_query_dict``, ``ignore_index``, ``image_token_index``."""
+
+    model_type = "aria"
+    sub_configs = {"text_config": AriaMoELMHFConfig, "vision_config": AriaVisionHFConfig}
+    has_no_defaults_at_init = True
+
+    def __init__(self, vision_config=None, text_config=None, projector_patch_to_query_dict=None, ignore_index: int = -100,
+                 image_token_index: int = 32000, **kwargs):
+        def sub(cls, v):
+            if isinstance(v, cls):
+                return v
+            if v is None:
+                return cls()
+            d = v if isinstance(v, dict) else {k: getattr(v, k) for k in (_TEXT_KEYS if cls is AriaMoELMHFConfig else _VISION_KEYS)}
+            return cls(**{k: x for k, x in d.items() if k != "model_type"})
+
+        self.vision_config = sub(AriaVisionHFConfig, vision_config)
+        self.text_config = sub(AriaMoELMHFConfig, text_config)
+        p2q = projector_patch_to_query_dict or {1225: 128, 4900: 256}
+        self.projector_patch_to_query_dict = {int(k): int(v) for k, v in p2q.items()}
+        self.ignore_index = ignore_index
+        self.image_token_index = image_token_index
+        kwargs.setdefault("tie_word_embeddings", False)
+        super().__init__(**kwargs)
+
+    def to_dict(self):
+        d = super().to_dict()
+        d["projector_patch_to_query_dict"] = {str(k): v for k, v in self.projector_patch_to_query_dict.items()}  # JSON keys are strings
+        return d
+
+    def to_native(self) -> native.AriaConfig:
+        t = {k: getattr(self.text_config, k) for k in _TEXT_KEYS}
+        v = {k: getattr(self.vision_config, k) for k in _VISION_KEYS}
+        return native.AriaConfig(vision_config=v, text_config=t, projector_patch_to_query_dict=dict(self.projector_patch_to_query_dict),
+                                 ignore_index=self.ignore_index, image_token_index=self.image_token_index)
+
+    # the generation utilities look these up on the top-level config
+    @property
+    def vocab_size(self):
+        return self.text_config.vocab_size
+
+    @property
+    def num_hidden_layers(self):
+        return self.text_config.num_hidden_layers
+
+    @property
+    def hidden_size(self):
+        return self.text_config.hidden_size
+
+
+class AriaPretrainedModel(PreTrainedModel):
+    """modeling_aria.py:38-58."""
+
+    config_class = AriaHFConfig
+    config: AriaHFConfig
+    base_model_prefix = "model"
+    _no_split_modules = ["MoEDecoderLayer", "VisionEncoderLayer"]
+    supports_gradient_checkpointing = True
+    _skip_keys_device_placement = "past_key_values"
+    _supports_flash_attn = True       # the attention IS a flash kernel (attn.hip); the flags only tell HF not to reject the config
+    _supports_sdpa = True
+    _supports_cache_class = False     # see the module docstring: the KV-cache engine is the gptfast surface
+    _supports_static_cache = False
+    main_input_name = "input_ids"
+
+    def _init_weights(self, module):
+        """modeling_aria.py:60-88 (normal(0, initializer_range) for Linear / Embedding, ones for norms) + the tensors the reference
+        leaves as ``torch.empty`` garbage (router / expert weights): N(0, 0.02) too."""
+        std = 0.02
+        for name, p in module.named_parameters(recurse=False):
+            with torch.no_grad():
+                if "norm" in type(module).__name__.lower() and name == "weight":
+                    p.fill_(1.0)
+                elif name == "bias":
+                    p.zero_()
+                else:
+                    p.normal_(0.0, std)
+
+
+class AriaForConditionalGeneration(AriaPretrainedModel, GenerationMixin):
+    """modeling_aria.py:125-365 on the native modules.  Sub-module names, parameter names and shapes are the reference's."""
+
+    def __init__(self, config: AriaHFConfig):
+        super().__init__(config)
+        ncfg = config.to_native()
+        self.native_config = ncfg
+        core = native.AriaForConditionalGeneration(ncfg)
+        self.vision_tower = core.vision_tower
+        self.multi_modal_projector = core.multi_modal_projector
+        self.language_model = core.language_model
+        self.vocab_size = ncfg.text_config.vocab_size
+        self.post_init()
+
+    # ---- the native implementation's methods, bound to this class (they only use the three sub-modules and .config fields)
+    freeze_vit = native.AriaForConditionalGeneration.freeze_vit
+    freeze_projector = native.AriaForConditionalGeneration.freeze_projector
+    freeze_llm = native.AriaForConditionalGeneration.freeze_llm
+    set_moe_z_loss_coeff = native.AriaForConditionalGeneration.set_moe_z_loss_coeff
+    set_moe_aux_loss_coeff = native.AriaForConditionalGeneration.set_moe_aux_loss_coeff
+    image_features = native.AriaForConditionalGeneration.image_features
+    enable_expert_parallel = native.AriaForConditionalGeneration.enable_expert_parallel
+
+    def get_input_embeddings(self):
+        return self.language_model.get_input_embeddings()
+
+    def get_output_embeddings(self):
+        return self.language_model.lm_head
+
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
+        self.native_config.text_config.gradient_checkpointing = True   # per-layer recompute inside the fused decoder node
+
+    def gradient_checkpointing_disable(self):
+        self.native_config.text_config.gradient_checkpointing = False
+
+    @property
+    def is_gradient_checkpointing(self) -> bool:
+        return bool(self.native_config.text_config.gradient_checkpointing)
+
+    def _core(self) -> native.AriaForConditionalGeneration:
+        """A native model object sharing this module's sub-modules (no copy): the fast generate / gptfast bridge live on it."""
+        core = getattr(self, "_native_core", None)
+        if core is None:
+            core = native.AriaForConditionalGeneration.__new__(native.AriaForConditionalGeneration)
+            torch.nn.Module.__init__(core)
+            core.config = self.native_config
+            core.vision_tower, core.multi_modal_projector, core.language_model = self.vision_tower, self.multi_modal_projector, self.language_model
+            core.vocab_size = self.vocab_size
+            object.__setattr__(self, "_native_core", core)
+        return core
+
+    def generate_fast(self, *args, **kwargs):
+        """The native generate (gptfast twin + one-call-per-token decode engine, gptfast/generate.py:112-177)."""
+        return self._core().generate(*args, **kwargs)
+
+    def forward(self, input_ids: Optional[torch.Tensor] = None, pixel_values: Optional[torch.Tensor] = None,
+                pixel_mask: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None, position_ids=None,
+                past_key_values=None, inputs_embeds: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+                use_cache: Optional[bool] = None, output_attentions=None, output_hidden_states=None, return_dict=None,
+                num_logits_to_keep: int = 0, logits_to_keep: int = 0, cache_position=None, **kwargs) -> CausalLMOutputWithPast:
+        """modeling_aria.py:194-335 (same keyword arguments).  ``past_key_values`` must be None (no HF cache on this path)."""
+        if past_key_values is not None and not (hasattr(past_key_values, "get_seq_length") and past_key_values.get_seq_length() == 0):
+            raise NotImplementedError("aria_amd HF surface: no HF KV cache (use generate_fast / the gptfast surface for cached decoding)")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("output_attentions / output_hidden_states: the flash kernels never materialise them")
+        keep = int(num_logits_to_keep or logits_to_keep or 0)
+        self.native_config.image_token_index = self.config.image_token_index
+        out = native.AriaForConditionalGeneration.forward(self._core(), input_ids=input_ids, pixel_values=pixel_values, pixel_mask=pixel_mask,
+                                                          attention_mask=attention_mask, inputs_embeds=inputs_embeds, labels=labels,
+                                                          num_logits_to_keep=keep, return_logits=True if labels is None else None,
+                                                          validate_image_tokens=kwargs.pop("validate_image_tokens", True))
+        # (the Trainer scales the loss in place; the native loss is a view produced by a custom autograd node)
+        return CausalLMOutputWithPast(loss=None if out.loss is None else out.loss.clone(), logits=out.logits, past_key_values=None)
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, pixel_values=None,
+                                      pixel_mask=None, **kwargs):
+        """modeling_aria.py:337-365 without a cache: every step sees the whole sequence (and therefore the pixel inputs), and asks for
+        the last position's logits only."""
+        return {"input_ids": input_ids, "attention_mask": attention_mask, "pixel_values": pixel_values, "pixel_mask": pixel_mask,
+                "num_logits_to_keep": 1, "use_cache": False}
+
+    def generate(self, *args, **kwargs):
+        kwargs["use_cache"] = False
+        return super().generate(*args, **kwargs)
+
+    def _supports_default_dynamic_cache(self) -> bool:  # GenerationMixin: do not build a DynamicCache for us
+        return False
+
+
+def register() -> None:
+    """``AutoConfig`` / ``AutoModelForCausalLM`` resolve the reference's model types to these classes.  transformers >= 4.48 ships its own
+    port of Aria under the same ``model_type = "aria"`` (different module / parameter names: it cannot read the reference's checkpoints
+    of this layout); importing ``aria_amd.hf`` overrides that mapping for the process, like the reference's ``trust_remote_code`` does."""
+    for cfg in (AriaMoELMHFConfig, AriaVisionHFConfig, AriaHFConfig):
+        AutoConfig.register(cfg.model_type, cfg, exist_ok=True)
+    AutoModelForCausalLM.register(AriaHFConfig, AriaForConditionalGeneration, exist_ok=True)
+
+
+register()
