@@ -143,7 +143,8 @@ def shard_expert_weights(fc1: torch.Tensor, fc2: torch.Tensor, rank: int, world:
 def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w, down_w, cfg: Fn.MoEConfig,
                    group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """MoELayer.forward with the routed experts sharded over `group`.  x [T, D] (this rank's tokens) -> [T, D].
-    One small host sync per call for the row counts of the all-to-all (as in Megatron's alltoall dispatcher)."""
+    One small host sync per call for the row counts of the all-to-all (as in Megatron's alltoall dispatcher; the reference's LOCAL path
+    had two per layer: ``tokens_per_expert.cpu()`` per grouped GEMM, moe_lm.py:478).  The backward re-uses the forward's split sizes."""
     W, rank = dist.get_world_size(group), dist.get_rank(group)
     E, k = cfg.num_experts, cfg.topk
     El = E // W
@@ -161,23 +162,23 @@ def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w
         gathered = [torch.empty_like(send_counts) for _ in range(W)]
         dist.all_gather(gathered, send_counts, group=group)
         recv_counts = torch.stack([g[rank] for g in gathered])
-    send_splits = send_counts.sum(1).tolist()
-    rc = recv_counts.cpu()
-    recv_splits = rc.sum(1).tolist()
+    # ONE host sync per layer forward (the all-to-all's split sizes are host integers in torch.distributed; the backward re-uses them):
+    # both count matrices travel in a single copy.  Everything else -- the reorder permutation, the local offsets -- is built on the device.
+    both = torch.stack([send_counts, recv_counts]).cpu()
+    send_splits, recv_splits = both[0].sum(1).tolist(), both[1].sum(1).tolist()
     rows = AllToAllRowsFn.apply(perm, send_splits, recv_splits, group)             # ordered (source rank, local expert)
-    # reorder to local-expert-major for the grouped GEMM
+    # reorder to local-expert-major for the grouped GEMM: destination segment (e, s) takes source segment (s, e)
     R = rows.shape[0]
-    seg_start = torch.zeros((W, El), dtype=torch.long)
-    flat = rc.reshape(-1).long()
-    seg_start.view(-1)[1:] = torch.cumsum(flat, 0)[:-1]
-    order_parts = [torch.arange(int(seg_start[s, e]), int(seg_start[s, e]) + int(rc[s, e])) for e in range(El) for s in range(W)]
-    order = (torch.cat(order_parts) if order_parts else torch.zeros(0, dtype=torch.long)).to(torch.int32).to(x.device)
+    rcd = recv_counts.long()                                                       # [source rank, local expert] on the device
+    src_start = (torch.cumsum(rcd.reshape(-1), 0) - rcd.reshape(-1)).view(W, El)   # where segment (s, e) starts in `rows`
+    lens_em, src_em = rcd.t().reshape(-1), src_start.t().reshape(-1)               # expert-major order of the segments
+    dst_start = torch.cumsum(lens_em, 0) - lens_em
+    order = (torch.repeat_interleave(src_em - dst_start, lens_em, output_size=R) + torch.arange(R, device=x.device)).to(torch.int32)
     inverse = torch.empty_like(order)
     inverse[order.long()] = torch.arange(R, dtype=torch.int32, device=x.device)
     local_in = GatherRowsFn.apply(rows, order, inverse)
-    local_off = torch.zeros(El + 1, dtype=torch.int32)
-    local_off[1:] = torch.cumsum(rc.sum(0), 0).to(torch.int32)
-    local_off = local_off.to(x.device)
+    local_off = torch.zeros(El + 1, dtype=torch.int32, device=x.device)
+    local_off[1:] = torch.cumsum(rcd.sum(0), 0).to(torch.int32)
     h1 = AG.ExpertsGemmFn.apply(local_in, fc1_local, local_off)
     eo_local = AG.ExpertsGemmFn.apply(AG.SwiGLUFn.apply(h1), fc2_local, local_off)
     back = GatherRowsFn.apply(eo_local, inverse, order)                            # (source rank, local expert) order again
