@@ -2,6 +2,8 @@
 ``aria_amd.functional`` differentiable drop-ins (seams B1-B3 of SURVEY.md section 8b)."""
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -141,12 +143,15 @@ _LAYER_KEYS = ("ln1", "wq", "wk", "wv", "wo", "ln2", "router", "fc1", "fc2", "ga
 class DecoderLayerFn(torch.autograd.Function):
     """One MoEDecoderLayer (moe_lm.py:580-602) as a single autograd node with a hand-written backward.
     With ``recompute`` the forward keeps only the layer input and re-runs itself inside backward
-    (= the reference recipe's gradient_checkpointing, recipes/config_full.yaml:17)."""
+    (= the reference recipe's gradient_checkpointing, recipes/config_full.yaml:17) -- selectively: the flash-attention output and
+    its log-sum-exp (one [T, D] bf16 tensor per layer) are kept, so the recomputation skips the attention kernel, which is more than
+    half of a layer's forward at 64K tokens (ARIA_RECOMPUTE_KEEP_ATTN=0: recompute it too)."""
 
     @staticmethod
     def forward(ctx, x, cos, sin, B, S, acfg, mcfg, eps, kv_len, recompute, *params):
         p = dict(zip(_LAYER_KEYS, params))
-        out, c = Fn.decoder_layer_fwd(x, p, cos, sin, B, S, acfg, mcfg, eps, kv_len, save=not recompute)
+        keep = recompute and os.environ.get("ARIA_RECOMPUTE_KEEP_ATTN", "1") != "0"
+        out, c = Fn.decoder_layer_fwd(x, p, cos, sin, B, S, acfg, mcfg, eps, kv_len, save=not recompute, keep_attn=keep)
         ctx.c = c
         ctx.meta = (B, S, acfg, mcfg, eps, kv_len, recompute)
         ctx.save_for_backward(x, cos, sin, *params)
@@ -159,7 +164,8 @@ class DecoderLayerFn(torch.autograd.Function):
         p = dict(zip(_LAYER_KEYS, params))
         c = ctx.c
         if recompute:
-            _, c = Fn.decoder_layer_fwd(x, p, cos, sin, B, S, acfg, mcfg, eps, kv_len, save=True)
+            _, c = Fn.decoder_layer_fwd(x, p, cos, sin, B, S, acfg, mcfg, eps, kv_len, save=True,
+                                        attn_cache=None if c is None else c.get("attn_cache"))
         wanted = {k for k, w in zip(_LAYER_KEYS, ctx.needs_input_grad[10:]) if w}   # frozen parameters: no weight-gradient GEMM
         dx, g = Fn.decoder_layer_bwd(_c(dout), c, p, cos, sin, None if len(wanted) == len(_LAYER_KEYS) else wanted)
         ctx.c = None

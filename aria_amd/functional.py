@@ -175,8 +175,11 @@ def sdpa_bwd(do, ctx, B, S, H, hd, scale, causal, kv_len=None, dq=None, dk=None,
                              dq=dq, dk=dk, dv=dv)
 
 
-def attn_block_fwd(x, wq, wk, wv, wo, cos, sin, B: int, S: int, cfg: AttnConfig, kv_len=None, save: bool = True):
-    """LlamaAttention.forward on normalised x [B*S, D]: q/k/v proj, half-split RoPE, causal flash attention, o proj."""
+def attn_block_fwd(x, wq, wk, wv, wo, cos, sin, B: int, S: int, cfg: AttnConfig, kv_len=None, save: bool = True, attn_cache=None,
+                   keep_attn: bool = False):
+    """LlamaAttention.forward on normalised x [B*S, D]: q/k/v proj, half-split RoPE, causal flash attention, o proj.
+    ``keep_attn`` (with save=False): the returned ctx holds only the flash kernel's (o, lse); ``attn_cache`` = such a pair from an
+    earlier, identical forward: the flash kernel is skipped (selective recompute: at 64K tokens it is 55 % of a layer's forward)."""
     H, Hkv, hd = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
     if Hkv != H:
         raise NotImplementedError("GQA (num_key_value_heads != num_attention_heads): Aria is MHA (gptfast/model.py:56-58)")
@@ -186,9 +189,16 @@ def attn_block_fwd(x, wq, wk, wv, wo, cos, sin, B: int, S: int, cfg: AttnConfig,
     wqkv = fused_weight(wq, wk, wv)
     ops.gemm(x, wqkv, out=qkv)
     ops.rope_(qkv[:, :2 * Dq], cos, sin, S, 2 * H, hd)
-    o, actx = sdpa_fwd(qkv[:, :Dq], qkv[:, Dq:2 * Dq], qkv[:, 2 * Dq:], B, S, H, hd, hd ** -0.5, cfg.causal, kv_len)
+    if attn_cache is not None and _pad_hd(hd) == hd:
+        o, lse = attn_cache
+        actx = dict(q=qkv[:, :Dq], k=qkv[:, Dq:2 * Dq], v=qkv[:, 2 * Dq:], o=o, lse=lse, hdp=hd)
+    else:
+        o, actx = sdpa_fwd(qkv[:, :Dq], qkv[:, Dq:2 * Dq], qkv[:, 2 * Dq:], B, S, H, hd, hd ** -0.5, cfg.causal, kv_len)
     out = ops.gemm(o if o.is_contiguous() else o.contiguous(), wo)
-    ctx = dict(x=x, o=o, actx=actx, B=B, S=S, cfg=cfg, kv_len=kv_len, wqkv=wqkv) if save else None
+    if save:
+        ctx = dict(x=x, o=o, actx=actx, B=B, S=S, cfg=cfg, kv_len=kv_len, wqkv=wqkv)
+    else:
+        ctx = dict(attn_cache=(actx["o"], actx["lse"])) if keep_attn and actx["hdp"] == hd else None
     return out, ctx
 
 
@@ -214,14 +224,15 @@ def attn_block_bwd(dout, ctx, wq, wk, wv, wo, cos, sin, need=None):
 
 # ----------------------------------------------------------------------------------------------- decoder layer
 def decoder_layer_fwd(x, p: dict, cos, sin, B: int, S: int, acfg: AttnConfig, mcfg: MoEConfig, eps: float, kv_len=None,
-                      save: bool = True):
-    """h = x + Attn(RMSNorm(x)); out = h + MoE(RMSNorm(h)).  p: dict of the layer's parameter tensors."""
+                      save: bool = True, attn_cache=None, keep_attn: bool = False):
+    """h = x + Attn(RMSNorm(x)); out = h + MoE(RMSNorm(h)).  p: dict of the layer's parameter tensors.
+    save=False, keep_attn=True -> ctx = {"attn_cache": (o, lse)} for a later recomputing call with attn_cache=..."""
     xn, _, rstd1 = ops.rmsnorm(x, p["ln1"], eps, want_rstd=save)
-    a, actx = attn_block_fwd(xn, p["wq"], p["wk"], p["wv"], p["wo"], cos, sin, B, S, acfg, kv_len, save)
+    a, actx = attn_block_fwd(xn, p["wq"], p["wk"], p["wv"], p["wo"], cos, sin, B, S, acfg, kv_len, save, attn_cache, keep_attn)
     hn, h, rstd2 = ops.rmsnorm(a, p["ln2"], eps, residual=x, want_rstd=save)   # fused residual add
     mo, mctx = moe_fwd(hn, p["router"], p["fc1"], p["fc2"], p["gate"], p["up"], p["down"], mcfg, save)
     out = ops.add(h, mo)
-    ctx = dict(x=x, h=h, rstd1=rstd1, rstd2=rstd2, actx=actx, mctx=mctx, eps=eps) if save else None
+    ctx = dict(x=x, h=h, rstd1=rstd1, rstd2=rstd2, actx=actx, mctx=mctx, eps=eps) if save else actx
     return out, ctx
 
 
