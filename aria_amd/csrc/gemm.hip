@@ -382,6 +382,59 @@ int aria_grouped_gemm_bf16(const void* A, const void* B, void* C, const int32_t*
     return g_last_variant = 1, launch_gemm(p, 0, b_oc, p.ntn * max_tm, 1, stream);
 }
 
+// shared validation of the fused fc1 + SwiGLU entries: N2 = 2 I with I % 128 == 0 (a tile = 128 gate + 128 up columns), 16-byte aligned rows
+static int glu_check(const void* A, const void* B, const void* H, const void* ACT, int64_t M, int64_t N2, int64_t K, int64_t lda, int64_t ldb,
+                     int64_t ldh, int64_t ldact) {
+    if (!A || !B || !ACT || M < 0 || N2 <= 0 || K <= 0) return ARIA_ERR_INVALID;
+    if (!aligned16(A) || !aligned16(B) || !aligned16(ACT) || (H && !aligned16(H)) || (lda & 7) || (ldb & 7) || (K & 7) || (ldact & 7) ||
+        (H && (ldh & 7)))
+        return ARIA_ERR_ALIGN;
+    if ((N2 & 1) || ((N2 / 2) % 128) || K < 64 || 2 * lda >= (1ll << 24) || 2 * ldb >= (1ll << 24)) return ARIA_ERR_UNSUPPORTED;
+    return ARIA_OK;
+}
+
+int aria_grouped_gemm_swiglu_bf16(const void* A, const void* B, void* H, void* ACT, const int32_t* offsets, int64_t E, int64_t M_total,
+                                  int64_t N2, int64_t K, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldh, int64_t ldact,
+                                  void* stream) {
+    if (!offsets || E <= 0) return ARIA_ERR_INVALID;
+    const int rc = glu_check(A, B, H, ACT, M_total, N2, K, lda, ldb, ldh, ldact);
+    if (rc != ARIA_OK) return rc;
+    if (strideB & 7) return ARIA_ERR_ALIGN;
+    if (2 * M_total * lda >= (1ll << 32) || 2 * K * ldb >= (1ll << 32)) return ARIA_ERR_UNSUPPORTED;
+    if (M_total == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A);
+    p.B = static_cast<const bf16_t*>(B);
+    p.C = H;
+    p.C2 = ACT;
+    p.lda = lda, p.ldb = ldb, p.ldc = ldh, p.ldc2 = ldact;
+    p.M = int(M_total), p.N = int(N2), p.K = int(K);
+    p.mode = 1;
+    p.offsets = offsets;
+    p.E = int(E);
+    p.strideB = strideB;
+    p.glu = 1;
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, 1, int(M_total / 256 + E), stream);
+}
+
+int aria_gemm_swiglu_bf16(const void* A, const void* B, void* H, void* ACT, int64_t M, int64_t N2, int64_t K, int64_t lda, int64_t ldb,
+                          int64_t ldh, int64_t ldact, void* stream) {
+    const int rc = glu_check(A, B, H, ACT, M, N2, K, lda, ldb, ldh, ldact);
+    if (rc != ARIA_OK) return rc;
+    if (2 * M * lda >= (1ll << 32) || 2 * N2 * ldb >= (1ll << 32)) return ARIA_ERR_UNSUPPORTED;
+    if (M == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A);
+    p.B = static_cast<const bf16_t*>(B);   // [N2, K] row-major (nn.Linear layout: gate rows, then up rows)
+    p.C = H;
+    p.C2 = ACT;
+    p.lda = lda, p.ldb = ldb, p.ldc = ldh, p.ldc2 = ldact;
+    p.M = int(M), p.N = int(N2), p.K = int(K);
+    p.mode = 0;
+    p.glu = 1;
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int((M + 255) / 256), stream);
+}
+
 int aria_grouped_gemm_wgrad_bf16(const void* A, const void* dY, void* dW, const int32_t* offsets, int64_t E, int64_t K,
                                  int64_t N, int64_t lda, int64_t ldy, int c_f32, int accumulate, void* stream) {
     if (!A || !dY || !dW || !offsets || E <= 0) return ARIA_ERR_INVALID;

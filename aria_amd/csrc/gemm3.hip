@@ -127,6 +127,7 @@ struct Stage {  // everything a wave needs to issue its two DMA pieces of any ha
     // per launch (wave-uniform)
     int w, late;               // wave id; DMA pieces are issued inside the MFMA section instead of before the barrier
     int limA, limB;            // rows of the A operand (M) / of the B operand (N): sources are clamped to the last one
+    int bhalf;                 // distance between the first rows of the two B halves of a tile: 128, or N / 2 with the fused SwiGLU epilogue
     uint32_t ldA2, ldB2;       // leading dimensions in bytes
     long long kstepA, kstepB;  // bytes per K-tile along k
     char* lds;                 // smem + 2048 * w
@@ -149,7 +150,7 @@ __device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
     LaneSrc<OC> ls;
     ls.a = OPERAND == 0 ? st.la_a : st.lb_a;
     ls.b = OPERAND == 0 ? st.la_b : st.lb_b;
-    const int first = (OPERAND == 0 ? st.m0 : st.n0) + HALF * 128, limit = OPERAND == 0 ? st.limA : st.limB;
+    const int first = OPERAND == 0 ? st.m0 + HALF * 128 : st.n0 + HALF * st.bhalf, limit = OPERAND == 0 ? st.limA : st.limB;
     const uint32_t ld2 = OPERAND == 0 ? st.ldA2 : st.ldB2;
     const char* s0 = g + ls.offset(0, first, limit, ld2);
     const char* s1 = g + ls.offset(1, first, limit, ld2);
@@ -170,6 +171,7 @@ __device__ __forceinline__ void stage_init(Stage& st, const P& p, int w, int l, 
     st.late = (p.order >> 8) & 1;
     st.limA = p.M;
     st.limB = p.N;
+    st.bhalf = p.glu ? p.N / 2 : 128;
     st.ldA2 = uint32_t(2 * p.lda);
     st.ldB2 = uint32_t(2 * p.ldb);
     st.kstepA = A_OC ? 2 * BK * p.lda : 2 * BK;
@@ -536,6 +538,65 @@ __device__ __forceinline__ void store_tile3_wide(const P& p, const f32x16 (&acc)
             }
 }
 
+// Fused SwiGLU epilogue (p.glu): accumulator block b = 0 holds gate columns n0 + wn*32 + c, block b = 1 the up columns I + the same, so a
+// lane owns gate and up of the same output elements.  Rounding points as the unfused chain materialises them (moe_lm.py:505-507 on bf16
+// tensors: h = fc1(x) rounded to bf16, silu(h_gate) rounded, the product rounded): act = bf16(bf16(silu(bf16(gate))) * bf16(up)).
+// Everything leaves through the wide path (three 4 KiB blocks per 64-row group in the wave's 16 KiB of idle LDS): act -> C2, and, if C
+// is given, the two halves of h -> C.
+__device__ __forceinline__ float silu3(float a) { return a / (1.f + expf(-a)); }
+
+template <class P>
+__device__ __forceinline__ void store_tile3_glu(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
+                                                int wm, int wn, char* smem) {
+    const int c = l & 31, h = l >> 5, odd = l & 1;
+    char* mine = smem + 16384 * w;  // [gate | up | act][64 rows][64 bytes]
+    const int rr = l >> 2, cc = (l & 3) * 8;
+    const int I = p.N / 2;
+    bf16_t* H = reinterpret_cast<bf16_t*>(C);
+    bf16_t* ACT = static_cast<bf16_t*>(p.C2);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) {
+                const int r = 2 * rp;
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;
+                float g[2], u[2], y[2];
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    g[z] = rbf(acc[a][i][0][r + z]);
+                    u[z] = rbf(acc[a][i][1][r + z]);
+                    y[z] = rbf(silu3(g[z])) * u[z];
+                }
+                // pair exchange: every lane ends up with two adjacent columns of one row (as in the plain epilogue)
+                const float gg = shfl_xor(odd ? g[0] : g[1], 1), uu = shfl_xor(odd ? u[0] : u[1], 1), yy = shfl_xor(odd ? y[0] : y[1], 1);
+                const int off = row * 64 + (c & ~1) * 2;
+                *reinterpret_cast<uint32_t*>(mine + off) = odd ? pack2bf(gg, g[1]) : pack2bf(g[0], gg);
+                *reinterpret_cast<uint32_t*>(mine + 4096 + off) = odd ? pack2bf(uu, u[1]) : pack2bf(u[0], uu);
+                *reinterpret_cast<uint32_t*>(mine + 8192 + off) = odd ? pack2bf(yy, y[1]) : pack2bf(y[0], yy);
+            }
+        wave_barrier();
+#pragma unroll
+        for (int s16 = 0; s16 < 4; ++s16) {
+            const int row = s16 * 16 + rr;
+            const int m = m0 + a * 128 + wm * 64 + row;
+            const int n = n0 + wn * 32 + cc;
+            const u32x4 vg = *reinterpret_cast<const u32x4*>(mine + row * 64 + cc * 2);
+            const u32x4 vu = *reinterpret_cast<const u32x4*>(mine + 4096 + row * 64 + cc * 2);
+            const u32x4 vy = *reinterpret_cast<const u32x4*>(mine + 8192 + row * 64 + cc * 2);
+            if (m < m_end) {
+                if (H) {
+                    *reinterpret_cast<u32x4*>(H + (long long)m * p.ldc + n) = vg;
+                    *reinterpret_cast<u32x4*>(H + (long long)m * p.ldc + I + n) = vu;
+                }
+                *reinterpret_cast<u32x4*>(ACT + (long long)m * p.ldc2 + n) = vy;
+            }
+        }
+    }
+}
+
 // The same with a 2 KiB staging buffer per wave (one 32 x 32 accumulator tile pair at a time): for the persistent form, whose operand
 // images are already being refilled for the next tile when a tile's accumulators are written out.
 template <class P>
@@ -593,7 +654,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     }
     long long b_off = 0, c_off = 0;
     int m0 = 0, m_end = 0, k_begin = 0, k_len = p.K;
-    int n0 = tn * BN;
+    const int bn_step = p.glu ? 128 : BN;  // fused SwiGLU: a tile covers 128 gate + the matching 128 up columns
+    int n0 = tn * bn_step;
     if (p.mode == 0) {
         m0 = tmi * BM;
         m_end = p.M;
@@ -609,7 +671,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     } else {
         int expert = 0;
         if (!aria_grouped_tile(p, blockIdx.x, l, expert, m0, m_end, tn)) return;
-        n0 = tn * BN;
+        n0 = tn * bn_step;
         b_off = (long long)expert * p.strideB;
     }
     char* C = static_cast<char*>(p.C) + c_off * (p.c_f32 ? 4 : 2);
@@ -646,8 +708,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     s16x8 fa[2][4], fb[2][4];  // A fragments of the current A half; B fragments of BOTH halves (B0 is used by phases 1 and 4)
 
     // rows / columns of this wave's part of half 0 that are in range (half 1 lies 128 further)
-    const int rows_left = m_end - m0 - wm * 64, cols_left = p.N - n0 - wn * 32;
-    const bool interior = m0 + BM <= m_end && n0 + BN <= p.N;
+    const int rows_left = m_end - m0 - wm * 64, cols_left = p.glu ? BN : p.N - n0 - wn * 32;  // (glu: I % 128 == 0, no column edge)
+    const bool interior = m0 + BM <= m_end && (p.glu || n0 + BN <= p.N);
     if (VER == 3) {
         // ---- prologue: tile 0 completely, A0 and B0 of tile 1 (phases 1 and 2 of tile 0 issue its A1 and B1) -- the steady-state
         // queue shape
@@ -720,7 +782,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
                         dst[(a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + b * 128 + wn * 32 + c] = acc[a][i][b][r];
         return;
     }
-    if (!p.c_f32 && !p.accumulate && n0 + BN <= p.N && p.wide_store)
+    if (p.glu)
+        store_tile3_glu(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
+    else if (!p.c_f32 && !p.accumulate && n0 + BN <= p.N && p.wide_store)
         store_tile3_wide(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
     else
         store_tile3(p, acc, C, m0, m_end, n0, l, wm, wn);
@@ -1055,7 +1119,7 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     const unsigned grid_y = p.mode == 2 ? unsigned(p.E) : 1u;
     const size_t shmem = size_t(2) * LDS_OPERAND;
     const size_t shmem_p = size_t(LDS_TOTAL3);  // + the persistent form's tile / stage descriptors
-    const int ntn = (p.N + BN - 1) / BN;
+    const int ntn = p.glu ? (p.N / 2) / 128 : (p.N + BN - 1) / BN;
     GemmParams q = p;
     q.ntn = ntn;
     q.ntm = ntm;
@@ -1063,7 +1127,7 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     q.split_first = 0;
     q.ws = nullptr;
     long long R = 0;
-    if (p.mode == 0 && workspace) {
+    if (p.mode == 0 && workspace && !p.glu) {
         const int S = plan_split((long long)ntn * ntm, (p.K + BK - 1) / BK, &R);
         if (S > 1 && workspace_bytes >= R * S * (long long)(BM * BN) * 4) {
             q.split = S;
@@ -1082,7 +1146,7 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     const char* pg = std::getenv("ARIA_GEMM_PERSIST_GRID");
     const int pgrid_n = pg ? (std::atoi(pg) + 7) / 8 * 8 : 256;
     const long long tiles_bound = (long long)ntn * ntm * (p.mode == 2 ? p.E : 1);
-    const bool persist = pe && pe[0] != '0' && q.split == 1 && pgrid_n >= 8 && (tiles_bound > pgrid_n || pe[0] == '2');
+    const bool persist = pe && pe[0] != '0' && q.split == 1 && !p.glu && pgrid_n >= 8 && (tiles_bound > pgrid_n || pe[0] == '2');
     // bit 8 = DMA pieces inside the MFMA section: measured +4..6 % with two k-contiguous operands, -5 % when an operand goes through
     // the transposing reads (profiles/r01_gemm_tuning.md)
     q.order = ord ? std::atoi(ord) : (!a_oc && !b_oc ? 256 + 4 : 4);

@@ -20,6 +20,13 @@ struct GemmParams {
     // ranges into fp32 slabs (ws), which a second kernel sums in a fixed order.  split <= 1: off.
     int split, split_first;
     float* ws;
+    // v3, fused SwiGLU epilogue (GroupedMLP.forward's fc1 + glu, moe_lm.py:505-507,522-523; the shared expert's gate/up + act): the B
+    // operand holds [gate | up] columns (N = 2 I); a workgroup's two 128-column B halves are gate columns n0.. and up columns I + n0..,
+    // so gate and up of one output element meet in one lane.  C2 [M, I] receives silu(gate) * up with the reference's rounding points;
+    // C ([M, 2 I], may be null) the un-activated product.
+    int glu;
+    void* C2;
+    long long ldc2;
     int wide_store;  // v3: C rows are 16-byte aligned at every 8th column (pointer, ldc, strideC): full-width column tiles take the wide epilogue
     int order;     // tile-order variant (tuning knob): 0 = XCD-contiguous row-major, 1 = plain, >= 2 = groups of `order` row tiles
 };

@@ -63,15 +63,21 @@ def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save: b
     scores, idx, counts = ops.moe_route(logits, k)                   # routing :261-269 (device-side histogram)
     offsets, sorted_src, inv = ops.moe_sort(idx, counts)             # token_permutation :326-334 (stable)
     perm = ops.moe_permute(x, sorted_src, k)
-    h1 = ops.grouped_gemm(perm, fc1, offsets)                        # experts.fc1 :522 (no D2H sync)
-    act = ops.swiglu(h1)                                             # glu :505-507
+    if ops.glu_fusable(fc1.shape[1], fc1.shape[2]):                  # experts.fc1 :522 + glu :505-507 in ONE launch (no D2H sync)
+        h1, act = ops.grouped_gemm_swiglu(perm, fc1, offsets, want_h=save)   # (h1 is only kept for the backward of glu)
+    else:
+        h1 = ops.grouped_gemm(perm, fc1, offsets)
+        act = ops.swiglu(h1)
     eo = ops.grouped_gemm(act, fc2, offsets)                         # experts.fc2 :524
     T = x.shape[0]
     I2 = gate_w.shape[0]
-    gu = torch.empty((T, 2 * I2), dtype=bf16, device=x.device)       # SharedExpertMLP :368-395
-    wgu = fused_weight(gate_w, up_w)
-    ops.gemm(x, wgu, out=gu)
-    sact = ops.swiglu(gu)
+    wgu = fused_weight(gate_w, up_w)                                 # SharedExpertMLP :368-395
+    if ops.glu_fusable(x.shape[1], 2 * I2):
+        gu, sact = ops.gemm_swiglu(x, wgu, want_h=save)
+    else:
+        gu = torch.empty((T, 2 * I2), dtype=bf16, device=x.device)
+        ops.gemm(x, wgu, out=gu)
+        sact = ops.swiglu(gu)
     sh = ops.gemm(sact, down_w)
     out = ops.moe_unpermute(eo, inv, scores, k, add=sh)              # token_unpermutation :336-365 + `output += shared` :576
     ctx = None

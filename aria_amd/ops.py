@@ -118,6 +118,42 @@ def grouped_gemm(a: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, *, w_i
     return out
 
 
+def glu_fusable(K: int, N2: int) -> bool:
+    """Shapes the fused fc1 + SwiGLU launch takes (a tile = 128 gate + 128 up columns; ARIA_FUSE_SWIGLU=0 switches the fusion off)."""
+    import os
+
+    return os.environ.get("ARIA_FUSE_SWIGLU", "1") != "0" and N2 % 2 == 0 and (N2 // 2) % 128 == 0 and K >= 64 and K % 8 == 0
+
+
+def grouped_gemm_swiglu(a: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, want_h: bool = True):
+    """fc1 + glu of GroupedMLP.forward (moe_lm.py:505-507, 522-523) in one launch: -> (h [M, 2I] or None, act [M, I]).
+    Bit-identical to ``swiglu(grouped_gemm(a, w, offsets))``."""
+    _chk(a, name="a"), _chk(w, name="w"), _chk(offsets, torch.int32, "offsets")
+    if w.dim() != 3 or not w.is_contiguous() or w.shape[1] != a.shape[1]:
+        raise ValueError("grouped_gemm_swiglu: w must be a contiguous [E, K, 2I] tensor")
+    lda = _rowmajor_2d(a, "a")
+    M, K = a.shape
+    E, _, N2 = w.shape
+    h = torch.empty((M, N2), dtype=bf16, device=a.device) if want_h else None
+    act = torch.empty((M, N2 // 2), dtype=bf16, device=a.device)
+    hip.get_lib().call("aria_grouped_gemm_swiglu_bf16", _p(a), _p(w), _p(h) if want_h else None, _p(act), _p(offsets), E, M, N2, K, lda, N2,
+                       K * N2, N2, N2 // 2, _stream(a))
+    return h, act
+
+
+def gemm_swiglu(x: torch.Tensor, w: torch.Tensor, want_h: bool = True):
+    """act(gate_proj(x)) * up_proj(x) on the row-wise concatenation w = [gate_proj.weight; up_proj.weight] ([2I, K]) in one launch:
+    -> (h [M, 2I] or None, act [M, I]); bit-identical to ``swiglu(gemm(x, w))``."""
+    _chk(x, name="x"), _chk(w, name="w")
+    lda, ldb = _rowmajor_2d(x, "x"), _rowmajor_2d(w, "w")
+    M, K = x.shape
+    N2 = w.shape[0]
+    h = torch.empty((M, N2), dtype=bf16, device=x.device) if want_h else None
+    act = torch.empty((M, N2 // 2), dtype=bf16, device=x.device)
+    hip.get_lib().call("aria_gemm_swiglu_bf16", _p(x), _p(w), _p(h) if want_h else None, _p(act), M, N2, K, lda, ldb, N2, N2 // 2, _stream(x))
+    return h, act
+
+
 def grouped_gemm_wgrad(a: torch.Tensor, dy: torch.Tensor, offsets: torch.Tensor, E: int, *,
                        out: Optional[torch.Tensor] = None, out_dtype=bf16, accumulate: bool = False) -> torch.Tensor:
     """dW[e] = a[s_e:s_e+n_e]^T @ dy[s_e:s_e+n_e]  -> [E, K, N]."""

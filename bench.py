@@ -250,6 +250,24 @@ def main():
     timed_grouped_gemm.variant = 0
     ops.grouped_gemm = timed_grouped_gemm
 
+    # the default path launches experts.fc1 fused with its SwiGLU epilogue (one launch: same GEMM, epilogue included in its time)
+    orig_ggs = ops.grouped_gemm_swiglu
+
+    def timed_grouped_gemm_swiglu(a, w, offsets, want_h=True):
+        if not timed_grouped_gemm.on or fc1_events is None:
+            return orig_ggs(a, w, offsets, want_h=want_h)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = orig_ggs(a, w, offsets, want_h=want_h)
+        e.record()
+        fc1_events.append((s, e))
+        timed_grouped_gemm.variant = hip.get_lib().cdll.aria_last_gemm_variant()
+        timed_grouped_gemm.fused = True
+        return r
+
+    timed_grouped_gemm.fused = False
+    ops.grouped_gemm_swiglu = timed_grouped_gemm_swiglu
+
     dense_events = {}  # --time-grouped also classifies the dense GEMMs by operand form and size class (diagnostics)
     orig_gemm = ops.gemm
 
@@ -332,7 +350,8 @@ def main():
                        "grad_exchange": None if world == 1 else ("all_reduce" if args.allreduce else "reduce_scatter (ZeRO-2)"), "grad_checkpointing": bool(args.recompute),
                        "optimizer_in_step": False,  # metric = fwd+bwd; AdamW state (299 GB fp32) only exists sharded over >= 2 GPUs
                        "loss": round(float(loss), 4)},
-            "roofline": {"kernel": fc1_kernel_tag(timed_grouped_gemm.variant) + " grouped-M (experts.fc1 forward)", "bound": "mfma",
+            "roofline": {"kernel": fc1_kernel_tag(timed_grouped_gemm.variant) + " grouped-M (experts.fc1 forward" +
+                                   (" + SwiGLU epilogue)" if timed_grouped_gemm.fused else ")"), "bound": "mfma",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / peak, 4),
                          "traffic": pmc_traffic(timed_grouped_gemm.variant),

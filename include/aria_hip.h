@@ -72,6 +72,18 @@ int aria_grouped_gemm_bf16(const void* A, const void* B, void* C, const int32_t*
                            int64_t N, int64_t K, int b_oc, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldc,
                            void* stream);
 
+/* GroupedMLP.forward's first half as ONE launch: fc1 (experts_gemm, [K, 2I] weights) + glu (aria/model/moe_lm.py:505-507, 522-523):
+ *   H[s_e:s_e+n_e, :] = A[s_e:s_e+n_e, :] * B_e  (written only if H != NULL: the backward of glu needs it)
+ *   ACT[:, j] = silu(H[:, j]) * H[:, I + j],  I = N2 / 2,  with the bf16 rounding points of the unfused chain (bit-identical to
+ *   aria_grouped_gemm_bf16 followed by aria_swiglu_fwd).  Needs I % 128 == 0 (else ARIA_ERR_UNSUPPORTED: call the two-step form). */
+int aria_grouped_gemm_swiglu_bf16(const void* A, const void* B, void* H, void* ACT, const int32_t* offsets, int64_t E, int64_t M_total,
+                                  int64_t N2, int64_t K, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldh, int64_t ldact,
+                                  void* stream);
+/* The dense counterpart (SharedExpertMLP = LlamaMLP, moe_lm.py:368-395: act(gate_proj(x)) * up_proj(x)) on a [2I, K] weight whose first I
+ * rows are gate_proj.weight and last I rows up_proj.weight. */
+int aria_gemm_swiglu_bf16(const void* A, const void* B, void* H, void* ACT, int64_t M, int64_t N2, int64_t K, int64_t lda, int64_t ldb,
+                          int64_t ldh, int64_t ldact, void* stream);
+
 /* autograd backward of experts_gemm w.r.t. weight:  dW[e] (K x N) (+)= A[s_e:s_e+n_e]^T * dY[s_e:s_e+n_e].
  * Experts with zero rows get zeros (or keep dW when accumulate). */
 int aria_grouped_gemm_wgrad_bf16(const void* A, const void* dY, void* dW, const int32_t* offsets, int64_t E, int64_t K,

@@ -94,7 +94,7 @@ class _Recorder:
 
     def __enter__(self):
         ops = self.ops
-        self._route, self._gg = ops.moe_route, ops.grouped_gemm
+        self._route, self._gg, self._ggs = ops.moe_route, ops.grouped_gemm, ops.grouped_gemm_swiglu
 
         def route(logits, k):
             r = self._route(logits, k)
@@ -107,11 +107,18 @@ class _Recorder:
             self.variants.append(int(self.hip.get_lib().cdll.aria_last_gemm_variant()))
             return r
 
-        ops.moe_route, ops.grouped_gemm = route, gg
+        def ggs(*a, **kw):
+            r = self._ggs(*a, **kw)
+            self.variants.append(int(self.hip.get_lib().cdll.aria_last_gemm_variant()))
+            self.fused += 1
+            return r
+
+        self.fused = 0
+        ops.moe_route, ops.grouped_gemm, ops.grouped_gemm_swiglu = route, gg, ggs
         return self
 
     def __exit__(self, *exc):
-        self.ops.moe_route, self.ops.grouped_gemm = self._route, self._gg
+        self.ops.moe_route, self.ops.grouped_gemm, self.ops.grouped_gemm_swiglu = self._route, self._gg, self._ggs
         return False
 
 
@@ -178,6 +185,8 @@ def case_lm(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, B,
     assert len(rec.idx) == layers
     if expect_big_gemm:  # the 256x256 kernel families (v2 / v3) are what runs at this size -- the point of the case
         assert rec.variants and min(rec.variants) >= 2, rec.variants
+    if inter % 128 == 0:  # the fused fc1 + SwiGLU launch is the one under test wherever the width allows it
+        assert rec.fused == layers, (rec.fused, layers)
     REPORT.setdefault(case, {})["grouped_gemm_variants"] = sorted(set(rec.variants))
     with _OracleLogits() as ol, O.forced_routing(rec.idx), torch.no_grad():
         want = O.lm_forward(wf["model.embed_tokens.weight"][ids], wf, ocfg)

@@ -125,6 +125,37 @@ def case_grouped_gemm(dev, counts, K=72, N=136):
     close(dwb, want_dw.to(bf16), 1e-2, 1e-2 * max(1, max(counts)) ** 0.5)
 
 
+def case_gemm_swiglu_fused(dev, counts, K, I, T_dense):
+    """fc1 + glu in one launch (aria_grouped_gemm_swiglu_bf16 / aria_gemm_swiglu_bf16) == the two-step chain, bit for bit: h (both halves),
+    act, with and without the h output; ragged / empty experts; the chain itself is checked against the oracle (moe_lm.py:505-507)."""
+    from aria_amd import ops
+
+    E, M = len(counts), sum(counts)
+    a = rnd(M, K, seed=71).to(dev)
+    w = rnd(E, K, 2 * I, seed=72, scale=0.2).to(dev)
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(torch.tensor(counts), 0)
+    offd = off.to(dev)
+    assert ops.glu_fusable(K, 2 * I)
+    h_ref = ops.grouped_gemm(a, w, offd)
+    act_ref = ops.swiglu(h_ref)
+    want = O.glu(O.sequential_gemm(a.cpu().float(), w.cpu().float(), torch.tensor(counts)).to(bf16).float())
+    close(act_ref, want.to(bf16), 2e-2, 2e-2)
+    h, act = ops.grouped_gemm_swiglu(a, w, offd, want_h=True)
+    assert torch.equal(h.cpu(), h_ref.cpu()) and torch.equal(act.cpu(), act_ref.cpu())
+    h2, act2 = ops.grouped_gemm_swiglu(a, w, offd, want_h=False)
+    assert h2 is None and torch.equal(act2.cpu(), act_ref.cpu())
+    # dense form on [gate; up] rows (shared expert)
+    x = rnd(T_dense, K, seed=73).to(dev)
+    wd = rnd(2 * I, K, seed=74, scale=0.2).to(dev)
+    hd_ref = ops.gemm(x, wd)
+    actd_ref = ops.swiglu(hd_ref)
+    hd, actd = ops.gemm_swiglu(x, wd, want_h=True)
+    assert torch.equal(hd.cpu(), hd_ref.cpu()) and torch.equal(actd.cpu(), actd_ref.cpu())
+    _, actd2 = ops.gemm_swiglu(x, wd, want_h=False)
+    assert torch.equal(actd2.cpu(), actd_ref.cpu())
+
+
 # ------------------------------------------------------------------------------------------ routing
 def case_route(dev, T, E, k, dtype, exact):
     from aria_amd import ops

@@ -15,7 +15,7 @@ def _emu():
 
 
 def test_lm_case_small():
-    F.case_lm("cpu", "emu_lm", hidden=128, heads=2, experts=8, topk=2, inter=32, vocab=160, layers=2, B=2, S=24, expect_big_gemm=False,
+    F.case_lm("cpu", "emu_lm", hidden=128, heads=2, experts=8, topk=2, inter=128, vocab=160, layers=2, B=2, S=24, expect_big_gemm=False,
               act_tol=(3e-2, 8e-2), grad_tol=(8e-2, 2e-1))
     assert "grad model.layers.1.mlp.experts.fc1.weight" in F.REPORT["emu_lm"] and "router.layer1" in F.REPORT["emu_lm"]
 

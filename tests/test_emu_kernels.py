@@ -155,6 +155,11 @@ def test_grouped_gemm_v3_ragged_everything(force_gemm_v3):
     C.case_grouped_gemm(DEV, [3, 0, 130, 5, 0, 0, 300, 1])  # K = 72, N = 136: no dimension is a multiple of the tile
 
 
+@pytest.mark.parametrize("counts,K,I,T", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300), ([130, 520], 192, 256, 72)])
+def test_gemm_swiglu_fused(force_gemm_v3, counts, K, I, T):
+    C.case_gemm_swiglu_fused(DEV, counts, K, I, T)
+
+
 # v3 persistent form (gemm3p): 8 workgroups walk the tile list, the K-tile stream continues across tile boundaries (chained) or is
 # drained where a reduction is shorter than two K-tiles.  Forced on with a tiny grid so that every workgroup runs several tiles.
 @pytest.fixture(params=["0", "1"], ids=["dma-early", "dma-late"])

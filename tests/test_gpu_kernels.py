@@ -177,3 +177,8 @@ def test_gemm_v3_split_k(a_oc, b_oc):
     finally:
         ops.GEMM_SPLIT_K = True
     assert torch.allclose(got, ref, rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("counts,K,I,T", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300), ([1536] * 8 + [1500, 1580], 2560, 1664, 4096)])
+def test_gemm_swiglu_fused(counts, K, I, T):
+    C.case_gemm_swiglu_fused(DEV, counts, K, I, T)
