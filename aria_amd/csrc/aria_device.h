@@ -197,6 +197,14 @@ __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 __device__ __forceinline__ u32x4 zero16() { return u32x4{0u, 0u, 0u, 0u}; }
+// streaming 16-byte store (non-temporal: the line is not kept in the L2 for a reader that will not come from this XCD)
+__device__ __forceinline__ void st16_stream(void* p, u32x4 v) {
+#ifdef ARIA_EMU
+    *reinterpret_cast<u32x4*>(p) = v;
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+#endif
+}
 
 // ---- LDS-DMA (global_load_lds_dwordx4) and the explicit counters / barriers that pipeline it ----
 // Every lane fetches 16 bytes from ITS OWN global address; the wave's 1 KiB lands lane-linearly at lds_wave_base + 16 * lane

@@ -49,6 +49,9 @@
 namespace {
 using namespace ad;
 
+#ifndef ARIA_ABL
+#define ARIA_ABL 0
+#endif
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int LDS_OPERAND = 65536, LDS_HALF = 32768, LDS_BUF = 16384;  // byte strides: operand (A,B) / half / buffer
 
@@ -306,9 +309,6 @@ __device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4
 // (80 KiB per CU); every piece has 4-5 phases to land.
 // ARIA_ABL (timing experiments only, never defined in the product build): bit 0 no MFMAs, bit 1 no fragment reads, bit 2 no DMA / vmcnt
 // waits, bit 3 no barriers
-#ifndef ARIA_ABL
-#define ARIA_ABL 0
-#endif
 __device__ __forceinline__ void keep_alive(const s16x8& f) {
 #if !defined(ARIA_EMU) && ARIA_ABL
     asm volatile("" ::"v"(f));
@@ -533,9 +533,51 @@ __device__ __forceinline__ void store_tile3_wide(const P& p, const f32x16 (&acc)
                 const int row = s16 * 16 + rr;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(mine + (a * 2 + b) * 4096 + row * 64 + cc * 2);
                 const int m = m0 + a * 128 + wm * 64 + row;
-                if (m < m_end)
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + n0 + b * 128 + wn * 32 + cc) = v;
+                if (m < m_end) {
+                    bf16_t* dst = reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + n0 + b * 128 + wn * 32 + cc;
+                    if (ARIA_ABL & 256)
+                        st16_stream(dst, v);
+                    else
+                        *reinterpret_cast<u32x4*>(dst) = v;
+                }
             }
+}
+
+// Row form of the wide epilogue (p.wide_store == 2): the WHOLE workgroup parks the 256 x 256 tile in LDS ([256 rows][512 + 16 bytes]) and,
+// after one barrier, wave w writes rows 32 w .. 32 w + 31 -- every store instruction covers two complete 512-byte tile rows (four full
+// cache lines each) instead of sixteen 64-byte row pieces that meet their neighbours from other waves in the L2 at some other time.
+constexpr int ROWP3 = 528;  // LDS row pitch of the parked tile (bytes)
+template <class P>
+__device__ __forceinline__ void store_tile3_rows(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
+                                                 int wm, int wn, char* smem) {
+    const int c = l & 31, h = l >> 5, odd = l & 1;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + b * 128 + wn * 32 + c;
+        const float bv = p.bias ? bf2f(p.bias[n]) : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    const float v0 = aria_epilogue_act(p, acc[a][i][b][2 * rp] + bv), v1 = aria_epilogue_act(p, acc[a][i][b][2 * rp + 1] + bv);
+                    const int r = 2 * rp;
+                    const int row = a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;  // inside the tile
+                    const float got = shfl_xor(odd ? v0 : v1, 1);
+                    const float lo = odd ? got : v0, hi = odd ? v1 : got;
+                    *reinterpret_cast<uint32_t*>(smem + row * ROWP3 + (b * 128 + wn * 32 + (c & ~1)) * 2) = pack2bf(lo, hi);
+                }
+    }
+    sync();
+    const int rr = l >> 5, cc = (l & 31) * 8;  // two rows per instruction, 32 lanes x 16 bytes each
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+        const int row = w * 32 + s2 * 2 + rr;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * ROWP3 + cc * 2);
+        const int m = m0 + row;
+        if (m < m_end) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + n0 + cc) = v;
+    }
 }
 
 // Fused SwiGLU epilogue (p.glu): accumulator block b = 0 holds gate columns n0 + wn*32 + c, block b = 1 the up columns I + the same, so a
@@ -639,6 +681,16 @@ template <bool A_OC, bool B_OC, int VER>
 __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     ARIA_DYN_SMEM(smem);
     const int t = threadIdx.x, l = t & 63, w = first_lane(t >> 6), wm = w >> 2, wn = w & 3;
+#ifndef ARIA_EMU
+    // Start-up stagger (ARIA_GEMM_STAGGER, experiment; measured: no gain): a tile's ~11 us of fixed cost is NOT write-burst contention
+    // between lock-stepped CUs -- ONE tile alone on the chip already takes 10.5 us at K = 64 (tools/_probe11.py) -- but the serial chain
+    // inside a CU (store issue, write latency, workgroup turnover, first fetch), which only a second resident workgroup could hide.
+    // The first workgroup of every CU (ids < 256) waits (its slot inside the XCD) x p.stagger / 32 sleep units.
+    if (p.stagger > 0 && blockIdx.x < 256) {
+        const int n = int((blockIdx.x >> 3) * p.stagger) >> 5;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 
     // XCD-aware bijective remap of the workgroup id + grouped tile order (same scheme as v2)
     int tn = 0, tmi = 0, slab = -1, ks = 0;  // slab >= 0: this workgroup computes one K range of a split tile into ws
@@ -710,7 +762,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     // rows / columns of this wave's part of half 0 that are in range (half 1 lies 128 further)
     const int rows_left = m_end - m0 - wm * 64, cols_left = p.glu ? BN : p.N - n0 - wn * 32;  // (glu: I % 128 == 0, no column edge)
     const bool interior = m0 + BM <= m_end && (p.glu || n0 + BN <= p.N);
-    if (VER == 3) {
+    if (ARIA_ABL & 128) {
+        // (timing experiment: no prologue, no K loop -- launch + tile lookup + epilogue only)
+    } else if (VER == 3) {
         // ---- prologue: tile 0 completely, A0 and B0 of tile 1 (phases 1 and 2 of tile 0 issue its A1 and B1) -- the steady-state
         // queue shape
         if (nk > 0) {
@@ -782,8 +836,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
                         dst[(a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + b * 128 + wn * 32 + c] = acc[a][i][b][r];
         return;
     }
+    if (ARIA_ABL & 64) return;  // (timing experiment: no C write-out)
     if (p.glu)
         store_tile3_glu(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
+    else if (!p.c_f32 && !p.accumulate && n0 + BN <= p.N && p.wide_store == 2)
+        store_tile3_rows(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
     else if (!p.c_f32 && !p.accumulate && n0 + BN <= p.N && p.wide_store)
         store_tile3_wide(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
     else
@@ -1117,7 +1174,7 @@ long long aria_gemm3_workspace_bytes(long long M, long long N, long long K) {
 // v3 eligibility is decided by the caller (gemm.hip): K % 64 == 0, K >= 64, mode 0 or 1, operand bytes < 4 GiB
 int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* stream, void* workspace, long long workspace_bytes) {
     const unsigned grid_y = p.mode == 2 ? unsigned(p.E) : 1u;
-    const size_t shmem = size_t(2) * LDS_OPERAND;
+    const size_t shmem = size_t(256) * ROWP3;  // the operand images (128 KiB) or, at the end, the parked output tile (row form of the epilogue)
     const size_t shmem_p = size_t(LDS_TOTAL3);  // + the persistent form's tile / stage descriptors
     const int ntn = p.glu ? (p.N / 2) / 128 : (p.N + BN - 1) / BN;
     GemmParams q = p;
@@ -1153,6 +1210,9 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     // wide epilogue: every 8-column piece of a C row must be 16-byte aligned.  ARIA_GEMM_WIDE_STORE=0 switches it off (A/B measurements).
     const char* wsd = std::getenv("ARIA_GEMM_WIDE_STORE");
     q.wide_store = !(wsd && wsd[0] == '0') && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.ldc & 7) == 0 && (p.strideC & 7) == 0;
+    if (q.wide_store && !(wsd && wsd[0] == '1')) q.wide_store = 2;  // row form (whole tile parked, complete 512-byte rows per store): +0.6..2.9 % over the per-wave form (=1)
+    const char* stg = std::getenv("ARIA_GEMM_STAGGER");
+    q.stagger = stg ? std::atoi(stg) : 0;
     if (ntn * ntm <= 0) return ARIA_OK;
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
     if (persist) {
