@@ -683,7 +683,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     const int t = threadIdx.x, l = t & 63, w = first_lane(t >> 6), wm = w >> 2, wn = w & 3;
 #ifndef ARIA_EMU
     // Start-up stagger (ARIA_GEMM_STAGGER, experiment; measured: no gain): a tile's ~11 us of fixed cost is NOT write-burst contention
-    // between lock-stepped CUs -- ONE tile alone on the chip already takes 10.5 us at K = 64 (tools/_probe11.py) -- but the serial chain
+    // between lock-stepped CUs -- ONE tile alone on the chip already takes 10.5 us at K = 64 (tools/probes/tiles_vs_latency.py) -- but the serial chain
     // inside a CU (store issue, write latency, workgroup turnover, first fetch), which only a second resident workgroup could hide.
     // The first workgroup of every CU (ids < 256) waits (its slot inside the XCD) x p.stagger / 32 sleep units.
     if (p.stagger > 0 && blockIdx.x < 256) {
