@@ -89,6 +89,7 @@ template <class T>
 __device__ __forceinline__ T shfl(T v, int src) { return emu::shfl(v, src); }
 template <class T>
 __device__ __forceinline__ T shfl_xor(T v, int mask) { return emu::shfl(v, emu::lane() ^ mask); }
+__device__ __forceinline__ float xor1(float v) { return emu::shfl(v, emu::lane() ^ 1); }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return emu::ballot(p); }
 __device__ __forceinline__ int lane_id() { return emu::lane(); }
 __device__ __forceinline__ int first_lane(int v) { return emu::shfl(v, __builtin_ctzll(emu::ballot(true))); }
@@ -101,6 +102,12 @@ template <class T>
 __device__ __forceinline__ T shfl(T v, int src) { return __shfl(v, src, 64); }
 template <class T>
 __device__ __forceinline__ T shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
+// the value lane l ^ 1 holds: ONE DPP move on the vector ALU (quad_perm [1,0,3,2]).  __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt
+// lgkmcnt(0) -- a round trip through the LDS per call; 64 of them in a row were 4 of the 6 us a GEMM tile spent packing its accumulators
+// (profiles/r02_gemm_tile_timeline.md)
+__device__ __forceinline__ float xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }

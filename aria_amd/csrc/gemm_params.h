@@ -126,6 +126,11 @@ template <class P>
 __device__ __forceinline__ float aria_epilogue_act(const P& p, float v) {
     return p.act == 1 ? ad::gelu_tanh(ad::rbf(v)) : v;
 }
+// the same with the activation as a compile-time constant: inside an unrolled epilogue the run-time form costs one branch PER VALUE
+template <int ACT>
+__device__ __forceinline__ float aria_epilogue_act_c(float v) {
+    return ACT == 1 ? ad::gelu_tanh(ad::rbf(v)) : v;
+}
 
 // v2 launcher (gemm2.hip); returns ARIA_* status
 int aria_launch_gemm2(const GemmParams& p, int a_oc, int b_oc, int ntm_or_max_tm, int grid_y, void* stream);
