@@ -115,38 +115,10 @@ struct FragAddr {
         }
     }
     // fragment of rows tile_base + 32 i + (l & 31), k = 16 kk + 8 (l >> 5) + 0..7
-    // RAW (oc operands, hardware): the two transposing reads are issued as inline assembly and the CALLER waits (s_waitcnt lgkmcnt)
-    // before the first use.  hipcc puts `s_waitcnt vmcnt(0)` in front of every __builtin_amdgcn_ds_read_tr16_b64 that follows an
-    // LDS-DMA in flight (it cannot tell the read from the DMA's pending LDS write; plain ds_read_b128 loads carry the alias
-    // information that spares them) -- two complete drains of the prefetch queue per K-tile in the kernels with [k][n] operands
-    // (profiles/r02_gemm_tile_timeline.md).
-    template <bool RAW = false>
     __device__ __forceinline__ s16x8 read(const char* half, int i, int kk) const {
         if (!OC) {
             return *reinterpret_cast<const s16x8*>(half + (v[0] ^ uint32_t(kk << 5)) + i * 4096);
         } else {
-#ifndef ARIA_EMU
-            if (RAW) {
-                const uint32_t a = uint32_t(reinterpret_cast<uintptr_t>(half)) + v[i];  // (low half of a flat LDS address = the LDS offset)
-                s16x4 a0, a1;
-                if (kk == 0) {
-                    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(a0), "=&v"(a1) : "v"(a));
-                } else if (kk == 1) {
-                    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:4096\n\tds_read_b64_tr_b16 %1, %2 offset:5120" : "=&v"(a0), "=&v"(a1) : "v"(a));
-                } else if (kk == 2) {
-                    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:8192\n\tds_read_b64_tr_b16 %1, %2 offset:9216" : "=&v"(a0), "=&v"(a1) : "v"(a));
-                } else {
-                    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:12288\n\tds_read_b64_tr_b16 %1, %2 offset:13312" : "=&v"(a0), "=&v"(a1) : "v"(a));
-                }
-                s16x8 f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    f[e] = a0[e];
-                    f[4 + e] = a1[e];
-                }
-                return f;
-            }
-#endif
             const bf16_t* p = reinterpret_cast<const bf16_t*>(half + v[i] + kk * 4096);
             const s16x4 a0 = ds_read_tr16(p);
             const s16x4 a1 = ds_read_tr16(p + 512);  // four k-rows further
@@ -158,6 +130,47 @@ struct FragAddr {
             }
             return f;
         }
+    }
+    // The same fragment, read by INLINE ASSEMBLY from the half image that starts BASE bytes into the workgroup's LDS (v3 K loop on
+    // hardware); the CALLER waits (s_waitcnt lgkmcnt) before the first use.  hipcc's own wait insertion costs the pipeline dearly here:
+    // it puts `s_waitcnt vmcnt(0)` in front of every __builtin_amdgcn_ds_read_tr16_b64 that follows an LDS-DMA in flight (it cannot
+    // tell the read from the DMA's pending LDS write) -- two complete drains of the prefetch queue per K-tile in the kernels with
+    // [k][n] operands -- and an lgkmcnt(0) in the middle of a phase's ds_read_b128 run (profiles/r02_gemm_tile_timeline.md).
+    template <int BASE>
+    __device__ __forceinline__ s16x8 read_raw(const char* smem, int i, int kk) const {
+#ifdef ARIA_EMU
+        return read(smem + BASE, i, kk);
+#else
+        constexpr int HI = BASE >= 65536 ? 65536 : 0, OFF = BASE - HI;  // (the instruction's offset field has 16 bits)
+        const uint32_t lds0 = uint32_t(reinterpret_cast<uintptr_t>(smem)) + HI;  // low half of a flat LDS address = the LDS offset
+        if (!OC) {
+            const uint32_t a = lds0 + (v[0] ^ uint32_t(kk << 5));
+            s16x8 f;
+            if (i == 0)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(a), "n"(OFF));
+            else
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(a), "n"(OFF + 4096));
+            return f;
+        } else {
+            const uint32_t a = lds0 + v[i];
+            s16x4 a0, a1;
+            if (kk == 0)
+                asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" : "=&v"(a0), "=&v"(a1) : "v"(a), "n"(OFF), "n"(OFF + 1024));
+            else if (kk == 1)
+                asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" : "=&v"(a0), "=&v"(a1) : "v"(a), "n"(OFF + 4096), "n"(OFF + 5120));
+            else if (kk == 2)
+                asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" : "=&v"(a0), "=&v"(a1) : "v"(a), "n"(OFF + 8192), "n"(OFF + 9216));
+            else
+                asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" : "=&v"(a0), "=&v"(a1) : "v"(a), "n"(OFF + 12288), "n"(OFF + 13312));
+            s16x8 f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[e] = a0[e];
+                f[4 + e] = a1[e];
+            }
+            return f;
+        }
+#endif
     }
 };
 
@@ -236,18 +249,16 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
     const bool col_ok = !EDGE || QB * 128 < cols_left;
     const bool row_ok[2] = {!EDGE || QA * 128 < rows_left, !EDGE || QA * 128 + 32 < rows_left};
     if (LOAD_B && (!EDGE || (col_ok && rows_left > 0))) {
-        const char* hb = smem + LDS_OPERAND + QB * LDS_HALF + BUF * LDS_BUF;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fb[QB][kk] = ab.template read<true>(hb, 0, kk);
+        for (int kk = 0; kk < 4; ++kk) fb[QB][kk] = ab.template read_raw<LDS_OPERAND + QB * LDS_HALF + BUF * LDS_BUF>(smem, 0, kk);
     }
     sched_fence();
     if (LOAD_A) {
-        const char* ha = smem + QA * LDS_HALF + BUF * LDS_BUF;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (row_ok[i]) {
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) fa[i][kk] = aa.template read<true>(ha, i, kk);
+                for (int kk = 0; kk < 4; ++kk) fa[i][kk] = aa.template read_raw<QA * LDS_HALF + BUF * LDS_BUF>(smem, i, kk);
             }
     }
     sched_fence();
