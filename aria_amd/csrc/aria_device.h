@@ -273,10 +273,9 @@ __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
 // gelu_pytorch_tanh (ViT MLP activation, transformers ACT2FN["gelu_pytorch_tanh"]); shared by the stand-alone kernel (vit.hip) and
 // the GEMM epilogues so that the fused and the unfused path round identically
-__device__ __forceinline__ float gelu_tanh(float x) {
-    const float k = 0.7978845608028654f;  // sqrt(2/pi)
-    return 0.5f * x * (1.f + tanhf(k * (x + 0.044715f * x * x * x)));
-}
+// (0.5 x (1 + tanh u) = x / (1 + 2^(-2 u log2 e)): one v_exp_f32 and one v_rcp_f32, both good to 1 ulp, instead of libdevice's branching
+// tanhf -- ~50 instructions per value, 11 us of a 256 x 256 tile's epilogue in the ViT fc1 GEMM.)
+__device__ __forceinline__ float gelu_tanh(float x);
 
 // 2^x straight on v_exp_f32 (no denormal range fix-up: results below 2^-126 flush to 0, which is what softmax wants)
 __device__ __forceinline__ float exp2_fast(float x) {
@@ -285,6 +284,20 @@ __device__ __forceinline__ float exp2_fast(float x) {
 #else
     return __builtin_amdgcn_exp2f(x);
 #endif
+}
+__device__ __forceinline__ float rcp_fast(float x) {
+#ifdef ARIA_EMU
+    return 1.f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+// x * sigmoid(x) (SiLU): x / (1 + e^-x) on v_exp_f32 + v_rcp_f32.  ONE definition for the fused GEMM epilogue, the stand-alone SwiGLU
+// kernels and the decode path, so that all of them round identically.
+__device__ __forceinline__ float silu_fast(float a) { return a * rcp_fast(1.f + exp2_fast(-1.4426950408889634f * a)); }
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float k2 = 2.f * 0.7978845608028654f * 1.4426950408889634f;  // 2 sqrt(2/pi) log2(e)
+    return x * rcp_fast(1.f + exp2_fast(-k2 * (x + 0.044715f * x * x * x)));
 }
 
 // ds_read_b64_tr_b16: every lane passes the LDS address of 4 consecutive bf16 (8-byte aligned); within each 16-lane group

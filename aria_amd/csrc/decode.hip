@@ -21,7 +21,7 @@
 namespace {
 using namespace ad;
 
-__device__ __forceinline__ float silu(float a) { return a / (1.f + expf(-a)); }
+__device__ __forceinline__ float silu(float a) { return silu_fast(a); }
 
 // x[K] (bf16) -> this lane's chunks c = l + 64 i (i < NC) as packed bf16 pairs, optionally RMS-normalised exactly like
 // rmsnorm_fwd_kernel (norm.hip: same lane <-> chunk mapping and reduction order, so the same rstd).  Chunks past K read as zeros;

@@ -652,7 +652,7 @@ __device__ __forceinline__ void store_any3(const P& p, const f32x16 (&acc)[2][2]
 // tensors: h = fc1(x) rounded to bf16, silu(h_gate) rounded, the product rounded): act = bf16(bf16(silu(bf16(gate))) * bf16(up)).
 // Everything leaves through the wide path (three 4 KiB blocks per 64-row group in the wave's 16 KiB of idle LDS): act -> C2, and, if C
 // is given, the two halves of h -> C.
-__device__ __forceinline__ float silu3(float a) { return a / (1.f + expf(-a)); }
+__device__ __forceinline__ float silu3(float a) { return silu_fast(a); }
 
 template <class P>
 __device__ __forceinline__ void store_tile3_glu(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,

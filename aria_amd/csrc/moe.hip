@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(const bf16_t* logits, co
 }
 
 // ------------------------------------------------------------------------------------------- swiglu
-__device__ __forceinline__ float silu_f(float a) { return a / (1.f + expf(-a)); }
+__device__ __forceinline__ float silu_f(float a) { return silu_fast(a); }
 
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* h, const bf16_t* h2, bf16_t* act, long long nchunks,
                                                          int I, long long lda, long long ldb) {
