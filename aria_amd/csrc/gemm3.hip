@@ -179,7 +179,7 @@ __device__ const uint32_t aria_zero_page[64] = {};
 
 struct Stage {  // everything a wave needs to issue its two DMA pieces of any half-tile
     // per launch (wave-uniform)
-    int w, late;               // wave id; DMA pieces are issued inside the MFMA section instead of before the barrier
+    int w;                     // wave id
     int limA, limB;            // rows of the A operand (M) / of the B operand (N): sources are clamped to the last one
     int bhalf;                 // distance between the first rows of the two B halves of a tile: 128, or N / 2 with the fused SwiGLU epilogue
     uint32_t ldA2, ldB2;       // leading dimensions in bytes
@@ -195,7 +195,7 @@ struct Stage {  // everything a wave needs to issue its two DMA pieces of any ha
     int la_a, la_b, lb_a, lb_b;
 };
 
-template <bool A_OC, bool B_OC, int OPERAND, int HALF, int BUF>
+template <bool A_OC, bool B_OC, int OPERAND, int HALF, int BUF, bool TAIL = true>
 __device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
     constexpr bool OC = OPERAND == 0 ? A_OC : B_OC;
     const int tile = gtile - st.g0;
@@ -208,7 +208,7 @@ __device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
     const uint32_t ld2 = OPERAND == 0 ? st.ldA2 : st.ldB2;
     const char* s0 = g + ls.offset(0, first, limit, ld2);
     const char* s1 = g + ls.offset(1, first, limit, ld2);
-    if (st.tail_k < BK && tile == st.nk - 1) {  // wave-uniform: the ragged end of the reduction -> granules past it read zeros
+    if (TAIL && st.tail_k < BK && tile == st.nk - 1) {  // wave-uniform: the ragged end of the reduction -> granules past it read zeros
         // first reduction index (inside the tile) of this lane's 16 bytes, pieces 0 and 1
         const int k0 = OC ? ls.a : ls.b >> 1, k1 = OC ? ls.a + 4 : (ls.b ^ 64) >> 1;
         const int l = lane_id();
@@ -222,7 +222,6 @@ __device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
 template <bool A_OC, bool B_OC, class P>
 __device__ __forceinline__ void stage_init(Stage& st, const P& p, int w, int l, char* smem) {
     st.w = w;
-    st.late = (p.order >> 8) & 1;
     st.limA = p.M;
     st.limB = p.N;
     st.bhalf = p.glu ? p.N / 2 : 128;
@@ -242,10 +241,15 @@ __device__ __forceinline__ void stage_init(Stage& st, const P& p, int w, int l, 
 // EDGE (block-uniform): the tile hangs over the edge of its row group / of N; 32-row and 32-column MFMA tiles that are wholly
 // outside (wave-uniform tests on rows_left / cols_left, counted from the wave's first row / column) are skipped together with
 // their fragment reads -- a grouped GEMM's last row tile per expert usually holds only a few rows.
-template <bool A_OC, bool B_OC, int QA, int QB, bool LOAD_A, bool LOAD_B, int BUF, int SO, int SH, int SB, int WAIT, bool EDGE>
+// STEADY (interior tiles only): the K-tile this phase stages is neither beyond the reduction nor its ragged last one, and more pieces
+// are in flight behind every wait -- the phase is straight-line code (the general form spends two scalar branches, a handful of selects
+// and a chain of compares per phase on conditions that only change in a tile's last three K-tiles).
+template <bool A_OC, bool B_OC, int QA, int QB, bool LOAD_A, bool LOAD_B, int BUF, int SO, int SH, int SB, int WAIT, bool EDGE,
+          bool STEADY = false>
 __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                       const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int stage_tile, bool do_stage,
                                       bool more_in_flight, int rows_left, int cols_left) {
+    static_assert(!(STEADY && EDGE), "the steady form is for interior tiles");
     const bool col_ok = !EDGE || QB * 128 < cols_left;
     const bool row_ok[2] = {!EDGE || QA * 128 < rows_left, !EDGE || QA * 128 + 32 < rows_left};
     if (LOAD_B && (!EDGE || (col_ok && rows_left > 0))) {
@@ -262,27 +266,26 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
             }
     }
     sched_fence();
-    // DMA placement (st.late, wave-uniform): 0 = with the LDS reads, before the barrier; 1 = inside the MFMA section, where the
-    // piece's issue cost hides under the matrix pipe (this phase's two pieces are then not yet issued at the wait)
-    if (do_stage && !st.late) stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
-    if (WAIT == 1) {  // phase 1: B1 and A1 of THIS tile must have landed; newer = A0, B0 (and, early placement, A1) of the next tile
-        if (!more_in_flight)
-            wait_vm<0>();
-        else if (st.late)
-            wait_vm<4>();
-        else
+    // the phase's two DMA pieces go out with the LDS reads, before the barrier.  (Issuing them inside the MFMA section instead was
+    // measured in round 1 -- no gain -- and the run-time switch for it cost a branch per phase; removed.)
+    if (STEADY)
+        stage_half<A_OC, B_OC, SO, SH, SB, false>(st, stage_tile);
+    else if (do_stage)
+        stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
+    if (WAIT == 1) {  // phase 1: B1 and A1 of THIS tile must have landed; newer = A0, B0 and A1 of the next tile
+        if (STEADY || more_in_flight)
             wait_vm<6>();
+        else
+            wait_vm<0>();
     }
-    if (WAIT == 4) {  // phase 4: A0 and B0 of the NEXT tile must have landed; newer = its A1, B1 and A0 (, B0) of the tile after
-        if (!more_in_flight)
-            wait_vm<0>();
-        else if (st.late)
-            wait_vm<6>();
-        else
+    if (WAIT == 4) {  // phase 4: A0 and B0 of the NEXT tile must have landed; newer = its A1, B1 and A0, B0 of the tile after
+        if (STEADY || more_in_flight)
             wait_vm<8>();
+        else
+            wait_vm<0>();
     }
     raw_barrier();
-    wait_lds();  // the fragment reads above (the raw ones are invisible to the compiler's own counting)
+    wait_lds();  // the fragment reads above (invisible to the compiler's own counting)
     sched_fence();
     wave_prio<1>();
     if (!EDGE) {
@@ -290,14 +293,8 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc[QA][i][QB] = mfma32(fa[i][kk], fb[QB][kk], acc[QA][i][QB]);
-            if (kk == 0) {
-                sched_fence();
-                if (do_stage && st.late) stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
-                sched_fence();
-            }
         }
     } else {
-        if (do_stage && st.late) stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
         if (col_ok) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -311,20 +308,28 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
     raw_barrier();
 }
 
-template <bool A_OC, bool B_OC, int BUF, bool EDGE>
+template <bool A_OC, bool B_OC, int BUF, bool EDGE, bool STEADY = false>
 __device__ __forceinline__ void k_tile(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                        const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int t, int nk, int rl, int cl) {
     const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-    phase<A_OC, B_OC, 0, 0, true, true, BUF, 0, 1, BUF ^ 1, 1, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, n1, rl, cl);
-    phase<A_OC, B_OC, 0, 1, false, true, BUF, 1, 1, BUF ^ 1, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
-    phase<A_OC, B_OC, 1, 1, true, false, BUF, 0, 0, BUF, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, false, rl, cl);
-    phase<A_OC, B_OC, 1, 0, false, false, BUF, 1, 0, BUF, 4, EDGE>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, n2, rl, cl);
+    phase<A_OC, B_OC, 0, 0, true, true, BUF, 0, 1, BUF ^ 1, 1, EDGE, STEADY>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, n1, rl, cl);
+    phase<A_OC, B_OC, 0, 1, false, true, BUF, 1, 1, BUF ^ 1, 0, EDGE, STEADY>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
+    phase<A_OC, B_OC, 1, 1, true, false, BUF, 0, 0, BUF, 0, EDGE, STEADY>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, false, rl, cl);
+    phase<A_OC, B_OC, 1, 0, false, false, BUF, 1, 0, BUF, 4, EDGE, STEADY>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, n2, rl, cl);
 }
 
 template <bool A_OC, bool B_OC, bool EDGE>
 __device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                         const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int nk, int rl, int cl) {
     int kt = 0;
+    if (!EDGE) {
+        // steady part: K-tile t stages tiles t + 1 and t + 2, both of which must exist and be full -- t + 2 <= last full tile
+        const int last_full = st.tail_k < BK ? nk - 2 : nk - 1;
+        for (; kt + 1 <= last_full - 2; kt += 2) {
+            k_tile<A_OC, B_OC, 0, false, true>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
+            k_tile<A_OC, B_OC, 1, false, true>(acc, fa, fb, aa, ab, smem, st, kt + 1, nk, rl, cl);
+        }
+    }
     for (; kt + 1 < nk; kt += 2) {
         k_tile<A_OC, B_OC, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
         k_tile<A_OC, B_OC, 1, EDGE>(acc, fa, fb, aa, ab, smem, st, kt + 1, nk, rl, cl);
