@@ -266,21 +266,25 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
             }
     }
     sched_fence();
-    // the phase's two DMA pieces go out with the LDS reads, before the barrier.  (Issuing them inside the MFMA section instead was
-    // measured in round 1 -- no gain -- and the run-time switch for it cost a branch per phase; removed.)
-    if (STEADY)
-        stage_half<A_OC, B_OC, SO, SH, SB, false>(st, stage_tile);
-    else if (do_stage)
-        stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
-    if (WAIT == 1) {  // phase 1: B1 and A1 of THIS tile must have landed; newer = A0, B0 and A1 of the next tile
+    // DMA placement (compile time): with the LDS reads, before the barrier -- or LATE, inside the MFMA section behind the first two
+    // MFMAs, where the pieces' issue cost hides under the matrix pipe (this phase's two pieces are then not yet issued at the wait):
+    // measured +4..6 % with two k-contiguous operands, -5 % when an operand goes through the transposing reads (r01_gemm_tuning.md)
+    constexpr bool LATE = !A_OC && !B_OC;
+    if (!LATE) {
+        if (STEADY)
+            stage_half<A_OC, B_OC, SO, SH, SB, false>(st, stage_tile);
+        else if (do_stage)
+            stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
+    }
+    if (WAIT == 1) {  // phase 1: B1 and A1 of THIS tile must have landed; newer = A0, B0 (and, early placement, A1) of the next tile
         if (STEADY || more_in_flight)
-            wait_vm<6>();
+            wait_vm<LATE ? 4 : 6>();
         else
             wait_vm<0>();
     }
-    if (WAIT == 4) {  // phase 4: A0 and B0 of the NEXT tile must have landed; newer = its A1, B1 and A0, B0 of the tile after
+    if (WAIT == 4) {  // phase 4: A0 and B0 of the NEXT tile must have landed; newer = its A1, B1 and A0 (, B0) of the tile after
         if (STEADY || more_in_flight)
-            wait_vm<8>();
+            wait_vm<LATE ? 6 : 8>();
         else
             wait_vm<0>();
     }
@@ -293,8 +297,17 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc[QA][i][QB] = mfma32(fa[i][kk], fb[QB][kk], acc[QA][i][QB]);
+            if (LATE && kk == 0) {
+                sched_fence();
+                if (STEADY)
+                    stage_half<A_OC, B_OC, SO, SH, SB, false>(st, stage_tile);
+                else if (do_stage)
+                    stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
+                sched_fence();
+            }
         }
     } else {
+        if (LATE && do_stage) stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
         if (col_ok) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
