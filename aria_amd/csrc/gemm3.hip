@@ -267,9 +267,10 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
     }
     sched_fence();
     // DMA placement (compile time): with the LDS reads, before the barrier -- or LATE, inside the MFMA section behind the first two
-    // MFMAs, where the pieces' issue cost hides under the matrix pipe (this phase's two pieces are then not yet issued at the wait):
-    // measured +4..6 % with two k-contiguous operands, -5 % when an operand goes through the transposing reads (r01_gemm_tuning.md)
-    constexpr bool LATE = !A_OC && !B_OC;
+    // MFMAs, where the pieces' issue cost hides under the matrix pipe (this phase's two pieces are then not yet issued at the wait).
+    // LATE measures +4 % with two k-contiguous operands and +1..2 % with transposing reads (round 1 had -5 % there: that was the
+    // compiler's vmcnt(0) in front of every transposing read, see FragAddr::read_raw)
+    constexpr bool LATE = true;
     if (!LATE) {
         if (STEADY)
             stage_half<A_OC, B_OC, SO, SH, SB, false>(st, stage_tile);
