@@ -252,12 +252,12 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
     static_assert(!(STEADY && EDGE), "the steady form is for interior tiles");
     const bool col_ok = !EDGE || QB * 128 < cols_left;
     const bool row_ok[2] = {!EDGE || QA * 128 < rows_left, !EDGE || QA * 128 + 32 < rows_left};
-    if (LOAD_B && (!EDGE || (col_ok && rows_left > 0))) {
+    if (!(ARIA_ABL & 2) && LOAD_B && (!EDGE || (col_ok && rows_left > 0))) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fb[QB][kk] = ab.template read_raw<LDS_OPERAND + QB * LDS_HALF + BUF * LDS_BUF>(smem, 0, kk);
     }
     sched_fence();
-    if (LOAD_A) {
+    if (!(ARIA_ABL & 2) && LOAD_A) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (row_ok[i]) {
@@ -277,19 +277,19 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
         else if (do_stage)
             stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
     }
-    if (WAIT == 1) {  // phase 1: B1 and A1 of THIS tile must have landed; newer = A0, B0 (and, early placement, A1) of the next tile
+    if (!(ARIA_ABL & 32) && WAIT == 1) {  // phase 1: B1 and A1 of THIS tile must have landed; newer = A0, B0 (and, early placement, A1) of the next tile
         if (STEADY || more_in_flight)
             wait_vm<LATE ? 4 : 6>();
         else
             wait_vm<0>();
     }
-    if (WAIT == 4) {  // phase 4: A0 and B0 of the NEXT tile must have landed; newer = its A1, B1 and A0 (, B0) of the tile after
+    if (!(ARIA_ABL & 32) && WAIT == 4) {  // phase 4: A0 and B0 of the NEXT tile must have landed; newer = its A1, B1 and A0 (, B0) of the tile after
         if (STEADY || more_in_flight)
             wait_vm<LATE ? 6 : 8>();
         else
             wait_vm<0>();
     }
-    raw_barrier();
+    if (!(ARIA_ABL & 8)) raw_barrier();
     wait_lds();  // the fragment reads above (invisible to the compiler's own counting)
     sched_fence();
     wave_prio<1>();
@@ -297,10 +297,13 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[QA][i][QB] = mfma32(fa[i][kk], fb[QB][kk], acc[QA][i][QB]);
+            for (int i = 0; i < 2; ++i)
+                if (!(ARIA_ABL & 1)) acc[QA][i][QB] = mfma32(fa[i][kk], fb[QB][kk], acc[QA][i][QB]);
             if (LATE && kk == 0) {
                 sched_fence();
-                if (STEADY)
+                if (ARIA_ABL & 4) {
+                    // (timing experiment: no DMA)
+                } else if (STEADY)
                     stage_half<A_OC, B_OC, SO, SH, SB, false>(st, stage_tile);
                 else if (do_stage)
                     stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
@@ -319,7 +322,7 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
         }
     }
     wave_prio<0>();
-    raw_barrier();
+    if (!(ARIA_ABL & 8)) raw_barrier();
 }
 
 template <bool A_OC, bool B_OC, int BUF, bool EDGE, bool STEADY = false>
