@@ -831,8 +831,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     st.g0 = 0;
     st.nk = nk;
     st.tail_k = (kt_first + nk == nk_all && nk_all > 0) ? k_len - (nk_all - 1) * BK : BK;  // only the overall last K-tile is ragged
-    st.m0 = m0;
-    st.n0 = n0;
+    st.m0 = (ARIA_ABL & 2048) ? 0 : m0;  // (timing experiment: every workgroup loads tile (0, 0)'s operands -- all L2 hits)
+    st.n0 = (ARIA_ABL & 2048) ? 0 : n0;
     FragAddr<A_OC> aa;
     FragAddr<B_OC> ab;
     aa.init(wm * 64, l);

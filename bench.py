@@ -72,7 +72,8 @@ def init_params(model, seed):
                     flat[o:o + chunk].normal_(0.0, 0.02, generator=g)
 
 
-PMC_KERNEL_TAG = "gemm3_kernel<rc,oc,3>+wide_store+expert_major"   # the fc1 launch the committed PMC pass profiled
+KERNEL_REV = "r02b"   # bumped with every change of the v3 K loop / epilogues: a PMC pass of an older build does not describe this one
+PMC_KERNEL_TAG = "gemm3_kernel<rc,oc,3>+wide_store+expert_major+swiglu@r02b"   # the fc1 launch the committed PMC pass profiled
 
 
 def fc1_kernel_tag(variant):
@@ -82,12 +83,14 @@ def fc1_kernel_tag(variant):
     v4 = os.environ.get("ARIA_GEMM_V4") == "1"
     wide = os.environ.get("ARIA_GEMM_WIDE_STORE", "1") != "0"
     persist = os.environ.get("ARIA_GEMM_PERSIST", "0") not in ("0", "")
-    return f"gemm3{'p' if persist else ''}_kernel<rc,oc,{4 if v4 else 3}>" + ("+wide_store" if wide else "") + "+expert_major"
+    fused = os.environ.get("ARIA_FUSE_SWIGLU", "1") != "0"
+    return (f"gemm3{'p' if persist else ''}_kernel<rc,oc,{4 if v4 else 3}>" + ("+wide_store" if wide else "") + "+expert_major"
+            + ("+swiglu" if fused else "") + "@" + KERNEL_REV)
 
 
 def pmc_traffic(variant=3):
     """Bytes beyond the L2s per fc1 launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
-    tools/gemm_pmc_target.py = the same shape; gfx950 FETCH_SIZE x2 correction applied) -- counters cannot be read inside the timed run.
+    tools/gemm_pmc_target.py = the same shape and the same fused launch; gfx950 FETCH_SIZE x2 correction applied) -- counters cannot be read inside the timed run.
     None unless the pass profiled exactly the kernel / epilogue / tile order this run launched."""
     try:
         with open(os.path.join(ROOT, "profiles", "r02_pmc_fc1.json")) as f:
