@@ -263,6 +263,16 @@ __device__ __forceinline__ void wave_prio() {
     __builtin_amdgcn_s_setprio(P);
 #endif
 }
+// Make the compiler finish the load that produced `v` HERE (an empty asm that reads the register): a value fetched by a global load in
+// front of a loop and first used inside it otherwise gets its `s_waitcnt vmcnt(0)` placed at that first use -- inside the loop, where on
+// every later iteration it drains the loop's own prefetch loads (seen in the attention kernels: the wave sat out the whole global-load
+// latency of the NEXT key tile in front of its first MFMA of every tile).
+template <class T>
+__device__ __forceinline__ void settle(const T& v) {
+#ifndef ARIA_EMU
+    asm volatile("" ::"v"(v));
+#endif
+}
 __device__ __forceinline__ void sched_fence() {
 #ifndef ARIA_EMU
     __builtin_amdgcn_sched_barrier(0);

@@ -184,6 +184,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
         if (q_abs < Sq && col < HD) v = ld16(Qb + (long long)q_abs * ldq + col);
         qf[kk] = __builtin_bit_cast(s16x8, v);
     }
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) settle(qf[kk]);  // (see settle(): keeps the wait for Q out of the key-tile loop)
     f32x16 o[C::DT];
 #pragma unroll
     for (int i = 0; i < C::DT; ++i) o[i] = zero_acc();
@@ -415,6 +417,11 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dkdv_kernel(const bf16_t* Q, con
         kf[kk] = __builtin_bit_cast(s16x8, a);
         vf[kk] = __builtin_bit_cast(s16x8, c);
     }
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+        settle(kf[kk]);
+        settle(vf[kk]);
+    }
     f32x16 dk[DT], dv[DT];
 #pragma unroll
     for (int i = 0; i < DT; ++i) {
@@ -547,11 +554,18 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dq_kernel(const bf16_t* Q, const
         qf[kk] = __builtin_bit_cast(s16x8, a);
         dof[kk] = __builtin_bit_cast(s16x8, c);
     }
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+        settle(qf[kk]);
+        settle(dof[kk]);
+    }
     float lse2 = 0.f, del = 0.f;
     if (q_abs < Sq) {
         lse2 = LSE[((long long)b * H + head) * Sq + q_abs] * 1.4426950408889634f;
         del = DELTA[((long long)b * H + head) * Sq + q_abs];
     }
+    settle(lse2);
+    settle(del);
     const bool all_q_ok = q_wmin + 31 < Sq;
     f32x16 dq[DT];
 #pragma unroll
@@ -752,6 +766,8 @@ __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, co
         if (kv_abs < S) a = ld16(own + (long long)kv_abs * ldown + kk * 16 + h2 * 8);
         of[kk] = __builtin_bit_cast(s16x8, a);
     }
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) settle(of[kk]);
     f32x16 acc[C::DT];  // dV (role A) / dK (role B): rows = keys, cols = features
 #pragma unroll
     for (int i = 0; i < C::DT; ++i) acc[i] = zero_acc();
@@ -906,6 +922,10 @@ __global__ __launch_bounds__(512) void attn_bwd3_dq_kernel(const bf16_t* Q, cons
         lse2 = LSE[((long long)b * H + head) * Sq + q_abs] * 1.4426950408889634f;
         del = DELTA[((long long)b * H + head) * Sq + q_abs];
     }
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) settle(of[kk]);
+    settle(lse2);
+    settle(del);
     const bool all_q_ok = q_wmin + 31 < Sq;
     f32x16 acc[DTH];
 #pragma unroll

@@ -13,4 +13,10 @@ for name, (B, S, H, hd, causal) in {"vit 16 x 4900 x 16 heads x 72": (16, 4900, 
     t = timeit(f, 5, 2)
     fl = 4 * B * H * S * S * hd * (0.5 if causal else 1.0)
     res[name] = [round(t * 1e3, 3), round(fl / t / 1e12, 1)]
+    if hd == 128:
+        o, lse = f()
+        do = torch.randn_like(o)
+        g = lambda: ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, do, lse, B, S, H, hd, hd ** -0.5, causal)
+        tb = timeit(g, 4, 2)
+        res[name + " bwd"] = [round(tb * 1e3, 3), round(2.5 * fl / tb / 1e12, 1)]
 print(json.dumps(res))
