@@ -57,7 +57,11 @@ using namespace ad;
 // 4 stores issued, 5 stores acknowledged -- read back with aria_abl_ts()
 __device__ unsigned long long aria_ts[4096 * 8];
 __device__ __forceinline__ void ts_mark(int i) {
-    if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) aria_ts[blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
+        aria_ts[blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+        // slots 6 / 7: the SHADER-clock counter at marks 1 / 2 (K loop start / end) -> average core clock inside the K loop
+        if (i == 1 || i == 2) aria_ts[blockIdx.x * 8 + 5 + i] = __builtin_readcyclecounter();
+    }
 }
 #else
 __device__ __forceinline__ void ts_mark(int) {}

@@ -2,7 +2,7 @@
 import ctypes, json, os, sys, numpy as np, torch
 root = os.environ.get("GRAFT_REPO_ROOT", ".")
 os.environ["ARIA_GEMM_FORCE"] = "3"
-lib = ctypes.CDLL(os.path.join(root, "build", "abl", "libgemm_abl512.so"))
+lib = ctypes.CDLL(os.path.join(root, "build", "abl", os.environ.get("ABL_LIB", "libgemm_abl512.so")))
 fn = lib.aria_gemm_bf16
 fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 3 + [ctypes.c_int] * 2 + [ctypes.c_int64] * 3 + [ctypes.c_int] * 2 + [ctypes.c_void_p]
 lib.aria_abl_ts.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -19,12 +19,15 @@ for (M, N, K) in ((4096, 4096, 640), (4096, 4096, 2560), (16384, 8192, 640), (16
     n = min(ntile, 4096)
     ts = np.zeros(4096 * 8, dtype=np.uint64)
     lib.aria_abl_ts(ts.ctypes.data, 4096 * 8)
-    t = ts.reshape(4096, 8)[:n, :6].astype(np.int64)
+    full = ts.reshape(4096, 8)[:n].astype(np.int64)
+    t = full[:, :6]
+    clk = (full[:, 7] - full[:, 6]) / ((full[:, 2] - full[:, 1]) * 10.0)  # shader-counter ticks per ns inside the K loop
     t0 = t[:, 0].min()
     rel = (t - t0) * 0.01  # us
     seg = np.diff(rel, axis=1)
     names = ["entry->first data", "K loop", "pack+park+sync", "store issue", "store ack"]
-    r = {"tiles": ntile, "kernel span us": round(float(rel[:, 5].max()), 2)}
+    r = {"tiles": ntile, "kernel span us": round(float(rel[:, 5].max()), 2),
+         "shader counter GHz inside the K loop p10/50/90": [round(float(np.percentile(clk, q)), 3) for q in (10, 50, 90)]}
     for i, nm in enumerate(names):
         r[nm] = [round(float(np.percentile(seg[:, i], q)), 2) for q in (10, 50, 90)]
     r["tile total (entry->ack) p10/50/90"] = [round(float(np.percentile(rel[:, 5] - rel[:, 0], q)), 2) for q in (10, 50, 90)]
