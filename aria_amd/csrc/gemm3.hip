@@ -1309,7 +1309,7 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     const bool persist = pe && pe[0] != '0' && q.split == 1 && !p.glu && pgrid_n >= 8 && (tiles_bound > pgrid_n || pe[0] == '2');
     // bit 8 = DMA pieces inside the MFMA section: measured +4..6 % with two k-contiguous operands, -5 % when an operand goes through
     // the transposing reads (profiles/r01_gemm_tuning.md)
-    q.order = ord ? std::atoi(ord) : (!a_oc && !b_oc ? 256 + 4 : 4);
+    q.order = ord ? std::atoi(ord) : 4;  // groups of 4 row tiles (dense); bit 9 = ragged-last (grouped rows, gemm_params.h)
     // wide epilogue: every 8-column piece of a C row must be 16-byte aligned.  ARIA_GEMM_WIDE_STORE=0 switches it off (A/B measurements).
     const char* wsd = std::getenv("ARIA_GEMM_WIDE_STORE");
     q.wide_store = !(wsd && wsd[0] == '0') && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.ldc & 7) == 0 && (p.strideC & 7) == 0;
