@@ -1,0 +1,115 @@
+"""Guards on the COMPILED code of the hot kernels (CPU only: hipcc cross-compiles gfx950).
+
+Three silent performance bugs of round 2 were wait instructions the compiler placed, none of them visible in the source
+(profiles/r02_gemm_tile_timeline.md):
+  * `s_waitcnt vmcnt(0)` in front of every transposing LDS read that follows an LDS-DMA in flight (GEMM K loop drained twice per K-tile),
+  * `__shfl_xor(v, 1)` = `ds_bpermute_b32` + `lgkmcnt(0)`, 64 serialized LDS round trips per wave in the GEMM epilogues,
+  * the wait for a fragment loaded in front of a loop landing at its first use INSIDE the loop (attention: the next tile's prefetch
+    drained in front of the first MFMA of every tile).
+These tests look at the ISA so that a compiler or source change that brings one of them back fails here and not in a benchmark."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+
+_ISA = {}
+
+
+def isa(src):
+    if src not in _ISA:
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Iinclude", "-Iaria_amd/csrc", "-S", "--cuda-device-only",
+                            os.path.join("aria_amd", "csrc", src), "-o", "-"], cwd=ROOT, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        _ISA[src] = r.stdout.split("\n")
+    return _ISA[src]
+
+
+def kernel_body(lines, mangled_fragment):
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + re.escape(mangled_fragment) + r"\w*:", l))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    return lines[start:end]
+
+
+def loops(body):
+    """[(header label, [lines])] for every innermost loop LLVM annotated."""
+    out = []
+    for i, l in enumerate(body):
+        m = re.match(r"^\.(LBB\d+_\d+):.*Loop Header", l)
+        if not m:
+            continue
+        tag = "Header=" + m.group(1)[1:]
+        j = i + 1
+        while j < len(body):
+            if re.match(r"^\.LBB\d+_\d+:", body[j]) and tag not in body[j]:
+                break
+            j += 1
+        ls = body[i:j]
+        back = [k for k, x in enumerate(ls) if re.search(r"s_c?branch\w*\s+\." + m.group(1) + r"\b", x)]
+        if back:  # cut behind the last back edge (the annotation of the exit block is not reliable)
+            ls = ls[:back[-1] + 1]
+        out.append((m.group(1), ls))
+    return out
+
+
+def code(lines):
+    """instruction lines with a flag: inside an inline-assembly block or not"""
+    in_asm, res = False, []
+    for l in lines:
+        s = l.strip()
+        if "#ASMSTART" in s:
+            in_asm = True
+        elif "#ASMEND" in s:
+            in_asm = False
+        elif s and not s.startswith(";") and not s.startswith("."):
+            res.append((s, in_asm))
+    return res
+
+
+GEMM3 = ["12gemm3_kernelILb0ELb0ELi3", "12gemm3_kernelILb0ELb1ELi3", "12gemm3_kernelILb1ELb1ELi3"]
+
+
+@pytest.mark.parametrize("kernel", GEMM3)
+def test_gemm3_steady_loop_has_no_compiler_waits_and_no_branches(kernel):
+    body = kernel_body(isa("gemm3.hip"), kernel)
+    steady = None
+    for _, ls in loops(body):
+        c = code(ls)
+        n_mfma = sum(1 for s, _ in c if s.startswith("v_mfma"))
+        n_br = sum(1 for s, _ in c if s.startswith("s_cbranch") or s.startswith("s_branch"))
+        if n_mfma == 64 and n_br == 1:  # two K-tiles, only the back edge
+            steady = c
+    assert steady is not None, "no straight-line 64-MFMA loop: the steady-state K loop is gone"
+    own = [s for s, a in steady if s.startswith("s_waitcnt") and not a]
+    assert own == [], f"compiler-inserted waits in the steady K loop: {own}"
+    assert sum(1 for s, _ in steady if s.startswith("global_load_lds_dwordx4")) == 16  # 4 half-tiles x 2 pieces per wave and K-tile
+    assert sum(1 for s, _ in steady if s.startswith("s_barrier")) == 16
+
+
+@pytest.mark.parametrize("kernel", GEMM3)
+def test_gemm3_epilogues_exchange_through_dpp(kernel):
+    c = code(kernel_body(isa("gemm3.hip"), kernel))
+    n_perm = sum(1 for s, _ in c if s.startswith("ds_bpermute_b32"))
+    n_dpp = sum(1 for s, _ in c if "quad_perm:[1,0,3,2]" in s)
+    assert n_perm <= 24, f"{n_perm} ds_bpermute_b32 (only the grouped tile lookup's wave collectives may use it)"
+    assert n_dpp >= 64
+
+
+ATTN = ["16attn_fwd2_kernelILi72ELi12", "16attn_fwd2_kernelILi128ELi8", "21attn_bwd3_dkdv_kernelILi128", "19attn_bwd3_dq_kernelILi128"]
+
+
+@pytest.mark.parametrize("kernel", ATTN)
+def test_attention_tile_loop_does_not_drain_its_prefetch_before_the_first_mfma(kernel):
+    body = kernel_body(isa("attn.hip"), kernel)
+    main = max((ls for _, ls in loops(body)), key=lambda ls: sum(1 for s, _ in code(ls) if s.startswith("v_mfma")))
+    c = [s for s, _ in code(main)]
+    first_mfma = next(i for i, s in enumerate(c) if s.startswith("v_mfma"))
+    loads = [i for i, s in enumerate(c[:first_mfma]) if s.startswith("global_load")]
+    assert loads, "the next tile's loads are expected in front of the first MFMA"
+    drains = [s for s in c[loads[0]:first_mfma] if s.startswith("s_waitcnt") and "vmcnt(0)" in s]
+    assert drains == [], f"the tile loop waits for its own prefetch before its first MFMA: {drains}"
