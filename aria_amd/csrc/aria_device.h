@@ -90,6 +90,14 @@ __device__ __forceinline__ T shfl(T v, int src) { return emu::shfl(v, src); }
 template <class T>
 __device__ __forceinline__ T shfl_xor(T v, int mask) { return emu::shfl(v, emu::lane() ^ mask); }
 __device__ __forceinline__ float xor1(float v) { return emu::shfl(v, emu::lane() ^ 1); }
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = emu::shfl(v, (emu::lane() - d) & 63);
+        if (emu::lane() >= d) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_bcast(int v, int lane) { return emu::shfl(v, lane); }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return emu::ballot(p); }
 __device__ __forceinline__ int lane_id() { return emu::lane(); }
 __device__ __forceinline__ int first_lane(int v) { return emu::shfl(v, __builtin_ctzll(emu::ballot(true))); }
@@ -108,6 +116,19 @@ __device__ __forceinline__ T shfl_xor(T v, int mask) { return __shfl_xor(v, mask
 __device__ __forceinline__ float xor1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
+// inclusive prefix sum over the wave's 64 lanes on the vector ALU: four DPP row shifts (scan inside each row of 16) and the two row
+// broadcasts of gfx9 (lane 15 -> next row, lane 31 -> rows 2, 3) -- 6 adds instead of 6 ds_bpermute round trips through the LDS
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// the value a wave-uniform lane holds (v_readlane_b32; __shfl would be a ds_bpermute)
+__device__ __forceinline__ int wave_bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }

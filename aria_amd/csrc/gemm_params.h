@@ -85,13 +85,8 @@ __device__ __forceinline__ bool aria_grouped_tile(const P& p, int bid, int l, in
             cf = (split ? n / 256 : (n + 255) / 256) * p.ntn;
             cr = (split && (n & 255)) ? p.ntn : 0;
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            cf += ad::shfl_xor(cf, d);
-            cr += ad::shfl_xor(cr, d);
-        }
-        TF += cf;
-        TR += cr;
+        TF += ad::wave_bcast(ad::wave_incl_scan(cf), 63);
+        if (split) TR += ad::wave_bcast(ad::wave_incl_scan(cr), 63);
     }
     const int xcd = bid & 7, idx = bid >> 3;
     const int loF = int((long long)TF * xcd / 8), nF = int((long long)TF * (xcd + 1) / 8) - loF;
@@ -110,17 +105,12 @@ __device__ __forceinline__ bool aria_grouped_tile(const P& p, int bid, int l, in
         const int n = o1 - o0;
         const int nt = split ? n / 256 : (n + 255) / 256;  // row tiles of this expert in the full list
         const int c = ragged ? ((n & 255) ? p.ntn : 0) : nt * p.ntn;
-        int incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int u = ad::shfl(incl, (l - d) & 63);
-            if (l >= d) incl += u;
-        }
+        const int incl = ad::wave_incl_scan(c);  // (DPP, no LDS round trips: this runs in front of every grouped tile)
         const int excl = base + incl - c;
         const unsigned long long mask = ad::ballot(c > 0 && v >= excl && v < excl + c);
         if (mask) {
             const int src = __builtin_ctzll(mask);
-            const int local = v - ad::shfl(excl, src), nts = ad::shfl(nt, src);
+            const int local = v - ad::wave_bcast(excl, src), nts = ad::wave_bcast(nt, src);
             expert = e0 + src;
             int row;
             if (ragged) {  // the expert's last (partial) row tile, columns in order
@@ -130,11 +120,11 @@ __device__ __forceinline__ bool aria_grouped_tile(const P& p, int bid, int l, in
                 tn = local / nts;
                 row = local % nts;
             }
-            m0 = ad::shfl(o0, src) + row * 256;
-            m_end = ad::shfl(o1, src);
+            m0 = ad::wave_bcast(o0, src) + row * 256;
+            m_end = ad::wave_bcast(o1, src);
             return true;
         }
-        base += ad::shfl(incl, 63);
+        base += ad::wave_bcast(incl, 63);
     }
     return false;
 }
