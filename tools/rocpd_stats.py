@@ -10,7 +10,7 @@ def short(name):
     return name[:110]
 
 
-def by_grid(path, pattern, top=12):
+def by_grid(path, pattern, top=40):
     """the launches of kernels whose name contains `pattern`, split by grid size (e.g. fc1 vs fc2 launches of the grouped GEMM)"""
     db = sqlite3.connect(path)
     cur = db.cursor()
@@ -22,7 +22,7 @@ def by_grid(path, pattern, top=12):
         return
     g = gcols[0]
     rows = cur.execute(f"select {name_col}, {g}, count(*), avg(end-start), min(end-start), max(end-start) from kernels where {name_col} like ? "
-                       f"group by {name_col}, {g} order by 3 desc", (f"%{pattern}%",)).fetchall()
+                       f"group by {name_col}, {g} order by count(*) * avg(end-start) desc", (f"%{pattern}%",)).fetchall()
     print(f"-- launches of *{pattern}* by {g}")
     for n, gx, c, a, mn, mx in rows[:top]:
         print(f"{short(n)[:70]:70s} {g}={gx:<10} calls={c:<6d} avg_us={a/1e3:10.2f} min_us={mn/1e3:9.2f} max_us={mx/1e3:9.2f}")
