@@ -828,6 +828,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         nk = int((long long)nk * (ks + 1) / p.split) - kt_first;
     }
 
+    // order bit 10 (experiment): the two wave groups run IN STEP instead of one barrier apart -- both waves of a SIMD are then in their MFMA
+    // sections together (the matrix pipe takes one 32x32x16 MFMA per 16 cycles from two waves, only one per 32 from a single wave:
+    // tools/probes/src/mfma_issue.hip) at the price of exposed fragment reads
+    const bool stagger_groups = !((p.order >> 10) & 1);
     Stage st;
     stage_init<A_OC, B_OC>(st, p, w, l, smem);
     st.gA = reinterpret_cast<const char*>(p.A) + (A_OC ? 2 * k_begin * p.lda : 2 * (long long)k_begin) + kt_first * st.kstepA;
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         }
         raw_barrier();
         ts_mark(1);
-        if (wm == 1) raw_barrier();  // waves 4-7 run one barrier behind waves 0-3
+        if (wm == 1 && stagger_groups) raw_barrier();  // waves 4-7 run one barrier behind waves 0-3
         if (interior)
             k_loop3<A_OC, B_OC, false>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
         else
@@ -915,7 +919,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         else
             k_loop4<A_OC, B_OC, true>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
     }
-    if (wm == 0) raw_barrier();  // balance the barrier count of the two groups
+    if (wm == 0 && (stagger_groups || VER != 3)) raw_barrier();  // balance the barrier count of the two groups
     ts_mark(2);
 
     const int c = l & 31, h = l >> 5, odd = l & 1;

@@ -26,7 +26,7 @@ def run(lib, b_oc):
 
 
 names = {0: "full", 1: "no MFMA", 2: "no fragment reads", 4: "no DMA", 8: "no barriers", 6: "MFMA + barriers only", 5: "fragment reads + barriers only",
-         3: "DMA + waits + barriers only", 2048: "every workgroup loads tile (0,0) (all L2 hits)", 12: "MFMA + fragment reads, no barriers", 32: "full without vmcnt waits"}
+         3: "DMA + waits + barriers only", 2048: "every workgroup loads tile (0,0) (all L2 hits)", 12: "MFMA + fragment reads, no barriers", 14: "MFMA only, no barriers", 32: "full without vmcnt waits"}
 root = os.environ.get("GRAFT_REPO_ROOT", ".")
 res = {}
 libs = [(0, os.path.join(root, "aria_amd", "libaria_hip.so"))] + sorted((int(f.split("abl")[-1].split(".")[0]), f) for f in glob.glob(os.path.join(root, "build", "abl", "libgemm_abl*.so")))
