@@ -127,8 +127,10 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
     return v;
 }
-// the value a wave-uniform lane holds (v_readlane_b32; __shfl would be a ds_bpermute)
-__device__ __forceinline__ int wave_bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// the value a wave-uniform lane holds.  (v_readlane_b32 would avoid the ds_bpermute, but the scalar results it produces made the v4 GEMM
+// kernels spill 200-366 VGPRs in their hot loop -- scalar register pressure pushed back into vector registers -- for no measurable gain:
+// the five broadcasts of a grouped tile lookup hide under the prologue's DMA wait.)
+__device__ __forceinline__ int wave_bcast(int v, int lane) { return __shfl(v, lane, 64); }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -913,13 +913,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         }
         if (nk > 1) wait_vm<6>(); else wait_vm<0>();   // B1 of tile 0 (read in phase 1) -- its A1 is waited for at the end of phase 1
         raw_barrier();
-        if (wm == 1) raw_barrier();  // waves 4-7 run one barrier behind waves 0-3
+        if (wm == 1 && stagger_groups) raw_barrier();  // waves 4-7 run one barrier behind waves 0-3
         if (interior)
             k_loop4<A_OC, B_OC, false>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
         else
             k_loop4<A_OC, B_OC, true>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
     }
-    if (wm == 0 && (stagger_groups || VER != 3)) raw_barrier();  // balance the barrier count of the two groups
+    if (wm == 0 && stagger_groups) raw_barrier();  // balance the barrier count of the two groups
     ts_mark(2);
 
     const int c = l & 31, h = l >> 5, odd = l & 1;
