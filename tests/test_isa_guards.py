@@ -89,6 +89,7 @@ def test_gemm3_steady_loop_has_no_compiler_waits_and_no_branches(kernel):
     assert own == [], f"compiler-inserted waits in the steady K loop: {own}"
     assert sum(1 for s, _ in steady if s.startswith("global_load_lds_dwordx4")) == 16  # 4 half-tiles x 2 pieces per wave and K-tile
     assert sum(1 for s, _ in steady if s.startswith("s_barrier")) == 16
+    assert not any(s.startswith("scratch_") for s, _ in steady), "register spills inside the steady K loop"
 
 
 @pytest.mark.parametrize("kernel", GEMM3)
