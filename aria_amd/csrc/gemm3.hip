@@ -1084,9 +1084,17 @@ __device__ __forceinline__ void k_loop3p(f32x16 (&acc)[2][2][2], const FragAddr<
         ++tl, ++g;
     };
     if ((g & 1) && nk > 0) one(std::integral_constant<int, 1>{});
+    const int last_full = st.tail_k < BK ? nk - 2 : nk - 1;  // (as k_loop3: a pair is steady when every K-tile it stages exists, is full and is this tile's)
     while (tl + 1 < nk) {
-        one(std::integral_constant<int, 0>{});
-        one(std::integral_constant<int, 1>{});
+        if (!EDGE && tl + 3 <= last_full) {
+            s16x8 fa[2][4], fb[2][4];
+            k_tile<A_OC, B_OC, 0, false, true>(acc, fa, fb, aa, ab, smem, st, g, 0, rl, cl);
+            k_tile<A_OC, B_OC, 1, false, true>(acc, fa, fb, aa, ab, smem, st, g + 1, 0, rl, cl);
+            tl += 2, g += 2;
+        } else {
+            one(std::integral_constant<int, 0>{});
+            one(std::integral_constant<int, 1>{});
+        }
     }
     if (tl < nk) one(std::integral_constant<int, 0>{});
 }

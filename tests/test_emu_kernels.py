@@ -171,10 +171,11 @@ def force_gemm_v3p(monkeypatch, request):
 
 
 @pytest.mark.parametrize("M,N,K,a_oc,b_oc", [(1296, 1032, 192, False, False), (1040, 520, 136, False, True), (520, 1288, 64, True, True),
-                                             (780, 600, 320, True, True)])
+                                             (780, 600, 320, True, True), (1024, 768, 712, False, False), (1024, 768, 576, False, True)])
 def test_gemm_v3_persistent_layouts(force_gemm_v3p, M, N, K, a_oc, b_oc):
     """24-30 tiles on 8 workgroups: 3-4 tiles each, odd and even K-tile counts (buffer parity carries over), K = 64 -> drained
-    boundaries (one K-tile per tile), ragged K = 136, edge tiles in both directions."""
+    boundaries (one K-tile per tile), ragged K = 136, edge tiles in both directions; K = 712 / 576: interior tiles with 12 (ragged last) / 9
+    K-tiles -> runs of straight-line steady pairs between the general K-tiles at the tile boundaries."""
     C.case_gemm_layouts(DEV, M, N, K, a_oc, b_oc)
 
 
