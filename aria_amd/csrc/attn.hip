@@ -27,11 +27,13 @@ constexpr int NT = 256;  // 4 waves
 
 template <int HD>
 struct Cfg {
-    static constexpr int PITCH = HD + 8;   // elements; 16-byte fragments of 16 consecutive rows hit distinct bank slots
+    static constexpr int KS = (HD + 15) / 16;   // k-substeps over the head dim (hd 72: 5 -- the reduction is padded to 80 with zero columns)
+    static constexpr int DT = (HD + 31) / 32;   // 32-wide feature tiles (hd 72: 3 -- feature rows 72..95 of the transposed results are discarded)
+    static constexpr int HDP = DT * 32 > KS * 16 ? DT * 32 : KS * 16;  // columns a tile row must hold for the fragment reads
+    static constexpr bool PADDED = HDP != HD;    // hd 72 (ViT / projector): LDS pad columns HD..HDP-1 are zeroed once, loads and stores are guarded
+    static constexpr int PITCH = HDP + 8;  // elements; 16-byte fragments of 16 consecutive rows hit distinct bank slots (pitches 72 / 104 / 136 elements = 36 / 52 / 68 dwords: 16 rows -> 16 different multiples of 4 dwords mod 64)
     static constexpr int CPR = HD / 8;     // 16-byte chunks per row
-    static constexpr int NCH64 = 64 * CPR / NT;  // chunks per thread for a 64-row tile
-    static constexpr int KS = HD / 16;     // k-substeps over the head dim
-    static constexpr int DB = HD / 64;     // 64-wide feature blocks (two MFMA tiles each)
+    static constexpr int NCH64 = (64 * CPR + NT - 1) / NT;  // chunks per thread for a 64-row tile
 };
 
 // ---- 64-row tile: global -> registers -> LDS ------------------------------------------------------------
@@ -42,7 +44,7 @@ __device__ __forceinline__ void tile_load(u32x4 (&r)[Cfg<HD>::NCH64], const bf16
     for (int p = 0; p < Cfg<HD>::NCH64; ++p) {
         const int c = t + NT * p;
         const int row = row0 + c / Cfg<HD>::CPR, col = (c % Cfg<HD>::CPR) * 8;
-        r[p] = row < row_end ? ld16(base + (long long)row * ld + col) : zero16();
+        r[p] = (row < row_end && (!Cfg<HD>::PADDED || c < 64 * Cfg<HD>::CPR)) ? ld16(base + (long long)row * ld + col) : zero16();
     }
 }
 template <int HD>
@@ -50,7 +52,16 @@ __device__ __forceinline__ void tile_store(const u32x4 (&r)[Cfg<HD>::NCH64], bf1
 #pragma unroll
     for (int p = 0; p < Cfg<HD>::NCH64; ++p) {
         const int c = t + NT * p;
-        st16(s + (c / Cfg<HD>::CPR) * Cfg<HD>::PITCH + (c % Cfg<HD>::CPR) * 8, r[p]);
+        if (!Cfg<HD>::PADDED || c < 64 * Cfg<HD>::CPR) st16(s + (c / Cfg<HD>::CPR) * Cfg<HD>::PITCH + (c % Cfg<HD>::CPR) * 8, r[p]);
+    }
+}
+// hd 72: zero the pad columns HD..HDP-1 of `ntiles` 64-row tiles once (tile_store never touches them): the reduction's pad must be zero in
+// BOTH operands, and the discarded feature rows must not turn into NaN traps for anybody reading the dump
+template <int HD>
+__device__ __forceinline__ void tile_zero_pads(bf16_t* s, int ntiles, int t) {
+    if (Cfg<HD>::PADDED) {
+        constexpr int PC = (Cfg<HD>::HDP - HD) / 8;  // 16-byte pad chunks per row
+        for (int i = t; i < ntiles * 64 * PC; i += NT) st16(s + (i / PC) * Cfg<HD>::PITCH + HD + (i % PC) * 8, zero16());
     }
 }
 
@@ -385,7 +396,7 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dkdv_kernel(const bf16_t* Q, con
                                                             long long ldq, long long ldk, long long ldv, long long lddo,
                                                             long long lddk, long long lddv, float scale, int causal) {
     using C = Cfg<HD>;
-    constexpr int DT = HD / 32;
+    constexpr int DT = C::DT;
     ARIA_DYN_SMEM(smem);
     bf16_t* sQ = reinterpret_cast<bf16_t*>(smem);       // [2][64][PITCH]
     bf16_t* sdO = sQ + 2 * 64 * C::PITCH;               // [2][64][PITCH]
@@ -410,7 +421,7 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dkdv_kernel(const bf16_t* Q, con
 #pragma unroll
     for (int kk = 0; kk < C::KS; ++kk) {
         u32x4 a = zero16(), c = zero16();
-        if (kv_abs < S) {
+        if (kv_abs < S && (!C::PADDED || kk * 16 + h2 * 8 < HD)) {
             a = ld16(Kb + (long long)kv_abs * ldk + kk * 16 + h2 * 8);
             c = ld16(Vb + (long long)kv_abs * ldv + kk * 16 + h2 * 8);
         }
@@ -431,6 +442,7 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dkdv_kernel(const bf16_t* Q, con
     const int q_begin = causal ? (kv0 / 64) * 64 : 0;
     const int ntiles = kv0 < klen ? (Sq - q_begin + 63) / 64 : 0;
     u32x4 rq[C::NCH64], rdo[C::NCH64];
+    tile_zero_pads<HD>(sQ, 4, t);  // (sQ and sdO are contiguous: 4 tiles)
     if (ntiles > 0) {
         tile_load<HD>(rq, Qb, ldq, q_begin, Sq, t);
         tile_load<HD>(rdo, dOb, lddo, q_begin, Sq, t);
@@ -514,6 +526,7 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dkdv_kernel(const bf16_t* Q, con
             const int kv = kv_wmin + acc_row(r, l);
             if (kv >= S) continue;
             const int d = 32 * dt + (l & 31);
+            if (C::PADDED && d >= HD) continue;
             dK[(tok0 + kv) * lddk + head * HD + d] = f2bf(dk[dt][r]);
             dV[(tok0 + kv) * lddv + head * HD + d] = f2bf(dv[dt][r]);
         }
@@ -526,7 +539,7 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dq_kernel(const bf16_t* Q, const
                                                           long long ldk, long long ldv, long long lddo, long long lddq,
                                                           float scale, int causal) {
     using C = Cfg<HD>;
-    constexpr int DT = HD / 32;
+    constexpr int DT = C::DT;
     ARIA_DYN_SMEM(smem);
     bf16_t* sK = reinterpret_cast<bf16_t*>(smem);   // [2][64][PITCH]
     bf16_t* sV = sK + 2 * 64 * C::PITCH;            // [2][64][PITCH]
@@ -547,7 +560,7 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dq_kernel(const bf16_t* Q, const
 #pragma unroll
     for (int kk = 0; kk < C::KS; ++kk) {
         u32x4 a = zero16(), c = zero16();
-        if (q_abs < Sq) {
+        if (q_abs < Sq && (!C::PADDED || kk * 16 + h2 * 8 < HD)) {
             a = ld16(Qb + (long long)q_abs * ldq + kk * 16 + h2 * 8);
             c = ld16(dOb + (long long)q_abs * lddo + kk * 16 + h2 * 8);
         }
@@ -574,6 +587,7 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dq_kernel(const bf16_t* Q, const
     if (causal) kv_end = min(kv_end, q0 + 128);
     const int ntiles = (kv_end + 63) / 64;
     u32x4 rk[C::NCH64], rv[C::NCH64];
+    tile_zero_pads<HD>(sK, 4, t);  // (sK and sV are contiguous: 4 tiles)
     if (ntiles > 0) {
         tile_load<HD>(rk, Kb, ldk, 0, S, t);
         tile_load<HD>(rv, Vb, ldv, 0, S, t);
@@ -654,6 +668,7 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dq_kernel(const bf16_t* Q, const
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int d0 = 32 * dt + 8 * rg + 4 * h2;
+                if (C::PADDED && d0 >= HD) continue;
                 u32x2 v;
                 v[0] = pack2bf(dq[dt][4 * rg], dq[dt][4 * rg + 1]);
                 v[1] = pack2bf(dq[dt][4 * rg + 2], dq[dt][4 * rg + 3]);
@@ -1088,7 +1103,7 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                   float scale, int causal, void* stream) {
     if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv || B < 0 || Sq < 0 || Skv < 0 || H <= 0)
         return ARIA_ERR_INVALID;
-    if (hd != 64 && hd != 128) return ARIA_ERR_UNSUPPORTED;
+    if (hd != 64 && hd != 72 && hd != 128) return ARIA_ERR_UNSUPPORTED;
     if (causal && Sq != Skv) return ARIA_ERR_UNSUPPORTED;
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(d_o) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) ||
         (lddq & 3) || (lddk & 1) || (lddv & 1) || (reinterpret_cast<uintptr_t>(dq) & 7))
@@ -1125,6 +1140,15 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
             ARIA_LAUNCH((attn_bwd3_dq_kernel<128>), dim3(attn_grid((Sq + 127) / 128, H, B)), dim3(512), size_t(4 * Cfg3<128>::TILE + 2 * 4 * 8192 + 128 + 16), stream, Q,
                         K, V, dO, lse, (const float*)delta, static_cast<bf16_t*>(dq), kv_len, key_mask, int(Sq), int(Skv), int(H),
                         (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddq, scale, causal, int(B));
+    } else if (hd == 72) {  // ViT / projector heads (an unfrozen ViT, the trainable projector's cross-attention): the v2 pair with padded tiles
+        using C = Cfg<72>;
+        ARIA_LAUNCH((attn_bwd2_dkdv_kernel<72>), gridk, block, size_t(4 * 64 * C::PITCH * 2 + 256 * 4), stream, Q, K, V, dO, lse,
+                    (const float*)delta, static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), kv_len, key_mask, int(Sq), int(Skv),
+                    int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddk, (long long)lddv, scale,
+                    causal);
+        ARIA_LAUNCH((attn_bwd2_dq_kernel<72>), gridq, block, size_t(4 * 64 * C::PITCH * 2 + 128 + 16), stream, Q, K, V, dO, lse,
+                    (const float*)delta, static_cast<bf16_t*>(dq), kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq,
+                    (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddq, scale, causal);
     } else {
         using C = Cfg<64>;
         ARIA_LAUNCH((attn_bwd2_dkdv_kernel<64>), gridk, block, size_t(4 * 64 * C::PITCH * 2 + 256 * 4), stream, Q, K, V, dO, lse,

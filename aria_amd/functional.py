@@ -133,7 +133,7 @@ class AttnConfig:
     causal: bool = True
 
 
-_SUPPORTED_HD = (64, 128)      # forward + backward kernels
+_SUPPORTED_HD = (64, 72, 128)  # forward + backward kernels (72 = ViT / projector heads: native, tiles padded inside the kernels)
 _FWD_ONLY_HD = (64, 72, 128)   # forward kernel (72 = ViT / projector heads, native: no padding)
 
 

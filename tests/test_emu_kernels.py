@@ -73,12 +73,13 @@ def test_cross_entropy(T, V):
 
 @pytest.mark.parametrize("B,S,H,hd,causal,use_len", [(2, 70, 2, 64, True, False), (1, 200, 1, 64, False, True),
                                                      (1, 130, 1, 128, True, False), (2, 64, 1, 64, False, False),
-                                                     (2, 200, 2, 128, False, True), (1, 333, 1, 128, True, False)])
+                                                     (2, 200, 2, 128, False, True), (1, 333, 1, 128, True, False),
+                                                     (2, 70, 2, 72, False, True), (1, 200, 3, 72, False, False), (1, 130, 1, 72, True, False)])
 def test_attention_fwd_bwd(B, S, H, hd, causal, use_len):
     C.case_attention(DEV, B, S, H, hd, causal, use_len)
 
 
-@pytest.mark.parametrize("B,Sq,Skv,H,hd", [(2, 40, 150, 2, 64), (1, 130, 70, 1, 128)])
+@pytest.mark.parametrize("B,Sq,Skv,H,hd", [(2, 40, 150, 2, 64), (1, 130, 70, 1, 128), (2, 40, 150, 2, 72), (1, 256, 300, 16, 72)])
 def test_attention_cross_masked(B, Sq, Skv, H, hd):
     C.case_attention_cross_masked(DEV, B, Sq, Skv, H, hd)
 
