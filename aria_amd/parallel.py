@@ -45,11 +45,14 @@ def shard_bounds(n: int, world: int, rank: int):
 
 class GradSync:
     def __init__(self, module: torch.nn.Module, process_group: Optional[dist.ProcessGroup] = None, overlap: bool = True,
-                 mode: str = "all_reduce"):
+                 mode: str = "all_reduce", ep_dp_group: Optional[dist.ProcessGroup] = None):
+        """``ep_dp_group`` (DP x EP grid, expert-parallel degree < world): the ranks that hold the SAME expert shard -- one per data-parallel
+        replica of the expert-parallel group.  Their shard gradients each cover the tokens of one replica and are summed over this group."""
         if mode not in ("all_reduce", "reduce_scatter"):
             raise ValueError(f"GradSync mode {mode!r}")
         self.module = module
         self.pg = process_group
+        self.ep_dp_group = ep_dp_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.overlap = overlap
@@ -128,7 +131,15 @@ class GradSync:
         (mode all_reduce) or, for large tensors under reduce_scatter, the rank-average in this rank's ``shard_bounds`` slice."""
         if self.world <= 1:
             return
-        for p in self.ep_local:  # the owner accumulated the contributions of EVERY rank's tokens (sum): same 1/W as the averaged replicas
+        ep_handles = []
+        if self.ep_dp_group is not None and dist.get_world_size(self.ep_dp_group) > 1:
+            for p in self.ep_local:  # DP x EP: every replica of the shard saw its own expert-parallel group's tokens -> sum over the replicas
+                if p.grad is not None:
+                    self.bytes_exchanged += p.grad.numel() * p.grad.element_size()
+                    ep_handles.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.ep_dp_group, async_op=True))
+        for h in ep_handles:
+            h.wait()
+        for p in self.ep_local:  # the owner(s) accumulated the contributions of EVERY rank's tokens (sum): same 1/W as the averaged replicas
             if p.grad is not None:
                 p.grad.div_(self.world)
         for p in self.large_pending:

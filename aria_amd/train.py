@@ -57,6 +57,29 @@ def load_config(argv):
     return cfg
 
 
+def expert_parallel_groups(rank: int, world: int, ep: int):
+    """DP x EP grid for ``expert_parallel_size = ep`` < world: ranks [d*ep, (d+1)*ep) form the expert-parallel group of data-parallel replica d
+    (the all-to-all dispatch stays inside it -- on one node: neighbouring GPUs), ranks {r, r + ep, ...} hold the same expert shard.
+    -> (this rank's expert-parallel group, its shard-replica group); (None, None) when ep == world (one group: the default).
+    Every rank creates every group, in the same order (torch.distributed's rule)."""
+    import torch.distributed as dist
+
+    if ep <= 0 or world % ep:
+        raise ValueError(f"expert_parallel_size {ep} does not divide the world size {world}")
+    if ep == world:
+        return None, None
+    mine_ep = mine_dp = None
+    for d in range(world // ep):
+        g = dist.new_group(list(range(d * ep, (d + 1) * ep)))
+        if rank // ep == d:
+            mine_ep = g
+    for r in range(ep):
+        g = dist.new_group(list(range(r, world, ep)))
+        if rank % ep == r:
+            mine_dp = g
+    return mine_ep, mine_dp
+
+
 def build_model(cfg, device):
     from .modeling_aria import AriaConfig, AriaForConditionalGeneration
     from .moe_lm import AriaMoELMConfig
@@ -206,8 +229,9 @@ def load_checkpoint(model, opt, path: str, cfg, rank: int, world: int):
         sd = load_checkpoint_dir(path)
         if cfg.get("expert_parallel"):  # the checkpoint holds all experts: keep this rank's
             for k in [k for k in sd if k.endswith(("mlp.experts.fc1.weight", "mlp.experts.fc2.weight"))]:
-                per = sd[k].shape[0] // world
-                sd[k] = sd[k][rank * per:(rank + 1) * per]
+                ep = int(cfg.get("expert_parallel_size") or world)
+                per, r = sd[k].shape[0] // ep, rank % ep
+                sd[k] = sd[k][r * per:(r + 1) * per]
         load_hf_into(model, sd, strict=True)
     shard = torch.load(os.path.join(path, f"optimizer_rank{rank}.pt"), map_location="cpu")
     opt.load_state_dict(shard)
@@ -279,15 +303,17 @@ def main(argv=None, tokenizer=None):
 
     torch.manual_seed(int(cfg["seed"]))   # set_seed(training_args.seed): adapter init and dropout draw from the global generator -- the same on every rank
     model, acfg = build_model(cfg, device)
-    if cfg.get("expert_parallel") and world > 1:  # BASELINE config #5: routed experts sharded over all ranks (EP = world), the rest data-parallel
+    ep_dp_group = None
+    if cfg.get("expert_parallel") and world > 1:  # BASELINE config #5: routed experts sharded over an expert-parallel group, the rest data-parallel
         if cfg.get("use_peft"):
             raise NotImplementedError("expert_parallel with use_peft")
-        model.enable_expert_parallel()
+        ep_group, ep_dp_group = expert_parallel_groups(rank, world, int(cfg.get("expert_parallel_size") or world))
+        model.enable_expert_parallel(ep_group)
     accum = int(cfg["gradient_accumulation_steps"])
     aux_scale_before = MoEAuxLossAutoScaler.main_loss_backward_scale
     MoEAuxLossAutoScaler.set_loss_scale(1.0 / accum)                     # aria/train.py:229 (a process-wide setting, restored on return)
     # ZeRO-2 (recipes/accelerate_configs/zero2.yaml): gradients reduce-scattered onto the rank that owns their optimizer shard
-    sync = GradSync(model, mode=str(cfg.get("grad_exchange", "reduce_scatter"))) if world > 1 else None
+    sync = GradSync(model, mode=str(cfg.get("grad_exchange", "reduce_scatter")), ep_dp_group=ep_dp_group) if world > 1 else None
     opt = ShardedAdamW(model.named_parameters(), lr=cfg["learning_rate"], betas=(0.9, cfg["adam_beta2"]), weight_decay=cfg["weight_decay"])
     gen = torch.Generator(device=device).manual_seed(cfg["seed"] + rank)
     # data: the recipe's dataset_mixer (aria/data.py format) unless synthetic_data=true / no dataset is configured (throughput runs, tests)

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, outdir, ep):
+def _worker(rank, world, port, outdir, ep, ep_size=0):
     import sys
 
     sys.path.insert(0, ROOT)
@@ -31,7 +31,8 @@ def _worker(rank, world, port, outdir, ep):
 
     hist = main(["--tiny", "per_device_train_batch_size=2", "gradient_accumulation_steps=1", "max_seq_length=24", "max_steps=2",
                  "learning_rate=1e-2", "weight_decay=0.0", "warmup_ratio=0.0", "images_per_sample=1", "logging_steps=100", "synthetic_fixed=true",
-                 f"expert_parallel={'true' if ep else 'false'}", "save_final=true", f"output_dir={outdir}/{'ep' if ep else 'dp'}"])
+                 f"expert_parallel={'true' if ep else 'false'}", "save_final=true", f"output_dir={outdir}/{'ep' if ep else 'dp'}"]
+                + ([f"expert_parallel_size={ep_size}"] if ep and ep_size else []))
     torch.save(hist, os.path.join(outdir, f"hist_{'ep' if ep else 'dp'}_{rank}.pt"))
 
 
@@ -56,5 +57,31 @@ def test_expert_parallel_training_matches_data_parallel():
               "language_model.model.layers.0.self_attn.q_proj.weight", "language_model.lm_head.weight"):
         # two Adam steps of 1e-2 each: an element whose tiny gradient changes sign under bf16 noise lands one or two steps apart, so
         # compare in the mean (<= a sixth of one step) and bound the worst element by three steps
+        diff = (w_ep[k].float() - w_dp[k].float()).abs()
+        assert float(diff.mean()) <= 1.7e-3 and float(diff.max()) <= 6.1e-2, (k, float(diff.mean()), float(diff.max()))
+
+
+def test_dp_x_ep_grid_matches_data_parallel():
+    """Four ranks as a 2 x 2 grid (``expert_parallel_size=2``): ranks {0,1} and {2,3} are the two expert-parallel groups (all-to-all inside),
+    ranks {0,2} and {1,3} hold the same expert shard and sum its gradient; the run must train like plain data parallelism on four ranks and
+    gather the same reference-layout checkpoint."""
+    from safetensors.torch import load_file
+
+    world = 4
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), d, False), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), d, True, 2), nprocs=world, join=True)
+        dp = [torch.load(os.path.join(d, f"hist_dp_{r}.pt")) for r in range(world)]
+        eph = [torch.load(os.path.join(d, f"hist_ep_{r}.pt")) for r in range(world)]
+        w_dp, w_ep = load_file(os.path.join(d, "dp", "model.safetensors")), load_file(os.path.join(d, "ep", "model.safetensors"))
+    for r in range(world):
+        assert len(eph[r]) == 2 and eph[r][-1] < eph[r][0]
+        for a, b in zip(eph[r], dp[r]):
+            assert abs(a - b) <= 2e-2 * abs(b), (r, eph[r], dp[r])
+    assert set(w_dp) == set(w_ep)
+    for k in w_dp:
+        assert w_dp[k].shape == w_ep[k].shape, k
+    for k in ("language_model.model.layers.0.mlp.experts.fc1.weight", "language_model.model.layers.1.mlp.experts.fc2.weight",
+              "language_model.model.layers.0.self_attn.q_proj.weight", "language_model.lm_head.weight"):
         diff = (w_ep[k].float() - w_dp[k].float()).abs()
         assert float(diff.mean()) <= 1.7e-3 and float(diff.max()) <= 6.1e-2, (k, float(diff.mean()), float(diff.max()))
