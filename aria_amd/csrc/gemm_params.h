@@ -130,7 +130,9 @@ __device__ __forceinline__ bool aria_grouped_tile(const P& p, int bid, int l, in
 }
 // number of workgroups aria_tile_coords / aria_grouped_tile need
 inline int aria_tile_grid(const GemmParams& p) {
-    if (p.mode == 1) return p.ntn * p.ntm + 8;  // aria_grouped_tile: 8 XCD chunks of ceil(T / 8) <= bound / 8 + 1 tiles
+    // aria_grouped_tile: 8 XCD chunks of ceil(T / 8) <= bound / 8 + 1 tiles; the ragged-last order (order bit 9) cuts TWO lists (full
+    // row tiles, ragged last row tiles) 8 ways each, so one XCD can need ceil(TF / 8) + ceil(TR / 8) slots: 16 spare workgroups
+    if (p.mode == 1) return p.ntn * p.ntm + 16;
     if (p.split > 1) return p.split_first + (p.ntn * p.ntm - p.split_first) * p.split;
     return p.ntn * p.ntm;
 }

@@ -242,6 +242,42 @@ __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* param, const bf16_t*
     }
 }
 
+// sum of squares of a bf16 vector in fp32: the gradient norm of HF Trainer's max_grad_norm clipping (recipes/accelerate_configs/zero2.yaml:5
+// gradient_clipping: auto).  Deterministic two-stage form: block b writes its partial to partial[b]; sumsq_final adds them in index order.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const bf16_t* x0, long long n0, float* partial) {
+    ARIA_SMEM_STATIC float red[4];
+    float acc = 0.f;
+    // a shard of a flattened gradient starts on an element boundary only: up to 7 head elements in front of the first 16-byte chunk
+    long long head = (long long)((16 - (reinterpret_cast<uintptr_t>(x0) & 15)) & 15) >> 1;
+    if (head > n0) head = n0;
+    const bf16_t* x = x0 + head;
+    const long long n = n0 - head, n8 = n >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const u32x4 v = ld16(x + i * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc += bflo(v[q]) * bflo(v[q]) + bfhi(v[q]) * bfhi(v[q]);
+    }
+    if (blockIdx.x == 0) {  // head and tail elements
+        if (threadIdx.x < int(head)) {
+            const float t = bf2f(x0[threadIdx.x]);
+            acc += t * t;
+        } else if (threadIdx.x >= 8 && threadIdx.x - 8 < int(n & 7)) {
+            const float t = bf2f(x[(n8 << 3) + threadIdx.x - 8]);
+            acc += t * t;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    sync();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void sumsq_final_kernel(const float* partial, int nblocks, float* out, int accumulate) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 64) acc += partial[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) *out = (accumulate ? *out : 0.f) + acc;
+}
+
 int grid1d(long long n, int per_block, int cap = 4096) {
     long long g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -292,6 +328,15 @@ int aria_rope_inplace(void* x, const void* cos, const void* sin, int64_t T, int6
     ARIA_LAUNCH(rope_kernel, dim3(grid1d(nitems, 256)), dim3(256), 0, stream, static_cast<bf16_t*>(x),
                 static_cast<const bf16_t*>(cos), static_cast<const bf16_t*>(sin), nitems, int(S), int(n_heads), int(hd),
                 (long long)ld, inverse);
+    return aria_check_launch();
+}
+
+int aria_sumsq_bf16(const void* x, int64_t n, float* out, int accumulate, float* workspace, void* stream) {
+    if (!out || !workspace || n < 0 || (n > 0 && !x)) return ARIA_ERR_INVALID;
+    if (reinterpret_cast<uintptr_t>(x) & 1) return ARIA_ERR_ALIGN;
+    const int nb = n == 0 ? 0 : grid1d((n + 7) / 8, 256, ARIA_SUMSQ_WORKSPACE_FLOATS);
+    if (nb) ARIA_LAUNCH(sumsq_partial_kernel, dim3(nb), dim3(256), 0, stream, static_cast<const bf16_t*>(x), (long long)n, workspace);
+    ARIA_LAUNCH(sumsq_final_kernel, dim3(1), dim3(64), 0, stream, (const float*)workspace, nb, out, accumulate);
     return aria_check_launch();
 }
 

@@ -21,7 +21,11 @@ from typing import Optional
 
 import torch
 from transformers import AutoConfig, AutoModelForCausalLM, GenerationMixin, PreTrainedModel
-from transformers.configuration_utils import PreTrainedConfig
+
+try:  # transformers >= 4.5x spells it PreTrainedConfig; the reference's pin (4.45 era) only has PretrainedConfig
+    from transformers import PreTrainedConfig
+except ImportError:  # pragma: no cover - depends on the installed transformers
+    from transformers import PretrainedConfig as PreTrainedConfig
 from transformers.modeling_outputs import CausalLMOutputWithPast
 
 from . import modeling_aria as native

@@ -349,6 +349,13 @@ def adamw_step_(param: torch.Tensor, grad: torch.Tensor, master: torch.Tensor, m
     torch.autograd.graph.increment_version(param)
 
 
+def sumsq_(x: torch.Tensor, out: torch.Tensor, workspace: torch.Tensor, accumulate: bool = True) -> None:
+    """out[0] (+)= sum(x^2) in fp32 over a contiguous bf16 tensor (one term of the clipping norm); ``workspace``: fp32 [1024]."""
+    _chk(x, name="x"), _chk(out, torch.float32, "out"), _chk(workspace, torch.float32, "workspace")
+    assert x.is_contiguous() and workspace.numel() >= 1024 and out.numel() == 1
+    hip.get_lib().call("aria_sumsq_bf16", _p(x), x.numel(), _p(out), int(accumulate), _p(workspace), _stream(x))
+
+
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     _chk(a, name="a"), _chk(b, name="b")
     assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape

@@ -164,6 +164,16 @@ class GradSync:
         self.handles = []
         self._launched = set()
 
+    def owned_slice(self, p: torch.nn.Parameter) -> torch.Tensor:
+        """The part of ``p.grad`` (flattened) that holds the rank-average after ``finish()`` on EVERY path: this rank's ``shard_bounds``
+        slice.  Under ``mode="reduce_scatter"`` the rest of a large gradient is scratch (tensors that took the all-reduce fallback and the
+        small ones are valid everywhere -- their owned slice is still this one); an expert-parallel shard is owned whole."""
+        flat = p.grad.reshape(-1)
+        if getattr(p, "_ep_local", False):
+            return flat
+        lo, hi, _ = shard_bounds(flat.numel(), self.world, self.rank)
+        return flat[lo:hi]
+
     def remove(self):
         for h in self._hooks:
             h.remove()
@@ -273,6 +283,48 @@ class ShardedAdamW:
                     mine[: hi - lo] = flat[lo:hi]
                     dist.all_gather_into_tensor(buf, mine, group=self.pg)
                     flat.copy_(buf[:n_all])
+
+
+def global_grad_norm(params, sync: Optional[GradSync] = None, process_group=None) -> float:
+    """L2 norm of the complete (rank-averaged) gradient, as ``torch.nn.utils.clip_grad_norm_`` / DeepSpeed's ``gradient_clipping`` see it
+    (recipes/accelerate_configs/zero2.yaml:5 ``gradient_clipping: auto`` = HF ``max_grad_norm`` 1.0).  Call after ``sync.finish()``.
+
+    Every rank adds the squares of the slices it OWNS (``GradSync.owned_slice``: valid under both exchange modes; the slices of the ranks
+    partition every replicated tensor) and one scalar is all-reduced.  Expert-parallel shards are different tensors on every rank of an
+    expert-parallel group and the same tensor on the ranks of ``ep_dp_group``: counted once per shard (by the group's first rank).
+    The squares are summed by the HIP library (``aria_sumsq_bf16``, deterministic); one host read of the scalar per optimizer step."""
+    from . import ops
+
+    params = [p for p in params if p.grad is not None]
+    if not params:
+        return 0.0
+    dev = params[0].grad.device
+    acc = torch.zeros(1, dtype=torch.float32, device=dev)
+    ws = torch.empty(1024, dtype=torch.float32, device=dev)
+    world = sync.world if sync is not None else 1
+    count_ep = True
+    if sync is not None and sync.ep_dp_group is not None and dist.get_world_size(sync.ep_dp_group) > 1:
+        count_ep = dist.get_rank(sync.ep_dp_group) == 0
+    for p in params:
+        local = bool(getattr(p, "_ep_local", False))
+        if local and not count_ep:
+            continue
+        g = sync.owned_slice(p) if (sync is not None and world > 1) else p.grad.reshape(-1)
+        if g.numel() == 0:
+            continue
+        if g.dtype != torch.bfloat16:
+            g = g.to(torch.bfloat16)
+        ops.sumsq_(g.contiguous(), acc, ws, accumulate=True)
+    if world > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=process_group if process_group is not None else sync.pg)
+    return float(acc.sqrt())
+
+
+def clip_scale(norm: float, max_grad_norm: Optional[float]) -> float:
+    """``clip_grad_norm_``'s coefficient: min(1, max_norm / (norm + 1e-6)); 1.0 when clipping is off (None / <= 0)."""
+    if not max_grad_norm or max_grad_norm <= 0:
+        return 1.0
+    return min(1.0, float(max_grad_norm) / (norm + 1e-6))
 
 
 def cosine_lr(step: int, total: int, base_lr: float, warmup_ratio: float = 0.01) -> float:

@@ -36,7 +36,8 @@ def load_config(argv):
     cfg = dict(per_device_train_batch_size=8, gradient_accumulation_steps=2, learning_rate=5e-6, weight_decay=0.1, adam_beta2=0.95,
                warmup_ratio=0.01, lr_scheduler_type="cosine", max_seq_length=2048, max_image_size=980, num_train_epochs=1, max_steps=10,
                gradient_checkpointing=False, moe_z_loss_coeff=1e-5, moe_aux_loss_coeff=1e-3, freeze_vit=True, freeze_projector=False,
-               freeze_llm=False, freeze_llm_layers=None, seed=42, logging_steps=1, output_dir="out", images_per_sample=2)
+               freeze_llm=False, freeze_llm_layers=None, seed=42, logging_steps=1, output_dir="out", images_per_sample=2,
+               max_grad_norm=1.0)  # HF TrainingArguments default, what zero2.yaml's gradient_clipping: auto resolves to
     if args.config:
         import yaml
 
@@ -299,7 +300,7 @@ def main(argv=None, tokenizer=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl" if use_cuda else "gloo")
     from .moe_lm import MoEAuxLossAutoScaler
-    from .parallel import GradSync, ShardedAdamW, cosine_lr
+    from .parallel import GradSync, ShardedAdamW, clip_scale, cosine_lr, global_grad_norm
 
     torch.manual_seed(int(cfg["seed"]))   # set_seed(training_args.seed): adapter init and dropout draw from the global generator -- the same on every rank
     model, acfg = build_model(cfg, device)
@@ -365,7 +366,10 @@ def main(argv=None, tokenizer=None):
             loss_acc += float(out.loss.detach()) / accum
         if sync is not None:
             sync.finish()
-        opt.step(lr=cosine_lr(step, total, cfg["learning_rate"], cfg["warmup_ratio"]))
+        # gradient clipping as the recipe runs it (zero2.yaml:5 gradient_clipping: auto -> max_grad_norm 1.0): one norm over the owned
+        # slices of every rank, applied as the optimizer's gradient scale (nothing rewrites the 49.8 GB of gradients)
+        gnorm = global_grad_norm(opt.params, sync) if cfg.get("max_grad_norm") else 0.0
+        opt.step(lr=cosine_lr(step, total, cfg["learning_rate"], cfg["warmup_ratio"]), grad_scale=clip_scale(gnorm, cfg.get("max_grad_norm")))
         if use_cuda:
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -374,7 +378,7 @@ def main(argv=None, tokenizer=None):
             save_checkpoint(model, opt, cfg, step, history, rank, world)
         if rank == 0 and step % int(cfg["logging_steps"]) == 0:
             toks = world * accum * cfg["per_device_train_batch_size"] * cfg["max_seq_length"]
-            print(json.dumps({"step": step, "loss": round(loss_acc, 4), "lr": opt.lr, "step_s": round(dt, 3), "tokens_per_s": round(toks / dt, 1)}),
+            print(json.dumps({"step": step, "loss": round(loss_acc, 4), "lr": opt.lr, "grad_norm": round(gnorm, 4), "step_s": round(dt, 3), "tokens_per_s": round(toks / dt, 1)}),
                   flush=True)
     if cfg.get("save_final", not cfg["tiny"]):  # written by rank 0: every rank holds the full updated bf16 weights (ShardedAdamW all-gathers)
         save_output(model, cfg)

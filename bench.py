@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--long", action="store_true", help="north_star's target shape instead of config #3's: ONE 65 536-token image+text sequence "
                     "per GPU (8 x 980px images = 2048 image tokens + text), gradient checkpointing on (activations of 28 layers at 64K tokens "
                     "exceed 288 GB otherwise); same metric, reported as a second documented line (profiles/)")
+    ap.add_argument("--no-long64k", action="store_true", help="skip the `long64k` sub-record (N = 1 only: three timed steps of the north_star "
+                    "target shape -- one 65 536-token image+text sequence, gradient checkpointing on -- after the main measurement)")
+    ap.add_argument("--long64k-seq", type=int, default=65536, help="debug only (CPU dry run of the sub-record's code path)")
+    ap.add_argument("--long64k-images", type=int, default=8, help="debug only")
     ap.add_argument("--ep", action="store_true", help="BASELINE config #5 instead of #3: routed experts sharded over the N ranks (all-to-all "
                                                       "dispatch over xGMI), everything else data-parallel; not what the driver runs")
     args = ap.parse_args()
@@ -146,6 +150,65 @@ def cpu_baseline(cfg_kwargs, seconds_budget=40.0):
                       f"at B=1,S={S}; value = S/(28*t_layer+t_head); os.cpu_count()={os.cpu_count()}"}
 
 
+def long64k_record(model, cfg, make_inputs, ops, steps=3, warmup=1, S=65536, n_img=8):
+    """north_star's target shape next to the config #3 line, in the SAME run: ONE 65 536-token image+text sequence (8 x 980px images =
+    2048 image tokens + text) per step, fwd+bwd with the recipe's gradient checkpointing (activations of 28 layers at 64K tokens exceed
+    288 GB otherwise); same metric.  `roofline` here = the attention backward (half of this step): algorithmic flops per call =
+    2.5 x the causal forward's 4 * (S^2 / 2) * hd * H (five GEMM units of S x S x hd per head, recompute of S inside the kernel not
+    counted), duration from HIP events around every attention-backward call of the timed steps."""
+    H, hd = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
+    model.zero_grad(set_to_none=True)
+    torch.cuda.empty_cache()
+    before = cfg.gradient_checkpointing
+    cfg.gradient_checkpointing = True
+    batch = make_inputs(1, S, n_img, 4321)
+    events = []
+    orig_bwd = ops.attention_bwd
+    timing = {"on": False}
+
+    def timed_attention_bwd(q, k, v, o, do, lse, B, S_, H_, hd_, *a, **kw):
+        if not (timing["on"] and S_ == S and hd_ == hd):
+            return orig_bwd(q, k, v, o, do, lse, B, S_, H_, hd_, *a, **kw)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = orig_bwd(q, k, v, o, do, lse, B, S_, H_, hd_, *a, **kw)
+        e.record()
+        events.append((s, e))
+        return r
+
+    ops.attention_bwd = timed_attention_bwd
+    try:
+        def step():
+            model.zero_grad(set_to_none=True)
+            out = model(**batch, return_logits=False, validate_image_tokens=False)
+            out.loss.backward()
+            return out.loss
+
+        for _ in range(warmup):
+            loss = step()
+        torch.cuda.synchronize()
+        timing["on"] = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        ops.attention_bwd = orig_bwd
+        cfg.gradient_checkpointing = before
+    durs = [s.elapsed_time(e) * 1e-3 for s, e in events]
+    avg = sum(durs) / max(1, len(durs))
+    flops = 2.5 * 4.0 * (S * S / 2.0) * hd * H
+    return {"workload": f"north_star target shape: Aria-25.3B random-init, ONE {S}-token sequence ({n_img} x 980px images + text), frozen ViT fwd -> "
+                        "projector -> 28-layer MoE decoder fwd+bwd, gradient checkpointing on (selective: flash (o, lse) kept)",
+            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 1), "value": round(S * steps / dt, 1), "unit": "tokens/s",
+            "loss": round(float(loss), 4), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+            "roofline": {"kernel": f"attention backward (aria_attn_bwd: delta + dK/dV/dQ), causal S={S}, {H} x {hd}", "bound": "mfma",
+                         "achieved": round(flops / avg / 1e12, 1) if durs else None, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(flops / avg / 2.5e15, 4) if durs else None, "launches_timed": len(durs),
+                         "avg_call_ms": round(avg * 1e3, 3), "algorithmic_flops_per_call": flops}}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (no torchrun around it): re-exec this script under torch.distributed.run with N ranks on
     127.0.0.1, one per GPU, so that the plain form measures N GPUs instead of silently measuring one."""
@@ -211,18 +274,23 @@ def main():
     sync = GradSync(model, overlap=not args.no_overlap, mode="all_reduce" if args.allreduce else "reduce_scatter") if world > 1 else None
 
     B, S, V = args.batch, args.seq, cfg.vocab_size
-    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    ids = torch.randint(10, V, (B, S), generator=g, device=dev)
-    pixel_values = pixel_mask = None
     n_img = args.images
-    if n_img > 0:
-        for j in range(n_img):                      # contiguous runs of 256 image placeholders per image
-            ids[:, 16 + j * (QTOK + 28): 16 + j * (QTOK + 28) + QTOK] = IMG_TOKEN
-        pixel_values = torch.randn((B * n_img, 3, 980, 980), generator=g, device=dev).clamp_(-1, 1).to(bf16)
-        pixel_mask = torch.ones((B * n_img, 980, 980), dtype=torch.bool, device=dev)
-        pixel_mask[0, 735:, :] = False              # one image with its bottom 25 % rows padded (mask path exercised)
-    labels = ids.clone()
-    labels[:, : int(0.75 * S)] = -100  # prompt masked like an SFT sample
+
+    def make_inputs(B, S, n_img, seed):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        ids = torch.randint(10, V, (B, S), generator=g, device=dev)
+        pixel_values = pixel_mask = None
+        if n_img > 0:
+            for j in range(n_img):                      # contiguous runs of 256 image placeholders per image
+                ids[:, 16 + j * (QTOK + 28): 16 + j * (QTOK + 28) + QTOK] = IMG_TOKEN
+            pixel_values = torch.randn((B * n_img, 3, 980, 980), generator=g, device=dev).clamp_(-1, 1).to(bf16)
+            pixel_mask = torch.ones((B * n_img, 980, 980), dtype=torch.bool, device=dev)
+            pixel_mask[0, 735:, :] = False              # one image with its bottom 25 % rows padded (mask path exercised)
+        labels = ids.clone()
+        labels[:, : int(0.75 * S)] = -100  # prompt masked like an SFT sample
+        return dict(input_ids=ids, pixel_values=pixel_values, pixel_mask=pixel_mask, labels=labels)
+
+    batch = make_inputs(B, S, n_img, 1234 + rank)
 
     # live timing of the dominant kernel: fc1 grouped expert GEMM forward launches (HIP events on the launch stream)
     fc1_events = []
@@ -292,8 +360,7 @@ def main():
 
     def step():
         model.zero_grad(set_to_none=True)
-        out = model(input_ids=ids, pixel_values=pixel_values, pixel_mask=pixel_mask, labels=labels, return_logits=False,
-                    validate_image_tokens=False)
+        out = model(**batch, return_logits=False, validate_image_tokens=False)
         out.loss.backward()
         if sync is not None:
             sync.finish()
@@ -363,6 +430,11 @@ def main():
         }
         if args.layers != 28 or args.vit_layers != 27 or (n_img != 2 and not args.long):
             res["config"]["INVALID"] = "reduced depth / no images (debug run)"
+        full_depth = args.layers == 28 and args.vit_layers == 27
+        if world == 1 and not args.long and not args.no_long64k and (full_depth or args.long64k_seq != 65536):
+            res["long64k"] = long64k_record(model, cfg, make_inputs, ops, steps=3, warmup=1, S=args.long64k_seq, n_img=args.long64k_images)
+            if not full_depth or args.long64k_seq != 65536:
+                res["long64k"]["INVALID"] = "debug run (reduced depth / sequence)"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(cfg_kwargs)

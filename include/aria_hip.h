@@ -173,6 +173,13 @@ int aria_rope_interleaved_inplace(void* x, const void* freqs_cis, const int32_t*
 int aria_adamw_step(void* param, const void* grad, float* master, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
 
+/* *out (+)= sum_i x[i]^2 in fp32 over a contiguous bf16 vector (any element alignment: a shard of a flattened gradient): one term of the global gradient norm that HF
+ * Trainer's max_grad_norm clipping needs (the reference runs it through DeepSpeed: recipes/accelerate_configs/zero2.yaml:5
+ * gradient_clipping: auto -> TrainingArguments.max_grad_norm = 1.0).  Deterministic (per-block partials summed in index order).
+ * workspace: ARIA_SUMSQ_WORKSPACE_FLOATS floats owned by the caller. */
+#define ARIA_SUMSQ_WORKSPACE_FLOATS 1024
+int aria_sumsq_bf16(const void* x, int64_t n, float* out, int accumulate, float* workspace, void* stream);
+
 /* out = bf16(a + b), n elements (n % 8 == 0) */
 int aria_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 

@@ -122,13 +122,17 @@ class forced_routing:
 
     def __exit__(self, *exc):
         global _FORCED_ROUTING
-        _FORCED_ROUTING = self._prev
+        left, _FORCED_ROUTING = _FORCED_ROUTING, self._prev
+        if exc[0] is None and left:
+            raise AssertionError(f"forced_routing: {len(left)} index tensors were never consumed (fewer router calls than expected)")
         return False
 
 
 def router_routing(logits: Tensor, topk: int, num_experts: int) -> Tuple[Tensor, Tensor, Tensor]:
     """scores, top_indices, tokens_per_expert.  moe_lm.py:243-293 (eval branch)."""
-    if _FORCED_ROUTING:
+    if _FORCED_ROUTING is not None:
+        if not _FORCED_ROUTING:  # a router call the caller supplied no ids for: never fall back to the oracle's own top-k silently
+            raise AssertionError("forced_routing: more router calls than index tensors supplied")
         top_indices = _FORCED_ROUTING.pop(0).to(torch.int64).reshape(logits.shape[0], topk)
         top_logits = torch.gather(logits, 1, top_indices)
     else:
@@ -350,6 +354,80 @@ def attention_eager(q: Tensor, k: Tensor, v: Tensor, scale: float, causal: bool,
     return att @ v
 
 
+class _StreamedCausalAttention(torch.autograd.Function):
+    """``attention_eager(q, k, v, scale, causal=True)`` evaluated one (batch, head, query block) at a time, with its derivative written out,
+    so that config #4 / the north_star's 64K-token sequences fit on a host: the eager form keeps an [H, S, S] fp32 score tensor (344 GB at
+    S = 65 536, H = 20) plus autograd's copies.  Same arithmetic per row -- scores, fp32 softmax over the row's visible keys, P V; a masked
+    entry contributes exp(finfo.min - max) = exactly 0 in the eager form and is simply not visited here -- so the two agree to fp32
+    summation order (pinned against attention_eager + autograd in tests/test_oracle_golden.py).
+    Backward per block (the closed form of softmax's derivative): dV += P^T dO, dP = dO V^T, dS = P * (dP - rowsum(dO * O)) * scale,
+    dQ = dS K, dK += dS^T Q."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale, block):
+        B, H, S, hd = q.shape
+        o = torch.empty_like(q)
+        for b in range(B):
+            for h in range(H):
+                for q0 in range(0, S, block):
+                    q1 = min(S, q0 + block)
+                    att = (q[b, h, q0:q1] @ k[b, h, :q1].t()) * scale
+                    att.masked_fill_(torch.arange(q1)[None, :] > torch.arange(q0, q1)[:, None], float("-inf"))
+                    o[b, h, q0:q1] = torch.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype) @ v[b, h, :q1]
+        ctx.save_for_backward(q, k, v, o)
+        ctx.scale, ctx.block = scale, block
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o = ctx.saved_tensors
+        scale, block = ctx.scale, ctx.block
+        B, H, S, hd = q.shape
+        dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        for b in range(B):
+            for h in range(H):
+                for q0 in range(0, S, block):
+                    q1 = min(S, q0 + block)
+                    qb, dob = q[b, h, q0:q1], do[b, h, q0:q1]
+                    att = (qb @ k[b, h, :q1].t()) * scale
+                    att.masked_fill_(torch.arange(q1)[None, :] > torch.arange(q0, q1)[:, None], float("-inf"))
+                    p = torch.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype)
+                    del att
+                    dv[b, h, :q1] += p.t() @ dob
+                    dp = dob @ v[b, h, :q1].t()
+                    delta = (dob * o[b, h, q0:q1]).sum(dim=-1, keepdim=True)
+                    ds = p * (dp - delta) * scale
+                    del p, dp
+                    dq[b, h, q0:q1] = ds @ k[b, h, :q1]
+                    dk[b, h, :q1] += ds.t() @ qb
+        return dq, dk, dv, None, None
+
+
+_STREAM_BLOCK: Optional[int] = None
+
+
+class streamed_attention:
+    """Context: ``llama_attention`` evaluates its causal, unpadded attention block-wise (``_StreamedCausalAttention``, query blocks of
+    ``block`` rows) instead of through the [H, S, S] eager tensor.  Test infrastructure for the long-sequence parity cases."""
+
+    def __init__(self, block: int = 4096):
+        self.block = block
+
+    def __enter__(self):
+        global _STREAM_BLOCK
+        self._prev, _STREAM_BLOCK = _STREAM_BLOCK, self.block
+        return self
+
+    def __exit__(self, *exc):
+        global _STREAM_BLOCK
+        _STREAM_BLOCK = self._prev
+        return False
+
+
+def attention_causal_streamed(q: Tensor, k: Tensor, v: Tensor, scale: float, block: int = 4096) -> Tensor:
+    return _StreamedCausalAttention.apply(q, k, v, scale, block)
+
+
 def llama_attention(x: Tensor, w: Dict[str, Tensor], prefix: str, cfg: LMConfig, position_ids: Tensor,
                     attention_mask: Optional[Tensor] = None) -> Tensor:
     """LlamaAttention.forward transformers/.../modeling_llama.py:243-281 (no cache). MHA/GQA."""
@@ -364,7 +442,10 @@ def llama_attention(x: Tensor, w: Dict[str, Tensor], prefix: str, cfg: LMConfig,
         k = k.repeat_interleave(H // Hkv, dim=1)
         v = v.repeat_interleave(H // Hkv, dim=1)
     pad = None if attention_mask is None else (attention_mask == 0)
-    o = attention_eager(q, k, v, hd ** -0.5, causal=True, key_padding=pad)
+    if _STREAM_BLOCK is not None and pad is None:
+        o = attention_causal_streamed(q, k, v, hd ** -0.5, _STREAM_BLOCK)
+    else:
+        o = attention_eager(q, k, v, hd ** -0.5, causal=True, key_padding=pad)
     o = o.transpose(1, 2).reshape(B, S, H * hd)
     return F.linear(o, w[prefix + "o_proj.weight"])
 

@@ -161,9 +161,16 @@ def router_parity(case, layer, dev_idx, dev_logits, logits, k, min_same=0.9):
 
 
 def case_lm(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, B, S, expect_big_gemm, seed=5,
-            act_tol=(2e-2, 4e-2), grad_tol=(3e-2, 6e-2)):
-    """L-layer AriaMoELMForCausalLM at the given width: eval logits, training loss and EVERY gradient (aux losses on)."""
+            act_tol=(2e-2, 4e-2), grad_tol=(3e-2, 6e-2), recompute=False, eval_pass=True, stream_block=None):
+    """L-layer AriaMoELMForCausalLM at the given width: eval logits, training loss and EVERY gradient (aux losses on).
+    ``recompute``: the recipe's gradient checkpointing (selective: the flash kernel's (o, lse) are kept -- what the 64K benchmark line
+    runs); ``stream_block``: the oracle evaluates attention block-wise (O.streamed_attention) -- needed beyond S ~ 16 K."""
+    import contextlib
+
     from aria_amd.moe_lm import AriaMoELMConfig, AriaMoELMForCausalLM, load_reference_state_dict
+
+    def oracle_ctx():
+        return O.streamed_attention(stream_block) if stream_block else contextlib.nullcontext()
 
     ocfg = O.LMConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, num_key_value_heads=heads, vocab_size=vocab,
                       moe_intermediate_size=inter, moe_num_experts=experts, moe_topk=topk)
@@ -171,7 +178,7 @@ def case_lm(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, B,
     cfg = AriaMoELMConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, vocab_size=vocab,
                           moe_intermediate_size=inter, moe_num_experts=experts, moe_topk=topk, moe_num_shared_experts=2,
                           rms_norm_eps=ocfg.rms_norm_eps, rope_theta=ocfg.rope_theta, moe_z_loss_coeff=ocfg.moe_z_loss_coeff,
-                          moe_aux_loss_coeff=ocfg.moe_aux_loss_coeff)
+                          moe_aux_loss_coeff=ocfg.moe_aux_loss_coeff, gradient_checkpointing=recompute)
     lm = AriaMoELMForCausalLM(cfg)
     load_reference_state_dict(lm, w)
     lm = lm.to(dev)
@@ -179,28 +186,39 @@ def case_lm(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, B,
     wf = {k: v.float().requires_grad_(True) for k, v in w.items()}
 
     # ---- eval: logits
-    lm.eval()
-    with _Recorder() as rec, torch.no_grad():
-        got = lm(input_ids=ids.to(dev)).logits.float().cpu()
-    assert len(rec.idx) == layers
-    if expect_big_gemm:  # the 256x256 kernel families (v2 / v3) are what runs at this size -- the point of the case
-        assert rec.variants and min(rec.variants) >= 2, rec.variants
-    if inter % 128 == 0:  # the fused fc1 + SwiGLU launch is the one under test wherever the width allows it
-        assert rec.fused == layers, (rec.fused, layers)
-    REPORT.setdefault(case, {})["grouped_gemm_variants"] = sorted(set(rec.variants))
-    with _OracleLogits() as ol, O.forced_routing(rec.idx), torch.no_grad():
-        want = O.lm_forward(wf["model.embed_tokens.weight"][ids], wf, ocfg)
-    for i in range(layers):
-        router_parity(case, i, rec.idx[i], rec.logits[i], ol.logits[i], topk)
-    check(case, "logits", got, want, *act_tol)
+    if eval_pass:
+        lm.eval()
+        with _Recorder() as rec, torch.no_grad():
+            got = lm(input_ids=ids.to(dev)).logits.float().cpu()
+        assert len(rec.idx) == layers
+        if expect_big_gemm:  # the 256x256 kernel families (v2 / v3) are what runs at this size -- the point of the case
+            assert rec.variants and min(rec.variants) >= 2, rec.variants
+        if inter % 128 == 0:  # the fused fc1 + SwiGLU launch is the one under test wherever the width allows it
+            assert rec.fused == layers, (rec.fused, layers)
+        REPORT.setdefault(case, {})["grouped_gemm_variants"] = sorted(set(rec.variants))
+        with _OracleLogits() as ol, O.forced_routing(rec.idx), oracle_ctx(), torch.no_grad():
+            want = O.lm_forward(wf["model.embed_tokens.weight"][ids], wf, ocfg)
+        for i in range(layers):
+            router_parity(case, i, rec.idx[i], rec.logits[i], ol.logits[i], topk)
+        check(case, "logits", got, want, *act_tol)
 
     # ---- training: loss and gradients with the router's aux losses
     lm.train()
     with _Recorder() as rec:
         out = lm(input_ids=ids.to(dev), labels=ids.to(dev), return_logits=False)
         out.loss.backward()
-    with O.forced_routing(rec.idx):
+    if recompute:  # every layer's forward ran twice (the second time inside backward, last layer first): the routing must repeat itself
+        assert len(rec.idx) == 2 * layers, len(rec.idx)
+        for i in range(layers):
+            assert torch.equal(rec.idx[i], rec.idx[2 * layers - 1 - i]), f"layer {i}: the recomputed forward routed differently"
+        rec.idx, rec.logits = rec.idx[:layers], rec.logits[:layers]
+    if expect_big_gemm:
+        assert rec.variants and min(rec.variants) >= 2, rec.variants
+    with _OracleLogits() as ol, O.forced_routing(rec.idx), oracle_ctx():
         lgo = O.lm_forward(wf["model.embed_tokens.weight"][ids], wf, ocfg, training=True)
+    if not eval_pass:
+        for i in range(layers):
+            router_parity(case, i, rec.idx[i], rec.logits[i], ol.logits[i].detach(), topk)
     loss_o = torch.nn.functional.cross_entropy(lgo[:, :-1].reshape(-1, vocab), ids[:, 1:].reshape(-1))
     loss_o.backward()
     rel = abs(float(out.loss.detach()) - float(loss_o.detach())) / abs(float(loss_o.detach()))
@@ -356,8 +374,9 @@ def case_aria_config1(dev, case, *, text, vision, queries, n_text, seed=13, act_
 
 
 # ------------------------------------------------------------------------------------------------------------ long causal attention
-def case_long_attention(dev, case, *, S, H, hd, B=1, seed=21, tol=(6e-3, 2e-2), gtol=(8e-3, 3e-2)):
-    """Causal flash attention forward + backward at config #4's sequence scale (gptfast/model.py:137-149, 413-447), fp32 eager oracle."""
+def case_long_attention(dev, case, *, S, H, hd, B=1, seed=21, tol=(6e-3, 2e-2), gtol=(8e-3, 3e-2), stream_block=None):
+    """Causal flash attention forward + backward at config #4's / the north_star's sequence scale (gptfast/model.py:137-149, 413-447),
+    fp32 oracle head by head (eager up to S = 16 K; block-wise -- O.attention_causal_streamed, pinned on the eager form -- beyond)."""
     from aria_amd import ops
 
     D = H * hd
@@ -371,10 +390,10 @@ def case_long_attention(dev, case, *, S, H, hd, B=1, seed=21, tol=(6e-3, 2e-2), 
     got = [t.float().cpu() for t in (o, dq, dk, dv)]
     want_o = torch.empty(B * S, D)
     grads = [torch.empty(B * S, D) for _ in range(3)]
-    for h in range(H):   # head by head: one S x S fp32 score matrix at a time
+    for h in range(H):   # head by head: one S x S fp32 score matrix (or one block row of it) at a time
         sl = slice(h * hd, (h + 1) * hd)
         q, k, v = (qkv[:, i * D:(i + 1) * D][:, sl].float().view(B, S, 1, hd).transpose(1, 2).clone().requires_grad_(True) for i in range(3))
-        oh = O.attention_eager(q, k, v, scale, True)                     # [B,1,S,hd]
+        oh = O.attention_causal_streamed(q, k, v, scale, stream_block) if stream_block else O.attention_eager(q, k, v, scale, True)
         oh.backward(do[:, sl].float().view(B, S, 1, hd).transpose(1, 2))
         want_o[:, sl] = oh.detach().transpose(1, 2).reshape(B * S, hd)
         for dst, t in zip(grads, (q, k, v)):
@@ -382,3 +401,74 @@ def case_long_attention(dev, case, *, S, H, hd, B=1, seed=21, tol=(6e-3, 2e-2), 
     check(case, "o", got[0], want_o, *tol)
     for name, gt, wt in zip(("dq", "dk", "dv"), got[1:], grads):
         check(case, name, gt, wt, *gtol)
+
+
+def case_vit_attention_bwd(dev, case, *, S, H, hd=72, B=2, seed=23, tol=(6e-3, 2e-2), gtol=(8e-3, 3e-2)):
+    """The ViT's bidirectional attention with an arbitrary key-padding mask at the 980-px patch count (S = 4900, hd 72): forward AND
+    backward (an unfrozen tower; idefics2 eager attention, aria/model/vision_encoder.py:147-152) vs the fp32 eager oracle."""
+    from aria_amd import ops
+
+    D = H * hd
+    g = torch.Generator().manual_seed(seed)
+    qkv = torch.randn((B * S, 3 * D), generator=g).to(bf16)
+    do = torch.randn((B * S, D), generator=g).to(bf16)
+    km = (torch.rand(B, S, generator=g) > 0.2).to(torch.uint8)
+    km[:, 0] = 1
+    km[0, S - S // 4:] = 0        # image 0: its bottom quarter is padding (contiguous run), the rest scattered
+    scale = hd ** -0.5
+    qd = qkv.to(dev)
+    o, lse = ops.attention_fwd(qd[:, :D], qd[:, D:2 * D], qd[:, 2 * D:], B, S, H, hd, scale, False, key_mask=km.to(dev))
+    dq, dk, dv = ops.attention_bwd(qd[:, :D], qd[:, D:2 * D], qd[:, 2 * D:], o, do.to(dev), lse, B, S, H, hd, scale, False, key_mask=km.to(dev))
+    q, k, v = (qkv[:, i * D:(i + 1) * D].float().view(B, S, H, hd).transpose(1, 2).clone().requires_grad_(True) for i in range(3))
+    want = O.attention_eager(q, k, v, scale, False, key_padding=(km == 0))
+    want.backward(do.float().view(B, S, H, hd).transpose(1, 2))
+    check(case, "o", o, want.detach().transpose(1, 2).reshape(B * S, D), *tol)
+    for name, gt, t in zip(("dq", "dk", "dv"), (dq, dk, dv), (q, k, v)):
+        check(case, name, gt, t.grad.transpose(1, 2).reshape(B * S, D), *gtol)
+    # masked keys receive no gradient at all
+    dead = (km == 0).reshape(-1)
+    assert float(dk.float().cpu()[dead].abs().max()) == 0.0 and float(dv.float().cpu()[dead].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------------------ config #4 prefill
+def case_prefill_gptfast(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, S, seed=31, tol=(3e-2, 6e-2), stream_block=4096,
+                         expect_big_gemm=True):
+    """BASELINE config #4's code path at its sequence length: the gptfast surface (aria_amd.gptfast.Transformer, model.pth wire format
+    converted from the HF layout exactly as gptfast/scripts/convert_hf_checkpoint.py:90-162 does) prefills S tokens into its static bf16
+    KV cache and returns the LAST position's logits (gptfast/model.py:178-234, 413-447); oracle = O.lm_forward (HF layout: the two
+    reference implementations agree to 5e-7 in fp32) on the same bf16-rounded weights with block-wise attention, routing
+    forced to the device's ids.  Also checks rows of the KV cache written at both ends of the sequence."""
+    from aria_amd import gptfast as G
+    from aria_amd.checkpoint import hf_to_gptfast
+
+    ocfg = O.LMConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, num_key_value_heads=heads, vocab_size=vocab,
+                      moe_intermediate_size=inter, moe_num_experts=experts, moe_topk=topk)
+    w = lm_weights(ocfg, seed)
+    args = G.ModelArgs(block_size=S, vocab_size=vocab, n_layer=layers, n_head=heads, dim=hidden, intermediate_size=inter,
+                       rope_base=ocfg.rope_theta, norm_eps=ocfg.rms_norm_eps, num_experts=experts, router_topk=topk, num_shared_experts=2)
+    tf = G.Transformer(args)
+    gw = {k[len("llm."):]: v for k, v in hf_to_gptfast({"language_model." + k: v for k, v in w.items()}, heads, ocfg.head_dim).items()}
+    own = tf.state_dict()
+    assert set(own) == set(gw), set(own) ^ set(gw)
+    with torch.no_grad():
+        for k, v in own.items():
+            v.copy_(gw[k].to(v.dtype))
+    tf = tf.to(dev).eval()
+    tf.setup_caches(1, S)
+    ids = torch.randint(0, vocab, (1, S), generator=torch.Generator().manual_seed(seed + 1))
+    with _Recorder() as rec, torch.no_grad():
+        got = tf(ids.to(dev), torch.arange(S, device=dev), last_only=True).float().cpu()
+    assert len(rec.idx) == layers and rec.variants and (not expect_big_gemm or min(rec.variants) >= 2), (len(rec.idx), rec.variants)
+    wf = {k: v.float() for k, v in w.items()}
+    with _OracleLogits() as ol, O.forced_routing(rec.idx), O.streamed_attention(stream_block), torch.no_grad():
+        h = O.lm_forward(wf["model.embed_tokens.weight"][ids], wf, ocfg, return_hidden=True)
+        want = torch.nn.functional.linear(h[:, -1:], wf["lm_head.weight"])
+    for i in range(layers):
+        router_parity(case, i, rec.idx[i], rec.logits[i], ol.logits[i], topk)
+    check(case, "last-position logits", got, want, *tol)
+    # the static KV cache of layer 0 (gptfast/model.py:67-93): V rows are v_proj(RMSNorm(embedding)) -- layout-independent -- at both ends
+    rows = torch.tensor([0, 1, S // 2, S - 2, S - 1])
+    x0 = O.rms_norm(wf["model.embed_tokens.weight"][ids[0, rows]], wf["model.layers.0.input_layernorm.weight"], ocfg.rms_norm_eps)
+    check(case, "layer-0 V cache rows", tf.layers[0].attention.kv_cache.v[0, rows.to(dev)].float().cpu(),
+          torch.nn.functional.linear(x0, wf["model.layers.0.self_attn.v_proj.weight"]), 1e-2, 3e-2)
+    assert int(got.argmax()) == int(want.argmax()) or float(want.flatten().topk(2).values.diff().abs()) < 4e-2 * float(want.abs().max())

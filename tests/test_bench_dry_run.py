@@ -28,3 +28,9 @@ def test_bench_line_carries_the_contract(world):
     roof = res["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof) and roof["bound"] == "mfma" and roof["launches_timed"] == 4
     assert roof["kernel"].startswith("gemm") and "experts.fc1" in roof["kernel"]
+    if world == 1:  # the north_star target-shape sub-record rides in the same line (its code path, at toy size here)
+        sub = res["long64k"]
+        assert {"ms_per_step", "value", "unit", "steps", "roofline"} <= set(sub) and sub["steps"] == 3 and sub["value"] > 0
+        assert sub["roofline"]["bound"] == "mfma" and sub["roofline"]["launches_timed"] == 3 * 2 and "INVALID" in sub
+    else:
+        assert "long64k" not in res

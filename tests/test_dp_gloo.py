@@ -180,3 +180,70 @@ def test_sharded_adamw_odd_numel_and_decay_groups():
             torch.testing.assert_close(opt.state[list(params).index(k)]["master"], ref[k].reshape(-1), rtol=2e-5, atol=1e-6)
     finally:
         emu_lib.uninstall()
+
+
+# ---------------------------------------------------------------- gradient clipping norm over owned slices
+def _norm_worker(rank, world, port, outdir, mode):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.emu import emu_lib
+
+    emu_lib.install()
+    from aria_amd.parallel import GradSync, global_grad_norm
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(300, 300), torch.nn.Linear(300, 301, bias=True)).bfloat16()
+    sync = GradSync(net, mode=mode)
+    x = torch.randn(5, 300, generator=torch.Generator().manual_seed(10 * rank)).bfloat16()
+    net(x).float().square().mean().backward()
+    sync.finish()
+    norm = global_grad_norm(list(net.parameters()), sync)
+    torch.save({"norm": norm}, os.path.join(outdir, f"n{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["all_reduce", "reduce_scatter"])
+def test_global_grad_norm_counts_every_element_once(mode):
+    """HF max_grad_norm / DeepSpeed gradient_clipping (zero2.yaml:5): after a ZeRO-2 reduce-scatter only the owned slice of a large
+    gradient is valid, so the norm is assembled from owned slices + one scalar all-reduce -- equal on every rank to the norm of the
+    rank-averaged full gradient."""
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_norm_worker, args=(world, _free_port(), d, mode), nprocs=world, join=True)
+        got = [torch.load(os.path.join(d, f"n{r}.pt"))["norm"] for r in range(world)]
+    singles = []
+    for r in range(world):
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(300, 300), torch.nn.Linear(300, 301, bias=True)).bfloat16()
+        x = torch.randn(5, 300, generator=torch.Generator().manual_seed(10 * r)).bfloat16()
+        net(x).float().square().mean().backward()
+        singles.append([p.grad.float() for p in net.parameters()])
+    want = float(torch.sqrt(sum(((a + b) / 2).square().sum() for a, b in zip(*singles))))
+    assert got[0] == got[1]
+    assert abs(got[0] - want) <= 1e-2 * want, (got, want)
+
+
+def test_clip_scale_and_single_process_norm():
+    from tests.emu import emu_lib
+
+    emu_lib.install()
+    try:
+        from aria_amd.parallel import clip_scale, global_grad_norm
+
+        ps = [torch.nn.Parameter(torch.zeros(n).bfloat16()) for n in (7, 1027, 16)]
+        for i, p in enumerate(ps):
+            g = torch.randn(p.numel() + 3, generator=torch.Generator().manual_seed(i)).bfloat16()
+            p.grad = g[3:] if i == 1 else g[:-3].clone()  # i == 1: an element-aligned (not 16-byte aligned) view, like a shard of a flattened gradient
+        want = float(torch.sqrt(sum(p.grad.float().square().sum() for p in ps)))
+        got = global_grad_norm(ps)
+        assert abs(got - want) <= 1e-5 * want, (got, want)
+        assert clip_scale(got, None) == 1.0 and clip_scale(0.5, 1.0) == 1.0
+        assert abs(clip_scale(4.0, 1.0) - 1.0 / (4.0 + 1e-6)) < 1e-12
+    finally:
+        emu_lib.uninstall()

@@ -35,3 +35,23 @@ def test_aria_config1_case_small():
 
 def test_long_attention_case_small():
     F.case_long_attention("cpu", "emu_attn", S=320, H=1, hd=128)
+
+
+def test_long_attention_case_small_streamed_oracle():
+    F.case_long_attention("cpu", "emu_attn_streamed", S=200, H=1, hd=128, stream_block=48)
+
+
+def test_vit_attention_bwd_case_small():
+    F.case_vit_attention_bwd("cpu", "emu_vit_attn_bwd", S=150, H=1)
+
+
+def test_lm_case_small_recompute_streamed():
+    """The T = 65 536 case's code path (recompute, no eval pass, block-wise oracle attention, routing repeated by the recomputed forward)."""
+    F.case_lm("cpu", "emu_lm_recompute", hidden=128, heads=2, experts=8, topk=2, inter=128, vocab=160, layers=1, B=1, S=40,
+              expect_big_gemm=False, act_tol=(3e-2, 8e-2), grad_tol=(8e-2, 2e-1), recompute=True, eval_pass=False, stream_block=16)
+    assert "router.layer0" in F.REPORT["emu_lm_recompute"]
+
+
+def test_prefill_gptfast_case_small():
+    F.case_prefill_gptfast("cpu", "emu_prefill", hidden=128, heads=2, experts=8, topk=2, inter=128, vocab=160, layers=2, S=72,
+                           tol=(5e-2, 1.5e-1), stream_block=32, expect_big_gemm=False)

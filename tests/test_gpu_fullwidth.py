@@ -47,3 +47,27 @@ def test_config1_end_to_end():
 
 def test_causal_attention_S16384_fwd_bwd():
     F.case_long_attention(DEV, "attention_causal_S16384", S=16384, H=2, hd=128)
+
+
+# ---------------------------------------------------------------- the north_star's target shape and config #4's (VERDICT r2 missing #1)
+def test_causal_attention_S65536_fwd_bwd():
+    """One head of a 65 536-token causal sequence: flash forward + backward against the block-wise fp32 oracle (pinned on the eager form)."""
+    F.case_long_attention(DEV, "attention_causal_S65536", S=65536, H=1, hd=128, stream_block=4096)
+
+
+def test_vit_attention_hd72_bwd_S4900_masked():
+    """hd-72 backward at the 980-px patch count (the r02 cases stopped at S = 300)."""
+    F.case_vit_attention_bwd(DEV, "vit_attention_hd72_S4900", S=4900, H=2)
+
+
+def test_decoder_layer_aria_width_T65536_recompute():
+    """ONE decoder layer at T = 65 536 (393 216 expert rows; byte offsets beyond 2^31 in the grouped GEMMs) with the recipe's gradient
+    checkpointing in its selective form (flash (o, lse) kept): loss and all 15 gradients of a 1-layer LM with a small vocabulary."""
+    F.case_lm(DEV, "decoder_layer_T65536_recompute", hidden=2560, heads=20, experts=64, topk=6, inter=1664, vocab=2048, layers=1, B=1,
+              S=65536, expect_big_gemm=True, seed=7, recompute=True, eval_pass=False, stream_block=4096)
+
+
+def test_config4_prefill_53248_two_layers():
+    """BASELINE config #4: 53 248-token prefill through the gptfast surface, 2 full-width layers, last-position logits."""
+    F.case_prefill_gptfast(DEV, "config4_prefill_S53248", hidden=2560, heads=20, experts=64, topk=6, inter=1664, vocab=4096, layers=2,
+                           S=53248)
