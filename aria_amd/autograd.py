@@ -103,6 +103,49 @@ class SwiGLUFn(torch.autograd.Function):
         return ops.swiglu_bwd(h, _c(dact))
 
 
+class ExpertsGluFn(torch.autograd.Function):
+    """glu(experts_gemm(input, fc1, tokens_per_expert)) -- GroupedMLP.forward's first half (moe_lm.py:505-507, 522-523) as ONE launch
+    (fc1 GEMM with the SwiGLU epilogue), differentiable in input and weight; bit-identical to SwiGLUFn(ExpertsGemmFn(...))."""
+
+    @staticmethod
+    def forward(ctx, inp, weight, offsets):
+        h, act = ops.grouped_gemm_swiglu(inp, weight, offsets, want_h=True)
+        ctx.save_for_backward(inp, weight, offsets, h)
+        return act
+
+    @staticmethod
+    def backward(ctx, dact):
+        inp, weight, offsets, h = ctx.saved_tensors
+        dh = ops.swiglu_bwd(h, _c(dact))
+        dx = ops.grouped_gemm(dh, weight, offsets, w_is_kn=False) if ctx.needs_input_grad[0] else None
+        dw = ops.grouped_gemm_wgrad(inp, dh, offsets, weight.shape[0]) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+class SharedGluFn(torch.autograd.Function):
+    """silu(gate_proj(x)) * up_proj(x) of SharedExpertMLP (moe_lm.py:368-395) as ONE GEMM over the row-wise concatenation of the two
+    weights with the SwiGLU epilogue; the input gradient is one GEMM with the long reduction, the two weight gradients one wide GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, gate_w, up_w):
+        wgu = Fn.fused_weight(gate_w, up_w)
+        gu, act = ops.gemm_swiglu(x, wgu, want_h=True)
+        ctx.save_for_backward(x, wgu, gu)
+        ctx.I2 = gate_w.shape[0]
+        return act
+
+    @staticmethod
+    def backward(ctx, dact):
+        x, wgu, gu = ctx.saved_tensors
+        d_gu = ops.swiglu_bwd(gu, _c(dact))
+        dx = ops.gemm(d_gu, wgu, b_oc=True) if ctx.needs_input_grad[0] else None
+        g_gate = g_up = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            g_gu = ops.gemm(d_gu, x, a_oc=True, b_oc=True)
+            g_gate, g_up = g_gu[:ctx.I2], g_gu[ctx.I2:]
+        return dx, g_gate, g_up
+
+
 class MoELayerFn(torch.autograd.Function):
     """MoELayer.forward (moe_lm.py:548-577) as one node: router -> permute -> experts -> unpermute + shared."""
 

@@ -720,6 +720,20 @@ __device__ __forceinline__ void tile_store3(const u32x4 (&r)[Cfg3<HD>::NCH], cha
         st16(s + row * Cfg3<HD>::ROW + ((ch ^ swz3(row)) << 4), r[p]);
     }
 }
+// the same 64-row tile image written by LDS-DMA (no staging registers, no ds_write pass): the wave's piece pc = w + 8 s is the 1 KiB at
+// pc * 1024, i.e. rows 4 pc + (l >> 4), image chunk l & 15 -- which holds SOURCE chunk (l & 15) ^ swz3(row), and swz3(4 pc + (l >> 4)) =
+// ((l >> 4) << 2) | (w & 3) does not depend on s.  Rows past row_last are clamped (finite data: whoever reads them masks the result).
+template <int HD>
+__device__ __forceinline__ void tile_dma3(const bf16_t* base, int ld, int row0, int row_last, char* s, int w, int l) {
+    static_assert(Cfg3<HD>::CPR == 16, "one wave piece = 4 rows of 16 chunks");
+    const int ch = (l & 15) ^ (((l >> 4) << 2) | (w & 3));
+#pragma unroll
+    for (int si = 0; si < 2; ++si) {
+        const int pc = w + 8 * si;
+        const int row = min(row0 + 4 * pc + (l >> 4), row_last);
+        glds16(base + (long long)row * ld + ch * 8, s + pc * 1024);
+    }
+}
 // row fragment: row `row`, reduction indices 16 kk + 8 (l >> 5) + 0..7
 template <int HD>
 __device__ __forceinline__ s16x8 frag_rc3(const char* s, int row, int kk, int l) {
@@ -1061,7 +1075,301 @@ __global__ __launch_bounds__(512) void attn_bwd3_dq_kernel(const bf16_t* Q, cons
 }
 
 
+// =========================================================================================== backward v4 (hd = 128): ONE pass
+// The two-kernel form computes S and dP twice (7 GEMM units of S x S x hd per head for the algorithm's 5).  Here the dK/dV workgroup of a
+// 128-key block also produces the block's contribution to dQ and ADDS it to an fp32 image of dQ:
+//
+//     role A:  S = Q K^T -> P -> publishes P (fp32) ....................... dV += P^T dO
+//     role B:  dP = dO V^T ............ dS = P (dP - delta) scale ......... dK += dS^T Q     publishes dS (bf16, [key][query])
+//     all 8 waves, one barrier later:   dQ[64 q][128 f] += dS[64 q][128 keys] K[128 keys][128 f]  -- wave w owns the 32 x 32 tile
+//     (queries 32 (w & 1).., features 32 (w >> 1)..), its eight K^T fragments live in registers for the whole kernel (the key block is
+//     fixed), the dS fragments come out of LDS through the transposing read; 8 MFMAs + 16 global_atomic_add_f32 per wave and tile.
+//
+// The dQ GEMM of tile t runs at the top of iteration t + 1 (between the two barriers that are there anyway), so the loop keeps two
+// barriers per 64-query tile.  16 + 16 + 8 MFMAs per wave and tile: 5 GEMM units.  The fp32 adds make dQ's summation order depend on the
+// schedule (not bit-reproducible run to run): the two-kernel form stays as the deterministic mode.
+template <int HD>
+struct Cfg4 {
+    using C3 = Cfg3<HD>;
+    static constexpr int DSP = 64 * 2 + 16;  // bytes per key row of the dS image: 64 queries bf16 + 16 B (rows 36 dwords apart: the 8-byte
+                                             // writes of 16 keys and the transposing reads of 4 rows x 32 B land in distinct banks)
+    static constexpr int SMEM = 4 * C3::TILE + 2 * 2 * 64 * 4 + 4 * 8 * 1024 + 128 * DSP + 2 * C3::TILE;  // ... + the block's K rows
+};
+
+// one (key block, head, batch) item; `agent`: the adds carry device scope (the item may run on any XCD) -- otherwise the caller guarantees
+// that every item of this (batch, head) runs on the XCD this workgroup is on
+template <int HD>
+__device__ __forceinline__ void attn_bwd4_item(char* smem, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
+                                               const float* LSE, const float* DELTA, bf16_t* dK, bf16_t* dV, float* dQacc,
+                                               const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H, int ldq,
+                                               int ldk, int ldv, int lddo, int lddk, int lddv,
+                                               int lddqa, float scale, int causal, int kblk, int head, int b, bool agent) {
+    using C = Cfg3<HD>;
+    using C4 = Cfg4<HD>;
+    static_assert(HD == 128, "the dQ tile split (2 x 4 tiles of 32 x 32 over 8 waves) is written for hd 128");
+    char* sQ = smem;                                   // [2] tiles
+    char* sdO = smem + 2 * C::TILE;                    // [2] tiles
+    float* sLse = reinterpret_cast<float*>(smem + 4 * C::TILE);  // [2][64] (lse * log2e)
+    float* sDel = sLse + 128;                          // [2][64]
+    char* sP = reinterpret_cast<char*>(sDel + 128);    // [4 pairs][8][64 lanes] x 16 bytes
+    char* sDS = sP + 4 * 8192;                         // [128 keys][DSP]: dS of the current tile, bf16, key-major
+    char* sK = sDS + 128 * C4::DSP;                    // [2] tiles: the block's 128 K rows (B operand of the dQ GEMM, read key-strided)
+    const int t = threadIdx.x, l = t & 63, w = first_lane(t >> 6), role = w >> 2, g = w & 3, h2 = l >> 5;
+    const int kv0 = kblk * 128;
+    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
+    const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
+    const bf16_t* dOb = dO + tokq0 * lddo + head * HD;
+    const bf16_t* Kb = K + tok0 * ldk + head * HD;
+    const float* lseb = LSE + ((long long)b * H + head) * Sq;
+    const float* delb = DELTA + ((long long)b * H + head) * Sq;
+    const int kv_wmin = kv0 + 32 * g, kv_abs = kv_wmin + (l & 31);
+    const int klen = kv_len ? min(S, kv_len[b]) : S;
+    const bool key_ok = kv_abs < klen && (!key_mask || key_mask[tok0 + kv_abs] != 0);
+    const bool all_keys_ok = ballot(key_ok) == ~0ull;
+    const float scale2 = scale * 1.4426950408889634f;
+
+    const int q_begin = causal ? (kv0 / 64) * 64 : 0;
+    const int ntiles = kv0 < klen ? (Sq - q_begin + 63) / 64 : 0;
+
+    // own fragment: K rows (role A) or V rows (role B) of the wave's 32 keys
+    const bf16_t* own = (role ? V + tok0 * ldv : K + tok0 * ldk) + head * HD;
+    const long long ldown = role ? ldv : ldk;
+    s16x8 of[C::KS];
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+        u32x4 a = zero16();
+        if (kv_abs < S) a = ld16(own + (long long)kv_abs * ldown + kk * 16 + h2 * 8);
+        of[kk] = __builtin_bit_cast(s16x8, a);
+    }
+    // B operand of the dQ GEMM: the block's 128 K rows stay in LDS for the whole item; the transposing read hands them out key-strided
+    // (eight register-resident fragments per wave would be 32 more VGPRs than two waves per SIMD leave)
+    const int qt_w = w & 1, ft_w = w >> 1;
+    u32x4 rq[C::NCH], rdo[C::NCH];
+    if (ntiles > 0) {
+        tile_load3<HD>(rq, Kb, ldk, kv0, S, t);
+        tile_load3<HD>(rdo, Kb, ldk, kv0 + 64, S, t);
+        tile_store3<HD>(rq, sK, t);
+        tile_store3<HD>(rdo, sK + C::TILE, t);   // (first read: behind the loop's first barrier)
+    }
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) settle(of[kk]);
+    f32x16 acc[C::DT];  // dV (role A) / dK (role B): rows = keys, cols = features
+#pragma unroll
+    for (int i = 0; i < C::DT; ++i) acc[i] = zero_acc();
+    char* myP = sP + g * 8192 + l * 16;
+    // dS image: this lane's key row (written by role B), and the lane part of the transposing read of the dQ GEMM's A operand
+    char* ds_row = sDS + (32 * g + (l & 31)) * C4::DSP + 8 * h2;
+    const char* ds_frag = sDS + (4 * h2 + ((l & 15) >> 2)) * C4::DSP + (32 * qt_w + 16 * ((l >> 4) & 1) + 4 * (l & 3)) * 2;
+    float* dq_lane = dQacc + (tokq0 + 32 * qt_w + 4 * h2) * lddqa + head * HD + 32 * ft_w + (l & 31);
+
+    // dQ[tile at q0] += dS K for the pairs that were active on it (their rows of the dS image are valid)
+    auto dq_tile = [&](int q0) {
+        f32x16 dq = zero_acc();
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            if (causal && kv0 + 32 * (kk >> 1) > q0 + 63) continue;  // wave-uniform: pair kk / 2 sat this tile out
+            const char* p = ds_frag + 16 * kk * C4::DSP;
+            const s16x4 a0 = ds_read_tr16(reinterpret_cast<const bf16_t*>(p));
+            const s16x4 a1 = ds_read_tr16(reinterpret_cast<const bf16_t*>(p + 8 * C4::DSP));
+            s16x8 f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[e] = a0[e];
+                f[4 + e] = a1[e];
+            }
+            dq = mfma32(f, frag_tr3<HD>(sK + (kk >> 2) * C::TILE, (kk & 3) * 16, 32 * ft_w, l), dq);
+        }
+        float* base = dq_lane + (long long)q0 * lddqa;
+        const int qrow = q0 + 32 * qt_w + 4 * h2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (qrow + dr < Sq) {
+                if (agent)
+                    atomic_add_f32_noret<true>(base + (long long)dr * lddqa, dq[r]);
+                else
+                    atomic_add_f32_noret<false>(base + (long long)dr * lddqa, dq[r]);
+            }
+        }
+    };
+
+    if (ntiles > 0) {
+        tile_load3<HD>(rq, Qb, ldq, q_begin, Sq, t);
+        tile_load3<HD>(rdo, dOb, lddo, q_begin, Sq, t);
+        tile_store3<HD>(rq, sQ, t);
+        tile_store3<HD>(rdo, sdO, t);
+        if (t < 64) {
+            const int q = q_begin + t;
+            sLse[t] = q < Sq ? lseb[q] * 1.4426950408889634f : 0.f;
+            sDel[t] = q < Sq ? delb[q] : 0.f;
+        }
+    }
+    for (int it = 0; it < ntiles; ++it) {
+        wait_vm<0>();  // this wave's LDS-DMA pieces of tile `it` have landed (and its adds of the previous tile have left)
+        sync();  // tile `it` is complete in buffer it & 1; the other buffer and the P exchange are free; the dS image of tile it - 1 is complete
+        const int cur = it & 1, qt0 = q_begin + it * 64;
+        const bool more = it + 1 < ntiles;
+        if (more) {  // next tile straight into the other buffer (its last readers finished before the barrier)
+            tile_dma3<HD>(Qb, ldq, qt0 + 64, Sq - 1, sQ + (cur ^ 1) * C::TILE, w, l);
+            tile_dma3<HD>(dOb, lddo, qt0 + 64, Sq - 1, sdO + (cur ^ 1) * C::TILE, w, l);
+        }
+        if (it > 0) dq_tile(qt0 - 64);
+        const char* cQ = sQ + cur * C::TILE;
+        const char* cdO = sdO + cur * C::TILE;
+        const char* first = role ? cdO : cQ;   // rc operand of the first GEMM
+        const char* second = role ? cQ : cdO;  // transposed operand of the second GEMM
+        const bool active = !(causal && kv_wmin > qt0 + 63);  // wave-uniform: some query of the tile can see some key of this pair
+        f32x16 sc[2];
+        if (active) {
+            sc[0] = zero_acc();
+            sc[1] = zero_acc();
+#pragma unroll
+            for (int kk = 0; kk < C::KS; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) sc[i] = mfma32(frag_rc3<HD>(first, i * 32 + (l & 31), kk, l), of[kk], sc[i]);
+            if (role == 0) {
+                const float* cL = sLse + cur * 64;
+                const bool need_mask = !all_keys_ok || (qt0 + 64 > Sq) || (causal && kv_wmin + 31 > qt0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const f32x4 ls = *reinterpret_cast<const f32x4*>(cL + i * 32 + 8 * rg + 4 * h2);
+                        f32x4 pv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float p = exp2_fast(sc[i][4 * rg + e] * scale2 - ls[e]);
+                            if (need_mask) {
+                                const int q = qt0 + i * 32 + 8 * rg + 4 * h2 + e;
+                                if (!(q < Sq && key_ok && !(causal && kv_abs > q))) p = 0.f;
+                            }
+                            sc[i][4 * rg + e] = p;
+                            pv[e] = p;
+                        }
+                        *reinterpret_cast<f32x4*>(myP + (i * 4 + rg) * 1024) = pv;
+                    }
+            }
+        }
+        sync();  // P published; every wave is done with the dS image of tile it - 1
+        if (active) {
+            if (role == 1) {
+                const float* cD = sDel + cur * 64;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const f32x4 pv = *reinterpret_cast<const f32x4*>(myP + (i * 4 + rg) * 1024);
+                        const f32x4 dl = *reinterpret_cast<const f32x4*>(cD + i * 32 + 8 * rg + 4 * h2);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sc[i][4 * rg + e] = pv[e] * (sc[i][4 * rg + e] - dl[e]) * scale;
+                        // the same bf16 values that enter dK: queries i * 32 + 8 rg + 4 h2 + 0..3 of this lane's key
+                        u32x2 dsv;
+                        dsv[0] = pack2bf(sc[i][4 * rg], sc[i][4 * rg + 1]);
+                        dsv[1] = pack2bf(sc[i][4 * rg + 2], sc[i][4 * rg + 3]);
+                        *reinterpret_cast<u32x2*>(ds_row + (i * 32 + 8 * rg) * 2) = dsv;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const s16x8 pf = pack_frag(sc[i], u);
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; ++dt) acc[dt] = mfma32(pf, frag_tr3<HD>(second, i * 32 + 16 * u, 32 * dt, l), acc[dt]);
+                }
+        }
+        if (more && t < 64) {
+            const int nb = cur ^ 1, q = qt0 + 64 + t;
+            sLse[nb * 64 + t] = q < Sq ? lseb[q] * 1.4426950408889634f : 0.f;
+            sDel[nb * 64 + t] = q < Sq ? delb[q] : 0.f;
+        }
+    }
+    if (ntiles > 0) {
+        sync();  // the dS image of the last tile is complete
+        dq_tile(q_begin + (ntiles - 1) * 64);
+    }
+    bf16_t* out = role ? dK : dV;
+    const long long ldout = role ? lddk : lddv;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kv = kv_wmin + acc_row(r, l);
+            if (kv >= S) continue;
+            out[(tok0 + kv) * ldout + head * HD + 32 * dt + (l & 31)] = f2bf(acc[dt][r]);
+        }
+}
+
+// Persistent scheduler around attn_bwd4_item.  The first n_excl (a multiple of 8) (batch, head) pairs are XCD-EXCLUSIVE: pair p belongs to
+// XCD p % 8 and only workgroups that find themselves on that XCD (HW_REG_XCC_ID -- not an assumption about placement) take its key blocks,
+// from a per-XCD ticket counter; their dQ adds are performed in that XCD's L2.  The remaining pairs (H B not a multiple of 8, or
+// n_excl = 0) sit in one global queue any workgroup pulls from once its own XCD's queue is empty; their adds carry device scope.
+// Both queues hand out key blocks longest first (causal: block 0 sees every query).  tickets: 9 counters, 64 bytes apart, zeroed.
+template <int HD>
+__global__ __launch_bounds__(512) void attn_bwd4_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
+                                                        const float* LSE, const float* DELTA, bf16_t* dK, bf16_t* dV, float* dQacc,
+                                                        int* tickets, const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
+                                                        int ldq, int ldk, int ldv, int lddo, int lddk, int lddv, int lddqa, float scale,
+                                                        int causal, int nbatch, int n_excl) {
+    ARIA_DYN_SMEM(smem);
+    int* sItem = reinterpret_cast<int*>(smem + Cfg4<HD>::SMEM);
+    const int nkb = (S + 127) / 128, nbh = H * nbatch, xcd = xcc_id() & 7;
+    const int per_xcd = n_excl >> 3, n_rem = nbh - n_excl;
+    const int n_local = per_xcd * nkb, n_global = n_rem * nkb;
+    for (;;) {
+        sync();  // every wave is done with the previous item's LDS (and with sItem)
+        if (threadIdx.x == 0) {
+            int item = -1;
+            if (n_local > 0) {
+                const int j = atomic_add(tickets + 16 * xcd, 1);
+                if (j < n_local) item = j;
+            }
+            if (item < 0 && n_global > 0) {
+                const int j = atomic_add(tickets + 16 * 8, 1);
+                if (j < n_global) item = n_local + j;
+            }
+            *sItem = item;
+        }
+        sync();
+        const int item = first_lane(*sItem);
+        if (item < 0) return;
+        int bh, kblk;
+        const bool agent = item >= n_local;
+        if (!agent) {
+            bh = xcd + 8 * (item % per_xcd);
+            kblk = item / per_xcd;
+        } else {
+            bh = n_excl + (item - n_local) % n_rem;
+            kblk = (item - n_local) / n_rem;
+        }
+        attn_bwd4_item<HD>(smem, Q, K, V, dO, LSE, DELTA, dK, dV, dQacc, kv_len, key_mask, Sq, S, H, ldq, ldk, ldv, lddo, lddk, lddv, lddqa,
+                           scale, causal, kblk, bh % H, bh / H, agent);
+    }
+}
+
+// fp32 image -> bf16 rows (and the zero fill in front of the accumulation)
+__global__ __launch_bounds__(256) void attn_dq_zero_kernel(float* acc, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        *reinterpret_cast<f32x4*>(acc + 4 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__global__ __launch_bounds__(256) void attn_dq_round_kernel(const float* acc, bf16_t* dq, long long rows, int cols, long long lda, long long lddq) {
+    const int cpr = cols / 8;  // 8-element chunks per row
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows * cpr; i += (long long)gridDim.x * 256) {
+        const long long row = i / cpr;
+        const int c = int(i % cpr) * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(acc + row * lda + c), b4 = *reinterpret_cast<const f32x4*>(acc + row * lda + c + 4);
+        u32x4 v;
+        v[0] = pack2bf(a[0], a[1]);
+        v[1] = pack2bf(a[2], a[3]);
+        v[2] = pack2bf(b4[0], b4[1]);
+        v[3] = pack2bf(b4[2], b4[3]);
+        *reinterpret_cast<u32x4*>(dq + row * lddq + c) = v;
+    }
+}
+
+thread_local int g_last_bwd_variant = 0;  // 2 / 3: the two-kernel generations, 4: single pass (tests assert which form they exercised)
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+unsigned grid_cap(long long g, long long cap) { return unsigned(g < 1 ? 1 : (g > cap ? cap : g)); }
 
 }  // namespace
 
@@ -1097,10 +1405,25 @@ int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     return aria_check_launch();
 }
 
+int aria_last_attn_bwd_variant(void) { return g_last_bwd_variant; }
+
+int64_t aria_attn_bwd_workspace_bytes(int64_t B, int64_t Sq, int64_t H, int64_t hd) {
+    if (hd != 128 || B <= 0 || Sq <= 0 || H <= 0) return 0;  // the single-pass form exists for hd 128 (the decoder's heads)
+    return B * Sq * H * hd * 4 + ARIA_ATTN_BWD_TICKET_BYTES;
+}
+
 int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
                   void* dq, void* dk, void* dv, const int32_t* kv_len, const uint8_t* key_mask, int64_t B, int64_t Sq, int64_t Skv,
                   int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
                   float scale, int causal, void* stream) {
+    return aria_attn_bwd_ws(q, k, v, o, d_o, lse, delta, dq, dk, dv, kv_len, key_mask, B, Sq, Skv, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv,
+                            scale, causal, nullptr, 0, stream);
+}
+
+int aria_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
+                     void* dq, void* dk, void* dv, const int32_t* kv_len, const uint8_t* key_mask, int64_t B, int64_t Sq, int64_t Skv,
+                     int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
+                     float scale, int causal, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv || B < 0 || Sq < 0 || Skv < 0 || H <= 0)
         return ARIA_ERR_INVALID;
     if (hd != 64 && hd != 72 && hd != 128) return ARIA_ERR_UNSUPPORTED;
@@ -1119,9 +1442,32 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                 (long long)ldo, nrows);
     dim3 gridk(unsigned((Skv + 127) / 128), unsigned(H), unsigned(B)), gridq(unsigned((Sq + 127) / 128), unsigned(H), unsigned(B));
     dim3 block(NT);
+    const char* old = std::getenv("ARIA_ATTN_BWD");  // "2" / "3": the two-kernel generations even when a workspace is offered (A/B measurements)
+    const int64_t ws_need = aria_attn_bwd_workspace_bytes(B, Sq, H, hd);
+    if (hd == 128 && workspace && ws_need > 0 && workspace_bytes >= ws_need && !(old && (old[0] == '2' || old[0] == '3'))) {
+        // single pass (5 GEMM units): dK, dV and the key block's share of dQ from ONE S / dP computation; dQ accumulates in the fp32 image
+        if ((reinterpret_cast<uintptr_t>(workspace) & 15) || (lddq & 7)) return ARIA_ERR_ALIGN;
+        float* acc = static_cast<float*>(workspace);
+        const long long n_acc = B * Sq * H * hd;
+        int* tickets = reinterpret_cast<int*>(acc + n_acc);
+        const long long n4 = (n_acc * 4 + ARIA_ATTN_BWD_TICKET_BYTES) / 16;
+        ARIA_LAUNCH(attn_dq_zero_kernel, dim3(grid_cap((n4 + 255) / 256, 4096)), dim3(256), 0, stream, acc, n4);
+        // which (batch, head) pairs accumulate inside ONE XCD's L2 (adds without scope bits): as many complete groups of 8 as there are;
+        // ARIA_ATTN_DQ_SCOPE=agent: none (every add carries device scope; A/B measurements)
+        const char* sc = std::getenv("ARIA_ATTN_DQ_SCOPE");
+        const int n_excl = (sc && sc[0] == 'a') ? 0 : int((H * B) & ~7ll);
+        ARIA_LAUNCH((attn_bwd4_kernel<128>), dim3(256), dim3(512), size_t(Cfg4<128>::SMEM + 16), stream, Q, K, V, dO, lse, (const float*)delta,
+                    static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), acc, tickets, kv_len, key_mask, int(Sq), int(Skv), int(H),
+                    int(ldq), int(ldk), int(ldv), int(ldo), int(lddk), int(lddv), int(H * hd), scale, causal, int(B), n_excl);
+        const long long nch = B * Sq * (H * hd / 8);
+        ARIA_LAUNCH(attn_dq_round_kernel, dim3(grid_cap((nch + 255) / 256, 8192)), dim3(256), 0, stream, (const float*)acc,
+                    static_cast<bf16_t*>(dq), (long long)(B * Sq), int(H * hd), (long long)(H * hd), (long long)lddq);
+        g_last_bwd_variant = 4;
+        return aria_check_launch();
+    }
+    g_last_bwd_variant = (hd == 128 && !(old && old[0] == '2')) ? 3 : 2;
     if (hd == 128) {
         using C = Cfg<128>;
-        const char* old = std::getenv("ARIA_ATTN_BWD");  // "2": previous generation (A/B measurements)
         if (old && old[0] == '2')
             ARIA_LAUNCH((attn_bwd2_dkdv_kernel<128>), gridk, block, size_t(4 * 64 * C::PITCH * 2 + 256 * 4), stream, Q, K, V, dO, lse,
                         (const float*)delta, static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), kv_len, key_mask, int(Sq), int(Skv),

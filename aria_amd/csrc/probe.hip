@@ -16,8 +16,47 @@ __global__ void probe_tr16_kernel(unsigned short* out, int mode) {
     s16x4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(lds + off));
     for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)v[j];
 }
+
+// ---- L2-scope fp32 atomics (the single-pass attention backward accumulates dQ with them) -----------------------------------------------
+// Every workgroup (256 threads) adds 1.0f `iters` times to every float of ITS region; a wave instruction covers 2 rows of 32 consecutive
+// floats (128 bytes each, `row_stride` floats apart) -- the access shape of an MFMA accumulator tile added to a row-major fp32 matrix.
+//   region of workgroup b:  region_mode 0: b & 7 (= the XCD under round-robin placement: each region is touched by ONE XCD only)
+//                           region_mode 1: b (private region)      region_mode 2: 0 (everybody, all XCDs)
+//   scope 0: no sc bits (performed in the issuing XCD's L2)   scope 1: sc1 (agent scope)
+// xcc[b] = HW_REG_XCC_ID of the workgroup (verifies the placement assumption).
+__global__ __launch_bounds__(256) void probe_atomic_kernel(float* buf, int* xcc, long long region_floats, int region_mode, int scope,
+                                                           int iters, int row_stride) {
+    const int b = blockIdx.x, t = threadIdx.x, l = t & 63, w = t >> 6;
+    if (t == 0) xcc[b] = int(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)));  // HW_REG_XCC_ID, bits [3:0]
+    const long long region = region_mode == 0 ? (b & 7) : region_mode == 1 ? b : 0;
+    float* base = buf + region * region_floats;
+    const long long rows = region_floats / row_stride;  // rows of `row_stride` floats; the first 128 floats of a row are used
+    for (int it = 0; it < iters; ++it)
+        for (long long r0 = 2 * w; r0 < rows; r0 += 8)
+            for (int c0 = 0; c0 < 128; c0 += 32) {
+                float* p = base + (r0 + (l >> 5)) * row_stride + c0 + (l & 31);
+                const float one = 1.0f;
+                if (scope == 0)
+                    asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(p), "v"(one) : "memory");
+                else
+                    asm volatile("global_atomic_add_f32 %0, %1, off sc1" ::"v"(p), "v"(one) : "memory");
+            }
+}
 }  // namespace
 #endif
+
+extern "C" int aria_probe_atomic(float* buf, int* xcc, int64_t nblocks, int64_t region_floats, int region_mode, int scope, int iters,
+                                 int row_stride, void* stream) {
+#ifdef ARIA_EMU
+    (void)buf; (void)xcc; (void)nblocks; (void)region_floats; (void)region_mode; (void)scope; (void)iters; (void)row_stride; (void)stream;
+    return ARIA_ERR_UNSUPPORTED;
+#else
+    if (!buf || !xcc || nblocks <= 0 || row_stride < 128 || region_floats % row_stride) return ARIA_ERR_INVALID;
+    hipLaunchKernelGGL(probe_atomic_kernel, dim3(unsigned(nblocks)), dim3(256), 0, static_cast<hipStream_t>(stream), buf, xcc,
+                       (long long)region_floats, region_mode, scope, iters, row_stride);
+    return aria_check_launch();
+#endif
+}
 
 extern "C" int aria_probe_tr16(void* out, int mode, void* stream) {
 #ifdef ARIA_EMU

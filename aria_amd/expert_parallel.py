@@ -179,12 +179,17 @@ def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w
     local_in = GatherRowsFn.apply(rows, order, inverse)
     local_off = torch.zeros(El + 1, dtype=torch.int32, device=x.device)
     local_off[1:] = torch.cumsum(rcd.sum(0), 0).to(torch.int32)
-    h1 = AG.ExpertsGemmFn.apply(local_in, fc1_local, local_off)
-    eo_local = AG.ExpertsGemmFn.apply(AG.SwiGLUFn.apply(h1), fc2_local, local_off)
+    if ops.glu_fusable(fc1_local.shape[1], fc1_local.shape[2]):                    # fc1 + glu in one launch, as on the local path
+        act = AG.ExpertsGluFn.apply(local_in, fc1_local, local_off)
+    else:
+        act = AG.SwiGLUFn.apply(AG.ExpertsGemmFn.apply(local_in, fc1_local, local_off))
+    eo_local = AG.ExpertsGemmFn.apply(act, fc2_local, local_off)
     back = GatherRowsFn.apply(eo_local, inverse, order)                            # (source rank, local expert) order again
     eo = AllToAllRowsFn.apply(back, recv_splits, send_splits, group)               # my rows, original expert-major order
     # shared expert (replicated) and weighted combine
-    I2 = gate_w.shape[0]
-    gu = torch.cat([AG.linear(x, gate_w), AG.linear(x, up_w)], dim=-1)
-    sh = AG.linear(AG.SwiGLUFn.apply(gu), down_w)
+    if ops.glu_fusable(x.shape[1], 2 * gate_w.shape[0]):                           # gate || up as one GEMM with the SwiGLU epilogue
+        sact = AG.SharedGluFn.apply(x, gate_w, up_w)
+    else:
+        sact = AG.SwiGLUFn.apply(torch.cat([AG.linear(x, gate_w), AG.linear(x, up_w)], dim=-1))
+    sh = AG.linear(sact, down_w)
     return UnpermuteFn.apply(eo, inv, scores, sh, k)

@@ -23,13 +23,15 @@ ERRORS = {
 
 P, I64, I32, F32 = c_void_p, c_int64, c_int, c_float
 RESTYPES = {"aria_gemm_workspace_bytes": c_int64, "aria_decode_scratch_bytes": c_int64, "aria_decode_graph_create": c_void_p,
-            "aria_decode_graph_destroy": None, "aria_decode_attn_workspace_bytes": c_int64}  # everything else returns an int status
+            "aria_decode_graph_destroy": None, "aria_decode_attn_workspace_bytes": c_int64,
+            "aria_attn_bwd_workspace_bytes": c_int64}  # everything else returns an int status
 
 # name -> argtypes (all return int).  Kept in one table so tests can check that the shared
 # library exports every symbol the header declares.
 SIGNATURES = {
     "aria_abi_version": [],
     "aria_last_gemm_variant": [],
+    "aria_last_attn_bwd_variant": [],
     "aria_decode_scratch_bytes": [P],
     "aria_decode_token": [P, P, F32, P],
     "aria_decode_attn_workspace_bytes": [I64, I64, I64],
@@ -64,6 +66,8 @@ SIGNATURES = {
     "aria_add_bf16": [P, P, P, I64, P],
     "aria_attn_fwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
     "aria_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
+    "aria_attn_bwd_ws": [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P, I64, P],
+    "aria_attn_bwd_workspace_bytes": [I64, I64, I64, I64],
     "aria_layernorm_fwd": [P, P, P, P, P, P, I64, I64, F32, P],
     "aria_layernorm_bwd": [P, P, P, P, P, P, P, P, I64, I64, I64, P],
     "aria_gelu_tanh_fwd": [P, P, I64, P],
@@ -75,6 +79,7 @@ SIGNATURES = {
     "aria_colsum_bf16": [P, P, I64, I64, I64, I64, P],
     "aria_cross_entropy": [P, P, P, P, P, F32, P, I64, I64, I64, P],
     "aria_probe_tr16": [P, I32, P],
+    "aria_probe_atomic": [P, P, I64, I64, I32, I32, I32, I32, P],
 }
 
 

@@ -475,7 +475,9 @@ def attention_fwd(q, k, v, B: int, S: int, H: int, hd: int, scale: float, causal
 
 def attention_bwd(q, k, v, o, do, lse, B: int, S: int, H: int, hd: int, scale: float, causal: bool,
                   kv_len: Optional[torch.Tensor] = None, dq=None, dk=None, dv=None, key_mask: Optional[torch.Tensor] = None,
-                  Skv: Optional[int] = None):
+                  Skv: Optional[int] = None, deterministic: Optional[bool] = None):
+    """``deterministic`` (default: ``torch.are_deterministic_algorithms_enabled()``): the two-kernel backward (7 GEMM units, bit-reproducible);
+    otherwise, where it exists (hd 128), the single-pass form that accumulates dQ with fp32 adds (5 GEMM units)."""
     dev = q.device
     Skv = S if Skv is None else Skv
     if dq is None:
@@ -485,10 +487,18 @@ def attention_bwd(q, k, v, o, do, lse, B: int, S: int, H: int, hd: int, scale: f
     if dv is None:
         dv = torch.empty((B * Skv, H * hd), dtype=bf16, device=dev)
     delta = torch.empty((B, H, S), dtype=torch.float32, device=dev)
-    hip.get_lib().call("aria_attn_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(kv_len),
-                       _p(key_mask), B, S, Skv, H, hd, _rowmajor_2d(q, "q"), _rowmajor_2d(k, "k"), _rowmajor_2d(v, "v"),
-                       _rowmajor_2d(o, "o"), _rowmajor_2d(dq, "dq"), _rowmajor_2d(dk, "dk"), _rowmajor_2d(dv, "dv"), float(scale),
-                       int(causal), _stream(q))
+    lib = hip.get_lib()
+    if deterministic is None:
+        deterministic = torch.are_deterministic_algorithms_enabled()
+    ws, ws_bytes = None, 0
+    if not deterministic:
+        ws_bytes = int(lib.cdll.aria_attn_bwd_workspace_bytes(B, S, H, hd))
+        if ws_bytes:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    lib.call("aria_attn_bwd_ws", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(kv_len),
+             _p(key_mask), B, S, Skv, H, hd, _rowmajor_2d(q, "q"), _rowmajor_2d(k, "k"), _rowmajor_2d(v, "v"),
+             _rowmajor_2d(o, "o"), _rowmajor_2d(dq, "dq"), _rowmajor_2d(dk, "dk"), _rowmajor_2d(dv, "dv"), float(scale),
+             int(causal), _p(ws), ws_bytes, _stream(q))
     return dq, dk, dv
 
 

@@ -236,11 +236,15 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.ep:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:  # --ep on one GPU: a one-rank RCCL group, so that the expert-parallel code path (all-to-all dispatch / combine on RCCL,
+            os.environ.setdefault("MASTER_PORT", "29531")   # _ep_local shards) runs on hardware even without a second GPU
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line would not measure what it names")
     if world > 1:
@@ -269,7 +273,7 @@ def main():
     init_params(model, seed=0)  # same weights on every rank (DP replicas)
     model.train()
     model.freeze_vit()          # recipes/config_full.yaml:39-42: ViT frozen, projector + LLM trainable
-    if args.ep and world > 1:
+    if args.ep:
         model.enable_expert_parallel()  # every rank built the same 64 experts (same seed) and keeps its 64 / N
     sync = GradSync(model, overlap=not args.no_overlap, mode="all_reduce" if args.allreduce else "reduce_scatter") if world > 1 else None
 
@@ -416,7 +420,7 @@ def main():
                                    "trainable projector (256 tok/img) -> 28-layer MoE decoder (64 experts top-6, D=2560, V=100352) "
                                    "fwd+bwd incl. lm_head+CE and router aux-loss grads",
                        "layers": args.layers, "vit_layers": args.vit_layers, "images_per_sample": n_img, "global_batch": world * B, "seq_len": S,
-                       "parallelism": (f"dp{world}+ep{world}" if args.ep else f"dp{world}") if world > 1 else "single",
+                       "parallelism": (f"dp{world}+ep{world}" if args.ep else f"dp{world}") if world > 1 else ("single+ep1" if args.ep else "single"),
                        "grad_exchange": None if world == 1 else ("all_reduce" if args.allreduce else "reduce_scatter (ZeRO-2)"), "grad_checkpointing": bool(args.recompute),
                        "optimizer_in_step": False,  # metric = fwd+bwd; AdamW state (299 GB fp32) only exists sharded over >= 2 GPUs
                        "loss": round(float(loss), 4)},
@@ -442,7 +446,7 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
                                        "sample": f"failed: {type(ex).__name__}: {ex}"}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or args.ep:
         import torch.distributed as dist
 
         dist.destroy_process_group()
