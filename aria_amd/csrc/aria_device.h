@@ -271,6 +271,21 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
 #endif
 }
+// The same DMA issued as the kernel's OWN instruction (inline assembly): hipcc cannot tell a later LDS read from the piece's pending LDS
+// write and puts `s_waitcnt vmcnt(0)` in front of every LDS read that follows a __builtin_amdgcn_global_load_lds -- a complete drain of
+// the prefetch at its first consumer.  Invisible to the compiler's counters, the piece stays in flight until the caller's wait_vm<N>().
+// (Compiler-issued loads stay correct next to it: a counted wait only ever waits longer when more operations are outstanding.)
+__device__ __forceinline__ void glds16_raw(const void* g, void* lds_wave_base) {
+#ifdef ARIA_EMU
+    emu::glds(g, static_cast<char*>(lds_wave_base) + 16 * emu::lane());
+#else
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    const uint32_t lds = __builtin_amdgcn_readfirstlane(uint32_t(reinterpret_cast<uintptr_t>(lds_wave_base)));
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory", "m0");
+#pragma clang diagnostic pop
+#endif
+}
 // wait until at most N of this wave's VMEM operations (LDS-DMA pieces included) are still outstanding
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -318,6 +333,14 @@ template <class T>
 __device__ __forceinline__ void settle(const T& v) {
 #ifndef ARIA_EMU
     asm volatile("" ::"v"(v));
+#endif
+}
+// The opposite of settle(): keep the compiler from touching `v` (hoisting arithmetic on it, and with it the wait for the load that
+// produced it) before this point -- the value passes through an empty asm that "modifies" it.
+template <class T>
+__device__ __forceinline__ void hold(T& v) {
+#ifndef ARIA_EMU
+    asm volatile("" : "+v"(v));
 #endif
 }
 __device__ __forceinline__ void sched_fence() {

@@ -731,7 +731,7 @@ __device__ __forceinline__ void tile_dma3(const bf16_t* base, int ld, int row0, 
     for (int si = 0; si < 2; ++si) {
         const int pc = w + 8 * si;
         const int row = min(row0 + 4 * pc + (l >> 4), row_last);
-        glds16(base + (long long)row * ld + ch * 8, s + pc * 1024);
+        glds16_raw(base + (long long)row * ld + ch * 8, s + pc * 1024);
     }
 }
 // row fragment: row `row`, reduction indices 16 kk + 8 (l >> 5) + 0..7
@@ -1096,14 +1096,13 @@ struct Cfg4 {
     static constexpr int SMEM = 4 * C3::TILE + 2 * 2 * 64 * 4 + 4 * 8 * 1024 + 128 * DSP + 2 * C3::TILE;  // ... + the block's K rows
 };
 
-// one (key block, head, batch) item; `agent`: the adds carry device scope (the item may run on any XCD) -- otherwise the caller guarantees
-// that every item of this (batch, head) runs on the XCD this workgroup is on
+// one (key block, head, batch) item
 template <int HD>
 __device__ __forceinline__ void attn_bwd4_item(char* smem, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
                                                const float* LSE, const float* DELTA, bf16_t* dK, bf16_t* dV, float* dQacc,
                                                const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H, int ldq,
                                                int ldk, int ldv, int lddo, int lddk, int lddv,
-                                               int lddqa, float scale, int causal, int kblk, int head, int b, bool agent) {
+                                               int lddqa, float scale, int causal, int kblk, int head, int b) {
     using C = Cfg3<HD>;
     using C4 = Cfg4<HD>;
     static_assert(HD == 128, "the dQ tile split (2 x 4 tiles of 32 x 32 over 8 waves) is written for hd 128");
@@ -1165,9 +1164,10 @@ __device__ __forceinline__ void attn_bwd4_item(char* smem, const bf16_t* Q, cons
     // dQ[tile at q0] += dS K for the pairs that were active on it (their rows of the dS image are valid)
     auto dq_tile = [&](int q0) {
         f32x16 dq = zero_acc();
+        const bool all_pairs = !(causal && kv0 + 96 > q0 + 63);  // wave-uniform; false only on the block's two diagonal tiles
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-            if (causal && kv0 + 32 * (kk >> 1) > q0 + 63) continue;  // wave-uniform: pair kk / 2 sat this tile out
+            if (!all_pairs && kv0 + 32 * (kk >> 1) > q0 + 63) continue;  // pair kk / 2 sat this tile out
             const char* p = ds_frag + 16 * kk * C4::DSP;
             const s16x4 a0 = ds_read_tr16(reinterpret_cast<const bf16_t*>(p));
             const s16x4 a1 = ds_read_tr16(reinterpret_cast<const bf16_t*>(p + 8 * C4::DSP));
@@ -1180,15 +1180,15 @@ __device__ __forceinline__ void attn_bwd4_item(char* smem, const bf16_t* Q, cons
             dq = mfma32(f, frag_tr3<HD>(sK + (kk >> 2) * C::TILE, (kk & 3) * 16, 32 * ft_w, l), dq);
         }
         float* base = dq_lane + (long long)q0 * lddqa;
-        const int qrow = q0 + 32 * qt_w + 4 * h2;
+        if (q0 + 64 <= Sq) {  // (wave-uniform) every row of the tile exists: sixteen adds, no branches
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dr = (r & 3) + 8 * (r >> 2);
-            if (qrow + dr < Sq) {
-                if (agent)
-                    atomic_add_f32_noret<true>(base + (long long)dr * lddqa, dq[r]);
-                else
-                    atomic_add_f32_noret<false>(base + (long long)dr * lddqa, dq[r]);
+            for (int r = 0; r < 16; ++r) atomic_add_f32_noret<true>(base + (long long)((r & 3) + 8 * (r >> 2)) * lddqa, dq[r]);
+        } else {  // the sequence's last tile
+            const int qrow = q0 + 32 * qt_w + 4 * h2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                if (qrow + dr < Sq) atomic_add_f32_noret<true>(base + (long long)dr * lddqa, dq[r]);
             }
         }
     };
@@ -1212,6 +1212,14 @@ __device__ __forceinline__ void attn_bwd4_item(char* smem, const bf16_t* Q, cons
         if (more) {  // next tile straight into the other buffer (its last readers finished before the barrier)
             tile_dma3<HD>(Qb, ldq, qt0 + 64, Sq - 1, sQ + (cur ^ 1) * C::TILE, w, l);
             tile_dma3<HD>(dOb, lddo, qt0 + 64, Sq - 1, sdO + (cur ^ 1) * C::TILE, w, l);
+        }
+        // next tile's statistics: fetched now (clamped index, no arithmetic on the value: the compiler waits at the first USE), parked in LDS
+        // at the end of the iteration -- a load issued there would hold wave 0, and with it the barrier, for a memory round trip
+        float lse_n = 0.f, del_n = 0.f;
+        if (more && t < 64) {
+            const int qn = min(qt0 + 64 + t, Sq - 1);
+            lse_n = lseb[qn];
+            del_n = delb[qn];
         }
         if (it > 0) dq_tile(qt0 - 64);
         const char* cQ = sQ + cur * C::TILE;
@@ -1279,9 +1287,11 @@ __device__ __forceinline__ void attn_bwd4_item(char* smem, const bf16_t* Q, cons
                 }
         }
         if (more && t < 64) {
-            const int nb = cur ^ 1, q = qt0 + 64 + t;
-            sLse[nb * 64 + t] = q < Sq ? lseb[q] * 1.4426950408889634f : 0.f;
-            sDel[nb * 64 + t] = q < Sq ? delb[q] : 0.f;
+            hold(lse_n);
+            hold(del_n);
+            const bool ok = qt0 + 64 + t < Sq;
+            sLse[(cur ^ 1) * 64 + t] = ok ? lse_n * 1.4426950408889634f : 0.f;
+            sDel[(cur ^ 1) * 64 + t] = ok ? del_n : 0.f;
         }
     }
     if (ntiles > 0) {
@@ -1300,51 +1310,20 @@ __device__ __forceinline__ void attn_bwd4_item(char* smem, const bf16_t* Q, cons
         }
 }
 
-// Persistent scheduler around attn_bwd4_item.  The first n_excl (a multiple of 8) (batch, head) pairs are XCD-EXCLUSIVE: pair p belongs to
-// XCD p % 8 and only workgroups that find themselves on that XCD (HW_REG_XCC_ID -- not an assumption about placement) take its key blocks,
-// from a per-XCD ticket counter; their dQ adds are performed in that XCD's L2.  The remaining pairs (H B not a multiple of 8, or
-// n_excl = 0) sit in one global queue any workgroup pulls from once its own XCD's queue is empty; their adds carry device scope.
-// Both queues hand out key blocks longest first (causal: block 0 sees every query).  tickets: 9 counters, 64 bytes apart, zeroed.
+// One workgroup per (key block, head, batch), longest key blocks first (attn_block_coords).  The adds carry device scope: measured on
+// MI355X (profiles/r03_l2_atomics.json) global_atomic_add_f32 retires at the same ~330 G adds/s with or without scope bits, XCD-local or
+// not -- there is no cheaper XCD-local form to schedule for.
 template <int HD>
 __global__ __launch_bounds__(512) void attn_bwd4_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
                                                         const float* LSE, const float* DELTA, bf16_t* dK, bf16_t* dV, float* dQacc,
-                                                        int* tickets, const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
+                                                        const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
                                                         int ldq, int ldk, int ldv, int lddo, int lddk, int lddv, int lddqa, float scale,
-                                                        int causal, int nbatch, int n_excl) {
+                                                        int causal, int nbatch) {
     ARIA_DYN_SMEM(smem);
-    int* sItem = reinterpret_cast<int*>(smem + Cfg4<HD>::SMEM);
-    const int nkb = (S + 127) / 128, nbh = H * nbatch, xcd = xcc_id() & 7;
-    const int per_xcd = n_excl >> 3, n_rem = nbh - n_excl;
-    const int n_local = per_xcd * nkb, n_global = n_rem * nkb;
-    for (;;) {
-        sync();  // every wave is done with the previous item's LDS (and with sItem)
-        if (threadIdx.x == 0) {
-            int item = -1;
-            if (n_local > 0) {
-                const int j = atomic_add(tickets + 16 * xcd, 1);
-                if (j < n_local) item = j;
-            }
-            if (item < 0 && n_global > 0) {
-                const int j = atomic_add(tickets + 16 * 8, 1);
-                if (j < n_global) item = n_local + j;
-            }
-            *sItem = item;
-        }
-        sync();
-        const int item = first_lane(*sItem);
-        if (item < 0) return;
-        int bh, kblk;
-        const bool agent = item >= n_local;
-        if (!agent) {
-            bh = xcd + 8 * (item % per_xcd);
-            kblk = item / per_xcd;
-        } else {
-            bh = n_excl + (item - n_local) % n_rem;
-            kblk = (item - n_local) / n_rem;
-        }
-        attn_bwd4_item<HD>(smem, Q, K, V, dO, LSE, DELTA, dK, dV, dQacc, kv_len, key_mask, Sq, S, H, ldq, ldk, ldv, lddo, lddk, lddv, lddqa,
-                           scale, causal, kblk, bh % H, bh / H, agent);
-    }
+    int kblk, head, b;
+    if (!attn_block_coords((S + 127) / 128, H, nbatch, causal, false, kblk, head, b)) return;  // key block 0 is the longest
+    attn_bwd4_item<HD>(smem, Q, K, V, dO, LSE, DELTA, dK, dV, dQacc, kv_len, key_mask, Sq, S, H, ldq, ldk, ldv, lddo, lddk, lddv, lddqa, scale,
+                       causal, kblk, head, b);
 }
 
 // fp32 image -> bf16 rows (and the zero fill in front of the accumulation)
@@ -1409,7 +1388,7 @@ int aria_last_attn_bwd_variant(void) { return g_last_bwd_variant; }
 
 int64_t aria_attn_bwd_workspace_bytes(int64_t B, int64_t Sq, int64_t H, int64_t hd) {
     if (hd != 128 || B <= 0 || Sq <= 0 || H <= 0) return 0;  // the single-pass form exists for hd 128 (the decoder's heads)
-    return B * Sq * H * hd * 4 + ARIA_ATTN_BWD_TICKET_BYTES;
+    return B * Sq * H * hd * 4;
 }
 
 int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
@@ -1449,16 +1428,11 @@ int aria_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o,
         if ((reinterpret_cast<uintptr_t>(workspace) & 15) || (lddq & 7)) return ARIA_ERR_ALIGN;
         float* acc = static_cast<float*>(workspace);
         const long long n_acc = B * Sq * H * hd;
-        int* tickets = reinterpret_cast<int*>(acc + n_acc);
-        const long long n4 = (n_acc * 4 + ARIA_ATTN_BWD_TICKET_BYTES) / 16;
+        const long long n4 = n_acc / 4;
         ARIA_LAUNCH(attn_dq_zero_kernel, dim3(grid_cap((n4 + 255) / 256, 4096)), dim3(256), 0, stream, acc, n4);
-        // which (batch, head) pairs accumulate inside ONE XCD's L2 (adds without scope bits): as many complete groups of 8 as there are;
-        // ARIA_ATTN_DQ_SCOPE=agent: none (every add carries device scope; A/B measurements)
-        const char* sc = std::getenv("ARIA_ATTN_DQ_SCOPE");
-        const int n_excl = (sc && sc[0] == 'a') ? 0 : int((H * B) & ~7ll);
-        ARIA_LAUNCH((attn_bwd4_kernel<128>), dim3(256), dim3(512), size_t(Cfg4<128>::SMEM + 16), stream, Q, K, V, dO, lse, (const float*)delta,
-                    static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), acc, tickets, kv_len, key_mask, int(Sq), int(Skv), int(H),
-                    int(ldq), int(ldk), int(ldv), int(ldo), int(lddk), int(lddv), int(H * hd), scale, causal, int(B), n_excl);
+        ARIA_LAUNCH((attn_bwd4_kernel<128>), dim3(attn_grid((Skv + 127) / 128, H, B)), dim3(512), size_t(Cfg4<128>::SMEM), stream, Q, K, V, dO,
+                    lse, (const float*)delta, static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), acc, kv_len, key_mask, int(Sq), int(Skv),
+                    int(H), int(ldq), int(ldk), int(ldv), int(ldo), int(lddk), int(lddv), int(H * hd), scale, causal, int(B));
         const long long nch = B * Sq * (H * hd / 8);
         ARIA_LAUNCH(attn_dq_round_kernel, dim3(grid_cap((nch + 255) / 256, 8192)), dim3(256), 0, stream, (const float*)acc,
                     static_cast<bf16_t*>(dq), (long long)(B * Sq), int(H * hd), (long long)(H * hd), (long long)lddq);

@@ -475,9 +475,11 @@ def attention_fwd(q, k, v, B: int, S: int, H: int, hd: int, scale: float, causal
 
 def attention_bwd(q, k, v, o, do, lse, B: int, S: int, H: int, hd: int, scale: float, causal: bool,
                   kv_len: Optional[torch.Tensor] = None, dq=None, dk=None, dv=None, key_mask: Optional[torch.Tensor] = None,
-                  Skv: Optional[int] = None, deterministic: Optional[bool] = None):
-    """``deterministic`` (default: ``torch.are_deterministic_algorithms_enabled()``): the two-kernel backward (7 GEMM units, bit-reproducible);
-    otherwise, where it exists (hd 128), the single-pass form that accumulates dQ with fp32 adds (5 GEMM units)."""
+                  Skv: Optional[int] = None, single_pass: Optional[bool] = None):
+    """Default: the deterministic two-kernel backward (7 GEMM units of S x S x hd per head).  ``single_pass`` (default: ARIA_ATTN_BWD=4 in the
+    environment; hd 128 only): one pass that adds each key block's share of dQ to an fp32 image (5 GEMM units) -- measured on MI355X the
+    chip retires ~330 G fp32 atomic adds per second however they are scoped or spread (profiles/r03_l2_atomics.json), which bounds that
+    form at > 130 ms per layer at S = 65 536 against 96 ms for the two kernels: it is kept for measurement, not as the default."""
     dev = q.device
     Skv = S if Skv is None else Skv
     if dq is None:
@@ -488,10 +490,12 @@ def attention_bwd(q, k, v, o, do, lse, B: int, S: int, H: int, hd: int, scale: f
         dv = torch.empty((B * Skv, H * hd), dtype=bf16, device=dev)
     delta = torch.empty((B, H, S), dtype=torch.float32, device=dev)
     lib = hip.get_lib()
-    if deterministic is None:
-        deterministic = torch.are_deterministic_algorithms_enabled()
+    if single_pass is None:
+        import os
+
+        single_pass = os.environ.get("ARIA_ATTN_BWD") == "4"
     ws, ws_bytes = None, 0
-    if not deterministic:
+    if single_pass:
         ws_bytes = int(lib.cdll.aria_attn_bwd_workspace_bytes(B, S, H, hd))
         if ws_bytes:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

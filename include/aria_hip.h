@@ -203,13 +203,13 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
 
 /* aria_attn_bwd with a caller-owned workspace: the SINGLE-PASS backward (hd 128, the decoder's heads).  The two-kernel form above runs
  * 7 GEMM units of S x S x hd per head (S and dP are computed once for dK/dV and once more for dQ); with a workspace of
- * aria_attn_bwd_workspace_bytes() bytes (16-byte aligned; fp32 image of dQ [B*Sq, H*hd] + scheduler tickets) one kernel per 128-key block
- * computes S / dP once and produces dK, dV and the block's share of dQ, which it adds to the fp32 image (global_atomic_add_f32; pairs of
- * (batch, head) are pinned to one XCD each so that the adds stay in that XCD's L2) -- the 5 GEMM units of the algorithm, i.e. what the
- * reference's flash-attn backward executes (aria/model/configuration_aria.py:78-100 selects flash_attention_2).  dQ's fp32 summation ORDER
- * then depends on the schedule: results are not bit-reproducible run to run.  workspace == NULL (or too small, or a head dim without the
- * single-pass kernel: aria_attn_bwd_workspace_bytes() == 0) selects the deterministic two-kernel form. */
-#define ARIA_ATTN_BWD_TICKET_BYTES 1024
+ * aria_attn_bwd_workspace_bytes() bytes (16-byte aligned; the fp32 image of dQ [B*Sq, H*hd]) one kernel per 128-key block computes
+ * S / dP once and produces dK, dV and the block's share of dQ, which it adds to the fp32 image (global_atomic_add_f32, device scope) --
+ * the 5 GEMM units of the algorithm, i.e. what the reference's flash-attn backward executes (aria/model/configuration_aria.py:78-100
+ * selects flash_attention_2).  dQ's fp32 summation ORDER then depends on the schedule: not bit-reproducible run to run.  MEASURED on
+ * MI355X: the chip retires ~330 G fp32 atomic adds per second (profiles/r03_l2_atomics.json), which makes this form slower than the two
+ * kernels at every sequence length of the model -- it is a measurement path, not the default.  workspace == NULL (or too small, or a
+ * head dim without the single-pass kernel: aria_attn_bwd_workspace_bytes() == 0) selects the deterministic two-kernel form. */
 int aria_last_attn_bwd_variant(void); /* which backward the calling thread's last aria_attn_bwd(_ws) ran: 2 / 3 two kernels, 4 single pass */
 int64_t aria_attn_bwd_workspace_bytes(int64_t B, int64_t Sq, int64_t H, int64_t hd);
 int aria_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,

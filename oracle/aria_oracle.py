@@ -367,12 +367,13 @@ class _StreamedCausalAttention(torch.autograd.Function):
     def forward(ctx, q, k, v, scale, block):
         B, H, S, hd = q.shape
         o = torch.empty_like(q)
+        tri = torch.ones(min(block, S), min(block, S), dtype=torch.bool).triu(1)  # key j > query i inside the diagonal block
         for b in range(B):
             for h in range(H):
                 for q0 in range(0, S, block):
                     q1 = min(S, q0 + block)
-                    att = (q[b, h, q0:q1] @ k[b, h, :q1].t()) * scale
-                    att.masked_fill_(torch.arange(q1)[None, :] > torch.arange(q0, q1)[:, None], float("-inf"))
+                    att = (q[b, h, q0:q1] @ k[b, h, :q1].t()).mul_(scale)
+                    att[:, q0:q1].masked_fill_(tri[: q1 - q0, : q1 - q0], float("-inf"))  # keys before q0 are visible to every row of the block
                     o[b, h, q0:q1] = torch.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype) @ v[b, h, :q1]
         ctx.save_for_backward(q, k, v, o)
         ctx.scale, ctx.block = scale, block
@@ -384,19 +385,20 @@ class _StreamedCausalAttention(torch.autograd.Function):
         scale, block = ctx.scale, ctx.block
         B, H, S, hd = q.shape
         dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        tri = torch.ones(min(block, S), min(block, S), dtype=torch.bool).triu(1)
         for b in range(B):
             for h in range(H):
                 for q0 in range(0, S, block):
                     q1 = min(S, q0 + block)
                     qb, dob = q[b, h, q0:q1], do[b, h, q0:q1]
-                    att = (qb @ k[b, h, :q1].t()) * scale
-                    att.masked_fill_(torch.arange(q1)[None, :] > torch.arange(q0, q1)[:, None], float("-inf"))
+                    att = (qb @ k[b, h, :q1].t()).mul_(scale)
+                    att[:, q0:q1].masked_fill_(tri[: q1 - q0, : q1 - q0], float("-inf"))
                     p = torch.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype)
                     del att
                     dv[b, h, :q1] += p.t() @ dob
                     dp = dob @ v[b, h, :q1].t()
                     delta = (dob * o[b, h, q0:q1]).sum(dim=-1, keepdim=True)
-                    ds = p * (dp - delta) * scale
+                    ds = dp.sub_(delta).mul_(p).mul_(scale)
                     del p, dp
                     dq[b, h, q0:q1] = ds @ k[b, h, :q1]
                     dk[b, h, :q1] += ds.t() @ qb

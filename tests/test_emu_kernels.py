@@ -79,24 +79,24 @@ def test_attention_fwd_bwd(B, S, H, hd, causal, use_len):
     C.case_attention(DEV, B, S, H, hd, causal, use_len)
 
 
-@pytest.mark.parametrize("B,S,H,causal,use_len,defer", [(1, 200, 9, True, False, "0"), (2, 150, 8, False, True, "1"), (3, 70, 1, True, False, "1"),
-                                                        (1, 300, 17, True, False, "0")])
-def test_attention_bwd_single_pass_scheduler(B, S, H, causal, use_len, defer, monkeypatch):
-    """The single-pass backward's persistent scheduler: (batch, head) pairs in complete groups of 8 are XCD-exclusive (per-XCD tickets, adds
-    without scope bits), the rest comes from the global queue (device-scope adds) -- 9 / 16 / 3 / 17 pairs cover both queues alone and
-    mixed; LDS-DMA of the Q / dO tiles under both landing models."""
+@pytest.mark.parametrize("B,S,H,causal,use_len,defer", [(1, 200, 3, True, False, "0"), (2, 150, 2, False, True, "1"), (3, 70, 1, True, False, "1")])
+def test_attention_bwd_single_pass(B, S, H, causal, use_len, defer, monkeypatch):
+    """The single-pass backward (dK, dV and the key block's share of dQ from one S / dP computation, fp32 adds into the dQ image; LDS-DMA
+    of the Q / dO tiles under both landing models) against the fp32 reference."""
     monkeypatch.setenv("ARIA_EMU_GLDS_DEFER", defer)
-    C.case_attention(DEV, B, S, H, 128, causal, use_len)
+    C.case_attention(DEV, B, S, H, 128, causal, use_len, single_pass=True)
 
 
-def test_attention_bwd_all_device_scope(monkeypatch):
-    monkeypatch.setenv("ARIA_ATTN_DQ_SCOPE", "agent")
-    C.case_attention(DEV, 1, 140, 9, 128, True, False)
+def test_attention_bwd_single_pass_selected_by_environment(monkeypatch):
+    from aria_amd import hip, ops
 
+    monkeypatch.setenv("ARIA_ATTN_BWD", "4")
+    import torch
 
-@pytest.mark.parametrize("B,S,H,causal", [(1, 130, 1, True), (2, 200, 2, False)])
-def test_attention_bwd_deterministic_mode_is_the_two_kernel_form(B, S, H, causal):
-    C.case_attention(DEV, B, S, H, 128, causal, False, deterministic=True)
+    q = torch.randn(70, 3 * 128).bfloat16()
+    o, lse = ops.attention_fwd(q[:, :128], q[:, 128:256], q[:, 256:], 1, 70, 1, 128, 0.1, True)
+    ops.attention_bwd(q[:, :128], q[:, 128:256], q[:, 256:], o, o, lse, 1, 70, 1, 128, 0.1, True)
+    assert int(hip.get_lib().cdll.aria_last_attn_bwd_variant()) == 4
 
 
 @pytest.mark.parametrize("B,Sq,Skv,H,hd", [(2, 40, 150, 2, 64), (1, 130, 70, 1, 128), (2, 40, 150, 2, 72), (1, 256, 300, 16, 72)])

@@ -60,6 +60,24 @@ def test_vit_attention_hd72_bwd_S4900_masked():
     F.case_vit_attention_bwd(DEV, "vit_attention_hd72_S4900", S=4900, H=2)
 
 
+SLOW = pytest.mark.skipif(os.environ.get("ARIA_SLOW_TESTS") != "1", reason="17 + 5 minutes of fp32 CPU oracle on the GPU box (20 heads of 64K x 64K "
+                          "attention): run with ARIA_SLOW_TESTS=1; measured results of the last run: profiles/r03_fullwidth_parity.json")
+
+
+def test_decoder_layer_aria_width_T16384_recompute():
+    """The always-on form of the long-sequence layer case: ONE full-width decoder layer at T = 16 384 (98 304 expert rows) with the recipe's
+    gradient checkpointing (selective: flash (o, lse) kept), block-wise oracle attention; loss and all 15 gradients."""
+    F.case_lm(DEV, "decoder_layer_T16384_recompute", hidden=2560, heads=20, experts=64, topk=6, inter=1664, vocab=2048, layers=1, B=1,
+              S=16384, expect_big_gemm=True, seed=8, recompute=True, eval_pass=False, stream_block=4096)
+
+
+def test_prefill_gptfast_16384_two_layers():
+    """The always-on form of the config #4 case: 16 384-token prefill through the gptfast surface, 2 full-width layers."""
+    F.case_prefill_gptfast(DEV, "prefill_gptfast_S16384", hidden=2560, heads=20, experts=64, topk=6, inter=1664, vocab=4096, layers=2,
+                           S=16384)
+
+
+@SLOW
 def test_decoder_layer_aria_width_T65536_recompute():
     """ONE decoder layer at T = 65 536 (393 216 expert rows; byte offsets beyond 2^31 in the grouped GEMMs) with the recipe's gradient
     checkpointing in its selective form (flash (o, lse) kept): loss and all 15 gradients of a 1-layer LM with a small vocabulary."""
@@ -67,6 +85,7 @@ def test_decoder_layer_aria_width_T65536_recompute():
               S=65536, expect_big_gemm=True, seed=7, recompute=True, eval_pass=False, stream_block=4096)
 
 
+@SLOW
 def test_config4_prefill_53248_two_layers():
     """BASELINE config #4: 53 248-token prefill through the gptfast surface, 2 full-width layers, last-position logits."""
     F.case_prefill_gptfast(DEV, "config4_prefill_S53248", hidden=2560, heads=20, experts=64, topk=6, inter=1664, vocab=4096, layers=2,
