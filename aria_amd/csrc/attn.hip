@@ -817,12 +817,21 @@ __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, co
         }
     }
     for (int it = 0; it < ntiles; ++it) {
+        wait_vm<0>();  // this wave's LDS-DMA pieces of tile `it` have landed
         sync();  // tile `it` is complete in buffer it & 1; the other buffer and the P exchange are free
         const int cur = it & 1, qt0 = q_begin + it * 64;
         const bool more = it + 1 < ntiles;
+        // next tile straight into the other buffer by LDS-DMA (its last readers finished before the barrier): no staging registers, no
+        // ds_write pass; issued as the kernel's own instruction so that the compiler does not drain it in front of the next LDS read
+        float lse_n = 0.f, del_n = 0.f;
         if (more) {
-            tile_load3<HD>(rq, Qb, ldq, qt0 + 64, Sq, t);
-            tile_load3<HD>(rdo, dOb, lddo, qt0 + 64, Sq, t);
+            tile_dma3<HD>(Qb, int(ldq), qt0 + 64, Sq - 1, sQ + (cur ^ 1) * C::TILE, w, l);
+            tile_dma3<HD>(dOb, int(lddo), qt0 + 64, Sq - 1, sdO + (cur ^ 1) * C::TILE, w, l);
+            if (t < 64) {  // the tile's statistics: fetched now, parked at the end of the iteration (a load issued there holds wave 0, and
+                const int qn = min(qt0 + 64 + t, Sq - 1);  // with it the barrier, for a memory round trip)
+                lse_n = lseb[qn];
+                del_n = delb[qn];
+            }
         }
         const char* cQ = sQ + cur * C::TILE;
         const char* cdO = sdO + cur * C::TILE;
@@ -883,15 +892,12 @@ __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, co
                     for (int dt = 0; dt < C::DT; ++dt) acc[dt] = mfma32(pf, frag_tr3<HD>(second, i * 32 + 16 * u, 32 * dt, l), acc[dt]);
                 }
         }
-        if (more) {
-            const int nb = cur ^ 1;
-            tile_store3<HD>(rq, sQ + nb * C::TILE, t);
-            tile_store3<HD>(rdo, sdO + nb * C::TILE, t);
-            if (t < 64) {
-                const int q = qt0 + 64 + t;
-                sLse[nb * 64 + t] = q < Sq ? lseb[q] * 1.4426950408889634f : 0.f;
-                sDel[nb * 64 + t] = q < Sq ? delb[q] : 0.f;
-            }
+        if (more && t < 64) {
+            hold(lse_n);
+            hold(del_n);
+            const bool ok = qt0 + 64 + t < Sq;
+            sLse[(cur ^ 1) * 64 + t] = ok ? lse_n * 1.4426950408889634f : 0.f;
+            sDel[(cur ^ 1) * 64 + t] = ok ? del_n : 0.f;
         }
     }
     bf16_t* out = role ? dK : dV;
@@ -978,12 +984,13 @@ __global__ __launch_bounds__(512) void attn_bwd3_dq_kernel(const bf16_t* Q, cons
         }
     }
     for (int it = 0; it < ntiles; ++it) {
+        wait_vm<0>();  // this wave's LDS-DMA pieces of tile `it` have landed
         sync();
         const int cur = it & 1, kv0 = it * 64;
         const bool more = it + 1 < ntiles;
-        if (more) {
-            tile_load3<HD>(rk, Kb, ldk, kv0 + 64, S, t);
-            tile_load3<HD>(rv, Vb, ldv, kv0 + 64, S, t);
+        if (more) {  // next K / V tile straight into the other buffers (rows past the sequence are clamped: those keys are masked)
+            tile_dma3<HD>(Kb, int(ldk), kv0 + 64, S - 1, sK + (cur ^ 1) * C::TILE, w, l);
+            tile_dma3<HD>(Vb, int(ldv), kv0 + 64, S - 1, sV + (cur ^ 1) * C::TILE, w, l);
         }
         const char* cK = sK + cur * C::TILE;
         const char* first = role ? sV + cur * C::TILE : cK;
@@ -1049,8 +1056,6 @@ __global__ __launch_bounds__(512) void attn_bwd3_dq_kernel(const bf16_t* Q, cons
         }
         if (more) {
             const int nb = cur ^ 1, kvn = kv0 + 64;
-            tile_store3<HD>(rk, sK + nb * C::TILE, t);
-            tile_store3<HD>(rv, sV + nb * C::TILE, t);
             if (kmb && t < 64) {
                 const uint8_t mv = (kvn + t < S) ? kmb[kvn + t] : 0;
                 sM[nb * 64 + t] = mv;
@@ -1069,6 +1074,152 @@ __global__ __launch_bounds__(512) void attn_bwd3_dq_kernel(const bf16_t* Q, cons
                 u32x2 v;
                 v[0] = pack2bf(acc[dt][4 * rg], acc[dt][4 * rg + 1]);
                 v[1] = pack2bf(acc[dt][4 * rg + 2], acc[dt][4 * rg + 3]);
+                *reinterpret_cast<u32x2*>(row + d0) = v;
+            }
+    }
+}
+
+
+// =========================================================================================== dQ v5 (hd = 128): no role split
+// bwd3's dQ kernel halves the feature columns between two waves that exchange P and dP through LDS (128 KiB of fp32 traffic and a second
+// barrier per key tile; 24 MFMAs per wave and tile against 40 KiB of LDS reads + 16 KiB of exchange).  With the key / value tiles brought
+// in by LDS-DMA there are no staging registers left in the loop, and ONE wave can hold the whole job for its 32 queries in < 256 VGPRs:
+// Q and dO fragments (32 + 32), S^T and dP^T score tiles (32 + 32), dQ^T accumulators for all 128 features (64).  So: 8 waves x 32 queries
+// = 256 queries per workgroup, per 64-key tile 16 + 16 + 16 MFMAs per wave against 48 KiB of fragment reads (1 KiB per MFMA, the ratio
+// of the forward kernel), no exchange, ONE barrier per tile.  Same arithmetic per element as bwd3 (bit-identical results).
+template <int HD>
+__global__ __launch_bounds__(512) void attn_bwd5_dq_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
+                                                           const float* LSE, const float* DELTA, bf16_t* dQ, const int32_t* kv_len,
+                                                           const uint8_t* key_mask, int Sq, int S, int H, int ldq, int ldk, int ldv,
+                                                           int lddo, int lddq, float scale, int causal, int nbatch) {
+    using C = Cfg3<HD>;
+    ARIA_DYN_SMEM(smem);
+    char* sK = smem;                                   // [2] tiles
+    char* sV = smem + 2 * C::TILE;                     // [2] tiles
+    uint8_t* sM = reinterpret_cast<uint8_t*>(smem + 4 * C::TILE);  // [2][64]
+    int* sFlag = reinterpret_cast<int*>(sM + 128);
+    const int t = threadIdx.x, l = t & 63, w = first_lane(t >> 6), h2 = l >> 5;
+    int qblk, head, b;
+    if (!attn_block_coords((Sq + 255) / 256, H, nbatch, causal, true, qblk, head, b)) return;
+    const int q0 = qblk * 256;
+    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
+    const bf16_t* Kb = K + tok0 * ldk + head * HD;
+    const bf16_t* Vb = V + tok0 * ldv + head * HD;
+    const uint8_t* kmb = key_mask ? key_mask + tok0 : nullptr;
+    const int q_wmin = q0 + 32 * w, q_abs = q_wmin + (l & 31);
+    const int klen = kv_len ? min(S, kv_len[b]) : S;
+    const float scale2 = scale * 1.4426950408889634f;
+    s16x8 qf[C::KS], dof[C::KS];
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+        u32x4 a = zero16(), c = zero16();
+        if (q_abs < Sq) {
+            a = ld16(Q + (tokq0 + q_abs) * ldq + head * HD + kk * 16 + h2 * 8);
+            c = ld16(dO + (tokq0 + q_abs) * lddo + head * HD + kk * 16 + h2 * 8);
+        }
+        qf[kk] = __builtin_bit_cast(s16x8, a);
+        dof[kk] = __builtin_bit_cast(s16x8, c);
+    }
+    float lse2 = 0.f, del = 0.f;
+    if (q_abs < Sq) {
+        lse2 = LSE[((long long)b * H + head) * Sq + q_abs] * 1.4426950408889634f;
+        del = DELTA[((long long)b * H + head) * Sq + q_abs];
+    }
+    const bool all_q_ok = q_wmin + 31 < Sq;
+    f32x16 dq[C::DT];  // dQ^T: rows = features, cols = this wave's queries
+#pragma unroll
+    for (int i = 0; i < C::DT; ++i) dq[i] = zero_acc();
+    int kv_end = klen;
+    if (causal) kv_end = min(kv_end, q0 + 256);
+    const int ntiles = (kv_end + 63) / 64;
+    if (ntiles > 0) {  // first tile through registers (rows past the sequence as zeros)
+        u32x4 rk[C::NCH], rv[C::NCH];
+        tile_load3<HD>(rk, Kb, ldk, 0, S, t);
+        tile_load3<HD>(rv, Vb, ldv, 0, S, t);
+        tile_store3<HD>(rk, sK, t);
+        tile_store3<HD>(rv, sV, t);
+        if (kmb && t < 64) {
+            const uint8_t mv = t < S ? kmb[t] : 0;
+            sM[t] = mv;
+            const unsigned long long all = ballot(mv != 0);
+            if (t == 0) sFlag[0] = (all == ~0ull);
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+        settle(qf[kk]);
+        settle(dof[kk]);
+    }
+    settle(lse2);
+    settle(del);
+    for (int it = 0; it < ntiles; ++it) {
+        wait_vm<0>();  // this wave's LDS-DMA pieces of tile `it` have landed
+        sync();        // tile `it` complete in buffer it & 1; every wave is done reading the other buffer
+        const int cur = it & 1, kv0 = it * 64;
+        const bool more = it + 1 < ntiles;
+        if (more) {  // rows past the sequence are clamped: those keys are masked below
+            tile_dma3<HD>(Kb, ldk, kv0 + 64, S - 1, sK + (cur ^ 1) * C::TILE, w, l);
+            tile_dma3<HD>(Vb, ldv, kv0 + 64, S - 1, sV + (cur ^ 1) * C::TILE, w, l);
+        }
+        const char* cK = sK + cur * C::TILE;
+        const char* cV = sV + cur * C::TILE;
+        if (!(causal && kv0 > q_wmin + 31)) {  // wave-uniform: this wave sees at least one key of the tile
+            f32x16 st[2], dpt[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                st[i] = zero_acc();
+                dpt[i] = zero_acc();
+            }
+#pragma unroll
+            for (int kk = 0; kk < C::KS; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    st[i] = mfma32(frag_rc3<HD>(cK, i * 32 + (l & 31), kk, l), qf[kk], st[i]);
+                    dpt[i] = mfma32(frag_rc3<HD>(cV, i * 32 + (l & 31), kk, l), dof[kk], dpt[i]);
+                }
+            const bool need_mask = !all_q_ok || (kv0 + 64 > klen) || (causal && kv0 + 63 > q_wmin) || (kmb && !sFlag[cur]);
+            const uint8_t* cM = sM + cur * 64;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float p = exp2_fast(st[i][r] * scale2 - lse2);
+                    if (need_mask) {
+                        const int kvl = i * 32 + acc_row(r, l);
+                        const int kv = kv0 + kvl;
+                        bool ok = q_abs < Sq && kv < klen && !(causal && kv > q_abs);
+                        if (kmb) ok = ok && cM[kvl];
+                        if (!ok) p = 0.f;
+                    }
+                    dpt[i][r] = p * (dpt[i][r] - del) * scale;
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const s16x8 dsf = pack_frag(dpt[i], u);
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; ++dt) dq[dt] = mfma32(frag_tr3<HD>(cK, i * 32 + 16 * u, 32 * dt, l), dsf, dq[dt]);
+                }
+        }
+        if (more && kmb && t < 64) {
+            const int nb = cur ^ 1, kvn = kv0 + 64;
+            const uint8_t mv = (kvn + t < S) ? kmb[kvn + t] : 0;
+            sM[nb * 64 + t] = mv;
+            const unsigned long long all = ballot(mv != 0);
+            if (t == 0) sFlag[nb] = (all == ~0ull);
+        }
+    }
+    if (q_abs < Sq) {
+        bf16_t* row = dQ + (tokq0 + q_abs) * lddq + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d0 = 32 * dt + 8 * rg + 4 * h2;
+                u32x2 v;
+                v[0] = pack2bf(dq[dt][4 * rg], dq[dt][4 * rg + 1]);
+                v[1] = pack2bf(dq[dt][4 * rg + 2], dq[dt][4 * rg + 3]);
                 *reinterpret_cast<u32x2*>(row + d0) = v;
             }
     }
@@ -1346,7 +1497,7 @@ __global__ __launch_bounds__(256) void attn_dq_round_kernel(const float* acc, bf
     }
 }
 
-thread_local int g_last_bwd_variant = 0;  // 2 / 3: the two-kernel generations, 4: single pass (tests assert which form they exercised)
+thread_local int g_last_bwd_variant = 0;  // 2 / 3 / 5: the two-kernel generations (5 = bwd3 dK/dV + dQ v5), 4: single pass (tests assert which form ran)
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 unsigned grid_cap(long long g, long long cap) { return unsigned(g < 1 ? 1 : (g > cap ? cap : g)); }
 
@@ -1439,7 +1590,7 @@ int aria_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o,
         g_last_bwd_variant = 4;
         return aria_check_launch();
     }
-    g_last_bwd_variant = (hd == 128 && !(old && old[0] == '2')) ? 3 : 2;
+    g_last_bwd_variant = hd != 128 || (old && old[0] == '2') ? 2 : (old && old[0] == '3') ? 3 : 5;
     if (hd == 128) {
         using C = Cfg<128>;
         if (old && old[0] == '2')
@@ -1456,10 +1607,14 @@ int aria_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o,
             ARIA_LAUNCH((attn_bwd2_dq_kernel<128>), gridq, block, size_t(4 * 64 * C::PITCH * 2 + 128 + 16), stream, Q, K, V, dO, lse,
                         (const float*)delta, static_cast<bf16_t*>(dq), kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq,
                         (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddq, scale, causal);
-        else
+        else if (old && old[0] == '3')  // the role-split dQ kernel of the previous generation (A/B measurements)
             ARIA_LAUNCH((attn_bwd3_dq_kernel<128>), dim3(attn_grid((Sq + 127) / 128, H, B)), dim3(512), size_t(4 * Cfg3<128>::TILE + 2 * 4 * 8192 + 128 + 16), stream, Q,
                         K, V, dO, lse, (const float*)delta, static_cast<bf16_t*>(dq), kv_len, key_mask, int(Sq), int(Skv), int(H),
                         (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddq, scale, causal, int(B));
+        else
+            ARIA_LAUNCH((attn_bwd5_dq_kernel<128>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(4 * Cfg3<128>::TILE + 128 + 16), stream, Q, K, V,
+                        dO, lse, (const float*)delta, static_cast<bf16_t*>(dq), kv_len, key_mask, int(Sq), int(Skv), int(H), int(ldq), int(ldk),
+                        int(ldv), int(ldo), int(lddq), scale, causal, int(B));
     } else if (hd == 72) {  // ViT / projector heads (an unfrozen ViT, the trainable projector's cross-attention): the v2 pair with padded tiles
         using C = Cfg<72>;
         ARIA_LAUNCH((attn_bwd2_dkdv_kernel<72>), gridk, block, size_t(4 * 64 * C::PITCH * 2 + 256 * 4), stream, Q, K, V, dO, lse,

@@ -210,7 +210,7 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
  * MI355X: the chip retires ~330 G fp32 atomic adds per second (profiles/r03_l2_atomics.json), which makes this form slower than the two
  * kernels at every sequence length of the model -- it is a measurement path, not the default.  workspace == NULL (or too small, or a
  * head dim without the single-pass kernel: aria_attn_bwd_workspace_bytes() == 0) selects the deterministic two-kernel form. */
-int aria_last_attn_bwd_variant(void); /* which backward the calling thread's last aria_attn_bwd(_ws) ran: 2 / 3 two kernels, 4 single pass */
+int aria_last_attn_bwd_variant(void); /* which backward the calling thread's last aria_attn_bwd(_ws) ran: 2 / 3 / 5 two kernels (5: dQ without role split), 4 single pass */
 int64_t aria_attn_bwd_workspace_bytes(int64_t B, int64_t Sq, int64_t H, int64_t hd);
 int aria_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                      float* delta /* fp32 [B,H,Sq] scratch */, void* dq, void* dk, void* dv, const int32_t* kv_len,
