@@ -11,9 +11,12 @@ The arithmetic is the native path's (``aria_amd.modeling_aria.AriaForConditional
 only adds the HF plumbing.  State-dict keys are the reference's (``vision_tower.*``, ``multi_modal_projector.*``, ``language_model.*``),
 so checkpoints written by either class load into the other and into the reference.
 
-KV cache: the hot path's fast decode engine lives behind the gptfast surface (``.generate_fast`` = the native ``generate``).  The HF
-``generate()`` loop is supported for compatibility without a cache (every step re-runs the prefix: ``use_cache`` is forced off) -- correct,
-quadratic; it is what lets recipes that call ``model.generate(**inputs)`` with arbitrary ``GenerationConfig`` options run unchanged.
+KV cache (modeling_aria.py:43-58, 337-365): HF ``generate()`` runs WITH a cache.  ``past_key_values`` is an ``AriaStaticKVCache`` -- the
+static bf16 cache ``[1, S_max, H * hd]`` per layer of the model's gptfast twin (gptfast/model.py:67-93) with the one-call-per-token decode
+engine (csrc/decode.hip) behind it: the first forward prefills the prompt (ViT + projector run ONCE, tile kernels), every later forward
+decodes the new token against the cache -- linear time, any ``GenerationConfig`` sampling option of the HF loop.  Batch 1 without padding
+(what the decode engine serves); other inputs, or ``use_cache=False``, take the cache-free path (every step re-runs the prefix: correct,
+quadratic).  ``.generate_fast`` is the native sampling loop (gptfast/generate.py:112-177) on the same engine.
 """
 from __future__ import annotations
 
@@ -120,6 +123,37 @@ class AriaHFConfig(PreTrainedConfig):
         return self.text_config.hidden_size
 
 
+class AriaStaticKVCache:
+    """``past_key_values`` of the native HF class: the gptfast twin's static KV cache (``setup_caches`` gptfast/model.py:113-166, ``KVCache``
+    :67-93) and how many positions of it are filled.  Exposes what ``GenerationMixin`` asks of a cache object (``get_seq_length``,
+    ``is_compileable``, ``get_max_cache_shape``); the tensors live in ``twin.llm.layers[i].attention.kv_cache``."""
+
+    is_compileable = False   # the decode step is already one native call per token; there is nothing for torch.compile to capture
+    is_sliding = [False]
+
+    def __init__(self, twin, max_len: int):
+        self.twin, self.max_len, self.seen = twin, int(max_len), 0
+        twin.setup_caches(1, self.max_len)
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.seen
+
+    def get_max_cache_shape(self, layer_idx: int = 0) -> int:
+        return self.max_len
+
+    get_max_length = get_max_cache_shape
+
+    def __len__(self):
+        return len(self.twin.llm.layers)
+
+    def reorder_cache(self, beam_idx):
+        raise NotImplementedError("AriaStaticKVCache: beam search needs batch > 1; the static cache serves batch 1 (use use_cache=False)")
+
+    def crop(self, max_length: int):
+        """Forget positions >= max_length (assisted decoding rolls back rejected tokens): the rows stay in the buffer and are overwritten."""
+        self.seen = min(self.seen, max_length if max_length >= 0 else self.seen + max_length)
+
+
 class AriaPretrainedModel(PreTrainedModel):
     """modeling_aria.py:38-58."""
 
@@ -131,8 +165,8 @@ class AriaPretrainedModel(PreTrainedModel):
     _skip_keys_device_placement = "past_key_values"
     _supports_flash_attn = True       # the attention IS a flash kernel (attn.hip); the flags only tell HF not to reject the config
     _supports_sdpa = True
-    _supports_cache_class = False     # see the module docstring: the KV-cache engine is the gptfast surface
-    _supports_static_cache = False
+    _supports_cache_class = True      # modeling_aria.py:43-58; the cache object is AriaStaticKVCache (module docstring)
+    _supports_static_cache = True
     main_input_name = "input_ids"
 
     def _init_weights(self, module):
@@ -204,18 +238,62 @@ class AriaForConditionalGeneration(AriaPretrainedModel, GenerationMixin):
         """The native generate (gptfast twin + one-call-per-token decode engine, gptfast/generate.py:112-177)."""
         return self._core().generate(*args, **kwargs)
 
+    def _twin(self):
+        """The gptfast twin behind the KV cache (``native.to_gptfast``: the reference's own checkpoint conversion), rebuilt when a parameter
+        has been written since it was made (an optimizer step bumps the tensors' version counters)."""
+        core = self._core()
+        stamp = sum(p._version for p in self.parameters())
+        if getattr(core, "_gptfast_twin", None) is None or getattr(self, "_twin_stamp", None) != stamp:
+            object.__setattr__(core, "_gptfast_twin", core.to_gptfast())
+            object.__setattr__(core, "_gptfast_decoder", None)
+            object.__setattr__(self, "_twin_stamp", stamp)
+        return core._gptfast_twin
+
+    def make_cache(self, max_len: int) -> AriaStaticKVCache:
+        """A fresh ``past_key_values`` object for a sequence of up to ``max_len`` positions (prompt + new tokens)."""
+        return AriaStaticKVCache(self._twin(), max_len)
+
+    def _forward_cached(self, cache: AriaStaticKVCache, input_ids, pixel_values, pixel_mask, keep: int) -> torch.Tensor:
+        """One step of cached generation (modeling_aria.py:337-365 + gptfast/generate.py:71-110): the first call prefills the whole prompt
+        (image features merged once), later calls feed only the new token(s)."""
+        twin = cache.twin
+        if input_ids is None or input_ids.dim() != 2 or input_ids.shape[0] != 1:
+            raise NotImplementedError("cached generation serves batch 1 (input_ids [1, T]); pass use_cache=False for other shapes")
+        T = input_ids.shape[1]
+        if cache.seen + T > cache.max_len:
+            raise ValueError(f"AriaStaticKVCache of {cache.max_len} positions cannot take {cache.seen} + {T}")
+        dev = input_ids.device
+        with torch.no_grad():
+            if cache.seen == 0:                                   # prefill: ViT + projector once, all prompt positions into the cache
+                emb = twin.prepare_embeddings(input_ids, pixel_values, pixel_mask)
+                logits = twin(None, torch.arange(T, device=dev), emb, last_only=(keep == 1))
+            elif T == 1:                                          # decode: the native one-call-per-token engine
+                logits = twin(input_ids, torch.tensor([cache.seen], dtype=torch.int32, device=dev))
+            else:
+                raise NotImplementedError("several new tokens against a filled cache (assisted / speculative decoding): use use_cache=False")
+        cache.seen += T
+        return logits if keep != 1 else logits[:, -1:]
+
     def forward(self, input_ids: Optional[torch.Tensor] = None, pixel_values: Optional[torch.Tensor] = None,
                 pixel_mask: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None, position_ids=None,
                 past_key_values=None, inputs_embeds: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
                 use_cache: Optional[bool] = None, output_attentions=None, output_hidden_states=None, return_dict=None,
                 num_logits_to_keep: int = 0, logits_to_keep: int = 0, cache_position=None, **kwargs) -> CausalLMOutputWithPast:
-        """modeling_aria.py:194-335 (same keyword arguments).  ``past_key_values`` must be None (no HF cache on this path)."""
-        if past_key_values is not None and not (hasattr(past_key_values, "get_seq_length") and past_key_values.get_seq_length() == 0):
-            raise NotImplementedError("aria_amd HF surface: no HF KV cache (use generate_fast / the gptfast surface for cached decoding)")
+        """modeling_aria.py:194-335 (same keyword arguments).  ``past_key_values``: an ``AriaStaticKVCache`` (``make_cache`` / created by
+        ``generate``) selects cached generation; None (or an empty HF cache object) the full forward."""
         if output_attentions or output_hidden_states:
             raise NotImplementedError("output_attentions / output_hidden_states: the flash kernels never materialise them")
         keep = int(num_logits_to_keep or logits_to_keep or 0)
         self.native_config.image_token_index = self.config.image_token_index
+        if isinstance(past_key_values, AriaStaticKVCache):
+            if labels is not None or inputs_embeds is not None or self.training:
+                raise NotImplementedError("AriaStaticKVCache is an inference cache: no labels / inputs_embeds / training mode")
+            if attention_mask is not None and not bool(attention_mask.ne(0).all()):
+                raise NotImplementedError("cached generation: padded prompts are not supported (batch 1 has nothing to pad)")
+            logits = self._forward_cached(past_key_values, input_ids, pixel_values, pixel_mask, keep)
+            return CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=past_key_values)
+        if past_key_values is not None and not (hasattr(past_key_values, "get_seq_length") and past_key_values.get_seq_length() == 0):
+            raise NotImplementedError("aria_amd HF surface: past_key_values must be an AriaStaticKVCache (model.make_cache(max_len))")
         out = native.AriaForConditionalGeneration.forward(self._core(), input_ids=input_ids, pixel_values=pixel_values, pixel_mask=pixel_mask,
                                                           attention_mask=attention_mask, inputs_embeds=inputs_embeds, labels=labels,
                                                           num_logits_to_keep=keep, return_logits=True if labels is None else None,
@@ -225,16 +303,39 @@ class AriaForConditionalGeneration(AriaPretrainedModel, GenerationMixin):
 
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, pixel_values=None,
                                       pixel_mask=None, **kwargs):
-        """modeling_aria.py:337-365 without a cache: every step sees the whole sequence (and therefore the pixel inputs), and asks for
-        the last position's logits only."""
+        """modeling_aria.py:337-365: with a filled cache only the tokens it has not seen go in, and the pixel inputs only with the prompt;
+        without a cache every step sees the whole sequence.  Always asks for the last position's logits only."""
+        if isinstance(past_key_values, AriaStaticKVCache):
+            seen = past_key_values.seen
+            return {"input_ids": input_ids[:, seen:], "attention_mask": attention_mask, "past_key_values": past_key_values,
+                    "pixel_values": pixel_values if seen == 0 else None, "pixel_mask": pixel_mask if seen == 0 else None,
+                    "num_logits_to_keep": 1, "use_cache": True}
         return {"input_ids": input_ids, "attention_mask": attention_mask, "pixel_values": pixel_values, "pixel_mask": pixel_mask,
                 "num_logits_to_keep": 1, "use_cache": False}
 
     def generate(self, *args, **kwargs):
-        kwargs["use_cache"] = False
+        """HF ``generate`` with the static KV cache whenever the decode engine can serve the request (batch 1, no padding, eval mode, no
+        beam search); ``use_cache=False`` or any other request runs cache-free."""
+        use_cache = kwargs.pop("use_cache", True)
+        input_ids = kwargs.get("input_ids", args[0] if args else kwargs.get("inputs"))
+        am = kwargs.get("attention_mask")
+        gc = kwargs.get("generation_config") or self.generation_config
+        beams = kwargs.get("num_beams", getattr(gc, "num_beams", 1)) or 1
+        servable = (use_cache is not False and kwargs.get("past_key_values") is None and torch.is_tensor(input_ids) and input_ids.dim() == 2
+                    and input_ids.shape[0] == 1 and (am is None or bool(am.ne(0).all())) and beams == 1 and not self.training
+                    and kwargs.get("assistant_model") is None and (kwargs.get("num_return_sequences") or 1) == 1)
+        if servable:
+            T = input_ids.shape[1]
+            max_new = kwargs.get("max_new_tokens", getattr(gc, "max_new_tokens", None))
+            max_len = kwargs.get("max_length", getattr(gc, "max_length", None))
+            total = T + int(max_new) if max_new is not None else max(int(max_len or 0), T + 1)
+            kwargs["past_key_values"] = self.make_cache(total + 1)
+            kwargs["use_cache"] = True
+        elif not isinstance(kwargs.get("past_key_values"), AriaStaticKVCache):
+            kwargs["use_cache"] = False
         return super().generate(*args, **kwargs)
 
-    def _supports_default_dynamic_cache(self) -> bool:  # GenerationMixin: do not build a DynamicCache for us
+    def _supports_default_dynamic_cache(self) -> bool:  # GenerationMixin: do not build a DynamicCache for us (ours is AriaStaticKVCache)
         return False
 
 

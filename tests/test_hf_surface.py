@@ -82,10 +82,56 @@ def test_hf_generate_matches_native_greedy_decode():
     _, m = tiny()
     m.eval()
     ids, pv = batch()
-    got = m.generate(input_ids=ids, pixel_values=pv, max_new_tokens=5, do_sample=False)       # GenerationMixin loop, no cache
+    got = m.generate(input_ids=ids, pixel_values=pv, max_new_tokens=5, do_sample=False, use_cache=False)  # GenerationMixin loop, no cache
     want = m.generate_fast(input_ids=ids, pixel_values=pv, max_new_tokens=5, do_sample=False)  # gptfast twin + decode engine
     assert got.shape == (1, 17) and torch.equal(got[:, :12], ids)
     assert torch.equal(got.cpu(), want.cpu())
+
+
+def test_hf_generate_with_the_static_kv_cache_is_linear_and_equal():
+    """B3 (modeling_aria.py:43-58, 337-365): HF generate() with past_key_values = the static KV cache + decode engine.  The ViT runs once,
+    the prompt is prefilled once, every later step feeds ONE token; tokens equal the cache-free HF loop and the native fast loop."""
+    from aria_amd import gptfast as G
+
+    hf, m = tiny()
+    m.eval()
+    assert m._supports_cache_class and m._supports_static_cache
+    ids, pv = batch()
+    vit_calls, step_lengths = [], []
+    vit_forward, llm_forward = type(m.vision_tower).forward, G.Transformer.forward
+
+    def vit(self, *a, **k):
+        vit_calls.append(1)
+        return vit_forward(self, *a, **k)
+
+    def llm(self, idx, input_pos=None, input_embeds=None, last_only=False):
+        step_lengths.append((idx if idx is not None else input_embeds).shape[1])
+        return llm_forward(self, idx, input_pos, input_embeds, last_only=last_only)
+
+    type(m.vision_tower).forward, G.Transformer.forward = vit, llm
+    try:
+        got = m.generate(input_ids=ids, pixel_values=pv, max_new_tokens=5, do_sample=False)           # cached (the default)
+    finally:
+        type(m.vision_tower).forward, G.Transformer.forward = vit_forward, llm_forward
+    assert len(vit_calls) == 1 and step_lengths == [12, 1, 1, 1, 1], (vit_calls, step_lengths)       # linear: prompt once, then single tokens
+    nocache = m.generate(input_ids=ids, pixel_values=pv, max_new_tokens=5, do_sample=False, use_cache=False)
+    fast = m.generate_fast(input_ids=ids, pixel_values=pv, max_new_tokens=5, do_sample=False)
+    assert got.shape == (1, 17) and torch.equal(got, nocache) and torch.equal(got.cpu(), fast.cpu())
+    # the cache object by hand: prefill + two single-token forwards == the cache-free logits at those positions
+    cache = m.make_cache(20)
+    assert isinstance(cache, hf.AriaStaticKVCache) and cache.get_seq_length() == 0
+    with torch.no_grad():
+        out = m(input_ids=ids, pixel_values=pv, past_key_values=cache, num_logits_to_keep=1)
+        assert out.past_key_values is cache and cache.get_seq_length() == 12 and out.logits.shape == (1, 1, 512)
+        nxt = out.logits[:, -1].argmax(-1, keepdim=True)
+        out2 = m(input_ids=nxt, past_key_values=cache)
+        full = m(input_ids=torch.cat([ids, nxt], 1), pixel_values=pv).logits
+    assert cache.get_seq_length() == 13
+    err = (out2.logits[:, -1].float() - full[:, -1].float()).abs().max() / full[:, -1].float().abs().max()
+    assert float(err) <= 5e-2, float(err)
+    # sampling options of the HF loop work on the cached path too (top-k / temperature: just has to run and keep the prompt)
+    s1 = m.generate(input_ids=ids, pixel_values=pv, max_new_tokens=4, do_sample=True, top_k=5, temperature=0.7)
+    assert s1.shape == (1, 16) and torch.equal(s1[:, :12], ids)
 
 
 def test_two_steps_under_transformers_trainer():
