@@ -139,30 +139,6 @@ template <class T>
 __device__ __forceinline__ T atomic_add(T* p, T v) { return atomicAdd(p, v); }
 #endif
 
-// fire-and-forget fp32 add to global memory (global_atomic_add_f32, no return value).
-//   AGENT = false: no scope bits -- the add is performed in the L2 of the issuing XCD.  Correct only while every workgroup that touches
-//                  the line runs on ONE XCD for the whole kernel (the end-of-kernel release writes the L2 back like any dirty line).
-//   AGENT = true:  sc1 -- device scope, any placement.
-template <bool AGENT>
-__device__ __forceinline__ void atomic_add_f32_noret(float* p, float v) {
-#ifdef ARIA_EMU
-    *p += v;  // (the emulator runs workgroups one after the other)
-#else
-    if (AGENT)
-        asm volatile("global_atomic_add_f32 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-    else
-        asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(p), "v"(v) : "memory");
-#endif
-}
-// the XCD (0..7) this wave runs on: HW_REG_XCC_ID
-__device__ __forceinline__ int xcc_id() {
-#ifdef ARIA_EMU
-    return int(blockIdx.x & 7);
-#else
-    return int(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)));
-#endif
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);

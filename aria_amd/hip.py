@@ -23,8 +23,7 @@ ERRORS = {
 
 P, I64, I32, F32 = c_void_p, c_int64, c_int, c_float
 RESTYPES = {"aria_gemm_workspace_bytes": c_int64, "aria_decode_scratch_bytes": c_int64, "aria_decode_graph_create": c_void_p,
-            "aria_decode_graph_destroy": None, "aria_decode_attn_workspace_bytes": c_int64,
-            "aria_attn_bwd_workspace_bytes": c_int64}  # everything else returns an int status
+            "aria_decode_graph_destroy": None, "aria_decode_attn_workspace_bytes": c_int64}  # everything else returns an int status
 
 # name -> argtypes (all return int).  Kept in one table so tests can check that the shared
 # library exports every symbol the header declares.
@@ -66,8 +65,6 @@ SIGNATURES = {
     "aria_add_bf16": [P, P, P, I64, P],
     "aria_attn_fwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
     "aria_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
-    "aria_attn_bwd_ws": [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P, I64, P],
-    "aria_attn_bwd_workspace_bytes": [I64, I64, I64, I64],
     "aria_layernorm_fwd": [P, P, P, P, P, P, I64, I64, F32, P],
     "aria_layernorm_bwd": [P, P, P, P, P, P, P, P, I64, I64, I64, P],
     "aria_gelu_tanh_fwd": [P, P, I64, P],

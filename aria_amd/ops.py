@@ -475,11 +475,9 @@ def attention_fwd(q, k, v, B: int, S: int, H: int, hd: int, scale: float, causal
 
 def attention_bwd(q, k, v, o, do, lse, B: int, S: int, H: int, hd: int, scale: float, causal: bool,
                   kv_len: Optional[torch.Tensor] = None, dq=None, dk=None, dv=None, key_mask: Optional[torch.Tensor] = None,
-                  Skv: Optional[int] = None, single_pass: Optional[bool] = None):
-    """Default: the deterministic two-kernel backward (7 GEMM units of S x S x hd per head).  ``single_pass`` (default: ARIA_ATTN_BWD=4 in the
-    environment; hd 128 only): one pass that adds each key block's share of dQ to an fp32 image (5 GEMM units) -- measured on MI355X the
-    chip retires ~330 G fp32 atomic adds per second however they are scoped or spread (profiles/r03_l2_atomics.json), which bounds that
-    form at > 130 ms per layer at S = 65 536 against 96 ms for the two kernels: it is kept for measurement, not as the default."""
+                  Skv: Optional[int] = None):
+    """Two kernels (dK/dV per key block, dQ per query block: 7 GEMM units of S x S x hd per head, deterministic).  A single-pass form with
+    fp32 atomic dQ accumulation was built and measured slower at every length (profiles/r03_attention_notes.md)."""
     dev = q.device
     Skv = S if Skv is None else Skv
     if dq is None:
@@ -489,20 +487,10 @@ def attention_bwd(q, k, v, o, do, lse, B: int, S: int, H: int, hd: int, scale: f
     if dv is None:
         dv = torch.empty((B * Skv, H * hd), dtype=bf16, device=dev)
     delta = torch.empty((B, H, S), dtype=torch.float32, device=dev)
-    lib = hip.get_lib()
-    if single_pass is None:
-        import os
-
-        single_pass = os.environ.get("ARIA_ATTN_BWD") == "4"
-    ws, ws_bytes = None, 0
-    if single_pass:
-        ws_bytes = int(lib.cdll.aria_attn_bwd_workspace_bytes(B, S, H, hd))
-        if ws_bytes:
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    lib.call("aria_attn_bwd_ws", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(kv_len),
-             _p(key_mask), B, S, Skv, H, hd, _rowmajor_2d(q, "q"), _rowmajor_2d(k, "k"), _rowmajor_2d(v, "v"),
-             _rowmajor_2d(o, "o"), _rowmajor_2d(dq, "dq"), _rowmajor_2d(dk, "dk"), _rowmajor_2d(dv, "dv"), float(scale),
-             int(causal), _p(ws), ws_bytes, _stream(q))
+    hip.get_lib().call("aria_attn_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(kv_len),
+                       _p(key_mask), B, S, Skv, H, hd, _rowmajor_2d(q, "q"), _rowmajor_2d(k, "k"), _rowmajor_2d(v, "v"),
+                       _rowmajor_2d(o, "o"), _rowmajor_2d(dq, "dq"), _rowmajor_2d(dk, "dk"), _rowmajor_2d(dv, "dv"), float(scale),
+                       int(causal), _stream(q))
     return dq, dk, dv
 
 

@@ -201,22 +201,8 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                   const uint8_t* key_mask, int64_t B, int64_t Sq, int64_t Skv, int64_t H, int64_t hd, int64_t ldq, int64_t ldk,
                   int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal, void* stream);
 
-/* aria_attn_bwd with a caller-owned workspace: the SINGLE-PASS backward (hd 128, the decoder's heads).  The two-kernel form above runs
- * 7 GEMM units of S x S x hd per head (S and dP are computed once for dK/dV and once more for dQ); with a workspace of
- * aria_attn_bwd_workspace_bytes() bytes (16-byte aligned; the fp32 image of dQ [B*Sq, H*hd]) one kernel per 128-key block computes
- * S / dP once and produces dK, dV and the block's share of dQ, which it adds to the fp32 image (global_atomic_add_f32, device scope) --
- * the 5 GEMM units of the algorithm, i.e. what the reference's flash-attn backward executes (aria/model/configuration_aria.py:78-100
- * selects flash_attention_2).  dQ's fp32 summation ORDER then depends on the schedule: not bit-reproducible run to run.  MEASURED on
- * MI355X: the chip retires ~330 G fp32 atomic adds per second (profiles/r03_l2_atomics.json), which makes this form slower than the two
- * kernels at every sequence length of the model -- it is a measurement path, not the default.  workspace == NULL (or too small, or a
- * head dim without the single-pass kernel: aria_attn_bwd_workspace_bytes() == 0) selects the deterministic two-kernel form. */
-int aria_last_attn_bwd_variant(void); /* which backward the calling thread's last aria_attn_bwd(_ws) ran: 2 / 3 / 5 two kernels (5: dQ without role split), 4 single pass */
-int64_t aria_attn_bwd_workspace_bytes(int64_t B, int64_t Sq, int64_t H, int64_t hd);
-int aria_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
-                     float* delta /* fp32 [B,H,Sq] scratch */, void* dq, void* dk, void* dv, const int32_t* kv_len,
-                     const uint8_t* key_mask, int64_t B, int64_t Sq, int64_t Skv, int64_t H, int64_t hd, int64_t ldq, int64_t ldk,
-                     int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal, void* workspace,
-                     int64_t workspace_bytes, void* stream);
+/* which backward the calling thread's last aria_attn_bwd ran: 2 = padded-tile pair (hd 64 / 72), 5 = role-split dK/dV + dQ v5 (hd 128) */
+int aria_last_attn_bwd_variant(void);
 
 /* ------------------------------------------------------------------------------------------------
  * ViT / projector support (vit.hip)

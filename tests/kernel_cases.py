@@ -312,8 +312,7 @@ def attn_ref(q, k, v, B, S, H, hd, scale, causal, kv_len=None):
     return o.transpose(1, 2).reshape(B * S, H * hd)
 
 
-def case_attention(dev, B, S, H, hd, causal, use_len, bwd=True, single_pass=False):
-    """``single_pass``: the one-pass backward with fp32 dQ adds (hd 128) instead of the default two-kernel form."""
+def case_attention(dev, B, S, H, hd, causal, use_len, bwd=True):
     from aria_amd import hip, ops
 
     D = H * hd
@@ -334,9 +333,9 @@ def case_attention(dev, B, S, H, hd, causal, use_len, bwd=True, single_pass=Fals
     do = rnd(B * S, D, seed=31)
     want.backward(do.float())
     dq, dk, dv = ops.attention_bwd(qd[:, :D], qd[:, D:2 * D], qd[:, 2 * D:], o, do.to(dev), lse, B, S, H, hd, scale, causal,
-                                   None if kv_len is None else kv_len.to(dev), single_pass=single_pass)
+                                   None if kv_len is None else kv_len.to(dev))
     variant = int(hip.get_lib().cdll.aria_last_attn_bwd_variant())
-    assert variant == (4 if (hd == 128 and single_pass) else 5 if hd == 128 else 2), variant
+    assert variant == (5 if hd == 128 else 2), variant
     close(dq, qf.grad, 3e-2, 3e-2)
     close(dk, kf.grad, 3e-2, 3e-2)
     close(dv, vf.grad, 3e-2, 3e-2)

@@ -79,50 +79,14 @@ def test_attention_fwd_bwd(B, S, H, hd, causal, use_len):
     C.case_attention(DEV, B, S, H, hd, causal, use_len)
 
 
-@pytest.mark.parametrize("B,S,H,causal,use_len,defer", [(1, 200, 3, True, False, "0"), (2, 150, 2, False, True, "1"), (3, 70, 1, True, False, "1")])
-def test_attention_bwd_single_pass(B, S, H, causal, use_len, defer, monkeypatch):
-    """The single-pass backward (dK, dV and the key block's share of dQ from one S / dP computation, fp32 adds into the dQ image; LDS-DMA
-    of the Q / dO tiles under both landing models) against the fp32 reference."""
-    monkeypatch.setenv("ARIA_EMU_GLDS_DEFER", defer)
-    C.case_attention(DEV, B, S, H, 128, causal, use_len, single_pass=True)
-
-
 @pytest.mark.parametrize("defer", ["0", "1"])
 def test_attention_bwd_default_kernels_under_both_dma_models(defer, monkeypatch):
-    """bwd3 dK/dV + dQ v5 stage their tiles by LDS-DMA: pieces landing at once (adversarial for a slot restaged too early) and only at the
-    counted wait (adversarial for a read not covered by wait + barrier); causal with a ragged tail, and padded keys."""
+    """The hd-128 backward kernels stage their tiles by LDS-DMA: pieces landing at once (adversarial for a slot restaged too early) and
+    only at the counted wait (adversarial for a read not covered by wait + barrier); causal with a ragged tail, padded keys, Sq != Skv."""
     monkeypatch.setenv("ARIA_EMU_GLDS_DEFER", defer)
     C.case_attention(DEV, 1, 333, 2, 128, True, False)
     C.case_attention(DEV, 2, 200, 1, 128, False, True)
     C.case_attention_cross_masked(DEV, 1, 300, 170, 1, 128)
-
-
-def test_attention_bwd_role_split_dq_kernel_still_selectable(monkeypatch):
-    from aria_amd import hip, ops
-    import torch
-
-    monkeypatch.setenv("ARIA_ATTN_BWD", "3")
-    q = torch.randn(150, 3 * 128, generator=torch.Generator().manual_seed(0)).bfloat16()
-    o, lse = ops.attention_fwd(q[:, :128], q[:, 128:256], q[:, 256:], 1, 150, 1, 128, 0.1, True)
-    a = ops.attention_bwd(q[:, :128], q[:, 128:256], q[:, 256:], o, o, lse, 1, 150, 1, 128, 0.1, True)
-    assert int(hip.get_lib().cdll.aria_last_attn_bwd_variant()) == 3
-    monkeypatch.delenv("ARIA_ATTN_BWD")
-    b = ops.attention_bwd(q[:, :128], q[:, 128:256], q[:, 256:], o, o, lse, 1, 150, 1, 128, 0.1, True)
-    assert int(hip.get_lib().cdll.aria_last_attn_bwd_variant()) == 5
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)  # same arithmetic per element: bit-identical
-
-
-def test_attention_bwd_single_pass_selected_by_environment(monkeypatch):
-    from aria_amd import hip, ops
-
-    monkeypatch.setenv("ARIA_ATTN_BWD", "4")
-    import torch
-
-    q = torch.randn(70, 3 * 128).bfloat16()
-    o, lse = ops.attention_fwd(q[:, :128], q[:, 128:256], q[:, 256:], 1, 70, 1, 128, 0.1, True)
-    ops.attention_bwd(q[:, :128], q[:, 128:256], q[:, 256:], o, o, lse, 1, 70, 1, 128, 0.1, True)
-    assert int(hip.get_lib().cdll.aria_last_attn_bwd_variant()) == 4
 
 
 @pytest.mark.parametrize("B,Sq,Skv,H,hd", [(2, 40, 150, 2, 64), (1, 130, 70, 1, 128), (2, 40, 150, 2, 72), (1, 256, 300, 16, 72)])

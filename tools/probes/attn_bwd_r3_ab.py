@@ -1,6 +1,7 @@
 """Attention backward on one box: the round-2 library (build/old/libaria_hip.so: bwd3 dK/dV + role-split dQ, register-staged tiles) against
-this tree's (bwd3 dK/dV with LDS-DMA staging and early statistics + dQ v5 without role split; ARIA_ATTN_BWD=4: the single-pass form with
-fp32 dQ adds).  Loads each library by path through ctypes (no package import: the old build lacks the new symbols).  HIP-event timing of
+this tree's (bwd3 dK/dV with LDS-DMA staging and early statistics + dQ v5 without role split).  At the commit that produced
+profiles/r03_attn_bwd_ab.json the tree also held the role-split dQ kernel (ARIA_ATTN_BWD=3) and the single-pass form with fp32 dQ adds
+(aria_attn_bwd_ws; now tools/probes/src/attn_bwd4_single_pass.hip): those arms run only if the library still exports them.  Loads each library by path through ctypes (no package import: the old build lacks the new symbols).  HIP-event timing of
 the whole aria_attn_bwd call (delta + kernels).  Writes gpurun_out/attn_bwd_r3_ab.json."""
 import ctypes, json, os, sys
 import torch
@@ -68,12 +69,10 @@ for name, (B, S, H) in {"config3_8x2048_h20": (8, 2048, 20), "long_1x16384_h20":
     r["r02"], ref = bench(old, B, S, H, 128, True, iters=it)
     r["r03_two_kernels"], got = bench(new, B, S, H, 128, True, iters=it)
     r["bit_identical_to_r02"] = all(torch.equal(a, b) for a, b in zip(got, ref))
-    os.environ["ARIA_ATTN_BWD"] = "3"
-    r["r03_dkdv_with_r02_dq_kernel"], _ = bench(new, B, S, H, 128, True, iters=it)
-    os.environ.pop("ARIA_ATTN_BWD")
-    r["r03_single_pass_atomics"], sp = bench(new, B, S, H, 128, True, single_pass=True, iters=max(2, it // 2))
-    r["single_pass_max_abs_diff_dq"] = float((sp[0].float() - ref[0].float()).abs().max())
-    r["single_pass_dk_dv_identical"] = bool(torch.equal(sp[1], ref[1]) and torch.equal(sp[2], ref[2]))
+    if hasattr(new, "aria_attn_bwd_ws"):
+        r["r03_single_pass_atomics"], sp = bench(new, B, S, H, 128, True, single_pass=True, iters=max(2, it // 2))
+        r["single_pass_max_abs_diff_dq"] = float((sp[0].float() - ref[0].float()).abs().max())
+        r["single_pass_dk_dv_identical"] = bool(torch.equal(sp[1], ref[1]) and torch.equal(sp[2], ref[2]))
     r["r02_again"], _ = bench(old, B, S, H, 128, True, iters=it)
     res[name] = r
     print(json.dumps({name: r}), flush=True)
