@@ -101,7 +101,7 @@ def test_gemm3_epilogues_exchange_through_dpp(kernel):
     assert n_dpp >= 64
 
 
-ATTN = ["16attn_fwd2_kernelILi72ELi12", "16attn_fwd2_kernelILi128ELi8", "21attn_bwd3_dkdv_kernelILi128", "19attn_bwd3_dq_kernelILi128"]
+ATTN = ["16attn_fwd2_kernelILi72ELi12", "16attn_fwd2_kernelILi128ELi8", "21attn_bwd3_dkdv_kernelILi128", "19attn_bwd5_dq_kernelILi128"]
 
 
 @pytest.mark.parametrize("kernel", ATTN)
@@ -114,3 +114,21 @@ def test_attention_tile_loop_does_not_drain_its_prefetch_before_the_first_mfma(k
     assert loads, "the next tile's loads are expected in front of the first MFMA"
     drains = [s for s in c[loads[0]:first_mfma] if s.startswith("s_waitcnt") and "vmcnt(0)" in s]
     assert drains == [], f"the tile loop waits for its own prefetch before its first MFMA: {drains}"
+
+
+@pytest.mark.parametrize("kernel", ["21attn_bwd3_dkdv_kernelILi128", "19attn_bwd5_dq_kernelILi128"])
+def test_attention_backward_tiles_arrive_by_lds_dma_without_compiler_drains(kernel):
+    """Round 3: the hd-128 backward kernels stage the next tile with global_load_lds_dwordx4 issued as their OWN instruction (inline
+    assembly): hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS read that follows a __builtin_amdgcn_global_load_lds, i.e. it would
+    drain the prefetch at its first consumer.  In the tile loop: 4 DMA pieces per wave (2 tensors x 2 pieces), every one inside an asm block,
+    no register-staged ds_write_b128 pass left, and no compiler-inserted vmcnt(0) between the pieces and the loop's last MFMA."""
+    body = kernel_body(isa("attn.hip"), kernel)
+    main = max((ls for _, ls in loops(body)), key=lambda ls: sum(1 for s, _ in code(ls) if s.startswith("v_mfma")))
+    c = code(main)
+    dma = [(i, a) for i, (s, a) in enumerate(c) if s.startswith("global_load_lds_dwordx4")]
+    assert len(dma) == 4 and all(a for _, a in dma), dma
+    n_w128 = sum(1 for s, _ in c if s.startswith("ds_write_b128"))  # dK/dV: role A publishes P with 8 of them; dQ v5 has no exchange at all
+    assert n_w128 == (8 if "dkdv" in kernel else 0), f"{n_w128} ds_write_b128 in the loop: a register-staged tile store is back"
+    last_mfma = max(i for i, (s, _) in enumerate(c) if s.startswith("v_mfma"))
+    own = [s for s, a in c[dma[0][0]:last_mfma] if s.startswith("s_waitcnt") and "vmcnt(0)" in s and not a]
+    assert own == [], f"compiler-inserted drains between the DMA issue and the last MFMA of the tile: {own}"
