@@ -143,8 +143,9 @@ def shard_expert_weights(fc1: torch.Tensor, fc2: torch.Tensor, rank: int, world:
 def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w, down_w, cfg: Fn.MoEConfig,
                    group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """MoELayer.forward with the routed experts sharded over `group`.  x [T, D] (this rank's tokens) -> [T, D].
-    One small host sync per call for the row counts of the all-to-all (as in Megatron's alltoall dispatcher; the reference's LOCAL path
-    had two per layer: ``tokens_per_expert.cpu()`` per grouped GEMM, moe_lm.py:478).  The backward re-uses the forward's split sizes."""
+    One small device -> host copy per call for the row counts of the all-to-all (as in Megatron's alltoall dispatcher; the reference's
+    LOCAL path had two syncs per layer: ``tokens_per_expert.cpu()`` per grouped GEMM, moe_lm.py:478), hidden under the shared expert, which
+    runs on a side stream concurrently with the dispatch / combine all-to-alls.  The backward re-uses the forward's split sizes."""
     W, rank = dist.get_world_size(group), dist.get_rank(group)
     E, k = cfg.num_experts, cfg.topk
     El = E // W
@@ -162,9 +163,26 @@ def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w
         gathered = [torch.empty_like(send_counts) for _ in range(W)]
         dist.all_gather(gathered, send_counts, group=group)
         recv_counts = torch.stack([g[rank] for g in gathered])
-    # ONE host sync per layer forward (the all-to-all's split sizes are host integers in torch.distributed; the backward re-uses them):
-    # both count matrices travel in a single copy.  Everything else -- the reorder permutation, the local offsets -- is built on the device.
-    both = torch.stack([send_counts, recv_counts]).cpu()
+    # The all-to-all's split sizes are host integers in torch.distributed: ONE device -> host copy per layer forward carries both count
+    # matrices (the backward re-uses them); the reorder permutation and the local offsets are built on the device.  On the GPU the copy
+    # is asynchronous and the (replicated) shared expert is enqueued on a SIDE STREAM before the host waits for it: the GPU is never idle
+    # behind the sync, and the shared expert's GEMMs then run UNDER the dispatch all-to-all (which is issued from the main stream and
+    # waits only for `perm`) instead of after the combine.
+    both_dev = torch.stack([send_counts, recv_counts])
+    sh, side = None, None
+    if x.is_cuda:
+        both = torch.empty(both_dev.shape, dtype=both_dev.dtype, pin_memory=True)
+        both.copy_(both_dev, non_blocking=True)
+        copied = torch.cuda.Event()
+        copied.record()
+        main = torch.cuda.current_stream(x.device)
+        side = _side_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            sh = _shared_expert(x, gate_w, up_w, down_w)
+        copied.synchronize()
+    else:
+        both = both_dev.cpu()
     send_splits, recv_splits = both[0].sum(1).tolist(), both[1].sum(1).tolist()
     rows = AllToAllRowsFn.apply(perm, send_splits, recv_splits, group)             # ordered (source rank, local expert)
     # reorder to local-expert-major for the grouped GEMM: destination segment (e, s) takes source segment (s, e)
@@ -187,9 +205,30 @@ def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w
     back = GatherRowsFn.apply(eo_local, inverse, order)                            # (source rank, local expert) order again
     eo = AllToAllRowsFn.apply(back, recv_splits, send_splits, group)               # my rows, original expert-major order
     # shared expert (replicated) and weighted combine
-    if ops.glu_fusable(x.shape[1], 2 * gate_w.shape[0]):                           # gate || up as one GEMM with the SwiGLU epilogue
+    if sh is None:
+        sh = _shared_expert(x, gate_w, up_w, down_w)
+    else:  # computed on the side stream under the all-to-alls: the combine waits for it (and the allocator is told who uses what)
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        sh.record_stream(torch.cuda.current_stream(x.device))
+        x.record_stream(side)
+    return UnpermuteFn.apply(eo, inv, scores, sh, k)
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One extra stream per device for the shared expert (created once: stream creation is not free)."""
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+def _shared_expert(x, gate_w, up_w, down_w):
+    """SharedExpertMLP (moe_lm.py:368-395): gate || up as one GEMM with the SwiGLU epilogue where the width allows it."""
+    if ops.glu_fusable(x.shape[1], 2 * gate_w.shape[0]):
         sact = AG.SharedGluFn.apply(x, gate_w, up_w)
     else:
         sact = AG.SwiGLUFn.apply(torch.cat([AG.linear(x, gate_w), AG.linear(x, up_w)], dim=-1))
-    sh = AG.linear(sact, down_w)
-    return UnpermuteFn.apply(eo, inv, scores, sh, k)
+    return AG.linear(sact, down_w)

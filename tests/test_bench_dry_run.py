@@ -32,5 +32,6 @@ def test_bench_line_carries_the_contract(world):
         sub = res["long64k"]
         assert {"ms_per_step", "value", "unit", "steps", "roofline"} <= set(sub) and sub["steps"] == 3 and sub["value"] > 0
         assert sub["roofline"]["bound"] == "mfma" and sub["roofline"]["launches_timed"] == 3 * 2 and "INVALID" in sub
+        assert res["recipe_grad_checkpointing"]["steps"] == 3 and res["recipe_grad_checkpointing"]["value"] > 0
     else:
         assert "long64k" not in res

@@ -93,3 +93,43 @@ def test_model_with_expert_parallel_enabled_trains_like_the_local_one(rccl_one_r
     ga = dict(a.named_parameters())
     for n, p in b.named_parameters():
         _close(p.grad, ga[n].grad, n, 3e-2)
+
+
+def test_rccl_collectives_the_dp_path_relies_on(rccl_one_rank):
+    """The exact torch.distributed calls of aria_amd.parallel on RCCL (one rank: the values are trivial, the point is that this ROCm build
+    accepts them): in-place reduce_scatter_tensor onto the rank's slice with AVG and SUM on bf16, all_reduce AVG on bf16 and fp32,
+    all_gather_into_tensor of the updated slice, all_to_all_single with split sizes; then GradSync + ShardedAdamW + global_grad_norm on a
+    small module with the process group present."""
+    dist = rccl_one_rank
+    dev = torch.device("cuda", 0)
+    g = torch.arange(4096, device=dev, dtype=torch.float32).to(bf16)
+    ref = g.clone()
+    for op in (dist.ReduceOp.AVG, dist.ReduceOp.SUM):
+        flat = g.clone()
+        dist.reduce_scatter_tensor(flat[0:4096], flat, op=op)
+        assert torch.equal(flat, ref)
+    for dt in (bf16, torch.float32):
+        t = ref.to(dt).clone()
+        dist.all_reduce(t, op=dist.ReduceOp.AVG)
+        assert torch.equal(t, ref.to(dt))
+    out = torch.empty_like(ref)
+    dist.all_gather_into_tensor(out, ref.clone())
+    assert torch.equal(out, ref)
+    rows = torch.randn(10, 64, device=dev).to(bf16)
+    got = torch.empty_like(rows)
+    dist.all_to_all_single(got, rows, [10], [10])
+    assert torch.equal(got, rows)
+    from aria_amd.parallel import GradSync, ShardedAdamW, clip_scale, global_grad_norm
+
+    net = torch.nn.Sequential(torch.nn.Linear(512, 512, bias=False), torch.nn.Linear(512, 300)).to(dev).to(bf16)
+    sync = GradSync(net, mode="reduce_scatter")          # world 1: no hooks, finish() is a no-op -- the constructor's AVG probe still runs
+    opt = ShardedAdamW(net.named_parameters(), lr=1e-3)
+    x = torch.randn(8, 512, device=dev).to(bf16)
+    net(x).float().square().mean().backward()
+    sync.finish()
+    norm = global_grad_norm(opt.params, sync)
+    want = float(torch.sqrt(sum(p.grad.float().square().sum() for p in net.parameters())))
+    assert abs(norm - want) <= 1e-3 * want, (norm, want)
+    before = net[0].weight.detach().clone()
+    opt.step(grad_scale=clip_scale(norm, 1.0))
+    assert not torch.equal(before, net[0].weight.detach())
