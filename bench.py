@@ -84,12 +84,9 @@ def fc1_kernel_tag(variant):
     """What the default path launched for experts.fc1 in THIS run, spelled like profiles/r02_pmc_fc1.json's kernel_tag."""
     if variant != 3:
         return f"gemm{variant}_kernel<rc,oc>"
-    v4 = os.environ.get("ARIA_GEMM_V4") == "1"
     wide = os.environ.get("ARIA_GEMM_WIDE_STORE", "1") != "0"
-    persist = os.environ.get("ARIA_GEMM_PERSIST", "0") not in ("0", "")
     fused = os.environ.get("ARIA_FUSE_SWIGLU", "1") != "0"
-    return (f"gemm3{'p' if persist else ''}_kernel<rc,oc,{4 if v4 else 3}>" + ("+wide_store" if wide else "") + "+expert_major"
-            + ("+swiglu" if fused else "") + "@" + KERNEL_REV)
+    return "gemm3_kernel<rc,oc,3>" + ("+wide_store" if wide else "") + "+expert_major" + ("+swiglu" if fused else "") + "@" + KERNEL_REV
 
 
 def pmc_traffic(variant=3):

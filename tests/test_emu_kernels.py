@@ -171,32 +171,6 @@ def test_gemm_swiglu_fused(force_gemm_v3, counts, K, I, T):
     C.case_gemm_swiglu_fused(DEV, counts, K, I, T)
 
 
-# v3 persistent form (gemm3p): 8 workgroups walk the tile list, the K-tile stream continues across tile boundaries (chained) or is
-# drained where a reduction is shorter than two K-tiles.  Forced on with a tiny grid so that every workgroup runs several tiles.
-@pytest.fixture(params=["0", "1"], ids=["dma-early", "dma-late"])
-def force_gemm_v3p(monkeypatch, request):
-    monkeypatch.setenv("ARIA_GEMM_FORCE", "3")
-    monkeypatch.setenv("ARIA_GEMM_PERSIST", "2")
-    monkeypatch.setenv("ARIA_GEMM_PERSIST_GRID", "8")
-    monkeypatch.setenv("ARIA_EMU_GLDS_DEFER", request.param)
-
-
-@pytest.mark.parametrize("M,N,K,a_oc,b_oc", [(1296, 1032, 192, False, False), (1040, 520, 136, False, True), (520, 1288, 64, True, True),
-                                             (780, 600, 320, True, True), (1024, 768, 712, False, False), (1024, 768, 576, False, True)])
-def test_gemm_v3_persistent_layouts(force_gemm_v3p, M, N, K, a_oc, b_oc):
-    """24-30 tiles on 8 workgroups: 3-4 tiles each, odd and even K-tile counts (buffer parity carries over), K = 64 -> drained
-    boundaries (one K-tile per tile), ragged K = 136, edge tiles in both directions; K = 712 / 576: interior tiles with 12 (ragged last) / 9
-    K-tiles -> runs of straight-line steady pairs between the general K-tiles at the tile boundaries."""
-    C.case_gemm_layouts(DEV, M, N, K, a_oc, b_oc)
-
-
-@pytest.mark.parametrize("counts,K,N", [([300, 0, 700, 5, 0, 0, 300, 1, 260, 515], 128, 264), ([3, 0, 130, 5, 0, 0, 300, 1], 72, 136)])
-def test_grouped_gemm_v3_persistent(force_gemm_v3p, counts, K, N):
-    """grouped-M forward / dgrad (expert-major tile list) and the grouped-K weight gradient (reduction length = an expert's token
-    count: 0, 1, 5, 50, 70, 130, ... -> chained and drained boundaries mixed, ragged last K-tiles)."""
-    C.case_grouped_gemm(DEV, counts, K=K, N=N)
-
-
 @pytest.mark.parametrize("H,hd,pos,splits", [(2, 128, 0, 4), (2, 128, 63, 2), (3, 128, 64, 2), (2, 128, 777, 3), (2, 128, 2999, 16),
                                              (2, 128, 1500, 32), (3, 64, 127, 2), (2, 64, 128, 2), (2, 64, 1000, 5)])
 def test_decode_attention_split_kv(H, hd, pos, splits):
