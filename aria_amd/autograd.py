@@ -185,28 +185,35 @@ _LAYER_KEYS = ("ln1", "wq", "wk", "wv", "wo", "ln2", "router", "fc1", "fc2", "ga
 
 class DecoderLayerFn(torch.autograd.Function):
     """One MoEDecoderLayer (moe_lm.py:580-602) as a single autograd node with a hand-written backward.
-    With ``recompute`` the forward keeps only the layer input and re-runs itself inside backward
-    (= the reference recipe's gradient_checkpointing, recipes/config_full.yaml:17) -- selectively: the flash-attention output and
-    its log-sum-exp (one [T, D] bf16 tensor per layer) are kept, so the recomputation skips the attention kernel, which is more than
-    half of a layer's forward at 64K tokens (ARIA_RECOMPUTE_KEEP_ATTN=0: recompute it too)."""
+    ``recompute`` (= the reference recipe's gradient_checkpointing, recipes/config_full.yaml:17) is SELECTIVE.  Of the 36 KB per token a
+    layer's backward needs, 24 KB are the four expert-row tensors of the MoE block (perm, fc1 output, its activation, fc2 output: 6 rows
+    per token each); the default level ("moe") keeps everything else and rebuilds those four in the backward -- a row gather and the two
+    routed-expert GEMMs, 60 % of the layer's forward GEMM flops, none of its attention.  At 64K tokens that is 4.1 GB per layer kept
+    instead of 12 (115 GB for 28 layers next to 101 GB of weights and gradients).  ARIA_RECOMPUTE_LEVEL=layer: keep only the layer
+    input and the flash kernel's (o, lse) and run the whole layer again (round 2's form: 1.0 GB per layer at 64K)."""
 
     @staticmethod
     def forward(ctx, x, cos, sin, B, S, acfg, mcfg, eps, kv_len, recompute, *params):
         p = dict(zip(_LAYER_KEYS, params))
-        keep = recompute and os.environ.get("ARIA_RECOMPUTE_KEEP_ATTN", "1") != "0"
-        out, c = Fn.decoder_layer_fwd(x, p, cos, sin, B, S, acfg, mcfg, eps, kv_len, save=not recompute, keep_attn=keep)
+        level = os.environ.get("ARIA_RECOMPUTE_LEVEL", "moe") if recompute else None
+        if level == "moe":  # keep the layer's token-sized tensors, rebuild the four expert-row tensors (perm, h1, act, eo) in the backward
+            out, c = Fn.decoder_layer_fwd(x, p, cos, sin, B, S, acfg, mcfg, eps, kv_len, save="lean")
+        else:               # "layer": keep only the flash kernel's (o, lse), run the whole layer again
+            out, c = Fn.decoder_layer_fwd(x, p, cos, sin, B, S, acfg, mcfg, eps, kv_len, save=not recompute, keep_attn=bool(recompute))
         ctx.c = c
-        ctx.meta = (B, S, acfg, mcfg, eps, kv_len, recompute)
+        ctx.meta = (B, S, acfg, mcfg, eps, kv_len, level)
         ctx.save_for_backward(x, cos, sin, *params)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, cos, sin, *params = ctx.saved_tensors
-        B, S, acfg, mcfg, eps, kv_len, recompute = ctx.meta
+        B, S, acfg, mcfg, eps, kv_len, level = ctx.meta
         p = dict(zip(_LAYER_KEYS, params))
         c = ctx.c
-        if recompute:
+        if level == "moe":
+            Fn.moe_rematerialize(c["mctx"], p["fc1"], p["fc2"])
+        elif level is not None:
             _, c = Fn.decoder_layer_fwd(x, p, cos, sin, B, S, acfg, mcfg, eps, kv_len, save=True,
                                         attn_cache=None if c is None else c.get("attn_cache"))
         wanted = {k for k, w in zip(_LAYER_KEYS, ctx.needs_input_grad[10:]) if w}   # frozen parameters: no weight-gradient GEMM

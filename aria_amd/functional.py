@@ -56,15 +56,18 @@ def fused_weight(*ws: torch.Tensor) -> torch.Tensor:
     return torch.cat([w.detach() for w in ws], dim=0)
 
 
-def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save: bool = True):
-    """MoELayer.forward on x [T,D] -> (out [T,D], ctx)."""
+def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save=True):
+    """MoELayer.forward on x [T,D] -> (out [T,D], ctx).  ``save``: True = everything the backward needs; False = nothing; "lean" = everything
+    EXCEPT the four expert-row tensors (perm, h1, act, eo: 24 of the layer's 36 KB per token) -- ``moe_rematerialize`` rebuilds those in
+    the backward from what is kept (selective recompute: the routed experts only, 60 % of the layer's forward GEMM flops)."""
     k = cfg.topk
+    lean = save == "lean"
     logits = ops.gemm(x, router_w)                                   # TopKRouter.gating  moe_lm.py:190-201
     scores, idx, counts = ops.moe_route(logits, k)                   # routing :261-269 (device-side histogram)
     offsets, sorted_src, inv = ops.moe_sort(idx, counts)             # token_permutation :326-334 (stable)
     perm = ops.moe_permute(x, sorted_src, k)
     if ops.glu_fusable(fc1.shape[1], fc1.shape[2]):                  # experts.fc1 :522 + glu :505-507 in ONE launch (no D2H sync)
-        h1, act = ops.grouped_gemm_swiglu(perm, fc1, offsets, want_h=save)   # (h1 is only kept for the backward of glu)
+        h1, act = ops.grouped_gemm_swiglu(perm, fc1, offsets, want_h=bool(save) and not lean)   # (h1 is only kept for the backward of glu)
     else:
         h1 = ops.grouped_gemm(perm, fc1, offsets)
         act = ops.swiglu(h1)
@@ -73,7 +76,7 @@ def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save: b
     I2 = gate_w.shape[0]
     wgu = fused_weight(gate_w, up_w)                                 # SharedExpertMLP :368-395
     if ops.glu_fusable(x.shape[1], 2 * I2):
-        gu, sact = ops.gemm_swiglu(x, wgu, want_h=save)
+        gu, sact = ops.gemm_swiglu(x, wgu, want_h=bool(save))
     else:
         gu = torch.empty((T, 2 * I2), dtype=bf16, device=x.device)
         ops.gemm(x, wgu, out=gu)
@@ -82,9 +85,24 @@ def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save: b
     out = ops.moe_unpermute(eo, inv, scores, k, add=sh)              # token_unpermutation :336-365 + `output += shared` :576
     ctx = None
     if save:
-        ctx = dict(x=x, logits=logits, scores=scores, idx=idx, counts=counts, offsets=offsets, inv=inv, perm=perm, h1=h1,
-                   act=act, eo=eo, gu=gu, sact=sact, cfg=cfg, wgu=wgu)
+        ctx = dict(x=x, logits=logits, scores=scores, idx=idx, counts=counts, offsets=offsets, inv=inv, sorted_src=sorted_src,
+                   perm=None if lean else perm, h1=None if lean else h1, act=None if lean else act, eo=None if lean else eo,
+                   gu=gu, sact=sact, cfg=cfg, wgu=wgu)
     return out, ctx
+
+
+def moe_rematerialize(ctx, fc1, fc2) -> None:
+    """Rebuild the expert-row tensors a lean ``moe_fwd`` did not keep (same kernels on the same inputs: bit-identical to the kept ones)."""
+    if ctx["perm"] is not None:
+        return
+    k = ctx["cfg"].topk
+    perm = ops.moe_permute(ctx["x"], ctx["sorted_src"], k)
+    if ops.glu_fusable(fc1.shape[1], fc1.shape[2]):
+        h1, act = ops.grouped_gemm_swiglu(perm, fc1, ctx["offsets"], want_h=True)
+    else:
+        h1 = ops.grouped_gemm(perm, fc1, ctx["offsets"])
+        act = ops.swiglu(h1)
+    ctx.update(perm=perm, h1=h1, act=act, eo=ops.grouped_gemm(act, fc2, ctx["offsets"]))
 
 
 def _want(need, *keys) -> bool:
@@ -230,15 +248,17 @@ def attn_block_bwd(dout, ctx, wq, wk, wv, wo, cos, sin, need=None):
 
 # ----------------------------------------------------------------------------------------------- decoder layer
 def decoder_layer_fwd(x, p: dict, cos, sin, B: int, S: int, acfg: AttnConfig, mcfg: MoEConfig, eps: float, kv_len=None,
-                      save: bool = True, attn_cache=None, keep_attn: bool = False):
+                      save=True, attn_cache=None, keep_attn: bool = False):
     """h = x + Attn(RMSNorm(x)); out = h + MoE(RMSNorm(h)).  p: dict of the layer's parameter tensors.
-    save=False, keep_attn=True -> ctx = {"attn_cache": (o, lse)} for a later recomputing call with attn_cache=..."""
-    xn, _, rstd1 = ops.rmsnorm(x, p["ln1"], eps, want_rstd=save)
-    a, actx = attn_block_fwd(xn, p["wq"], p["wk"], p["wv"], p["wo"], cos, sin, B, S, acfg, kv_len, save, attn_cache, keep_attn)
-    hn, h, rstd2 = ops.rmsnorm(a, p["ln2"], eps, residual=x, want_rstd=save)   # fused residual add
+    save=False, keep_attn=True -> ctx = {"attn_cache": (o, lse)} for a later recomputing call with attn_cache=...;
+    save="lean" -> the full ctx minus the MoE block's expert-row tensors (``moe_rematerialize`` before ``decoder_layer_bwd``)."""
+    full = bool(save)
+    xn, _, rstd1 = ops.rmsnorm(x, p["ln1"], eps, want_rstd=full)
+    a, actx = attn_block_fwd(xn, p["wq"], p["wk"], p["wv"], p["wo"], cos, sin, B, S, acfg, kv_len, full, attn_cache, keep_attn)
+    hn, h, rstd2 = ops.rmsnorm(a, p["ln2"], eps, residual=x, want_rstd=full)   # fused residual add
     mo, mctx = moe_fwd(hn, p["router"], p["fc1"], p["fc2"], p["gate"], p["up"], p["down"], mcfg, save)
     out = ops.add(h, mo)
-    ctx = dict(x=x, h=h, rstd1=rstd1, rstd2=rstd2, actx=actx, mctx=mctx, eps=eps) if save else actx
+    ctx = dict(x=x, h=h, rstd1=rstd1, rstd2=rstd2, actx=actx, mctx=mctx, eps=eps) if full else actx
     return out, ctx
 
 

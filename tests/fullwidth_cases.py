@@ -207,11 +207,12 @@ def case_lm(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, B,
     with _Recorder() as rec:
         out = lm(input_ids=ids.to(dev), labels=ids.to(dev), return_logits=False)
         out.loss.backward()
-    if recompute:  # every layer's forward ran twice (the second time inside backward, last layer first): the routing must repeat itself
-        assert len(rec.idx) == 2 * layers, len(rec.idx)
-        for i in range(layers):
+    if recompute and len(rec.idx) != layers:  # ARIA_RECOMPUTE_LEVEL=layer: every layer's forward ran twice (the second time inside
+        assert len(rec.idx) == 2 * layers, len(rec.idx)   # backward, last layer first) -- the routing must repeat itself.  (The default
+        for i in range(layers):                           # level keeps the routing and rebuilds only the expert-row tensors.)
             assert torch.equal(rec.idx[i], rec.idx[2 * layers - 1 - i]), f"layer {i}: the recomputed forward routed differently"
         rec.idx, rec.logits = rec.idx[:layers], rec.logits[:layers]
+    assert len(rec.idx) == layers, len(rec.idx)
     if expect_big_gemm:
         assert rec.variants and min(rec.variants) >= 2, rec.variants
     with _OracleLogits() as ol, O.forced_routing(rec.idx), oracle_ctx():

@@ -45,8 +45,11 @@ def test_vit_attention_bwd_case_small():
     F.case_vit_attention_bwd("cpu", "emu_vit_attn_bwd", S=150, H=1)
 
 
-def test_lm_case_small_recompute_streamed():
-    """The T = 65 536 case's code path (recompute, no eval pass, block-wise oracle attention, routing repeated by the recomputed forward)."""
+@pytest.mark.parametrize("level", ["moe", "layer"])
+def test_lm_case_small_recompute_streamed(level, monkeypatch):
+    """The long-sequence layer case's code path (recompute at both levels -- "moe": the expert-row tensors rebuilt in the backward, "layer":
+    the whole layer re-run with the flash (o, lse) kept --, no eval pass, block-wise oracle attention)."""
+    monkeypatch.setenv("ARIA_RECOMPUTE_LEVEL", level)
     F.case_lm("cpu", "emu_lm_recompute", hidden=128, heads=2, experts=8, topk=2, inter=128, vocab=160, layers=1, B=1, S=40,
               expect_big_gemm=False, act_tol=(3e-2, 8e-2), grad_tol=(8e-2, 2e-1), recompute=True, eval_pass=False, stream_block=16)
     assert "router.layer0" in F.REPORT["emu_lm_recompute"]

@@ -28,6 +28,28 @@ def test_lm_golden(golden):
     M.case_lm_golden(DEV, golden)
 
 
+@pytest.mark.parametrize("level", ["moe", "layer"])
+def test_lm_golden_with_recompute_is_bit_identical(golden, level, monkeypatch):
+    """recipes/config_full.yaml:17 gradient_checkpointing through the fused decoder node, both selective levels ("moe": the expert-row
+    tensors are rebuilt in the backward; "layer": the layer re-runs with the flash (o, lse) kept): the reference fixture still holds and
+    every gradient equals the non-recomputing run BIT FOR BIT (the same kernels see the same inputs)."""
+    from aria_amd.moe_lm import AriaMoELMForCausalLM, load_reference_state_dict
+
+    monkeypatch.setenv("ARIA_RECOMPUTE_LEVEL", level)
+    M.case_lm_golden(DEV, golden, recompute=True)
+    g = golden("lm")
+    grads = []
+    for rec in (False, True):
+        lm = AriaMoELMForCausalLM(M.make_cfg(g["cfg"], gradient_checkpointing=rec))
+        load_reference_state_dict(lm, g["weights"])
+        lm.train()
+        lm(input_ids=g["input_ids"], labels=g["input_ids"], return_logits=False).loss.backward()
+        grads.append({n: p.grad.clone() for n, p in lm.named_parameters()})
+    assert set(grads[0]) == set(grads[1])
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
+
+
 def test_vit_projector_golden(golden):
     M.case_vit_projector_golden(DEV, golden)
 
