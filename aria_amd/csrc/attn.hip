@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
             const uint8_t mv = t < S ? kmb[t] : 0;
             sM[t] = mv;
             const unsigned long long all = ballot(mv != 0);
-            if (t == 0) sFlag[0] = (all == ~0ull);
+            if (t == 0) sFlag[0] = int(all == ~0ull) | (int(all == 0ull) << 1);  // bit 0: every key of the tile valid, bit 1: none
         }
     }
     for (int it = 0; it < ntiles; ++it) {
@@ -238,7 +238,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
         }
         const bf16_t* cK = sK + cur * 64 * C::KP;
         const bf16_t* cV = sV + cur * 64 * C::VP;
-        if (!(causal && kv0 > q_wmin + 31)) {  // wave-uniform: this wave has at least one visible key in the tile
+        // (a tile without a single valid key -- the padded bottom rows of an image are one contiguous patch range -- contributes exactly
+        // nothing: every probability is exp2(-inf) = 0 and the running maximum does not move)
+        if (!(causal && kv0 > q_wmin + 31) && !(kmb && (sFlag[cur] & 2))) {  // wave-uniform: this wave has at least one visible key in the tile
             f32x16 st[2];
             st[0] = zero_acc();
             st[1] = zero_acc();
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
             for (int kk = 0; kk < C::KS; ++kk)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) st[i] = mfma32(*reinterpret_cast<const s16x8*>(cK + (i * 32 + (l & 31)) * C::KP + kk * 16 + h2 * 8), qf[kk], st[i]);
-            const bool need_mask = (kv0 + 64 > klen) || (causal && kv0 + 63 > q_wmin) || (kmb && !sFlag[cur]);
+            const bool need_mask = (kv0 + 64 > klen) || (causal && kv0 + 63 > q_wmin) || (kmb && !(sFlag[cur] & 1));
             if (need_mask) {
                 const uint8_t* cM = sM + cur * 64;
 #pragma unroll
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
                 const uint8_t mv = (kvn + t < S) ? kmb[kvn + t] : 0;
                 sM[nb * 64 + t] = mv;
                 const unsigned long long all = ballot(mv != 0);
-                if (t == 0) sFlag[nb] = (all == ~0ull);
+                if (t == 0) sFlag[nb] = int(all == ~0ull) | (int(all == 0ull) << 1);
             }
         }
     }
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dq_kernel(const bf16_t* Q, const
             const uint8_t mv = t < S ? kmb[t] : 0;
             sM[t] = mv;
             const unsigned long long all = ballot(mv != 0);
-            if (t == 0) sFlag[0] = (all == ~0ull);
+            if (t == 0) sFlag[0] = int(all == ~0ull) | (int(all == 0ull) << 1);  // bit 0: every key of the tile valid, bit 1: none
         }
     }
     for (int it = 0; it < ntiles; ++it) {
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dq_kernel(const bf16_t* Q, const
         }
         const bf16_t* cK = sK + cur * 64 * C::PITCH;
         const bf16_t* cV = sV + cur * 64 * C::PITCH;
-        if (!(causal && kv0 > q_wmin + 31)) {
+        if (!(causal && kv0 > q_wmin + 31) && !(kmb && (sFlag[cur] & 2))) {
             f32x16 st[2], dpt[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dq_kernel(const bf16_t* Q, const
                     st[i] = mfma32(frag_rc<HD>(cK, i * 32 + (l & 31), kk, l), qf[kk], st[i]);
                     dpt[i] = mfma32(frag_rc<HD>(cV, i * 32 + (l & 31), kk, l), dof[kk], dpt[i]);
                 }
-            const bool need_mask = !all_q_ok || (kv0 + 64 > klen) || (causal && kv0 + 63 > q_wmin) || (kmb && !sFlag[cur]);
+            const bool need_mask = !all_q_ok || (kv0 + 64 > klen) || (causal && kv0 + 63 > q_wmin) || (kmb && !(sFlag[cur] & 1));
             const uint8_t* cM = sM + cur * 64;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dq_kernel(const bf16_t* Q, const
                 const uint8_t mv = (kvn + t < S) ? kmb[kvn + t] : 0;
                 sM[nb * 64 + t] = mv;
                 const unsigned long long all = ballot(mv != 0);
-                if (t == 0) sFlag[nb] = (all == ~0ull);
+                if (t == 0) sFlag[nb] = int(all == ~0ull) | (int(all == 0ull) << 1);
             }
         }
     }
@@ -976,7 +978,7 @@ __global__ __launch_bounds__(512) void attn_bwd5_dq_kernel(const bf16_t* Q, cons
             const uint8_t mv = t < S ? kmb[t] : 0;
             sM[t] = mv;
             const unsigned long long all = ballot(mv != 0);
-            if (t == 0) sFlag[0] = (all == ~0ull);
+            if (t == 0) sFlag[0] = int(all == ~0ull) | (int(all == 0ull) << 1);  // bit 0: every key of the tile valid, bit 1: none
         }
     }
 #pragma unroll
@@ -997,7 +999,7 @@ __global__ __launch_bounds__(512) void attn_bwd5_dq_kernel(const bf16_t* Q, cons
         }
         const char* cK = sK + cur * C::TILE;
         const char* cV = sV + cur * C::TILE;
-        if (!(causal && kv0 > q_wmin + 31)) {  // wave-uniform: this wave sees at least one key of the tile
+        if (!(causal && kv0 > q_wmin + 31) && !(kmb && (sFlag[cur] & 2))) {  // wave-uniform: this wave sees at least one key of the tile (and the tile has one)
             f32x16 st[2], dpt[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -1011,7 +1013,7 @@ __global__ __launch_bounds__(512) void attn_bwd5_dq_kernel(const bf16_t* Q, cons
                     st[i] = mfma32(frag_rc3<HD>(cK, i * 32 + (l & 31), kk, l), qf[kk], st[i]);
                     dpt[i] = mfma32(frag_rc3<HD>(cV, i * 32 + (l & 31), kk, l), dof[kk], dpt[i]);
                 }
-            const bool need_mask = !all_q_ok || (kv0 + 64 > klen) || (causal && kv0 + 63 > q_wmin) || (kmb && !sFlag[cur]);
+            const bool need_mask = !all_q_ok || (kv0 + 64 > klen) || (causal && kv0 + 63 > q_wmin) || (kmb && !(sFlag[cur] & 1));
             const uint8_t* cM = sM + cur * 64;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -1041,7 +1043,7 @@ __global__ __launch_bounds__(512) void attn_bwd5_dq_kernel(const bf16_t* Q, cons
             const uint8_t mv = (kvn + t < S) ? kmb[kvn + t] : 0;
             sM[nb * 64 + t] = mv;
             const unsigned long long all = ballot(mv != 0);
-            if (t == 0) sFlag[nb] = (all == ~0ull);
+            if (t == 0) sFlag[nb] = int(all == ~0ull) | (int(all == 0ull) << 1);
         }
     }
     if (q_abs < Sq) {

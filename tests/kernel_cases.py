@@ -419,6 +419,35 @@ def case_attention_cross_masked(dev, B, Sq, Skv, H, hd):
     close(dv, vf.grad, 3e-2, 3e-2)
 
 
+def case_attention_masked_tiles(dev, hd, H, B=2, S=330):
+    """A padded image masks a CONTIGUOUS patch range: key tiles without a single valid key are skipped by the forward and dQ kernels
+    (nothing to add: every probability of the tile is 0) -- the first tile, a middle run and the last tiles fully masked, plus scattered
+    keys, against the fp32 reference (idefics2 eager attention with the additive mask, vision_encoder.py:147-152); dK / dV of masked keys
+    are exactly zero."""
+    from aria_amd import ops
+
+    D = H * hd
+    g = torch.Generator().manual_seed(hd)
+    qkv = torch.randn(B * S, 3 * D, generator=g).to(bf16)
+    do = torch.randn(B * S, D, generator=g).to(bf16)
+    km = torch.ones(B, S, dtype=torch.uint8)
+    km[0, :64] = 0          # the FIRST tile has no valid key
+    km[0, 128:256] = 0      # two middle tiles
+    km[1, 192:] = 0         # everything from tile 3 on
+    km[1, 5:40:3] = 0       # and scattered ones
+    qd, kmd = qkv.to(dev), km.to(dev)
+    o, lse = ops.attention_fwd(qd[:, :D], qd[:, D:2 * D], qd[:, 2 * D:], B, S, H, hd, hd ** -0.5, False, key_mask=kmd)
+    dq, dk, dv = ops.attention_bwd(qd[:, :D], qd[:, D:2 * D], qd[:, 2 * D:], o, do.to(dev), lse, B, S, H, hd, hd ** -0.5, False, key_mask=kmd)
+    q, k, v = (qkv[:, i * D:(i + 1) * D].float().view(B, S, H, hd).transpose(1, 2).clone().requires_grad_(True) for i in range(3))
+    want = O.attention_eager(q, k, v, hd ** -0.5, False, key_padding=(km == 0))
+    want.backward(do.float().view(B, S, H, hd).transpose(1, 2))
+    close(o, want.detach().transpose(1, 2).reshape(B * S, D), 2e-2, 2e-2)
+    for got, t in zip((dq, dk, dv), (q, k, v)):
+        close(got, t.grad.transpose(1, 2).reshape(B * S, D), 3e-2, 3e-2)
+    dead = (km == 0).reshape(-1)
+    assert float(dk.float().cpu()[dead].abs().max()) == 0.0 and float(dv.float().cpu()[dead].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------ single-query decode attention
 def case_decode_attention(dev, H, hd, pos, splits, S_max=None):
     """aria_decode_attn (RoPE of q / k with freqs_cis[pos], cache write at row pos, softmax over rows 0..pos) against fp32 torch on the same

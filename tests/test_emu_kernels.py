@@ -79,6 +79,11 @@ def test_attention_fwd_bwd(B, S, H, hd, causal, use_len):
     C.case_attention(DEV, B, S, H, hd, causal, use_len)
 
 
+@pytest.mark.parametrize("hd,H", [(72, 2), (128, 1), (64, 1)])
+def test_attention_with_whole_key_tiles_masked(hd, H):
+    C.case_attention_masked_tiles(DEV, hd, H)
+
+
 @pytest.mark.parametrize("defer", ["0", "1"])
 def test_attention_bwd_default_kernels_under_both_dma_models(defer, monkeypatch):
     """The hd-128 backward kernels stage their tiles by LDS-DMA: pieces landing at once (adversarial for a slot restaged too early) and

@@ -91,6 +91,11 @@ def test_attention_cross_masked(B, Sq, Skv, H, hd):
     C.case_attention_cross_masked(DEV, B, Sq, Skv, H, hd)
 
 
+@pytest.mark.parametrize("hd,H,S", [(72, 16, 4900), (128, 2, 1000), (64, 2, 330)])
+def test_attention_with_whole_key_tiles_masked(hd, H, S):
+    C.case_attention_masked_tiles(DEV, hd, H, S=S)
+
+
 @pytest.mark.parametrize("B,Sq,Skv,H,masked", [(2, 70, 70, 2, True), (1, 300, 90, 1, False), (2, 4900, 4900, 4, True), (3, 256, 4900, 16, True)])
 def test_attention_hd72_forward(B, Sq, Skv, H, masked):
     C.case_attention_hd72_forward(DEV, B, Sq, Skv, H, masked)
