@@ -98,6 +98,7 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 __device__ __forceinline__ int wave_bcast(int v, int lane) { return emu::shfl(v, lane); }
+__device__ __forceinline__ int read_lane(int v, int lane) { return emu::shfl(v, lane); }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return emu::ballot(p); }
 __device__ __forceinline__ int lane_id() { return emu::lane(); }
 __device__ __forceinline__ int first_lane(int v) { return emu::shfl(v, __builtin_ctzll(emu::ballot(true))); }
@@ -131,6 +132,9 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 // kernels spill 200-366 VGPRs in their hot loop -- scalar register pressure pushed back into vector registers -- for no measurable gain:
 // the five broadcasts of a grouped tile lookup hide under the prologue's DMA wait.)
 __device__ __forceinline__ int wave_bcast(int v, int lane) { return __shfl(v, lane, 64); }
+// the value of lane `lane` (a compile-time constant or otherwise wave-uniform) as a SCALAR: v_readlane_b32, no LDS round trip -- for
+// values that become addresses of wave-uniform rows
+__device__ __forceinline__ int read_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -159,6 +159,132 @@ __global__ __launch_bounds__(256) void expert_down_kernel(const bf16_t* W2, cons
     }
 }
 
+// ---- fused schedule (6 launches per layer instead of 7; ARIA_DECODE_FUSE=0 keeps the 7-launch one for A/B and as the fallback for
+// widths the fused down-projection has no instantiation for) ------------------------------------------------------------------------
+// (a) Router logits AND the shared expert's up-projection pair + SwiGLU in ONE launch.  The router GEMV alone is 320 KB of gate matrix
+//     on 8 workgroups: pure launch + ramp latency in front of the one kernel that needs its result.  The shared expert (a quarter of
+//     the layer's up-projection bytes) needs no routing, so its rows ride along: blocks [0, nrb) compute the E logits exactly as
+//     gemv_kernel<2, NC> does (same rows per wave, same summation order -> the same bits), the rest the shared activation vector exactly
+//     as expert_up_kernel's j >= k slices do.  The routed up-projection (expert_up_kernel, grid.y = k) follows and reads the logits.
+template <int R, int NC>
+__global__ __launch_bounds__(256) void router_shared_up_kernel(const bf16_t* gate, int E, bf16_t* logits, const bf16_t* S1, const bf16_t* S3,
+                                                               int rows_s, const bf16_t* x, const bf16_t* norm_w, float eps, int K,
+                                                               bf16_t* act_s, int nrb) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32x4 xv[NC];
+    if (int(blockIdx.x) < nrb) {  // block-uniform
+        const int row0 = (blockIdx.x * 4 + w) * 2;
+        if (row0 >= E) return;
+        float acc[2];
+        load_vector<NC>(xv, x, norm_w, eps, K, l);
+        dot_rows<2, NC>(acc, gate, K, row0, E, xv, K, l);
+        if (l == 0) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (row0 + r < E) logits[row0 + r] = f2bf(acc[r]);
+        }
+        return;
+    }
+    const int row0 = ((int(blockIdx.x) - nrb) * 4 + w) * R;
+    if (row0 >= rows_s) return;
+    float a1[R], a3[R];
+    load_vector<NC>(xv, x, norm_w, eps, K, l);
+    dot_rows<R, NC>(a1, S1, K, row0, rows_s, xv, K, l);
+    dot_rows<R, NC>(a3, S3, K, row0, rows_s, xv, K, l);
+    if (l == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (row0 + r < rows_s) act_s[row0 + r] = f2bf(rbf(silu(rbf(a1[r]))) * rbf(a3[r]));
+    }
+}
+
+// (b) All k + 1 down-projections of ONE output row per wave, and the combine (token_unpermutation + shared add + residual,
+//     combine_kernel) as the epilogue: the k + 1 partial rows never visit HBM and the layer loses a launch.
+//     The workgroup's four waves share the activation vectors, kept in LDS as lane-chunk images (chunk c of expert j at
+//     [j][c], zeros past the end of the reduction) -- a lane's operand is one conflict-free ds_read_b128 at the point of use instead of
+//     (k NCI + NCS) x 4 live registers; every weight row chunk of the wave's row (k NCI + NCS 16-byte loads per lane, 31 at Aria's
+//     widths) is issued before the first use.  Per-expert dot products run in dot_rows' order and the epilogue rounds where
+//     expert_down_kernel / combine_kernel materialise bf16, so the hidden state equals the 7-launch schedule's bit for bit.
+constexpr int DOWN_KMAX = 6;  // routed experts the fused form holds weight rows for (Aria: top-6); wider routing takes the 7-launch schedule
+__device__ const uint32_t decode_zero_page[64] = {};  // 256 zero bytes: LDS-DMA source of the image chunks past the end of a reduction
+template <int NCI, int NCS>
+__global__ __launch_bounds__(256) void expert_down_combine_kernel(const bf16_t* W2, const bf16_t* S2, const int32_t* idx, const bf16_t* scores,
+                                                                  int k, int ns, const bf16_t* act, int I, int N, const bf16_t* h,
+                                                                  bf16_t* out) {
+    ARIA_DYN_SMEM(smem);
+    u32x4* sa = reinterpret_cast<u32x4*>(smem);  // [k][NCI * 64] routed images, then [NCS * 64] the shared expert's
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    const int nchI = I >> 3, nchS = (ns * I) >> 3;
+    const int n = blockIdx.x * 4 + w, nn = min(n, N - 1);  // rows past the end are clamped (computed, never stored): every wave reaches the barrier
+    // activation images by LDS-DMA (no staging registers; issued first, so they are the oldest operations in flight): instruction g
+    // fills image chunks 64 g .. 64 g + 63, the four waves take every fourth one
+    const int ninstr = k * NCI + NCS;
+    for (int g = w; g < ninstr; g += 4) {
+        const bf16_t* src;
+        if (g < k * NCI) {
+            const int j = g / NCI, cc = (g % NCI) * 64 + l;
+            src = cc < nchI ? act + (long long)j * I + cc * 8 : reinterpret_cast<const bf16_t*>(decode_zero_page) + 8 * (l & 15);
+        } else {
+            const int cc = (g - k * NCI) * 64 + l;
+            src = cc < nchS ? act + (long long)k * I + cc * 8 : reinterpret_cast<const bf16_t*>(decode_zero_page) + 8 * (l & 15);
+        }
+        glds16(src, sa + 64 * g);
+    }
+    // expert ids and scores of the k slots: ONE vector load each (lane j = slot j), broadcast as scalars -- an idx[j] read in front of every
+    // expert's rows made each expert wait for everything issued before it (six dependent round trips in the first build's ISA)
+    int my_e = 0, my_sc = 0;
+    if (l < k) {
+        my_e = idx[l];
+        my_sc = int(uint32_t(scores[l]) << 16);
+    }
+    int e[DOWN_KMAX];
+    float sc[DOWN_KMAX];
+#pragma unroll
+    for (int j = 0; j < DOWN_KMAX; ++j) {
+        e[j] = read_lane(my_e, j);
+        sc[j] = __builtin_bit_cast(float, read_lane(my_sc, j));
+    }
+    // every weight chunk of the wave's row: k NCI + NCS 16-byte loads per lane in flight before the first use
+    u32x4 wr[DOWN_KMAX][NCI], ws[NCS];
+    {
+        const bf16_t* row = S2 + (long long)nn * ns * I;
+#pragma unroll
+        for (int i = 0; i < NCS; ++i) ws[i] = ld16(row + min(l + 64 * i, nchS - 1) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < DOWN_KMAX; ++j)
+        if (j < k) {
+            const bf16_t* row = W2 + ((long long)e[j] * N + nn) * I;
+#pragma unroll
+            for (int i = 0; i < NCI; ++i) wr[j][i] = ld16(row + min(l + 64 * i, nchI - 1) * 8);
+        }
+    wait_vm<0>();  // this wave's image pieces have landed (the weight rows with them: they are needed next anyway)
+    sync();
+    float accs = 0.f;
+#pragma unroll
+    for (int j = 0; j < DOWN_KMAX; ++j)
+        if (j < k) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCI; ++i) {
+                const u32x4 xv = sa[j * NCI * 64 + l + 64 * i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s = dot2bf(wr[j][i][q], xv[q], s);
+            }
+            s = wave_sum(s);
+            accs += rbf(rbf(s) * sc[j]);  // bf16(eo_j * score_j), summed in fp32 in slot order (combine_kernel)
+        }
+    float sh = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCS; ++i) {
+        const u32x4 xv = sa[k * NCI * 64 + l + 64 * i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sh = dot2bf(ws[i][q], xv[q], sh);
+    }
+    sh = wave_sum(sh);
+    if (l == 0 && n < N) out[n] = f2bf(bf2f(h[n]) + rbf(rbf(accs) + rbf(sh)));
+}
+
 // TopKRouter.routing on the E logits of one token, exactly as route_kernel (moe.hip): k rounds of arg-max with ties to the lowest expert
 // id, softmax over the selected logits in fp32, scores cast to bf16.  One wave; the logits come from a regular (multi-workgroup) GEMV --
 // a single workgroup reading the whole 320 KB gate matrix cost 16 us per layer.
@@ -526,6 +652,13 @@ int decode_splits_for(int64_t Smax) {
     return int(n < 2 ? 2 : n > DECODE_MAX_SPLITS ? DECODE_MAX_SPLITS : n);
 }
 
+// ARIA_DECODE_FUSE: unset / "1" = the 6-launch schedule (router + shared up | routed up | down + combine); "0" = the 7-launch one
+// (tests compare the two bit for bit; tools/decode_bench.py times both)
+bool decode_fuse_enabled() {
+    const char* e = std::getenv("ARIA_DECODE_FUSE");
+    return !e || atoi(e) != 0;
+}
+
 // NC = 16-byte chunks per lane = ceil(K / 512), a template parameter so that every load of a wave is issued up front
 #define ARIA_NC_SWITCH(nc, CALL)   \
     switch (nc) {                  \
@@ -620,6 +753,7 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
         rc = (call);                \
         if (rc != ARIA_OK) return rc; \
     } while (0)
+    const bool fuse = decode_fuse_enabled();
     for (int64_t li = 0; li < L; ++li) {
         const void* const* lp = ptrs + ARIA_DECODE_HEADER_PTRS + ARIA_DECODE_LAYER_PTRS * li;
         const bf16_t *attn_norm = static_cast<const bf16_t*>(lp[0]), *wqkv = static_cast<const bf16_t*>(lp[1]),
@@ -643,38 +777,63 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
                                    0, stream));
         }
         ARIA_TRY(launch_gemv(int(D), stream, wo, (long long)D, s.ao, nullptr, 0.f, int(D), x, h));
-        // MoE block on hn = norm(h): out = h + ( sum_j score_j * expert_j(hn) + shared(hn) ) -- four launches
+        // MoE block on hn = norm(h): out = h + ( sum_j score_j * expert_j(hn) + shared(hn) )
         const int ncD = chunks_per_lane(D), ncI = chunks_per_lane(I), ncS = chunks_per_lane(Is);
-        ARIA_TRY(launch_gemv(int(E), stream, gate, (long long)D, h, ffn_norm, eps, int(D), nullptr, s.rl));
+        const bool fused_down = fuse && k <= DOWN_KMAX && ((ncI == 4 && ncS == 7) || (ncI == 1 && ncS == 1) || (ncI <= 2 && ncS <= 4));
+        const int ns_up = fuse ? 0 : ns;  // shared-expert slices handled by expert_up_kernel (fused schedule: by router_shared_up_kernel)
+        if (fuse) {  // three launches: router logits + shared up | routed up (top-k inside) | all down-projections + combine
+            const int nrb = int((E + 7) / 8);
+#define CALL(NC)                                                                                                                          \
+    ARIA_LAUNCH((router_shared_up_kernel<2, NC>), dim3(unsigned(nrb + (Is + 7) / 8)), dim3(256), 0, stream, gate, int(E), s.rl, sw1, sw3, \
+                int(Is), (const bf16_t*)h, ffn_norm, eps, int(D), s.act + k * I, nrb)
+            ARIA_NC_SWITCH(ncD, CALL)
+#undef CALL
+        } else {  // four launches: router logits | routed + shared up (top-k inside) | down-projections | combine
+            ARIA_TRY(launch_gemv(int(E), stream, gate, (long long)D, h, ffn_norm, eps, int(D), nullptr, s.rl));
+        }
         // (top-k + softmax of the router run inside expert_up_kernel; router_topk_kernel is the stand-alone form)
         if (I * (k + ns) >= 8192) {  // enough rows for 4 per wave (8 row reads of 5 KiB in flight per wave) and still > 2000 waves
 #define CALL(NC)                                                                                                                       \
-    ARIA_LAUNCH((expert_up_kernel<4, NC>), dim3(unsigned((I + 15) / 16), unsigned(k + ns)), dim3(256), 0, stream, w1, w3, sw1, sw3, \
+    ARIA_LAUNCH((expert_up_kernel<4, NC>), dim3(unsigned((I + 15) / 16), unsigned(k + ns_up)), dim3(256), 0, stream, w1, w3, sw1, sw3, \
                 (const bf16_t*)s.rl, int(E), s.scores, s.idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act)
             ARIA_NC_SWITCH(ncD, CALL)
 #undef CALL
         } else {
 #define CALL(NC)                                                                                                                      \
-    ARIA_LAUNCH((expert_up_kernel<2, NC>), dim3(unsigned((I + 7) / 8), unsigned(k + ns)), dim3(256), 0, stream, w1, w3, sw1, sw3, \
+    ARIA_LAUNCH((expert_up_kernel<2, NC>), dim3(unsigned((I + 7) / 8), unsigned(k + ns_up)), dim3(256), 0, stream, w1, w3, sw1, sw3, \
                 (const bf16_t*)s.rl, int(E), s.scores, s.idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act)
             ARIA_NC_SWITCH(ncD, CALL)
 #undef CALL
         }
+        if (fused_down) {
+#define DOWNC(NCI, NCS)                                                                                                                 \
+    ARIA_LAUNCH((expert_down_combine_kernel<NCI, NCS>), dim3(unsigned((D + 3) / 4)), dim3(256), size_t(k * NCI + NCS) * 1024, stream, w2, \
+                sw2, (const int32_t*)s.idx, (const bf16_t*)s.scores, int(k), ns, (const bf16_t*)s.act, int(I), int(D), (const bf16_t*)h, s.xb)
+            if (ncI == 4 && ncS == 7) {  // Aria: I = 1664, shared 3328
+                DOWNC(4, 7);
+            } else if (ncI == 1 && ncS == 1) {
+                DOWNC(1, 1);
+            } else {
+                DOWNC(2, 4);
+            }
+#undef DOWNC
+        } else {
 #define DOWN(NCI, NCS)                                                                                                               \
     ARIA_LAUNCH((expert_down_kernel<2, NCI, NCS>), dim3(unsigned((D + 7) / 8), unsigned(k + 1)), dim3(256), 0, stream, w2, sw2, \
                 (const int32_t*)s.idx, int(k), ns, (const bf16_t*)s.act, int(I), int(D), s.eo)
-        if (ncI == 4 && ncS == 7) {  // Aria: I = 1664, shared 3328
-            DOWN(4, 7);
-        } else if (ncI == 1 && ncS == 1) {
-            DOWN(1, 1);
-        } else if (ncI <= 2 && ncS <= 4) {
-            DOWN(2, 4);
-        } else {
-            DOWN(8, 8);  // any other width: correct (chunks past the end read as zeros), more load instructions than needed
-        }
+            if (ncI == 4 && ncS == 7) {  // Aria: I = 1664, shared 3328
+                DOWN(4, 7);
+            } else if (ncI == 1 && ncS == 1) {
+                DOWN(1, 1);
+            } else if (ncI <= 2 && ncS <= 4) {
+                DOWN(2, 4);
+            } else {
+                DOWN(8, 8);  // any other width: correct (chunks past the end read as zeros), more load instructions than needed
+            }
 #undef DOWN
-        ARIA_LAUNCH(combine_kernel, dim3(unsigned((D / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)s.eo, (const bf16_t*)s.scores,
-                    int(k), (const bf16_t*)(s.eo + k * D), (const bf16_t*)h, s.xb, int(D));
+            ARIA_LAUNCH(combine_kernel, dim3(unsigned((D / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)s.eo, (const bf16_t*)s.scores,
+                        int(k), (const bf16_t*)(s.eo + k * D), (const bf16_t*)h, s.xb, int(D));
+        }
         ARIA_TRY(aria_check_launch());
         x = s.xb;  // the next layer reads x = xb and writes its h into xa again (h is dead once this add has run)
     }

@@ -256,6 +256,9 @@ int aria_probe_atomic(float* buf, int* xcc, int64_t nblocks, int64_t region_floa
  * ONE call enqueues every kernel of every layer for one token: GEMV projections with RMSNorm / residual / SwiGLU folded in,
  * RoPE + KV-cache write, flash attention over the cache, device-indexed routed experts.  The position is read from device
  * memory (ptrs[4]), so the call needs no host sync and its launch sequence is identical for every token.
+ * Six launches per layer (qkv | attention | wo + residual | router logits + shared up-projection | routed up-projection with the
+ * top-k inside | every down-projection + combine + residual); ARIA_DECODE_FUSE=0 selects the older seven-launch schedule
+ * (bit-identical results: tests/model_cases.py::case_decode_engine_fused_schedule).
  *
  * ptrs (host array of device pointers): [0] freqs_cis bf16 [S_max, hd/2, 2]   [1] final norm weight [D]   [2] output weight [V, D]
  *   [3] scratch (aria_decode_scratch_bytes)   [4] pos int32 [1]   [5] input embedding bf16 [D]   [6] logits out bf16 [V]   [7] unused (non-NULL)

@@ -155,6 +155,16 @@ def test_decode_engine_aria_width():
     M.case_decode_engine_aria_width(DEV, n_tokens=3)
 
 
+def test_decode_engine_fused_schedule_is_bit_identical():
+    M.case_decode_engine_fused_schedule(DEV)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("ARIA_SLOW_TESTS") != "1", reason="~5 min through the emulator; runs on hardware in "
+                    "tests/test_gpu_model.py, and here with ARIA_SLOW_TESTS=1")
+def test_decode_engine_fused_schedule_aria_width():
+    M.case_decode_engine_fused_schedule(DEV, aria_width=True, n_tokens=2)
+
+
 def test_frozen_lm_head_skips_its_weight_gradient(golden):
     """freeze_llm-style runs: with lm_head frozen the fused lm_head + CE node still returns the hidden-state gradient but no [V, D] GEMM."""
     from aria_amd import autograd as AG

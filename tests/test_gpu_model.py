@@ -55,5 +55,10 @@ def test_decode_engine_aria_width():  # the decode kernels' Aria-width instantia
     M.case_decode_engine_aria_width(DEV, n_tokens=6)
 
 
+@pytest.mark.parametrize("aria_width", [False, True])
+def test_decode_engine_fused_schedule(aria_width):  # 6-launch decode schedule == 7-launch schedule, bit for bit (toy widths and Aria's)
+    M.case_decode_engine_fused_schedule(DEV, aria_width=aria_width, n_tokens=6 if aria_width else 4)
+
+
 def test_lora_linear_lm():  # last on purpose: newest composition of already-covered kernels
     M.case_lora_linear_lm(DEV)

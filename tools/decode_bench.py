@@ -1,5 +1,5 @@
-"""decode-step timing on the gptfast Transformer (random-init Aria-25.3B LLM, batch 1): engine with graph replay vs plain enqueue vs the
-tile-GEMM path, model step only (no sampling)."""
+"""decode-step timing on the gptfast Transformer (random-init Aria-25.3B LLM, batch 1): the engine's 6-launch schedule vs the 7-launch one
+(ARIA_DECODE_FUSE), graph replay vs plain enqueue, and the tile-GEMM path; model step only (no sampling)."""
 import json, os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 from aria_amd import gptfast as G
@@ -24,7 +24,9 @@ res = {}
 with torch.no_grad():
     m(ids, torch.arange(280, device=dev))
     tok = torch.tensor([[17]], device=dev)
-    for name, eng, graph in (("engine_graph", True, True), ("engine_enqueue", True, False), ("tile_path", False, False)):
+    for name, eng, graph, fuse in (("engine_fused6", True, False, "1"), ("engine_unfused7", True, False, "0"), ("engine_fused6_graph", True, True, "1"),
+                                   ("engine_fused6_again", True, False, "1"), ("tile_path", False, False, "1")):
+        os.environ["ARIA_DECODE_FUSE"] = fuse  # read by the library at every aria_decode_token call (csrc/decode.hip)
         m.use_decode_engine, m.decode_graph, m._engine = eng, graph, None
         pos = torch.tensor([280], device=dev, dtype=torch.int32)
         for _ in range(3):
