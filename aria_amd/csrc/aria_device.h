@@ -355,6 +355,14 @@ __device__ __forceinline__ float rcp_fast(float x) {
 // x * sigmoid(x) (SiLU): x / (1 + e^-x) on v_exp_f32 + v_rcp_f32.  ONE definition for the fused GEMM epilogue, the stand-alone SwiGLU
 // kernels and the decode path, so that all of them round identically.
 __device__ __forceinline__ float silu_fast(float a) { return a * rcp_fast(1.f + exp2_fast(-1.4426950408889634f * a)); }
+// Backward of y = bf16(silu(a)) * b for one element (GroupedMLP's glu, moe_lm.py:505-507): d_a = g b silu'(a), d_b = g bf16(silu(a)), with
+// silu(a) evaluated exactly as silu_fast does (so bf16(silu(a)) here IS the value the forward multiplied by).  ONE definition for the
+// stand-alone kernel (moe.hip) and the GEMM epilogue that absorbs it (gemm3.hip, VER 5): both round identically.
+__device__ __forceinline__ void swiglu_bwd_elem(float a, float b, float g, float& da, float& db) {
+    const float sig = rcp_fast(1.f + exp2_fast(-1.4426950408889634f * a));
+    db = g * rbf(a * sig);
+    da = g * b * (sig * (1.f + a * (1.f - sig)));
+}
 __device__ __forceinline__ float gelu_tanh(float x) {
     const float k2 = 2.f * 0.7978845608028654f * 1.4426950408889634f;  // 2 sqrt(2/pi) log2(e)
     return x * rcp_fast(1.f + exp2_fast(-k2 * (x + 0.044715f * x * x * x)));

@@ -435,6 +435,56 @@ int aria_gemm_swiglu_bf16(const void* A, const void* B, void* H, void* ACT, int6
     return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int((M + 255) / 256), stream);
 }
 
+// shared validation of the fused input-gradient + SwiGLU-backward entries (gemm3_kernel<.., .., 5>)
+static int dglu_check(const void* A, const void* B, const void* H, const void* DH, int64_t M, int64_t I, int64_t K, int64_t lda, int64_t ldb,
+                      int64_t ldh, int64_t lddh) {
+    if (!A || !B || !H || !DH || M < 0 || I <= 0 || K <= 0) return ARIA_ERR_INVALID;
+    if (!aligned16(A) || !aligned16(B) || !aligned16(H) || !aligned16(DH) || (lda & 7) || (ldb & 7) || (ldh & 7) || (lddh & 7)) return ARIA_ERR_ALIGN;
+    if ((I % 128) || (K % 64) || K < 64 || 2 * lda >= (1ll << 24) || 2 * ldb >= (1ll << 24)) return ARIA_ERR_UNSUPPORTED;
+    return ARIA_OK;
+}
+
+int aria_grouped_gemm_dswiglu_bf16(const void* dY, const void* B, const void* H, void* DH, const int32_t* offsets, int64_t E, int64_t M_total,
+                                   int64_t I, int64_t K, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldh, int64_t lddh, void* stream) {
+    if (!offsets || E <= 0) return ARIA_ERR_INVALID;
+    const int rc = dglu_check(dY, B, H, DH, M_total, I, K, lda, ldb, ldh, lddh);
+    if (rc != ARIA_OK) return rc;
+    if (strideB & 7) return ARIA_ERR_ALIGN;
+    if (2 * M_total * lda >= (1ll << 32) || 2 * I * ldb >= (1ll << 32)) return ARIA_ERR_UNSUPPORTED;  // per-lane DMA offsets are 32-bit
+    if (M_total == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(dY);
+    p.B = static_cast<const bf16_t*>(B);  // [E][I, K]: the "B operand" rows are the I output columns ([N, K] form)
+    p.C = DH;
+    p.H = static_cast<const bf16_t*>(H);
+    p.lda = lda, p.ldb = ldb, p.ldc = lddh, p.ldh = ldh;
+    p.M = int(M_total), p.N = int(I), p.K = int(K);
+    p.mode = 1;
+    p.offsets = offsets;
+    p.E = int(E);
+    p.strideB = strideB;
+    p.dglu = 1;
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int(M_total / 256 + E), stream);
+}
+
+int aria_gemm_dswiglu_bf16(const void* dY, const void* B, const void* H, void* DH, int64_t M, int64_t I, int64_t K, int b_oc, int64_t lda,
+                           int64_t ldb, int64_t ldh, int64_t lddh, void* stream) {
+    const int rc = dglu_check(dY, B, H, DH, M, I, K, lda, ldb, ldh, lddh);
+    if (rc != ARIA_OK) return rc;
+    if (2 * M * lda >= (1ll << 32) || 2 * (b_oc ? K : I) * ldb >= (1ll << 32)) return ARIA_ERR_UNSUPPORTED;
+    if (M == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(dY);
+    p.B = static_cast<const bf16_t*>(B);
+    p.C = DH;
+    p.H = static_cast<const bf16_t*>(H);
+    p.lda = lda, p.ldb = ldb, p.ldc = lddh, p.ldh = ldh;
+    p.M = int(M), p.N = int(I), p.K = int(K);
+    p.mode = 0;
+    p.dglu = 1;
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, b_oc ? 1 : 0, int((M + 255) / 256), stream);
+}
+
 int aria_grouped_gemm_wgrad_bf16(const void* A, const void* dY, void* dW, const int32_t* offsets, int64_t E, int64_t K,
                                  int64_t N, int64_t lda, int64_t ldy, int c_f32, int accumulate, void* stream) {
     if (!A || !dY || !dW || !offsets || E <= 0) return ARIA_ERR_INVALID;

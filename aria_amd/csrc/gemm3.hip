@@ -565,6 +565,82 @@ __device__ __forceinline__ void store_tile3_glu(const P& p, const f32x16 (&acc)[
     }
 }
 
+// Fused SwiGLU-backward epilogue (gemm3_kernel<.., .., 5>; GroupedMLP's glu backward moe_lm.py:505-507 behind experts.fc2's input
+// gradient, and the shared expert's): the tile is d_act = dY W2^T for columns n0 .. n0 + 255 of I.  Every wave parks its 128 x 64 block
+// as bf16 in its own 16 KiB of the idle operand images (the rounding point of the two-step chain's d_act tensor), then walks it in 16-byte
+// row pieces: gate and up of the same 8 elements come from H (two 16-byte loads per piece, the 16 of a 128-row half in flight before the
+// first use -- the accumulators are dead by then), swiglu_bwd_elem gives d_gate / d_up, two 16-byte stores.  Saves the d_act round trip
+// (write + read of M x I bf16) and a launch per GEMM; bit-identical to aria_swiglu_bwd on the unfused product.
+// Column blocks of 128 are all-or-nothing (I % 128 == 0, checked by the entry point); rows past m_end are predicated off.
+template <class P>
+__device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
+                                                 int wm, int wn, char* smem) {
+    const int c = l & 31, h = l >> 5, odd = l & 1;
+    char* mine = smem + 16384 * w;  // [a][b][64 rows][64 bytes]
+    const int I = p.N;
+    wave_barrier();
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {  // register pair (2rp, 2rp+1) = two consecutive rows
+                    const float v0 = acc[a][i][b][2 * rp], v1 = acc[a][i][b][2 * rp + 1];
+                    const int r = 2 * rp;
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;  // inside the 64-row block
+                    const float got = xor1(odd ? v0 : v1);
+                    const float lo = odd ? got : v0, hi = odd ? v1 : got;  // columns (c & ~1), (c | 1) of that row
+                    *reinterpret_cast<uint32_t*>(mine + (a * 2 + b) * 4096 + row * 64 + (c & ~1) * 2) = pack2bf(lo, hi);
+                }
+    wave_barrier();
+    sched_fence();  // (the H loads below must not be hoisted above the parking: the accumulators are still live there)
+    const int rr = l >> 2, cc = (l & 3) * 8;  // this lane's row inside a 16-row slab / first of its 8 columns
+    const bf16_t* H = p.H;
+    bf16_t* DH = reinterpret_cast<bf16_t*>(C);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        u32x4 vg[2][4], vu[2][4];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            if (n0 + b * 128 < I) {  // block-uniform
+#pragma unroll
+                for (int s16 = 0; s16 < 4; ++s16) {
+                    const int m = min(m0 + a * 128 + wm * 64 + s16 * 16 + rr, m_end - 1);  // clamped: loaded, never stored
+                    const bf16_t* src = H + (long long)m * p.ldh + n0 + b * 128 + wn * 32 + cc;
+                    vg[b][s16] = ld16(src);
+                    vu[b][s16] = ld16(src + I);
+                }
+            }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            if (n0 + b * 128 < I) {
+#pragma unroll
+                for (int s16 = 0; s16 < 4; ++s16) {
+                    const int row = s16 * 16 + rr;
+                    const u32x4 d = *reinterpret_cast<const u32x4*>(mine + (a * 2 + b) * 4096 + row * 64 + cc * 2);
+                    u32x4 og, ou;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float da[2], db[2];
+                        swiglu_bwd_elem(bflo(vg[b][s16][q]), bflo(vu[b][s16][q]), bflo(d[q]), da[0], db[0]);
+                        swiglu_bwd_elem(bfhi(vg[b][s16][q]), bfhi(vu[b][s16][q]), bfhi(d[q]), da[1], db[1]);
+                        og[q] = pack2bf(da[0], da[1]);
+                        ou[q] = pack2bf(db[0], db[1]);
+                    }
+                    const int m = m0 + a * 128 + wm * 64 + row;
+                    if (m < m_end) {
+                        bf16_t* dst = DH + (long long)m * p.ldc + n0 + b * 128 + wn * 32 + cc;
+                        *reinterpret_cast<u32x4*>(dst) = og;
+                        *reinterpret_cast<u32x4*>(dst + I) = ou;
+                    }
+                }
+            }
+        sched_fence();
+    }
+}
+
 template <bool A_OC, bool B_OC, int VER>
 __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     ARIA_DYN_SMEM(smem);
@@ -698,6 +774,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         return;
     }
     if ((ARIA_ABL & 64) && p.M > 0) return;  // (timing experiment: no C write-out)
+    if (VER == 5) {  // compile-time: the SwiGLU-backward instantiations carry only this epilogue, the default ones none of it
+        store_tile3_dglu(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
+        return;
+    }
     if (p.glu)
         store_tile3_glu(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
     else if (p.act == 1)  // (one wave-uniform branch here instead of one per value inside the unrolled epilogues)
@@ -806,6 +886,14 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     if (ntn * ntm <= 0) return ARIA_OK;
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
     dim3 grid(unsigned(aria_tile_grid(q)), grid_y), block(512);
+    if (p.dglu) {  // SwiGLU-backward epilogue: its own instantiations (the default kernels' code is untouched)
+        if (a_oc || p.glu || p.c_f32 || p.accumulate || p.bias || p.act || p.mode == 2) return ARIA_ERR_INVALID;
+        if (!b_oc)
+            ARIA_LAUNCH((gemm3_kernel<false, false, 5>), grid, block, shmem, stream, q);
+        else
+            ARIA_LAUNCH((gemm3_kernel<false, true, 5>), grid, block, shmem, stream, q);
+        return aria_check_launch();
+    }
     if (!a_oc && !b_oc)
         ARIA_LAUNCH((gemm3_kernel<false, false, 3>), grid, block, shmem, stream, q);
     else if (!a_oc && b_oc)

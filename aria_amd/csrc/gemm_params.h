@@ -30,6 +30,13 @@ struct GemmParams {
     int stagger;     // v3 experiment: first-round workgroups start up to this many s_sleep(127) units (~4 us each) apart, see gemm3.hip
     int wide_store;  // v3: C rows are 16-byte aligned at every 8th column (pointer, ldc, strideC): full-width column tiles take the wide epilogue
     int order;     // tile-order variant (tuning knob): 0 = XCD-contiguous row-major, 1 = plain, >= 2 = groups of `order` row tiles
+    // (appended: the fields above keep their kernarg offsets, the default kernels' ISA does not move)
+    // v3, fused SwiGLU-BACKWARD epilogue (dglu; gemm3_kernel<.., .., 5>): the GEMM is the down-projection's input gradient d_act = dY W2^T
+    // (N = I columns); H [M, 2 I] holds the forward's [gate | up]; C [M, 2 I] receives [d_gate | d_up] = swiglu_bwd(H, d_act) -- d_act
+    // itself (rounded to bf16 exactly where the two-step chain materialises it) never visits HBM.  Needs I % 128 == 0.
+    int dglu;
+    const ad::bf16_t* H;
+    long long ldh;
 };
 // (the device helpers below are templates on the block's type so that a kernel may also hand them the block where it lies in the
 // kernarg segment -- a reference into the constant address space: scalar loads at the point of use instead of registers held live)

@@ -353,10 +353,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* h, const 
                 const float av = z ? bfhi(a[q]) : bflo(a[q]);
                 const float bv = z ? bfhi(b[q]) : bflo(b[q]);
                 const float gv = z ? bfhi(g[q]) : bflo(g[q]);
-                const float sig = 1.f / (1.f + expf(-av));
-                const float sl = av * sig;
-                db[z] = gv * rbf(sl);
-                da[z] = gv * bv * (sig * (1.f + av * (1.f - sig)));
+                swiglu_bwd_elem(av, bv, gv, da[z], db[z]);
             }
             oa[q] = pack2bf(da[0], da[1]);
             ob[q] = pack2bf(db[0], db[1]);

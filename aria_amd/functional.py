@@ -118,16 +118,20 @@ def moe_bwd(dout, ctx, router_w, fc1, fc2, gate_w, up_w, down_w, need=None):
     I2 = gate_w.shape[0]
     # routed experts
     d_eo, dscores = ops.moe_unpermute_bwd(dout, ctx["eo"], inv, ctx["scores"], k)
-    d_act = ops.grouped_gemm(d_eo, fc2, offsets, w_is_kn=False)
+    if ops.dglu_fusable(fc2.shape[1], fc2.shape[2]):                 # fc2's input gradient + the backward of glu in ONE launch
+        d_h1 = ops.grouped_gemm_dswiglu(d_eo, fc2, offsets, ctx["h1"])
+    else:
+        d_h1 = ops.swiglu_bwd(ctx["h1"], ops.grouped_gemm(d_eo, fc2, offsets, w_is_kn=False))
     g_fc2 = ops.grouped_gemm_wgrad(ctx["act"], d_eo, offsets, E) if _want(need, "fc2") else None
-    d_h1 = ops.swiglu_bwd(ctx["h1"], d_act)
     d_perm = ops.grouped_gemm(d_h1, fc1, offsets, w_is_kn=False)
     g_fc1 = ops.grouped_gemm_wgrad(ctx["perm"], d_h1, offsets, E) if _want(need, "fc1") else None
     dx = ops.moe_unpermute(d_perm, inv, None, k)                     # backward of the row gather
     # shared expert
-    d_sact = ops.gemm(dout, down_w, b_oc=True)
+    if ops.dglu_fusable(down_w.shape[1], down_w.shape[0]):
+        d_gu = ops.gemm_dswiglu(dout, down_w, ctx["gu"], b_oc=True)
+    else:
+        d_gu = ops.swiglu_bwd(ctx["gu"], ops.gemm(dout, down_w, b_oc=True))
     g_down = ops.gemm(dout, ctx["sact"], a_oc=True, b_oc=True) if _want(need, "down") else None
-    d_gu = ops.swiglu_bwd(ctx["gu"], d_sact)
     ops.gemm(d_gu, ctx["wgu"], b_oc=True, out=dx, accumulate=True)
     # gate and up weight gradients as ONE wide GEMM ([2*I2, D] = d_gu^T x): 260 tiles of 256x256 instead of 2 x 130
     g_gate = g_up = None

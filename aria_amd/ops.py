@@ -154,6 +154,45 @@ def gemm_swiglu(x: torch.Tensor, w: torch.Tensor, want_h: bool = True):
     return h, act
 
 
+def dglu_fusable(I: int, K: int) -> bool:
+    """Shapes the fused input-gradient + SwiGLU-backward launches take (128-column blocks of I are all-or-nothing, the v3 K loop wants
+    K % 64 == 0; ARIA_FUSE_DSWIGLU=0 switches the fusion off: the two-step chain, bit-identical)."""
+    import os
+
+    return os.environ.get("ARIA_FUSE_DSWIGLU", "1") != "0" and I % 128 == 0 and K >= 64 and K % 64 == 0
+
+
+def grouped_gemm_dswiglu(dy: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+    """Backward of glu behind experts.fc2's input gradient in one launch (moe_lm.py:505-507, 524): dy [M, K] (gradient of the fc2 output
+    rows), w = fc2.weight [E, I, K], h [M, 2I] = the forward's [gate | up] -> d_h [M, 2I].
+    Bit-identical to ``swiglu_bwd(h, grouped_gemm(dy, w, offsets, w_is_kn=False))``; the [M, I] product never visits HBM."""
+    _chk(dy, name="dy"), _chk(w, name="w"), _chk(offsets, torch.int32, "offsets"), _chk(h, name="h")
+    if w.dim() != 3 or not w.is_contiguous() or w.shape[2] != dy.shape[1]:
+        raise ValueError("grouped_gemm_dswiglu: w must be a contiguous [E, I, K] tensor")
+    E, I, K = w.shape
+    M = dy.shape[0]
+    if h.shape != (M, 2 * I) or not h.is_contiguous():
+        raise ValueError("grouped_gemm_dswiglu: h must be a contiguous [M, 2I] tensor")
+    dh = torch.empty_like(h)
+    hip.get_lib().call("aria_grouped_gemm_dswiglu_bf16", _p(dy), _p(w), _p(h), _p(dh), _p(offsets), E, M, I, K, _rowmajor_2d(dy, "dy"), K,
+                       I * K, 2 * I, 2 * I, _stream(dy))
+    return dh
+
+
+def gemm_dswiglu(dy: torch.Tensor, w: torch.Tensor, h: torch.Tensor, *, b_oc: bool = True) -> torch.Tensor:
+    """The dense counterpart (SharedExpertMLP): dy [M, K], w = down_proj.weight [K, I] (``b_oc``) or [I, K], h [M, 2I] -> d_h [M, 2I];
+    bit-identical to ``swiglu_bwd(h, gemm(dy, w, b_oc=b_oc))``."""
+    _chk(dy, name="dy"), _chk(w, name="w"), _chk(h, name="h")
+    M, K = dy.shape
+    I = w.shape[1] if b_oc else w.shape[0]
+    if (w.shape[0] if b_oc else w.shape[1]) != K or h.shape != (M, 2 * I) or not h.is_contiguous():
+        raise ValueError("gemm_dswiglu: shapes")
+    dh = torch.empty_like(h)
+    hip.get_lib().call("aria_gemm_dswiglu_bf16", _p(dy), _p(w), _p(h), _p(dh), M, I, K, int(b_oc), _rowmajor_2d(dy, "dy"), _rowmajor_2d(w, "w"),
+                       2 * I, 2 * I, _stream(dy))
+    return dh
+
+
 def grouped_gemm_wgrad(a: torch.Tensor, dy: torch.Tensor, offsets: torch.Tensor, E: int, *,
                        out: Optional[torch.Tensor] = None, out_dtype=bf16, accumulate: bool = False) -> torch.Tensor:
     """dW[e] = a[s_e:s_e+n_e]^T @ dy[s_e:s_e+n_e]  -> [E, K, N]."""

@@ -84,6 +84,19 @@ int aria_grouped_gemm_swiglu_bf16(const void* A, const void* B, void* H, void* A
 int aria_gemm_swiglu_bf16(const void* A, const void* B, void* H, void* ACT, int64_t M, int64_t N2, int64_t K, int64_t lda, int64_t ldb,
                           int64_t ldh, int64_t ldact, void* stream);
 
+/* Backward of GroupedMLP's glu (moe_lm.py:505-507) fused behind experts.fc2's input gradient, ONE launch:
+ *   d_act[s_e:s_e+n_e, :] = dY[s_e:s_e+n_e, :] * W_e^T   (W_e = B + e*strideB is [I, K] row-major: fc2.weight[e], the forward's [K_fwd = I, N_fwd = K])
+ *   DH[:, j] = d_act[:, j] * H[:, I + j] * silu'(H[:, j]),   DH[:, I + j] = d_act[:, j] * bf16(silu(H[:, j]))
+ * with d_act rounded to bf16 where the two-step chain materialises it: bit-identical to aria_grouped_gemm_bf16 (b_oc = 0) followed by
+ * aria_swiglu_bwd, without the M x I round trip through HBM.  H, DH: [M_total, 2 I] ([gate | up]).  Needs I % 128 == 0, K % 64 == 0
+ * (else ARIA_ERR_UNSUPPORTED: call the two-step form). */
+int aria_grouped_gemm_dswiglu_bf16(const void* dY, const void* B, const void* H, void* DH, const int32_t* offsets, int64_t E, int64_t M_total,
+                                   int64_t I, int64_t K, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldh, int64_t lddh, void* stream);
+/* The dense counterpart (SharedExpertMLP's down_proj input gradient + act backward): d_act = dY * W with W [K, I] row-major
+ * (down_proj.weight, b_oc = 1 form) or, b_oc = 0, W [I, K]. */
+int aria_gemm_dswiglu_bf16(const void* dY, const void* B, const void* H, void* DH, int64_t M, int64_t I, int64_t K, int b_oc, int64_t lda,
+                           int64_t ldb, int64_t ldh, int64_t lddh, void* stream);
+
 /* autograd backward of experts_gemm w.r.t. weight:  dW[e] (K x N) (+)= A[s_e:s_e+n_e]^T * dY[s_e:s_e+n_e].
  * Experts with zero rows get zeros (or keep dW when accumulate). */
 int aria_grouped_gemm_wgrad_bf16(const void* A, const void* dY, void* dW, const int32_t* offsets, int64_t E, int64_t K,

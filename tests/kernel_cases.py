@@ -156,6 +156,41 @@ def case_gemm_swiglu_fused(dev, counts, K, I, T_dense):
     assert torch.equal(actd2.cpu(), actd_ref.cpu())
 
 
+def case_gemm_dswiglu_fused(dev, counts, K, I, T_dense):
+    """experts.fc2's input gradient + the backward of glu in one launch (aria_grouped_gemm_dswiglu_bf16 / aria_gemm_dswiglu_bf16,
+    gemm3_kernel<.., .., 5>) == the two-step chain (grouped GEMM with [N, K] weights, then aria_swiglu_bwd), bit for bit; ragged / empty
+    experts, a partial last column tile (I = 128 (mod 256)); the chain itself against autograd through the oracle's glu (moe_lm.py:505-507)."""
+    from aria_amd import ops
+
+    E, M = len(counts), sum(counts)
+    dy = rnd(M, K, seed=81).to(dev)
+    w = rnd(E, I, K, seed=82, scale=0.2).to(dev)          # fc2.weight [E, I, K]: forward act [., I] @ w[e] -> [., K]
+    h = rnd(M, 2 * I, seed=83, scale=1.5).to(dev)          # the forward's [gate | up]
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(torch.tensor(counts), 0)
+    offd = off.to(dev)
+    assert ops.dglu_fusable(I, K)
+    dact_ref = ops.grouped_gemm(dy, w, offd, w_is_kn=False)
+    dh_ref = ops.swiglu_bwd(h, dact_ref)
+    # oracle: d/dh of sum(glu(h) * d_act) with d_act as the device rounded it
+    hf = h.cpu().float().requires_grad_(True)
+    (O.glu(hf) * dact_ref.cpu().float()).sum().backward()
+    close(dh_ref, hf.grad.to(bf16), 3e-2, 3e-2)
+    dh = ops.grouped_gemm_dswiglu(dy, w, offd, h)
+    assert torch.equal(dh.cpu(), dh_ref.cpu()), float((dh.float() - dh_ref.float()).abs().max())
+    # dense forms (shared expert): down_proj.weight [K, I] read as the [k][n] operand, and the [I, K] form
+    g = rnd(T_dense, K, seed=84).to(dev)
+    hd = rnd(T_dense, 2 * I, seed=85, scale=1.5).to(dev)
+    wkn = rnd(K, I, seed=86, scale=0.2).to(dev)
+    ref = ops.swiglu_bwd(hd, ops.gemm(g, wkn, b_oc=True))
+    got = ops.gemm_dswiglu(g, wkn, hd, b_oc=True)
+    assert torch.equal(got.cpu(), ref.cpu()), float((got.float() - ref.float()).abs().max())
+    wnk = wkn.t().contiguous()
+    got2 = ops.gemm_dswiglu(g, wnk, hd, b_oc=False)
+    ref2 = ops.swiglu_bwd(hd, ops.gemm(g, wnk))
+    assert torch.equal(got2.cpu(), ref2.cpu())
+
+
 # ------------------------------------------------------------------------------------------ routing
 def case_route(dev, T, E, k, dtype, exact):
     from aria_amd import ops

@@ -190,6 +190,12 @@ def test_gemm_swiglu_fused(counts, K, I, T):
     C.case_gemm_swiglu_fused(DEV, counts, K, I, T)
 
 
+@pytest.mark.parametrize("counts,K,I,T", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300), ([130, 520], 192, 384, 72),
+                                          ([1536] * 8 + [1500, 1580], 2560, 1664, 4096)])
+def test_gemm_dswiglu_fused(counts, K, I, T):  # fc2 input gradient + glu backward in one launch == the two-step chain (Aria widths last)
+    C.case_gemm_dswiglu_fused(DEV, counts, K, I, T)
+
+
 @pytest.mark.parametrize("H,hd,pos,splits", [(2, 128, 63, 2), (3, 128, 64, 2), (2, 128, 2999, 16), (20, 128, 16383, 32), (3, 64, 127, 2),
                                              (2, 64, 1000, 5)])
 def test_decode_attention_split_kv(H, hd, pos, splits):

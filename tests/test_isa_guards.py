@@ -72,9 +72,10 @@ def code(lines):
 
 
 GEMM3 = ["12gemm3_kernelILb0ELb0ELi3", "12gemm3_kernelILb0ELb1ELi3", "12gemm3_kernelILb1ELb1ELi3"]
+GEMM3_DGLU = ["12gemm3_kernelILb0ELb0ELi5", "12gemm3_kernelILb0ELb1ELi5"]  # same K loop, SwiGLU-backward epilogue (round 3)
 
 
-@pytest.mark.parametrize("kernel", GEMM3)
+@pytest.mark.parametrize("kernel", GEMM3 + GEMM3_DGLU)
 def test_gemm3_steady_loop_has_no_compiler_waits_and_no_branches(kernel):
     body = kernel_body(isa("gemm3.hip"), kernel)
     steady = None
@@ -99,6 +100,27 @@ def test_gemm3_epilogues_exchange_through_dpp(kernel):
     n_dpp = sum(1 for s, _ in c if "quad_perm:[1,0,3,2]" in s)
     assert n_perm <= 24, f"{n_perm} ds_bpermute_b32 (only the grouped tile lookup's wave collectives may use it)"
     assert n_dpp >= 64
+
+
+@pytest.mark.parametrize("kernel", GEMM3_DGLU)
+def test_gemm3_dglu_epilogue_keeps_its_loads_in_flight_and_out_of_scratch(kernel):
+    """The SwiGLU-backward epilogue reads gate / up of the forward from HBM with the MFMAs finished and nothing else to hide the latency:
+    the 16 loads of a 128-row half must be issued back to back (no wait between them), and the epilogue must not spill (a first form that
+    fetched all 32 pieces up front kept them live next to the accumulators: 49 spilled VGPRs)."""
+    body = kernel_body(isa("gemm3.hip"), kernel)
+    c = [s for s, _ in code(body)]
+    last_mfma = max(i for i, s in enumerate(c) if s.startswith("v_mfma"))
+    tail = c[last_mfma:]
+    assert sum(1 for s in tail if s.startswith("scratch_store")) == 0, "the epilogue spills"
+    runs, cur = [], 0
+    for s in tail:
+        if s.startswith("global_load_dwordx4"):
+            cur += 1
+        elif s.startswith("s_waitcnt") and "vmcnt" in s:
+            if cur:
+                runs.append(cur)
+            cur = 0
+    assert runs and max(runs) >= 16, runs
 
 
 ATTN = ["16attn_fwd2_kernelILi72ELi12", "16attn_fwd2_kernelILi128ELi8", "21attn_bwd3_dkdv_kernelILi128", "19attn_bwd5_dq_kernelILi128"]
