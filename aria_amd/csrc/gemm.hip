@@ -435,6 +435,69 @@ int aria_gemm_swiglu_bf16(const void* A, const void* B, void* H, void* ACT, int6
     return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int((M + 255) / 256), stream);
 }
 
+// gate / up weights as two [.., I, K] tensors of one allocation (gptfast's w1 / w3): rows of the up tensor as an offset from the gate tensor
+static int glu_split_rows(const void* Bg, const void* Bu, int64_t I, int64_t ldb, int64_t extra_rows, int* up_rows) {
+    const long long diff = static_cast<const char*>(Bu) - static_cast<const char*>(Bg);
+    if (diff <= 0 || diff % (2 * ldb)) return ARIA_ERR_UNSUPPORTED;
+    const long long rows = diff / (2 * ldb);
+    // per-lane DMA offsets are 32-bit and the row index goes through a 24-bit multiply
+    if (rows < I || rows + extra_rows + I >= (1ll << 24) || (rows + extra_rows + I) * 2 * ldb >= (1ll << 32)) return ARIA_ERR_UNSUPPORTED;
+    *up_rows = int(rows);
+    return ARIA_OK;
+}
+
+int aria_grouped_gemm_swiglu_split_bf16(const void* A, const void* Bg, const void* Bu, void* H, void* ACT, const int32_t* offsets, int64_t E,
+                                        int64_t M_total, int64_t I, int64_t K, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldh,
+                                        int64_t ldact, void* stream) {
+    if (!offsets || E <= 0 || !Bu) return ARIA_ERR_INVALID;
+    int rc = glu_check(A, Bg, H, ACT, M_total, 2 * I, K, lda, ldb, ldh, ldact);
+    if (rc != ARIA_OK) return rc;
+    if ((strideB & 7) || !aligned16(Bu)) return ARIA_ERR_ALIGN;
+    if ((K % 64) || 2 * M_total * lda >= (1ll << 32)) return ARIA_ERR_UNSUPPORTED;
+    int up_rows = 0;
+    rc = glu_split_rows(Bg, Bu, I, ldb, 0, &up_rows);  // (the expert's base enters the 64-bit operand pointer, not the per-lane offset)
+    if (rc != ARIA_OK) return rc;
+    if (M_total == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A);
+    p.B = static_cast<const bf16_t*>(Bg);
+    p.C = H;
+    p.C2 = ACT;
+    p.lda = lda, p.ldb = ldb, p.ldc = ldh, p.ldc2 = ldact;
+    p.M = int(M_total), p.N = int(2 * I), p.K = int(K);
+    p.mode = 1;
+    p.offsets = offsets;
+    p.E = int(E);
+    p.strideB = strideB;
+    p.glu = 1;
+    p.glu_up_rows = up_rows;
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int(M_total / 256 + E), stream);
+}
+
+int aria_gemm_swiglu_split_bf16(const void* A, const void* Bg, const void* Bu, void* H, void* ACT, int64_t M, int64_t I, int64_t K, int64_t lda,
+                                int64_t ldb, int64_t ldh, int64_t ldact, void* stream) {
+    if (!Bu) return ARIA_ERR_INVALID;
+    int rc = glu_check(A, Bg, H, ACT, M, 2 * I, K, lda, ldb, ldh, ldact);
+    if (rc != ARIA_OK) return rc;
+    if (!aligned16(Bu)) return ARIA_ERR_ALIGN;
+    if ((K % 64) || 2 * M * lda >= (1ll << 32)) return ARIA_ERR_UNSUPPORTED;
+    int up_rows = 0;
+    rc = glu_split_rows(Bg, Bu, I, ldb, 0, &up_rows);
+    if (rc != ARIA_OK) return rc;
+    if (M == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A);
+    p.B = static_cast<const bf16_t*>(Bg);
+    p.C = H;
+    p.C2 = ACT;
+    p.lda = lda, p.ldb = ldb, p.ldc = ldh, p.ldc2 = ldact;
+    p.M = int(M), p.N = int(2 * I), p.K = int(K);
+    p.mode = 0;
+    p.glu = 1;
+    p.glu_up_rows = up_rows;
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int((M + 255) / 256), stream);
+}
+
 // shared validation of the fused input-gradient + SwiGLU-backward entries (gemm3_kernel<.., .., 5>)
 static int dglu_check(const void* A, const void* B, const void* H, const void* DH, int64_t M, int64_t I, int64_t K, int64_t lda, int64_t ldb,
                       int64_t ldh, int64_t lddh) {

@@ -223,12 +223,16 @@ __device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
     glds16(s1, d + 1024);
 }
 
-template <bool A_OC, bool B_OC, class P>
+template <bool A_OC, bool B_OC, bool SPLIT_GLU = false, class P>
 __device__ __forceinline__ void stage_init(Stage& st, const P& p, int w, int l, char* smem) {
     st.w = w;
     st.limA = p.M;
     st.limB = p.N;
     st.bhalf = p.glu ? p.N / 2 : 128;
+    if (SPLIT_GLU) {  // (gemm3_kernel<.., .., 6>) gate / up rows in two tensors of one allocation: the up rows lie glu_up_rows B-operand rows
+        st.bhalf = p.glu_up_rows;  // behind the gate rows; no column edge in glu mode (I % 128 == 0), so the row clamp is not needed
+        st.limB = 0x7fffffff;
+    }
     st.ldA2 = uint32_t(2 * p.lda);
     st.ldB2 = uint32_t(2 * p.ldb);
     st.kstepA = A_OC ? 2 * BK * p.lda : 2 * BK;
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     // one barrier apart -- both waves of a SIMD in their MFMA sections together, fragment reads exposed
     const bool stagger_groups = !((p.order >> 10) & 1);
     Stage st;
-    stage_init<A_OC, B_OC>(st, p, w, l, smem);
+    stage_init<A_OC, B_OC, VER == 6>(st, p, w, l, smem);
     st.gA = reinterpret_cast<const char*>(p.A) + (A_OC ? 2 * k_begin * p.lda : 2 * (long long)k_begin) + kt_first * st.kstepA;
     st.gB = reinterpret_cast<const char*>(p.B + b_off) + (B_OC ? 2 * k_begin * p.ldb : 2 * (long long)k_begin) + kt_first * st.kstepB;
     st.g0 = 0;
@@ -886,6 +890,11 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     if (ntn * ntm <= 0) return ARIA_OK;
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
     dim3 grid(unsigned(aria_tile_grid(q)), grid_y), block(512);
+    if (p.glu && p.glu_up_rows > 0) {  // fused SwiGLU with gate / up weights in two tensors ([N, K] form): its own instantiation
+        if (a_oc || b_oc || p.mode == 2) return ARIA_ERR_INVALID;
+        ARIA_LAUNCH((gemm3_kernel<false, false, 6>), grid, block, shmem, stream, q);
+        return aria_check_launch();
+    }
     if (p.dglu) {  // SwiGLU-backward epilogue: its own instantiations (the default kernels' code is untouched)
         if (a_oc || p.glu || p.c_f32 || p.accumulate || p.bias || p.act || p.mode == 2) return ARIA_ERR_INVALID;
         if (!b_oc)

@@ -69,6 +69,28 @@ class _W(nn.Module):
         self.weight = _p(*shape)
 
 
+def adjacent_pair(p1: nn.Parameter, p2: nn.Parameter) -> bool:
+    """Re-home two equal-shaped parameters in ONE allocation, ``p2`` directly behind ``p1`` (both stay contiguous tensors under their own
+    state-dict keys: the model.pth wire format is untouched).  The fused gate / up + SwiGLU launch reads w1 and w3 as ONE operand whose up
+    rows lie a fixed number of rows behind the gate rows (``ops.glu_split_fusable``).  ``module.to(device)`` gives every parameter its own
+    storage again; the feed-forward modules call this lazily (a 2 x tensor-size transient, once)."""
+    if p1.shape != p2.shape or p1.device != p2.device or p1.dtype != p2.dtype:
+        return False
+    buf = torch.empty((2,) + tuple(p1.shape), dtype=p1.dtype, device=p1.device)
+    buf[0].copy_(p1.data)
+    buf[1].copy_(p2.data)
+    p1.data, p2.data = buf[0], buf[1]
+    return True
+
+
+def _glu_pair_ready(w_gate: nn.Parameter, w_up: nn.Parameter) -> bool:
+    """True when the fused gate / up launch can take the pair (re-homing it once if only the layout is in the way)."""
+    I, K = w_gate.shape[-2], w_gate.shape[-1]
+    if I % 128 or K % 64 or K < 64 or not ops.swiglu_fusion_enabled():
+        return False
+    return ops.glu_split_fusable(w_gate, w_up) or (adjacent_pair(w_gate, w_up) and ops.glu_split_fusable(w_gate, w_up))
+
+
 class RMSNorm(nn.Module):
     def __init__(self, dim: int, eps: float):
         super().__init__()
@@ -151,11 +173,19 @@ class MOEFeedForward(nn.Module):
         offsets, sorted_src, inv = ops.moe_sort(idx, counts)           # token_permutation (:243-254)
         perm = ops.moe_permute(x2d, sorted_src, k)
         cf = self.cond_ffn
-        h1 = ops.grouped_gemm(perm, cf.w1, offsets, w_is_kn=False)     # sequential_gemm(w1) (:278-297): w1[e] is [I, D] = rc form
-        h3 = ops.grouped_gemm(perm, cf.w3, offsets, w_is_kn=False)
-        eo = ops.grouped_gemm(ops.swiglu(h1, h3), cf.w2, offsets, w_is_kn=False)
+        if _glu_pair_ready(cf.w1, cf.w3):   # w1 / w3 GEMMs + SwiGLU in ONE launch (no h1 / h3 round trip: 2 x [6T, I] written and read)
+            act = ops.grouped_gemm_swiglu_split(perm, cf.w1, cf.w3, offsets)[1]
+        else:
+            h1 = ops.grouped_gemm(perm, cf.w1, offsets, w_is_kn=False)     # sequential_gemm(w1) (:278-297): w1[e] is [I, D] = rc form
+            h3 = ops.grouped_gemm(perm, cf.w3, offsets, w_is_kn=False)
+            act = ops.swiglu(h1, h3)
+        eo = ops.grouped_gemm(act, cf.w2, offsets, w_is_kn=False)
         sf = self.shared_ffn
-        sh = ops.gemm(ops.swiglu(ops.gemm(x2d, sf.w1.weight), ops.gemm(x2d, sf.w3.weight)), sf.w2.weight)
+        if _glu_pair_ready(sf.w1.weight, sf.w3.weight):
+            sact = ops.gemm_swiglu_split(x2d, sf.w1.weight, sf.w3.weight)[1]
+        else:
+            sact = ops.swiglu(ops.gemm(x2d, sf.w1.weight), ops.gemm(x2d, sf.w3.weight))
+        sh = ops.gemm(sact, sf.w2.weight)
         return ops.moe_unpermute(eo, inv, scores, k, add=sh)
 
 
@@ -204,6 +234,10 @@ class Transformer(nn.Module):
                                                                  b.attention.hdp, dev)
         self.freqs_cis = precompute_freqs_cis(max(self.config.block_size, self.max_seq_length), self.config.head_dim,
                                               self.config.rope_base).to(dev).contiguous()
+        for b in self.layers:  # gate / up pairs into one allocation each NOW (the decode engine records parameter addresses later)
+            ff = b.feed_forward
+            _glu_pair_ready(ff.cond_ffn.w1, ff.cond_ffn.w3)
+            _glu_pair_ready(ff.shared_ffn.w1.weight, ff.shared_ffn.w3.weight)
 
     def forward(self, idx: Optional[torch.Tensor], input_pos: Optional[torch.Tensor] = None,
                 input_embeds: Optional[torch.Tensor] = None, last_only: bool = False) -> torch.Tensor:

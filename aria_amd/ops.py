@@ -118,11 +118,15 @@ def grouped_gemm(a: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, *, w_i
     return out
 
 
-def glu_fusable(K: int, N2: int) -> bool:
-    """Shapes the fused fc1 + SwiGLU launch takes (a tile = 128 gate + 128 up columns; ARIA_FUSE_SWIGLU=0 switches the fusion off)."""
+def swiglu_fusion_enabled() -> bool:
     import os
 
-    return os.environ.get("ARIA_FUSE_SWIGLU", "1") != "0" and N2 % 2 == 0 and (N2 // 2) % 128 == 0 and K >= 64 and K % 8 == 0
+    return os.environ.get("ARIA_FUSE_SWIGLU", "1") != "0"
+
+
+def glu_fusable(K: int, N2: int) -> bool:
+    """Shapes the fused fc1 + SwiGLU launch takes (a tile = 128 gate + 128 up columns; ARIA_FUSE_SWIGLU=0 switches the fusion off)."""
+    return swiglu_fusion_enabled() and N2 % 2 == 0 and (N2 // 2) % 128 == 0 and K >= 64 and K % 8 == 0
 
 
 def grouped_gemm_swiglu(a: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, want_h: bool = True):
@@ -151,6 +155,44 @@ def gemm_swiglu(x: torch.Tensor, w: torch.Tensor, want_h: bool = True):
     h = torch.empty((M, N2), dtype=bf16, device=x.device) if want_h else None
     act = torch.empty((M, N2 // 2), dtype=bf16, device=x.device)
     hip.get_lib().call("aria_gemm_swiglu_bf16", _p(x), _p(w), _p(h) if want_h else None, _p(act), M, N2, K, lda, ldb, N2, N2 // 2, _stream(x))
+    return h, act
+
+
+def glu_split_fusable(w_gate: torch.Tensor, w_up: torch.Tensor) -> bool:
+    """gate / up weights as two [.., I, K] tensors ([N, K] form, the gptfast wire format): the fused launch reaches the up rows as a ROW
+    offset from the gate rows, so both must be contiguous views of one allocation with the up tensor a whole number of rows behind the gate
+    tensor (``gptfast.adjacent_pair`` builds that layout); I % 128 == 0, K % 64 == 0."""
+    if not swiglu_fusion_enabled() or w_gate.shape != w_up.shape or not (w_gate.is_contiguous() and w_up.is_contiguous()):
+        return False
+    I, K = w_gate.shape[-2], w_gate.shape[-1]
+    diff = w_up.data_ptr() - w_gate.data_ptr()
+    same_storage = w_gate.untyped_storage().data_ptr() == w_up.untyped_storage().data_ptr()
+    return bool(same_storage and I % 128 == 0 and K % 64 == 0 and K >= 64 and diff >= 2 * K * w_gate.numel() // K and diff % (2 * K) == 0
+                and diff + 2 * (I + 128) * K < (1 << 32))
+
+
+def grouped_gemm_swiglu_split(a: torch.Tensor, w_gate: torch.Tensor, w_up: torch.Tensor, offsets: torch.Tensor, want_h: bool = False):
+    """silu(a @ w_gate[e]^T) * (a @ w_up[e]^T) per expert in one launch (gptfast ConditionalFeedForward, model.py:278-325): w_gate / w_up
+    [E, I, K]; -> (h [M, 2I] or None, act [M, I]); bit-identical to ``swiglu(grouped_gemm(a, w_gate, w_is_kn=False), grouped_gemm(a, w_up, ..))``."""
+    _chk(a, name="a"), _chk(w_gate, name="w_gate"), _chk(w_up, name="w_up"), _chk(offsets, torch.int32, "offsets")
+    E, I, K = w_gate.shape
+    M = a.shape[0]
+    h = torch.empty((M, 2 * I), dtype=bf16, device=a.device) if want_h else None
+    act = torch.empty((M, I), dtype=bf16, device=a.device)
+    hip.get_lib().call("aria_grouped_gemm_swiglu_split_bf16", _p(a), _p(w_gate), _p(w_up), _p(h) if want_h else None, _p(act), _p(offsets), E, M,
+                       I, K, _rowmajor_2d(a, "a"), K, I * K, 2 * I, I, _stream(a))
+    return h, act
+
+
+def gemm_swiglu_split(x: torch.Tensor, w_gate: torch.Tensor, w_up: torch.Tensor, want_h: bool = False):
+    """silu(x @ w_gate^T) * (x @ w_up^T) in one launch (gptfast FeedForward): w_gate / w_up [I, K] as in ``grouped_gemm_swiglu_split``."""
+    _chk(x, name="x"), _chk(w_gate, name="w_gate"), _chk(w_up, name="w_up")
+    I, K = w_gate.shape
+    M = x.shape[0]
+    h = torch.empty((M, 2 * I), dtype=bf16, device=x.device) if want_h else None
+    act = torch.empty((M, I), dtype=bf16, device=x.device)
+    hip.get_lib().call("aria_gemm_swiglu_split_bf16", _p(x), _p(w_gate), _p(w_up), _p(h) if want_h else None, _p(act), M, I, K,
+                       _rowmajor_2d(x, "x"), K, 2 * I, I, _stream(x))
     return h, act
 
 

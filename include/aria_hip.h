@@ -84,6 +84,18 @@ int aria_grouped_gemm_swiglu_bf16(const void* A, const void* B, void* H, void* A
 int aria_gemm_swiglu_bf16(const void* A, const void* B, void* H, void* ACT, int64_t M, int64_t N2, int64_t K, int64_t lda, int64_t ldb,
                           int64_t ldh, int64_t ldact, void* stream);
 
+/* The same two fusions for the gptfast wire format (gptfast/model.py:262-325: ConditionalFeedForward.w1 / w3 [E, I, K] and FeedForward.w1 / w3
+ * [I, K] are SEPARATE tensors in [N, K] form): Bg = w1 (gate rows), Bu = w3 (up rows).  Both must lie in ONE allocation with Bu a whole
+ * number of rows (ldb elements) behind Bg -- aria_amd.gptfast lays its parameters out that way -- because the kernel reaches the up rows as a
+ * row offset from the gate rows (32-bit per-lane addressing); anything else returns ARIA_ERR_UNSUPPORTED (call the two-step form).
+ * strideB = elements between consecutive experts of EITHER tensor.  H may be NULL.  Bit-identical to two aria_grouped_gemm_bf16 /
+ * aria_gemm_bf16 calls followed by aria_swiglu_fwd(h1, h3). */
+int aria_grouped_gemm_swiglu_split_bf16(const void* A, const void* Bg, const void* Bu, void* H, void* ACT, const int32_t* offsets, int64_t E,
+                                        int64_t M_total, int64_t I, int64_t K, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldh,
+                                        int64_t ldact, void* stream);
+int aria_gemm_swiglu_split_bf16(const void* A, const void* Bg, const void* Bu, void* H, void* ACT, int64_t M, int64_t I, int64_t K, int64_t lda,
+                                int64_t ldb, int64_t ldh, int64_t ldact, void* stream);
+
 /* Backward of GroupedMLP's glu (moe_lm.py:505-507) fused behind experts.fc2's input gradient, ONE launch:
  *   d_act[s_e:s_e+n_e, :] = dY[s_e:s_e+n_e, :] * W_e^T   (W_e = B + e*strideB is [I, K] row-major: fc2.weight[e], the forward's [K_fwd = I, N_fwd = K])
  *   DH[:, j] = d_act[:, j] * H[:, I + j] * silu'(H[:, j]),   DH[:, I + j] = d_act[:, j] * bf16(silu(H[:, j]))

@@ -156,6 +156,33 @@ def case_gemm_swiglu_fused(dev, counts, K, I, T_dense):
     assert torch.equal(actd2.cpu(), actd_ref.cpu())
 
 
+def case_gemm_swiglu_split(dev, counts, K, I, T_dense):
+    """The gptfast form of the fused gate / up + SwiGLU launch (aria_grouped_gemm_swiglu_split_bf16 / aria_gemm_swiglu_split_bf16,
+    gemm3_kernel<false, false, 6>): w1 and w3 are separate [E, I, K] tensors of one allocation ([N, K] form) == two grouped GEMMs + the
+    stand-alone SwiGLU, bit for bit (h halves and act); tensors that are not laid out that way are refused by the host check."""
+    from aria_amd import ops
+
+    E, M = len(counts), sum(counts)
+    a = rnd(M, K, seed=91).to(dev)
+    buf = rnd(2, E, I, K, seed=92, scale=0.2).to(dev)
+    w1, w3 = buf[0], buf[1]
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(torch.tensor(counts), 0)
+    offd = off.to(dev)
+    assert ops.glu_split_fusable(w1, w3) and not ops.glu_split_fusable(w3, w1) and not ops.glu_split_fusable(w1, w3.clone())
+    h1, h3 = ops.grouped_gemm(a, w1, offd, w_is_kn=False), ops.grouped_gemm(a, w3, offd, w_is_kn=False)
+    act_ref = ops.swiglu(h1, h3)
+    h, act = ops.grouped_gemm_swiglu_split(a, w1, w3, offd, want_h=True)
+    assert torch.equal(act.cpu(), act_ref.cpu()) and torch.equal(h[:, :I].cpu(), h1.cpu()) and torch.equal(h[:, I:].cpu(), h3.cpu())
+    assert torch.equal(ops.grouped_gemm_swiglu_split(a, w1, w3, offd)[1].cpu(), act_ref.cpu())
+    x = rnd(T_dense, K, seed=93).to(dev)
+    dbuf = rnd(2, 2 * I, K, seed=94, scale=0.2).to(dev)   # the shared expert: [2 I, K] each
+    s1, s3 = dbuf[0], dbuf[1]
+    assert ops.glu_split_fusable(s1, s3)
+    ref = ops.swiglu(ops.gemm(x, s1), ops.gemm(x, s3))
+    assert torch.equal(ops.gemm_swiglu_split(x, s1, s3)[1].cpu(), ref.cpu())
+
+
 def case_gemm_dswiglu_fused(dev, counts, K, I, T_dense):
     """experts.fc2's input gradient + the backward of glu in one launch (aria_grouped_gemm_dswiglu_bf16 / aria_gemm_dswiglu_bf16,
     gemm3_kernel<.., .., 5>) == the two-step chain (grouped GEMM with [N, K] weights, then aria_swiglu_bwd), bit for bit; ragged / empty

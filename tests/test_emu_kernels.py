@@ -176,6 +176,11 @@ def test_gemm_swiglu_fused(force_gemm_v3, counts, K, I, T):
     C.case_gemm_swiglu_fused(DEV, counts, K, I, T)
 
 
+@pytest.mark.parametrize("counts,K,I,T", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300), ([130, 520], 192, 256, 72)])
+def test_gemm_swiglu_split(force_gemm_v3, counts, K, I, T):
+    C.case_gemm_swiglu_split(DEV, counts, K, I, T)
+
+
 @pytest.mark.parametrize("counts,K,I,T", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300), ([130, 520], 192, 384, 72)])
 def test_gemm_dswiglu_fused(force_gemm_v3, counts, K, I, T):
     C.case_gemm_dswiglu_fused(DEV, counts, K, I, T)

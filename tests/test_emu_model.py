@@ -82,6 +82,53 @@ def test_moe_backward_fused_glu_epilogue_is_bit_identical(monkeypatch):
         assert torch.isfinite(grads["1"][n].float()).all() and torch.equal(grads["0"][n], grads["1"][n]), n
 
 
+def test_gptfast_gate_up_pairs_share_an_allocation_and_fuse(monkeypatch):
+    """gptfast surface (model.pth wire format: cond_ffn.w1 / w3 and shared_ffn.w1 / w3 are separate tensors): setup_caches re-homes each
+    pair in one allocation, the prefill then runs gate + up + SwiGLU as ONE launch (gemm3_kernel<false, false, 6>) -- logits equal to the
+    three-launch chain bit for bit, the state-dict surface and the decode engine (which records parameter addresses) unaffected, and a
+    ``.to()``-style re-allocation of the parameters is repaired lazily."""
+    from aria_amd import gptfast as G
+    from aria_amd import ops
+
+    args = G.ModelArgs(block_size=64, vocab_size=136, n_layer=2, n_head=2, dim=128, intermediate_size=128, n_local_heads=2, head_dim=64,
+                       rope_base=10000.0, norm_eps=1e-5, num_experts=8, router_topk=3, num_shared_experts=2)
+    torch.manual_seed(21)
+    m = G.Transformer(args)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_((torch.ones(p.shape) + 0.1 * torch.randn(p.shape)).to(torch.bfloat16) if "norm" in n else (torch.randn(p.shape) * 0.08).to(torch.bfloat16))
+    keys_before = list(m.state_dict())
+    ref_sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.eval()
+    m.setup_caches(1, 32)
+    ff = m.layers[1].feed_forward
+    assert ops.glu_split_fusable(ff.cond_ffn.w1, ff.cond_ffn.w3) and ops.glu_split_fusable(ff.shared_ffn.w1.weight, ff.shared_ffn.w3.weight)
+    assert list(m.state_dict()) == keys_before and all(torch.equal(v, ref_sd[k]) for k, v in m.state_dict().items())
+    calls = []
+    og, od = ops.grouped_gemm_swiglu_split, ops.gemm_swiglu_split
+    monkeypatch.setattr(ops, "grouped_gemm_swiglu_split", lambda *a, **k: (calls.append("g"), og(*a, **k))[1])
+    monkeypatch.setattr(ops, "gemm_swiglu_split", lambda *a, **k: (calls.append("d"), od(*a, **k))[1])
+    ids = torch.randint(1, 136, (1, 24), generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        fused = m(ids, torch.arange(24)).float().clone()
+        assert calls == ["g", "d"] * 2
+        step = m(torch.tensor([[7]]), torch.tensor([24], dtype=torch.int32)).float().clone()   # decode engine on the re-homed parameters
+        assert m._engine is not None
+        monkeypatch.setenv("ARIA_FUSE_SWIGLU", "0")
+        m.setup_caches(1, 32)
+        plain = m(ids, torch.arange(24)).float().clone()
+        step_plain = m(torch.tensor([[7]]), torch.tensor([24], dtype=torch.int32)).float().clone()
+        monkeypatch.delenv("ARIA_FUSE_SWIGLU")
+        assert torch.equal(fused, plain) and torch.equal(step, step_plain) and float(fused.abs().max()) > 0
+        # parameters re-allocated one by one (what module.to(device) does): repaired at the next forward
+        for p in m.parameters():
+            p.data = p.data.clone()
+        assert not ops.glu_split_fusable(ff.cond_ffn.w1, ff.cond_ffn.w3)
+        calls.clear()
+        again = m(ids, torch.arange(24)).float()
+        assert calls == ["g", "d"] * 2 and torch.equal(again, fused) and ops.glu_split_fusable(ff.cond_ffn.w1, ff.cond_ffn.w3)
+
+
 def test_vit_projector_golden(golden):
     M.case_vit_projector_golden(DEV, golden)
 

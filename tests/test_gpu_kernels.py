@@ -190,6 +190,11 @@ def test_gemm_swiglu_fused(counts, K, I, T):
     C.case_gemm_swiglu_fused(DEV, counts, K, I, T)
 
 
+@pytest.mark.parametrize("counts,K,I,T", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300), ([1536] * 8 + [1500, 1580], 2560, 1664, 4096)])
+def test_gemm_swiglu_split(counts, K, I, T):  # gptfast wire format: w1 / w3 as two tensors of one allocation
+    C.case_gemm_swiglu_split(DEV, counts, K, I, T)
+
+
 @pytest.mark.parametrize("counts,K,I,T", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300), ([130, 520], 192, 384, 72),
                                           ([1536] * 8 + [1500, 1580], 2560, 1664, 4096)])
 def test_gemm_dswiglu_fused(counts, K, I, T):  # fc2 input gradient + glu backward in one launch == the two-step chain (Aria widths last)
