@@ -179,7 +179,11 @@ def case_gemm_swiglu_split(dev, counts, K, I, T_dense):
     dbuf = rnd(2, 2 * I, K, seed=94, scale=0.2).to(dev)   # the shared expert: [2 I, K] each
     s1, s3 = dbuf[0], dbuf[1]
     assert ops.glu_split_fusable(s1, s3)
-    ref = ops.swiglu(ops.gemm(x, s1), ops.gemm(x, s3))
+    ops.GEMM_SPLIT_K = False  # (the stand-alone GEMMs may split the last round along K: another fp32 summation order)
+    try:
+        ref = ops.swiglu(ops.gemm(x, s1), ops.gemm(x, s3))
+    finally:
+        ops.GEMM_SPLIT_K = True
     assert torch.equal(ops.gemm_swiglu_split(x, s1, s3)[1].cpu(), ref.cpu())
 
 
@@ -205,17 +209,24 @@ def case_gemm_dswiglu_fused(dev, counts, K, I, T_dense):
     close(dh_ref, hf.grad.to(bf16), 3e-2, 3e-2)
     dh = ops.grouped_gemm_dswiglu(dy, w, offd, h)
     assert torch.equal(dh.cpu(), dh_ref.cpu()), float((dh.float() - dh_ref.float()).abs().max())
-    # dense forms (shared expert): down_proj.weight [K, I] read as the [k][n] operand, and the [I, K] form
+    # dense forms (shared expert): down_proj.weight [K, I] read as the [k][n] operand, and the [I, K] form.  The reference chain runs
+    # WITHOUT the remainder split-K (ops.GEMM_SPLIT_K: fp32 partial sums in another order -- at Aria's widths the stand-alone GEMM would
+    # take it; the fused launch never splits)
     g = rnd(T_dense, K, seed=84).to(dev)
     hd = rnd(T_dense, 2 * I, seed=85, scale=1.5).to(dev)
     wkn = rnd(K, I, seed=86, scale=0.2).to(dev)
-    ref = ops.swiglu_bwd(hd, ops.gemm(g, wkn, b_oc=True))
+    wnk = wkn.t().contiguous()
+    ops.GEMM_SPLIT_K = False
+    try:
+        ref = ops.swiglu_bwd(hd, ops.gemm(g, wkn, b_oc=True))
+        ref2 = ops.swiglu_bwd(hd, ops.gemm(g, wnk))
+    finally:
+        ops.GEMM_SPLIT_K = True
     got = ops.gemm_dswiglu(g, wkn, hd, b_oc=True)
     assert torch.equal(got.cpu(), ref.cpu()), float((got.float() - ref.float()).abs().max())
-    wnk = wkn.t().contiguous()
     got2 = ops.gemm_dswiglu(g, wnk, hd, b_oc=False)
-    ref2 = ops.swiglu_bwd(hd, ops.gemm(g, wnk))
     assert torch.equal(got2.cpu(), ref2.cpu())
+    close(ops.swiglu_bwd(hd, ops.gemm(g, wkn, b_oc=True)), got, 2e-2, 2e-2)  # (and the split-K chain agrees within bf16 rounding)
 
 
 # ------------------------------------------------------------------------------------------ routing

@@ -73,7 +73,11 @@ def fused_shared():
     return ops.gemm_dswiglu(dy2, w2, h2, b_oc=True)
 
 
-res["shared_equal"] = bool(torch.equal(chain_shared(), fused_shared()))
+ops.GEMM_SPLIT_K = False  # bit-for-bit comparison against the chain WITHOUT the remainder split-K (another fp32 summation order)
+res["shared_equal_no_splitk"] = bool(torch.equal(chain_shared(), fused_shared()))
+ops.GEMM_SPLIT_K = True
+d = (chain_shared().float() - fused_shared().float()).abs().max()
+res["shared_max_abs_diff_vs_splitk_chain"] = float(d)
 for _ in range(2):
     chain_shared(), fused_shared()
 a, b = [], []
