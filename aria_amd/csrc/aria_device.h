@@ -99,6 +99,10 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 }
 __device__ __forceinline__ int wave_bcast(int v, int lane) { return emu::shfl(v, lane); }
 __device__ __forceinline__ int read_lane(int v, int lane) { return emu::shfl(v, lane); }
+__device__ __forceinline__ float wave_max_bcast(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v = std::fmax(v, emu::shfl(v, emu::lane() ^ m));
+    return v;
+}
 __device__ __forceinline__ unsigned long long ballot(bool p) { return emu::ballot(p); }
 __device__ __forceinline__ int lane_id() { return emu::lane(); }
 __device__ __forceinline__ int first_lane(int v) { return emu::shfl(v, __builtin_ctzll(emu::ballot(true))); }
@@ -135,6 +139,21 @@ __device__ __forceinline__ int wave_bcast(int v, int lane) { return __shfl(v, la
 // the value of lane `lane` (a compile-time constant or otherwise wave-uniform) as a SCALAR: v_readlane_b32, no LDS round trip -- for
 // values that become addresses of wave-uniform rows
 __device__ __forceinline__ int read_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// maximum over the wave's 64 lanes as a wave-uniform value, on the vector ALU: the DPP ladder of wave_incl_scan (row shifts inside each
+// row of 16, then the two row broadcasts) with max instead of add, lane 63 read back as a scalar -- 6 VALU operations instead of 6
+// ds_bpermute round trips through the LDS (max is exact, so the result equals the butterfly's bit for bit)
+__device__ __forceinline__ float wave_max_bcast(float v) {
+    const int ninf = int(0xff800000u);
+#define ARIA_DPP_MAX(ctrl, rows) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v), ctrl, rows, 0xF, false)))
+    ARIA_DPP_MAX(0x111, 0xF);  // row_shr:1
+    ARIA_DPP_MAX(0x112, 0xF);  // row_shr:2
+    ARIA_DPP_MAX(0x114, 0xF);  // row_shr:4
+    ARIA_DPP_MAX(0x118, 0xF);  // row_shr:8  -> lane 15 of every row holds the row's maximum
+    ARIA_DPP_MAX(0x142, 0xA);  // row_bcast:15 into rows 1 and 3
+    ARIA_DPP_MAX(0x143, 0xC);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+#undef ARIA_DPP_MAX
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }

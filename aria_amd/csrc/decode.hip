@@ -30,14 +30,17 @@ template <int NC>
 __device__ __forceinline__ void load_vector(u32x4 (&xv)[NC], const bf16_t* x, const bf16_t* norm_w, float eps, int K, int l) {
     const int nch = K >> 3;
     u32x4 wv[NC];
+    const bf16_t* nw = norm_w ? norm_w : x;  // (no branch around the loads: with one, the compiler fetched chunk after chunk, a wait in between)
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-        const int c = l + 64 * i, cc = min(c, nch - 1);
-        const u32x4 a = ld16(x + cc * 8);
-        if (norm_w) wv[i] = ld16(norm_w + cc * 8);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xv[i][q] = c < nch ? a[q] : 0u;
+        const int cc = min(l + 64 * i, nch - 1);
+        xv[i] = ld16(x + cc * 8);
+        wv[i] = ld16(nw + cc * 8);
     }
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[i][q] = (l + 64 * i < nch) ? xv[i][q] : 0u;
     if (!norm_w) return;
     float ss = 0.f;
 #pragma unroll
@@ -56,19 +59,22 @@ __device__ __forceinline__ void load_vector(u32x4 (&xv)[NC], const bf16_t* x, co
             xv[i][q] = pack2bf(bflo(wv[i][q]) * rbf(bflo(xv[i][q]) * r), bfhi(wv[i][q]) * rbf(bfhi(xv[i][q]) * r));
 }
 
-// dot products of R consecutive weight rows with the lane-distributed vector; every lane returns the full sums.  Rows past the end
-// are clamped (their results are never stored) and every load is issued before the first use: R * NC 16-byte loads in flight per lane.
+// R consecutive weight rows as 16-byte chunks c = l + 64 i per lane.  Rows past the end are clamped (their results are never stored), no
+// branches: all R * NC loads of a wave are in flight together.  Kernels issue these BEFORE they fetch and normalise the vector: the vector
+// (L2 hits + a wave reduction + rsqrt, ~1.5 us of dependent latency) then hides under the HBM latency of the rows instead of in front of it.
 template <int R, int NC>
-__device__ __forceinline__ void dot_rows(float (&acc)[R], const bf16_t* w, long long ldw, int row0, int nrows, const u32x4 (&xv)[NC],
-                                         int K, int l) {
+__device__ __forceinline__ void load_rows(u32x4 (&a)[R][NC], const bf16_t* w, long long ldw, int row0, int nrows, int K, int l) {
     const int nch = K >> 3;
-    u32x4 a[R][NC];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const bf16_t* row = w + (long long)min(row0 + r, nrows - 1) * ldw;
 #pragma unroll
         for (int i = 0; i < NC; ++i) a[r][i] = ld16(row + min(l + 64 * i, nch - 1) * 8);
     }
+}
+// dot products of the loaded rows with the lane-distributed vector (chunks past K read as zeros there); every lane returns the full sums
+template <int R, int NC>
+__device__ __forceinline__ void dot_loaded(float (&acc)[R], const u32x4 (&a)[R][NC], const u32x4 (&xv)[NC]) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float s = 0.f;
@@ -79,6 +85,13 @@ __device__ __forceinline__ void dot_rows(float (&acc)[R], const bf16_t* w, long 
         acc[r] = wave_sum(s);
     }
 }
+template <int R, int NC>
+__device__ __forceinline__ void dot_rows(float (&acc)[R], const bf16_t* w, long long ldw, int row0, int nrows, const u32x4 (&xv)[NC],
+                                         int K, int l) {
+    u32x4 a[R][NC];
+    load_rows<R, NC>(a, w, ldw, row0, nrows, K, l);
+    dot_loaded<R, NC>(acc, a, xv);
+}
 
 // y[n] = bf16(W[n,:] . xn) (+ residual[n], added to the ROUNDED product like the stand-alone add kernel)
 template <int R, int NC>
@@ -87,10 +100,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* W, long long ld
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int row0 = (blockIdx.x * 4 + w) * R;
     if (row0 >= N) return;
-    u32x4 xv[NC];
+    u32x4 xv[NC], a[R][NC];
     float acc[R];
+    load_rows<R, NC>(a, W, ldw, row0, N, K, l);
     load_vector<NC>(xv, x, norm_w, eps, K, l);
-    dot_rows<R, NC>(acc, W, ldw, row0, N, xv, K, l);
+    dot_loaded<R, NC>(acc, a, xv);
     if (l == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -176,8 +190,10 @@ __global__ __launch_bounds__(256) void router_shared_up_kernel(const bf16_t* gat
         const int row0 = (blockIdx.x * 4 + w) * 2;
         if (row0 >= E) return;
         float acc[2];
+        u32x4 a[2][NC];
+        load_rows<2, NC>(a, gate, K, row0, E, K, l);
         load_vector<NC>(xv, x, norm_w, eps, K, l);
-        dot_rows<2, NC>(acc, gate, K, row0, E, xv, K, l);
+        dot_loaded<2, NC>(acc, a, xv);
         if (l == 0) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -188,9 +204,12 @@ __global__ __launch_bounds__(256) void router_shared_up_kernel(const bf16_t* gat
     const int row0 = ((int(blockIdx.x) - nrb) * 4 + w) * R;
     if (row0 >= rows_s) return;
     float a1[R], a3[R];
+    u32x4 r1[R][NC], r3[R][NC];
+    load_rows<R, NC>(r1, S1, K, row0, rows_s, K, l);
+    load_rows<R, NC>(r3, S3, K, row0, rows_s, K, l);
     load_vector<NC>(xv, x, norm_w, eps, K, l);
-    dot_rows<R, NC>(a1, S1, K, row0, rows_s, xv, K, l);
-    dot_rows<R, NC>(a3, S3, K, row0, rows_s, xv, K, l);
+    dot_loaded<R, NC>(a1, r1, xv);
+    dot_loaded<R, NC>(a3, r3, xv);
     if (l == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -299,24 +318,18 @@ __device__ __forceinline__ int route_one_token(const bf16_t* logits, int E, int 
     for (int j = 0; j < 8; ++j) {
         top[j] = -INFINITY;
         if (j < k) {
-            float bv = val[0];
-            int bi = l;
+            // round j: the largest remaining logit, ties to the LOWEST expert id.  The maximum comes from a DPP ladder (vector ALU) and the
+            // id from ballots over the four id-ordered slots -- every workgroup of the up-projection runs this in front of its first weight
+            // load, and the butterfly form (two ds_bpermute round trips per step, 6 steps, k rounds) was ~2 us of pure latency there
+            const float m = wave_max_bcast(fmaxf(fmaxf(val[0], val[1]), fmaxf(val[2], val[3])));
+            int bi = -1;
 #pragma unroll
-            for (int i = 1; i < 4; ++i)
-                if (val[i] > bv) {
-                    bv = val[i];
-                    bi = l + 64 * i;
-                }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const float ov = shfl_xor(bv, d);
-                const int oi = shfl_xor(bi, d);
-                if (ov > bv || (ov == bv && oi < bi)) {
-                    bv = ov;
-                    bi = oi;
-                }
+            for (int i = 0; i < 4; ++i) {
+                const unsigned long long hit = ballot(val[i] == m);
+                if (bi < 0 && hit) bi = __builtin_ctzll(hit) + 64 * i;
             }
-            top[j] = bv;
+            if (bi < 0) bi = 0;  // (NaN logits: no lane compares equal -- stay in range)
+            top[j] = m;
             if (l == j) topi = bi;
             if (j == want) wanted = bi;
             if ((bi & 63) == l) {
@@ -338,53 +351,15 @@ __device__ __forceinline__ int route_one_token(const bf16_t* logits, int E, int 
     return wanted;
 }
 
+// stand-alone form of the routing the up-projection runs in front of its rows (aria_decode_route: parity tests against aria_moe_route)
 __global__ __launch_bounds__(64) void router_topk_kernel(const bf16_t* logits, int E, int k, bf16_t* scores, int32_t* idx) {
     const int l = threadIdx.x & 63;
-    float val[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) val[i] = (l + 64 * i < E) ? bf2f(logits[l + 64 * i]) : -INFINITY;
-    float top[8];
-    int topi = -1;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        top[j] = -INFINITY;
-        if (j < k) {
-            float bv = val[0];
-            int bi = l;
-#pragma unroll
-            for (int i = 1; i < 4; ++i)
-                if (val[i] > bv) {
-                    bv = val[i];
-                    bi = l + 64 * i;
-                }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const float ov = shfl_xor(bv, d);
-                const int oi = shfl_xor(bi, d);
-                if (ov > bv || (ov == bv && oi < bi)) {
-                    bv = ov;
-                    bi = oi;
-                }
-            }
-            top[j] = bv;
-            if (l == j) topi = bi;
-            if ((bi & 63) == l) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i == (bi >> 6)) val[i] = -INFINITY;
-            }
-        }
-    }
-    const float mx = top[0];
-    float den = 0.f, mine = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (j < k) den += expf(top[j] - mx);
-        if (j == l) mine = top[j];
-    }
+    float my_score;
+    int my_idx;
+    route_one_token(logits, E, k, l, 0, my_score, my_idx);
     if (l < k) {
-        scores[l] = f2bf(expf(mine - mx) / den);
-        idx[l] = topi;
+        scores[l] = f2bf(my_score);
+        idx[l] = my_idx;
     }
 }
 
@@ -791,7 +766,7 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
         } else {  // four launches: router logits | routed + shared up (top-k inside) | down-projections | combine
             ARIA_TRY(launch_gemv(int(E), stream, gate, (long long)D, h, ffn_norm, eps, int(D), nullptr, s.rl));
         }
-        // (top-k + softmax of the router run inside expert_up_kernel; router_topk_kernel is the stand-alone form)
+        // (top-k + softmax of the router run inside expert_up_kernel)
         if (I * (k + ns) >= 8192) {  // enough rows for 4 per wave (8 row reads of 5 KiB in flight per wave) and still > 2000 waves
 #define CALL(NC)                                                                                                                       \
     ARIA_LAUNCH((expert_up_kernel<4, NC>), dim3(unsigned((I + 15) / 16), unsigned(k + ns_up)), dim3(256), 0, stream, w1, w3, sw1, sw3, \
@@ -840,6 +815,14 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
     ARIA_TRY(launch_gemv(int(V), stream, out_w, (long long)D, x, final_norm, eps, int(D), nullptr, logits));
 #undef ARIA_TRY
     return ARIA_OK;
+}
+
+int aria_decode_route(const void* logits, int64_t E, int64_t k, void* scores, int32_t* idx, void* stream) {
+    if (!logits || !scores || !idx || E <= 0 || k <= 0) return ARIA_ERR_INVALID;
+    if (E > 256 || k > 8 || k > E) return ARIA_ERR_UNSUPPORTED;
+    ARIA_LAUNCH(router_topk_kernel, dim3(1), dim3(64), 0, stream, static_cast<const bf16_t*>(logits), int(E), int(k), static_cast<bf16_t*>(scores),
+                idx);
+    return aria_check_launch();
 }
 
 int64_t aria_decode_attn_workspace_bytes(int64_t H, int64_t hd, int64_t splits) {

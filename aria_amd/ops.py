@@ -196,6 +196,17 @@ def gemm_swiglu_split(x: torch.Tensor, w_gate: torch.Tensor, w_up: torch.Tensor,
     return h, act
 
 
+def decode_route(logits: torch.Tensor, k: int):
+    """The decode engine's routing of ONE token (csrc/decode.hip route_one_token) on its own: logits [E] bf16 -> (scores [k] bf16,
+    idx [k] int32); the same function as ``moe_route`` on one row."""
+    _chk(logits, name="logits")
+    E = logits.numel()
+    scores = torch.empty(k, dtype=bf16, device=logits.device)
+    idx = torch.empty(k, dtype=torch.int32, device=logits.device)
+    hip.get_lib().call("aria_decode_route", _p(logits), E, k, _p(scores), _p(idx), _stream(logits))
+    return scores, idx
+
+
 def dglu_fusable(I: int, K: int) -> bool:
     """Shapes the fused input-gradient + SwiGLU-backward launches take (128-column blocks of I are all-or-nothing, the v3 K loop wants
     K % 64 == 0; ARIA_FUSE_DSWIGLU=0 switches the fusion off: the two-step chain, bit-identical)."""

@@ -296,6 +296,10 @@ int aria_probe_atomic(float* buf, int* xcc, int64_t nblocks, int64_t region_floa
 #define ARIA_DECODE_LAYER_PTRS 13
 int64_t aria_decode_scratch_bytes(const int64_t* dims);
 int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, void* stream);
+/* The routing step of the engine on its own (gptfast/model.py:359-363 for one token; what every workgroup of the routed up-projection
+ * runs in front of its rows): top-k of E bf16 logits with ties to the lowest expert id, softmax over the selected logits in fp32,
+ * scores as bf16 -- the same function as aria_moe_route on one row (bit-exact ids and scores). */
+int aria_decode_route(const void* logits, int64_t E, int64_t k, void* scores, int32_t* idx, void* stream);
 /* The attention step of the engine on its own (gptfast/model.py:413-447 with one new token): rotates q (in registers) and k with
  * freqs_cis[pos], writes k / v of the new token into the static cache at row pos (KVCache.update :67-93), then softmax(q K^T / sqrt(hd)) V
  * over cache rows 0..pos.  qkv bf16 [3 * H * hd] (q | k | v of the new token), caches bf16 [S_max, H * hd], pos int32 [1] on the device,

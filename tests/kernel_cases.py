@@ -248,6 +248,29 @@ def case_route(dev, T, E, k, dtype, exact):
         assert torch.allclose(scores.cpu(), ws, atol=1e-6)
 
 
+def case_decode_route(dev, E, k, n_rows=24):
+    """The decode engine's one-token routing (maximum on a DPP ladder, expert id from ballots over the id-ordered slots) == the batched
+    router kernel == the oracle (TopKRouter.routing, moe_lm.py:243-273), ids AND bf16 scores bit for bit, on rows full of ties: equal
+    values across lanes, across the four 64-expert slots of a lane, and a fully tied row."""
+    from aria_amd import ops
+
+    g = torch.Generator().manual_seed(E * 10 + k)
+    logits = (torch.randn(n_rows, E, generator=g) * 0.5).to(bf16)
+    logits[:, E // 2] = logits[:, 1]                    # ties in every row
+    if E > 70:
+        logits[:, 66] = logits[:, 2]                    # the same value in two slots of one lane
+        logits[3, 2] = logits[3].float().max().to(bf16)
+        logits[3, 66] = logits[3, 2]                    # ... as the row maximum
+    logits[0] = 0.25                                    # a fully tied row
+    logits[1, E - 1] = 3.0                              # the maximum in the last expert
+    ws, wi, _ = O.router_routing(logits, k, E)
+    bs, bi, _ = ops.moe_route(logits.to(dev), k)
+    for r in range(n_rows):
+        sc, idx = ops.decode_route(logits[r].to(dev).contiguous(), k)
+        assert torch.equal(idx.cpu().long(), wi[r]), (r, idx.cpu(), wi[r])
+        assert torch.equal(idx.cpu(), bi[r].cpu()) and torch.equal(sc.cpu(), bs[r].cpu()), r
+
+
 def case_dispatch(dev, T, E, k, exact, D=72):
     from aria_amd import ops
 

@@ -201,6 +201,11 @@ def test_gemm_dswiglu_fused(counts, K, I, T):  # fc2 input gradient + glu backwa
     C.case_gemm_dswiglu_fused(DEV, counts, K, I, T)
 
 
+@pytest.mark.parametrize("E,k", [(64, 6), (8, 3), (200, 8), (256, 2)])
+def test_decode_route_matches_the_batched_router(E, k):
+    C.case_decode_route(DEV, E, k)
+
+
 @pytest.mark.parametrize("H,hd,pos,splits", [(2, 128, 63, 2), (3, 128, 64, 2), (2, 128, 2999, 16), (20, 128, 16383, 32), (3, 64, 127, 2),
                                              (2, 64, 1000, 5)])
 def test_decode_attention_split_kv(H, hd, pos, splits):
