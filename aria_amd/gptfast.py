@@ -197,9 +197,18 @@ class TransformerBlock(nn.Module):
         self.ffn_norm = RMSNorm(config.dim, config.norm_eps)
         self.attention_norm = RMSNorm(config.dim, config.norm_eps)
 
-    def forward(self, x2d, B, S, freqs_cis, pos32, kv_len, prefill):
-        h = ops.add(x2d, self.attention(self.attention_norm(x2d), B, S, freqs_cis, pos32, kv_len, prefill))
-        return ops.add(h, self.feed_forward(self.ffn_norm(h)))
+    def forward(self, res, delta, B, S, freqs_cis, pos32, kv_len, prefill):
+        """gptfast/model.py:236-260 with the two residual adds folded into the norm that follows each (``rmsnorm`` with a residual: the
+        sum is rounded to bf16 and written once, then normalised -- the same bits as ``add`` followed by ``rmsnorm``, two launches and two
+        passes over [T, D] less per layer).  The block's input is ``res + delta`` (``delta`` None for the first block); it returns
+        (h, ffn_out), the two halves of its output, for the next block's attention_norm -- or the model's final norm -- to sum."""
+        if delta is None:
+            x, xn = res, self.attention_norm(res)
+        else:
+            xn, x, _ = ops.rmsnorm(delta, self.attention_norm.weight, self.attention_norm.eps, residual=res, want_rstd=False)
+        a = self.attention(xn, B, S, freqs_cis, pos32, kv_len, prefill)
+        hn, h, _ = ops.rmsnorm(a, self.ffn_norm.weight, self.ffn_norm.eps, residual=x, want_rstd=False)
+        return h, self.feed_forward(hn)
 
 
 class Transformer(nn.Module):
@@ -256,9 +265,10 @@ class Transformer(nn.Module):
         else:
             pos32 = input_pos.to(torch.int32).reshape(-1).expand(B).contiguous()
             kv_len = pos32 + 1
+        res, delta = x2d, None
         for layer in self.layers:
-            x2d = layer(x2d, B, S, self.freqs_cis, pos32, kv_len, prefill)
-        h = self.norm(x2d)
+            res, delta = layer(res, delta, B, S, self.freqs_cis, pos32, kv_len, prefill)
+        h = ops.rmsnorm(delta, self.norm.weight, self.norm.eps, residual=res, want_rstd=False)[0] if delta is not None else self.norm(res)
         if last_only:
             h = h.view(B, S, D)[:, -1].contiguous()
             return ops.gemm(h, self.output.weight).view(B, 1, -1)
