@@ -20,12 +20,15 @@ with torch.no_grad():
 m.eval()
 m.setup_caches(1, 512)
 ids = torch.randint(10, 100000, (1, 280), generator=g, device=dev)
+only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
 res = {}
 with torch.no_grad():
     m(ids, torch.arange(280, device=dev))
     tok = torch.tensor([[17]], device=dev)
     for name, eng, graph, fuse in (("engine_fused6", True, False, "1"), ("engine_unfused7", True, False, "0"), ("engine_fused6_graph", True, True, "1"),
                                    ("engine_fused6_again", True, False, "1"), ("tile_path", False, False, "1")):
+        if only and name not in only:
+            continue
         os.environ["ARIA_DECODE_FUSE"] = fuse  # read by the library at every aria_decode_token call (csrc/decode.hip)
         m.use_decode_engine, m.decode_graph, m._engine = eng, graph, None
         pos = torch.tensor([280], device=dev, dtype=torch.int32)
