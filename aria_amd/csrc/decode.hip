@@ -429,9 +429,14 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(bf16_t* qkv, const bf16
 // DecodeAttn<HD>::run is the body shared by the two kernels below: keys [kbeg, kend) of one head, `writes_new` (block-uniform) = this
 // workgroup owns the new position and puts the rotated key / value into the cache before reading it back.  On return the lanes with
 // w == 0 && grp == 0 hold the UNNORMALISED state (m, lsum, o[8] for features sub*8 ..) of the whole range.
-template <int HD>
+template <int HD, int NWV = 4>
 struct DecodeAttn {
-    static constexpr int LPK = HD / 8, KPW = 64 / LPK, U = 4, PER_ITER = 4 * KPW * U;
+    // NWV waves per workgroup, U keys per lane group and pass: NWV x KPW x U keys per pass over the range, all K / V rows of a pass in
+    // flight before the first use.  Round 3: the one-workgroup-per-head kernel went from 4 waves x U 4 (64 keys per pass at hd 128) to
+    // 16 waves x U 8 (512): at the 300-500 keys of a chat prompt its loop was 6 DEPENDENT HBM round trips -- 13 us per layer in the
+    // kernel trace, the third largest kernel of a token, for 3.4 MB of cache -- and is one now.  (Requesting the next pass ahead of the
+    // current one from two register sets did not survive the compiler: it merged the two bodies and drained the loads to do so.)
+    static constexpr int LPK = HD / 8, KPW = 64 / LPK, U = 8, PER_ITER = NWV * KPW * U;
 
     static __device__ __forceinline__ u32x4 rope(const u32x4& a, const u32x4& f) {
         u32x4 o;
@@ -453,7 +458,7 @@ struct DecodeAttn {
     }
 
     static __device__ __forceinline__ void run(const bf16_t* qkv, const bf16_t* fc, int ps, bf16_t* k_cache, bf16_t* v_cache, int D,
-                                               float scale, int head, int kbeg, int kend, bool writes_new, float (&red)[4][LPK][10],
+                                               float scale, int head, int kbeg, int kend, bool writes_new, float (&red)[NWV][LPK][10],
                                                float& m, float& lsum, float (&o)[8]) {
         const int l = threadIdx.x & 63, w = threadIdx.x >> 6, sub = l % LPK, grp = l / LPK;
         const long long col = (long long)head * HD + sub * 8;
@@ -498,7 +503,7 @@ struct DecodeAttn {
                 m = m_new;
             }
         }
-        // merge the lane groups of a wave (lanes with equal `sub`), then the four waves through LDS
+        // merge the lane groups of a wave (lanes with equal `sub`), then the waves through LDS
 #pragma unroll
         for (int d = LPK; d < 64; d <<= 1) {
             float o2[8];
@@ -515,7 +520,7 @@ struct DecodeAttn {
         }
         sync();
         if (w == 0 && grp == 0) {
-            for (int ww = 1; ww < 4; ++ww) {
+            for (int ww = 1; ww < NWV; ++ww) {
                 float o2[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o2[e] = red[ww][sub][2 + e];
@@ -525,12 +530,13 @@ struct DecodeAttn {
     }
 };
 
-// grid = heads: one workgroup walks the whole context of its head and normalises
+// grid = heads: one workgroup (16 waves) walks the whole context of its head and normalises
+constexpr int DECODE_ATTN_WAVES = 16;
 template <int HD>
-__global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* qkv, const bf16_t* fc, const int32_t* pos, bf16_t* k_cache,
-                                                          bf16_t* v_cache, bf16_t* out, int D, float scale) {
-    using A = DecodeAttn<HD>;
-    ARIA_SMEM_STATIC float red[4][A::LPK][10];
+__global__ __launch_bounds__(DECODE_ATTN_WAVES * 64) void decode_attn_kernel(const bf16_t* qkv, const bf16_t* fc, const int32_t* pos,
+                                                                            bf16_t* k_cache, bf16_t* v_cache, bf16_t* out, int D, float scale) {
+    using A = DecodeAttn<HD, DECODE_ATTN_WAVES>;
+    ARIA_SMEM_STATIC float red[DECODE_ATTN_WAVES][A::LPK][10];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, sub = l % A::LPK, grp = l / A::LPK, head = blockIdx.x;
     const int ps = pos[0];
     float m, lsum, o[8];
@@ -598,9 +604,9 @@ int launch_decode_attn(void* stream, const bf16_t* qkv, const bf16_t* freqs, con
     const float sc = 1.0f / sqrtf(float(hd));
     if (splits <= 1) {
         if (hd == 128)
-            ARIA_LAUNCH((decode_attn_kernel<128>), dim3(unsigned(H)), dim3(256), 0, stream, qkv, freqs, pos, kc, vc, out, int(D), sc);
+            ARIA_LAUNCH((decode_attn_kernel<128>), dim3(unsigned(H)), dim3(DECODE_ATTN_WAVES * 64), 0, stream, qkv, freqs, pos, kc, vc, out, int(D), sc);
         else
-            ARIA_LAUNCH((decode_attn_kernel<64>), dim3(unsigned(H)), dim3(256), 0, stream, qkv, freqs, pos, kc, vc, out, int(D), sc);
+            ARIA_LAUNCH((decode_attn_kernel<64>), dim3(unsigned(H)), dim3(DECODE_ATTN_WAVES * 64), 0, stream, qkv, freqs, pos, kc, vc, out, int(D), sc);
         return aria_check_launch();
     }
     if (hd == 128)
