@@ -103,6 +103,11 @@ __device__ __forceinline__ float wave_max_bcast(float v) {
     for (int m = 32; m >= 1; m >>= 1) v = std::fmax(v, emu::shfl(v, emu::lane() ^ m));
     return v;
 }
+template <int N>
+__device__ __forceinline__ float group_sum(float v) {  // sum over aligned groups of N = 8 / 16 lanes, every lane gets it
+    for (int d = 1; d < N; d <<= 1) v += emu::shfl(v, emu::lane() ^ d);
+    return v;
+}
 __device__ __forceinline__ unsigned long long ballot(bool p) { return emu::ballot(p); }
 __device__ __forceinline__ int lane_id() { return emu::lane(); }
 __device__ __forceinline__ int first_lane(int v) { return emu::shfl(v, __builtin_ctzll(emu::ballot(true))); }
@@ -139,6 +144,21 @@ __device__ __forceinline__ int wave_bcast(int v, int lane) { return __shfl(v, la
 // the value of lane `lane` (a compile-time constant or otherwise wave-uniform) as a SCALAR: v_readlane_b32, no LDS round trip -- for
 // values that become addresses of wave-uniform rows
 __device__ __forceinline__ int read_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// sum over aligned groups of N = 8 or 16 lanes (one DPP row or half of it), every lane of the group gets it: quad_perm [1,0,3,2] and
+// [2,3,0,1], then row_half_mirror (lane i <-> 7 - i: the other quad of the half row -- every lane of a quad already holds the quad's sum)
+// and row_mirror (i <-> 15 - i: the other half).  Each step adds the same two partial sums the xor butterfly adds (commuted), so the result
+// equals `for d: v += shfl_xor(v, d)` bit for bit -- on the vector ALU instead of log2(N) ds_bpermute round trips through the LDS.
+template <int N>
+__device__ __forceinline__ float group_sum(float v) {
+    static_assert(N == 8 || N == 16, "one DPP row or half of it");
+#define ARIA_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    ARIA_DPP_ADD(0xB1);   // quad_perm:[1,0,3,2]
+    ARIA_DPP_ADD(0x4E);   // quad_perm:[2,3,0,1]
+    ARIA_DPP_ADD(0x141);  // row_half_mirror
+    if (N == 16) ARIA_DPP_ADD(0x140);  // row_mirror
+#undef ARIA_DPP_ADD
+    return v;
+}
 // maximum over the wave's 64 lanes as a wave-uniform value, on the vector ALU: the DPP ladder of wave_incl_scan (row shifts inside each
 // row of 16, then the two row broadcasts) with max instead of add, lane 63 read back as a scalar -- 6 VALU operations instead of 6
 // ds_bpermute round trips through the LDS (max is exact, so the result equals the butterfly's bit for bit)

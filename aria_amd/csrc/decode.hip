@@ -488,8 +488,7 @@ struct DecodeAttn {
                 float sc = 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sc = dot2bf(kx[u][q], qr[q], sc);
-#pragma unroll
-                for (int d = 1; d < LPK; d <<= 1) sc += shfl_xor(sc, d);
+                sc = group_sum<LPK>(sc);  // the HD / 8 lanes of a key (DPP: no LDS round trips in front of every key's softmax step)
                 const float s2 = key[u] < kend ? sc * scale2 : -INFINITY;
                 const float m_new = fmaxf(m, s2);
                 if (m_new == -INFINITY) continue;  // nothing seen yet by this lane group (uniform within the group)
@@ -519,12 +518,26 @@ struct DecodeAttn {
             for (int e = 0; e < 8; ++e) red[w][sub][2 + e] = o[e];
         }
         sync();
-        if (w == 0 && grp == 0) {
-            for (int ww = 1; ww < NWV; ++ww) {
+        if (w == 0) {  // the NWV wave states as a tree: lane group g folds waves g, g + NG, ..., then the groups merge by butterfly
+            constexpr int NG = 64 / LPK;
+            if (grp > 0) {  // (group 0 starts from wave 0's own state, which every lane group of the wave holds after the butterfly above)
+                m = -INFINITY, lsum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = 0.f;
+            }
+            for (int ww = grp ? grp : NG; ww < NWV; ww += NG) {
                 float o2[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o2[e] = red[ww][sub][2 + e];
                 merge(m, lsum, o, red[ww][sub][0], red[ww][sub][1], o2);
+            }
+#pragma unroll
+            for (int d = LPK; d < 64; d <<= 1) {
+                float o2[8];
+                const float m2 = shfl_xor(m, d), l2 = shfl_xor(lsum, d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o2[e] = shfl_xor(o[e], d);
+                merge(m, lsum, o, m2, l2, o2);
             }
         }
     }
