@@ -108,6 +108,10 @@ __device__ __forceinline__ float group_sum(float v) {  // sum over aligned group
     for (int d = 1; d < N; d <<= 1) v += emu::shfl(v, emu::lane() ^ d);
     return v;
 }
+__device__ __forceinline__ float wave_sum_bcast(float v) {  // (the hardware form adds in another order: callers compare with a tolerance)
+    for (int m = 32; m >= 1; m >>= 1) v += emu::shfl(v, emu::lane() ^ m);
+    return v;
+}
 __device__ __forceinline__ unsigned long long ballot(bool p) { return emu::ballot(p); }
 __device__ __forceinline__ int lane_id() { return emu::lane(); }
 __device__ __forceinline__ int first_lane(int v) { return emu::shfl(v, __builtin_ctzll(emu::ballot(true))); }
@@ -158,6 +162,20 @@ __device__ __forceinline__ float group_sum(float v) {
     if (N == 16) ARIA_DPP_ADD(0x140);  // row_mirror
 #undef ARIA_DPP_ADD
     return v;
+}
+// sum over the wave's 64 lanes as a wave-uniform value on the vector ALU: the DPP ladder of wave_incl_scan (prefix sums inside each row of
+// 16, the two row broadcasts), lane 63 read back as a scalar -- 6 VALU operations instead of the butterfly's 6 ds_bpermute round trips.
+// The fp32 summation ORDER differs from wave_sum's butterfly: for reductions whose consumers compare with a tolerance (the decode GEMVs).
+__device__ __forceinline__ float wave_sum_bcast(float v) {
+#define ARIA_DPP_ADD0(ctrl, rows) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rows, 0xF, false))
+    ARIA_DPP_ADD0(0x111, 0xF);  // row_shr:1
+    ARIA_DPP_ADD0(0x112, 0xF);  // row_shr:2
+    ARIA_DPP_ADD0(0x114, 0xF);  // row_shr:4
+    ARIA_DPP_ADD0(0x118, 0xF);  // row_shr:8  -> lane 15 of every row holds the row's sum
+    ARIA_DPP_ADD0(0x142, 0xA);  // row_bcast:15 into rows 1 and 3
+    ARIA_DPP_ADD0(0x143, 0xC);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+#undef ARIA_DPP_ADD0
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // maximum over the wave's 64 lanes as a wave-uniform value, on the vector ALU: the DPP ladder of wave_incl_scan (row shifts inside each
 // row of 16, then the two row broadcasts) with max instead of add, lane 63 read back as a scalar -- 6 VALU operations instead of 6

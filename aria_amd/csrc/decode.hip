@@ -82,7 +82,7 @@ __device__ __forceinline__ void dot_loaded(float (&acc)[R], const u32x4 (&a)[R][
         for (int i = 0; i < NC; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) s = dot2bf(a[r][i][q], xv[i][q], s);
-        acc[r] = wave_sum(s);
+        acc[r] = wave_sum_bcast(s);  // (DPP ladder: no LDS round trips at the tail of every GEMV wave)
     }
 }
 template <int R, int NC>
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void expert_down_combine_kernel(const bf16_t* 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) s = dot2bf(wr[j][i][q], xv[q], s);
             }
-            s = wave_sum(s);
+            s = wave_sum_bcast(s);
             accs += rbf(rbf(s) * sc[j]);  // bf16(eo_j * score_j), summed in fp32 in slot order (combine_kernel)
         }
     float sh = 0.f;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void expert_down_combine_kernel(const bf16_t* 
 #pragma unroll
         for (int q = 0; q < 4; ++q) sh = dot2bf(ws[i][q], xv[q], sh);
     }
-    sh = wave_sum(sh);
+    sh = wave_sum_bcast(sh);
     if (l == 0 && n < N) out[n] = f2bf(bf2f(h[n]) + rbf(rbf(accs) + rbf(sh)));
 }
 
