@@ -75,11 +75,29 @@ def main():
         decoder(tok, pos)
     torch.cuda.synchronize()
     t_dec = (time.perf_counter() - t0) / 50
+    # the model step alone (embedding lookup + engine call, no sampling) and the bare engine call, same box
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        model.llm(tok, pos)
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / 50
+    eng = model.llm._engine
+    t_eng = None
+    if eng is not None:
+        stream = torch.cuda.current_stream().cuda_stream
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            eng._lib.call("aria_decode_token", eng.ptrs, eng._dims_p, eng.eps, stream)
+        torch.cuda.synchronize()
+        t_eng = (time.perf_counter() - t0) / 50
     weight_bytes = (28 * (6 * 3 * 2560 * 1664 + 3 * 2560 * 3328 + 64 * 2560 + 4 * 2560 * 2560) + 100352 * 2560) * 2
     res = {"metric": "generate tok/s (gptfast protocol, config #2)", "value": round(sum(ntok) / sum(lat), 2), "unit": "tokens/s",
            "published_h100": {"eager": 25.2, "compile": 130.0}, "new_tokens": a.new, "runs": a.runs,
            "prefill_ms_280tok_incl_vit": round(t_prefill * 1e3, 2), "prefill_tok_s": round(280 / t_prefill, 1),
            "decode_ms_per_token": round(t_dec * 1e3, 3), "decode_tok_s": round(1 / t_dec, 1),
+           "model_step_ms": round(t_step * 1e3, 3), "engine_call_ms": None if t_eng is None else round(t_eng * 1e3, 3),
            "decode_roofline": {"bound": "hbm", "achieved": round(weight_bytes / t_dec / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(weight_bytes / t_dec / 8e12, 4)},
            "config": {"layers": a.layers, "vit_layers": a.vit_layers, "hip_graph": bool(a.graph)}}
