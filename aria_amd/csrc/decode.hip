@@ -611,6 +611,112 @@ __global__ void decode_attn_merge_kernel(const float* part, bf16_t* out, int NS,
     out[(long long)head * HD + f] = f2bf(r);
 }
 
+// ---- sampling (gptfast/generate.py:35-58: logits_to_probs + multinomial_sample_one_no_sync) -------------------------------------------
+// One token's sampling as ONE launch of one workgroup (1024 threads) instead of ~20 tiny tensor kernels (temperature, top-k, where,
+// softmax, exponential, divide, arg-max, casts: 0.15 ms of a 2.16 ms token in the round-3 trace):
+//   keep the logits >= the k-th largest (ties kept, as `logits < v[k-1] -> -inf` does), p_i ~ exp((l_i - max) / T), return argmax_i p_i / q_i
+// with q_i ~ Exp(1) drawn by the caller (torch's generator: one `exponential_` launch, same seeds -> same stream as the tensor path).
+// The k-th largest value is found EXACTLY by a two-pass radix select on the 16 bits of a bf16 (order-preserving key: flip all bits of a
+// negative value, set the sign bit of a non-negative one): 256-bin histograms in LDS over the high byte, then over the low byte inside the
+// boundary bin.  The softmax's normaliser does not move the arg-max and is skipped.  The logits (200 KB) and q (400 KB) stay in the L2.
+constexpr int SAMPLE_THREADS = 1024;
+__device__ __forceinline__ uint32_t bf16_order_key(bf16_t b) { return (b & 0x8000u) ? (~uint32_t(b) & 0xffffu) : (uint32_t(b) | 0x8000u); }
+
+__global__ __launch_bounds__(SAMPLE_THREADS) void sample_topk_kernel(const bf16_t* logits, const float* q, int V, int k, float inv_temp,
+                                                                     int32_t* out) {
+    ARIA_SMEM_STATIC int hist[256];
+    ARIA_SMEM_STATIC int sel[4];          // [0] boundary high byte, [1] rank still wanted inside it, [2] threshold key
+    ARIA_SMEM_STATIC float red_v[SAMPLE_THREADS / 64];
+    ARIA_SMEM_STATIC int red_i[SAMPLE_THREADS / 64];
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    const bool all = k >= V;
+    float mx = -INFINITY;
+    // pass 1: histogram of the high byte (+ the maximum)
+    for (int i = t; i < 256; i += SAMPLE_THREADS) hist[i] = 0;
+    sync();
+    for (int i = t; i < V; i += SAMPLE_THREADS) {
+        const bf16_t b = logits[i];
+        mx = fmaxf(mx, bf2f(b));
+        if (!all) atomic_add(&hist[bf16_order_key(b) >> 8], 1);
+    }
+    mx = wave_max(mx);
+    if (l == 0) red_v[w] = mx;
+    sync();
+    if (t == 0) {
+        float m = red_v[0];
+        for (int i = 1; i < SAMPLE_THREADS / 64; ++i) m = fmaxf(m, red_v[i]);
+        red_v[0] = m;
+        int above = 0, b1 = 0;
+        if (!all) {
+            for (b1 = 255; b1 > 0; --b1) {
+                if (above + hist[b1] >= k) break;
+                above += hist[b1];
+            }
+        }
+        sel[0] = b1;
+        sel[1] = k - above;
+    }
+    sync();
+    mx = red_v[0];
+    const int b1 = sel[0], want = sel[1];
+    sync();
+    // pass 2: histogram of the low byte inside the boundary bin -> the exact 16-bit threshold
+    if (!all) {
+        for (int i = t; i < 256; i += SAMPLE_THREADS) hist[i] = 0;
+        sync();
+        for (int i = t; i < V; i += SAMPLE_THREADS) {
+            const uint32_t key = bf16_order_key(logits[i]);
+            if (int(key >> 8) == b1) atomic_add(&hist[key & 255u], 1);
+        }
+        sync();
+        if (t == 0) {
+            int cum = 0, b2 = 255;
+            for (; b2 > 0; --b2) {
+                cum += hist[b2];
+                if (cum >= want) break;
+            }
+            sel[2] = (b1 << 8) | b2;
+        }
+        sync();
+    }
+    const uint32_t thr = all ? 0u : uint32_t(sel[2]);
+    // pass 3: arg-max of p_i / q_i over the kept logits (first index wins ties, like torch.argmax on this path)
+    float best = -1.f;
+    int besti = 0x7fffffff;
+    for (int i = t; i < V; i += SAMPLE_THREADS) {
+        const bf16_t b = logits[i];
+        if (bf16_order_key(b) >= thr) {
+            const float s = expf((bf2f(b) - mx) * inv_temp) / q[i];
+            if (s > best) {  // (strictly greater: indices come in increasing order within a thread)
+                best = s;
+                besti = i;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ov = shfl_xor(best, d);
+        const int oi = shfl_xor(besti, d);
+        if (ov > best || (ov == best && oi < besti)) {
+            best = ov;
+            besti = oi;
+        }
+    }
+    if (l == 0) {
+        red_v[w] = best;
+        red_i[w] = besti;
+    }
+    sync();
+    if (t == 0) {
+        for (int i = 1; i < SAMPLE_THREADS / 64; ++i)
+            if (red_v[i] > best || (red_v[i] == best && red_i[i] < besti)) {
+                best = red_v[i];
+                besti = red_i[i];
+            }
+        out[0] = besti;
+    }
+}
+
 // splits == 1: the one-workgroup-per-head kernel; otherwise the split form + merge (part: H * splits * (hd + 2) floats)
 int launch_decode_attn(void* stream, const bf16_t* qkv, const bf16_t* freqs, const int32_t* pos, bf16_t* kc, bf16_t* vc, bf16_t* out,
                        float* part, int64_t H, int64_t hd, int64_t D, int splits) {
@@ -834,6 +940,15 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
     ARIA_TRY(launch_gemv(int(V), stream, out_w, (long long)D, x, final_norm, eps, int(D), nullptr, logits));
 #undef ARIA_TRY
     return ARIA_OK;
+}
+
+int aria_sample_topk(const void* logits, const float* q, int64_t V, int64_t top_k, float temperature, int32_t* out, void* stream) {
+    if (!logits || !q || !out || V <= 0) return ARIA_ERR_INVALID;
+    if (V >= (1ll << 31)) return ARIA_ERR_UNSUPPORTED;
+    const float t = temperature > 1e-5f ? temperature : 1e-5f;  // (gptfast/generate.py:47: max(temperature, 1e-5))
+    const int k = (top_k <= 0 || top_k >= V) ? int(V) : int(top_k);
+    ARIA_LAUNCH(sample_topk_kernel, dim3(1), dim3(SAMPLE_THREADS), 0, stream, static_cast<const bf16_t*>(logits), q, int(V), k, 1.0f / t, out);
+    return aria_check_launch();
 }
 
 int aria_decode_route(const void* logits, int64_t E, int64_t k, void* scores, int32_t* idx, void* stream) {

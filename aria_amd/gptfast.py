@@ -401,6 +401,10 @@ class DecodeGraph:
         # warm-up / capture run at the LAST cache slot so they never clobber live K/V rows
         self.pos = torch.full((1,), model.llm.max_seq_length - 1, dtype=torch.int32, device=dev)
         self.logits = torch.zeros((1, 1, model.config.vocab_size), dtype=bf16, device=dev)
+        # sampling as ONE launch (ops.sample_topk) on Exp(1) draws of torch's generator: same seeds -> same tokens as the tensor path
+        self._q = torch.empty(model.config.vocab_size, dtype=torch.float32, device=dev)
+        self._ring = torch.zeros(model.llm.max_seq_length + 8, dtype=torch.int32, device=dev)  # one slot per new token: callers keep views
+        self._slot = 0
         self.graph = None
         if use_graph and dev.type == "cuda":
             s = torch.cuda.Stream()
@@ -421,9 +425,16 @@ class DecodeGraph:
         self.pos.copy_(pos.view(1))
         if self.graph is not None:
             self.graph.replay()
-        else:
-            self._step()
-        return sample(self.logits, self.temperature, self.top_k)[0].view(-1)
+            lg = self.logits
+        else:  # the engine's own logits buffer (consumed here, before the next step overwrites it): no 200 KB copy
+            lg = self.model(self.tok, self.pos, last_only=True)
+        lg = lg.reshape(-1)
+        if lg.dtype != bf16 or not lg.is_contiguous():
+            return sample(lg.view(1, 1, -1), self.temperature, self.top_k)[0].view(-1)
+        self._q.exponential_(1)
+        out = self._ring[self._slot:self._slot + 1]
+        self._slot = (self._slot + 1) % self._ring.numel()
+        return ops.sample_topk(lg, self._q, self.temperature, self.top_k, out=out)
 
 
 import os as _os
@@ -469,7 +480,7 @@ def generate(model: Aria, input_ids: torch.Tensor, max_new_tokens: int, *, pixel
     toks: List[torch.Tensor] = [nxt.view(1)]
     pos = torch.tensor([T], device=dev, dtype=torch.int32)
     for _ in range(max_new_tokens - 1):
-        nxt = decoder(toks[-1].long(), pos)
+        nxt = decoder(toks[-1], pos)
         if _DEBUG_GEN:  # (formatting the message reads two device scalars: never on the normal path, it would sync every token)
             _dbg(f"decode pos {int(pos)} tok {int(nxt)}")
         toks.append(nxt.view(1))

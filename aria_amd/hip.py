@@ -34,6 +34,7 @@ SIGNATURES = {
     "aria_decode_scratch_bytes": [P],
     "aria_decode_token": [P, P, F32, P],
     "aria_decode_route": [P, I64, I64, P, P, P],
+    "aria_sample_topk": [P, P, I64, I64, F32, P, P],
     "aria_decode_attn_workspace_bytes": [I64, I64, I64],
     "aria_decode_attn": [P, P, P, P, P, P, I64, I64, I64, P, I64, P],
     "aria_decode_graph_create": [P, P, F32],

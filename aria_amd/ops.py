@@ -196,6 +196,17 @@ def gemm_swiglu_split(x: torch.Tensor, w_gate: torch.Tensor, w_up: torch.Tensor,
     return h, act
 
 
+def sample_topk(logits: torch.Tensor, q: torch.Tensor, temperature: float, top_k: Optional[int], out: Optional[torch.Tensor] = None):
+    """gptfast's ``sample`` (generate.py:35-58) for one token in one launch: logits [V] bf16, q [V] fp32 = Exp(1) draws (the caller's
+    generator) -> int32 [1] = argmax softmax(top-k filtered logits / T) / q; ties at the k-th value are kept, as the tensor path keeps them."""
+    _chk(logits, name="logits"), _chk(q, torch.float32, "q")
+    assert logits.is_contiguous() and q.is_contiguous() and logits.numel() == q.numel()
+    if out is None:
+        out = torch.empty(1, dtype=torch.int32, device=logits.device)
+    hip.get_lib().call("aria_sample_topk", _p(logits), _p(q), logits.numel(), int(top_k or 0), float(temperature), _p(out), _stream(logits))
+    return out
+
+
 def decode_route(logits: torch.Tensor, k: int):
     """The decode engine's routing of ONE token (csrc/decode.hip route_one_token) on its own: logits [E] bf16 -> (scores [k] bf16,
     idx [k] int32); the same function as ``moe_route`` on one row."""

@@ -296,6 +296,10 @@ int aria_probe_atomic(float* buf, int* xcc, int64_t nblocks, int64_t region_floa
 #define ARIA_DECODE_LAYER_PTRS 13
 int64_t aria_decode_scratch_bytes(const int64_t* dims);
 int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, void* stream);
+/* sample() of gptfast/generate.py:35-58 for one token as ONE launch: keep the logits >= the top_k-th largest (ties kept; top_k <= 0 or >= V:
+ * all), p_i ~ exp((l_i - max) / max(temperature, 1e-5)), out[0] = argmax_i p_i / q_i with q [V] fp32 the caller's Exp(1) draws
+ * (multinomial_sample_one_no_sync's trick: the caller's generator stays the source of randomness).  logits bf16 [V]. */
+int aria_sample_topk(const void* logits, const float* q, int64_t V, int64_t top_k, float temperature, int32_t* out, void* stream);
 /* The routing step of the engine on its own (gptfast/model.py:359-363 for one token; what every workgroup of the routed up-projection
  * runs in front of its rows): top-k of E bf16 logits with ties to the lowest expert id, softmax over the selected logits in fp32,
  * scores as bf16 -- the same function as aria_moe_route on one row (bit-exact ids and scores). */

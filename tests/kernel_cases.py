@@ -248,6 +248,33 @@ def case_route(dev, T, E, k, dtype, exact):
         assert torch.allclose(scores.cpu(), ws, atol=1e-6)
 
 
+def case_sample_topk(dev, V, top_k, temperature, seed=0):
+    """aria_sample_topk (one launch) == gptfast/generate.py's tensor path (logits_to_probs + multinomial_sample_one_no_sync, restated in
+    aria_amd.gptfast) on the SAME Exp(1) draws: the same token, with ties at the k-th largest logit (the tensor path keeps them), a
+    maximum shared by several tokens, negative and positive logits, top_k >= V and top_k None."""
+    from aria_amd import gptfast as G
+    from aria_amd import ops
+
+    g = torch.Generator().manual_seed(seed + V)
+    logits = (torch.randn(V, generator=g) * 3.0).to(bf16)
+    if V > 64:
+        srt = torch.sort(logits.float(), descending=True).values
+        kk = min(top_k or V, V)
+        logits[torch.randperm(V, generator=g)[:5]] = srt[kk - 1].to(bf16)      # ties exactly at the threshold
+        logits[torch.randperm(V, generator=g)[:3]] = srt[0].to(bf16)           # a shared maximum
+    for trial in range(6):
+        q = torch.empty(V).exponential_(1, generator=g)
+        x = logits.float() / max(temperature, 1e-5)
+        if top_k is not None:
+            v, _ = torch.topk(x, min(top_k, V))
+            x = torch.where(x < v[-1], torch.tensor(-float("inf")), x)
+        want = int(torch.argmax(torch.softmax(x, dim=-1) / q))
+        got = int(ops.sample_topk(logits.to(dev), q.to(dev), temperature, top_k).cpu())
+        if got != want:  # the normaliser is skipped: only an exact fp tie of p/q may pick the other index
+            pw, pg = (torch.softmax(x, -1) / q)[want], (torch.softmax(x, -1) / q)[got]
+            assert abs(float(pw - pg)) <= 1e-6 * float(pw) and x[got] > -float("inf"), (trial, got, want)
+
+
 def case_decode_route(dev, E, k, n_rows=24):
     """The decode engine's one-token routing (maximum on a DPP ladder, expert id from ballots over the id-ordered slots) == the batched
     router kernel == the oracle (TopKRouter.routing, moe_lm.py:243-273), ids AND bf16 scores bit for bit, on rows full of ties: equal

@@ -186,6 +186,11 @@ def test_gemm_dswiglu_fused(force_gemm_v3, counts, K, I, T):
     C.case_gemm_dswiglu_fused(DEV, counts, K, I, T)
 
 
+@pytest.mark.parametrize("V,top_k,temperature", [(5000, 200, 0.8), (1000, 1, 1.0), (300, 500, 0.7), (4099, None, 1.3), (40, 7, 1e-6)])
+def test_sample_topk_matches_the_tensor_path(V, top_k, temperature):
+    C.case_sample_topk(DEV, V, top_k, temperature)
+
+
 @pytest.mark.parametrize("E,k", [(64, 6), (8, 3), (200, 8), (256, 2)])
 def test_decode_route_matches_the_batched_router(E, k):
     C.case_decode_route(DEV, E, k)
