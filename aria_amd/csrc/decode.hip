@@ -624,33 +624,57 @@ __device__ __forceinline__ uint32_t bf16_order_key(bf16_t b) { return (b & 0x800
 
 __global__ __launch_bounds__(SAMPLE_THREADS) void sample_topk_kernel(const bf16_t* logits, const float* q, int V, int k, float inv_temp,
                                                                      int32_t* out) {
-    ARIA_SMEM_STATIC int hist[256];
+    constexpr int NWV = SAMPLE_THREADS / 64;
+    ARIA_SMEM_STATIC int hist[NWV][256];  // one histogram per wave (logits cluster in a handful of exponent bins: 16 waves adding into
+                                          // ONE set of counters serialised on them), summed into hist[0] afterwards
     ARIA_SMEM_STATIC int sel[4];          // [0] boundary high byte, [1] rank still wanted inside it, [2] threshold key
-    ARIA_SMEM_STATIC float red_v[SAMPLE_THREADS / 64];
-    ARIA_SMEM_STATIC int red_i[SAMPLE_THREADS / 64];
+    ARIA_SMEM_STATIC float red_v[NWV];
+    ARIA_SMEM_STATIC int red_i[NWV];
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const bool all = k >= V;
+    const int nch = V >> 3;  // 16-byte chunks (8 logits); the tail (V % 8) goes element-wise
     float mx = -INFINITY;
+    auto clear = [&]() {
+        for (int i = t; i < NWV * 256; i += SAMPLE_THREADS) (&hist[0][0])[i] = 0;
+        sync();
+    };
+    auto fold = [&]() {  // hist[0][b] = sum over the waves
+        sync();
+        if (t < 256) {
+            int c = 0;
+            for (int ww = 0; ww < NWV; ++ww) c += hist[ww][t];
+            hist[0][t] = c;
+        }
+        sync();
+    };
     // pass 1: histogram of the high byte (+ the maximum)
-    for (int i = t; i < 256; i += SAMPLE_THREADS) hist[i] = 0;
-    sync();
-    for (int i = t; i < V; i += SAMPLE_THREADS) {
+    clear();
+    for (int c = t; c < nch; c += SAMPLE_THREADS) {
+        const u32x4 v = ld16(logits + (long long)c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bf16_t b = bf16_t(e & 1 ? v[e >> 1] >> 16 : v[e >> 1] & 0xffffu);
+            mx = fmaxf(mx, bf2f(b));
+            if (!all) atomic_add(&hist[w][bf16_order_key(b) >> 8], 1);
+        }
+    }
+    for (int i = nch * 8 + t; i < V; i += SAMPLE_THREADS) {
         const bf16_t b = logits[i];
         mx = fmaxf(mx, bf2f(b));
-        if (!all) atomic_add(&hist[bf16_order_key(b) >> 8], 1);
+        if (!all) atomic_add(&hist[w][bf16_order_key(b) >> 8], 1);
     }
     mx = wave_max(mx);
     if (l == 0) red_v[w] = mx;
-    sync();
+    fold();
     if (t == 0) {
         float m = red_v[0];
-        for (int i = 1; i < SAMPLE_THREADS / 64; ++i) m = fmaxf(m, red_v[i]);
+        for (int i = 1; i < NWV; ++i) m = fmaxf(m, red_v[i]);
         red_v[0] = m;
         int above = 0, b1 = 0;
         if (!all) {
             for (b1 = 255; b1 > 0; --b1) {
-                if (above + hist[b1] >= k) break;
-                above += hist[b1];
+                if (above + hist[0][b1] >= k) break;
+                above += hist[0][b1];
             }
         }
         sel[0] = b1;
@@ -662,17 +686,24 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_topk_kernel(const bf16_
     sync();
     // pass 2: histogram of the low byte inside the boundary bin -> the exact 16-bit threshold
     if (!all) {
-        for (int i = t; i < 256; i += SAMPLE_THREADS) hist[i] = 0;
-        sync();
-        for (int i = t; i < V; i += SAMPLE_THREADS) {
-            const uint32_t key = bf16_order_key(logits[i]);
-            if (int(key >> 8) == b1) atomic_add(&hist[key & 255u], 1);
+        clear();
+        for (int c = t; c < nch; c += SAMPLE_THREADS) {
+            const u32x4 v = ld16(logits + (long long)c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t key = bf16_order_key(bf16_t(e & 1 ? v[e >> 1] >> 16 : v[e >> 1] & 0xffffu));
+                if (int(key >> 8) == b1) atomic_add(&hist[w][key & 255u], 1);
+            }
         }
-        sync();
+        for (int i = nch * 8 + t; i < V; i += SAMPLE_THREADS) {
+            const uint32_t key = bf16_order_key(logits[i]);
+            if (int(key >> 8) == b1) atomic_add(&hist[w][key & 255u], 1);
+        }
+        fold();
         if (t == 0) {
             int cum = 0, b2 = 255;
             for (; b2 > 0; --b2) {
-                cum += hist[b2];
+                cum += hist[0][b2];
                 if (cum >= want) break;
             }
             sel[2] = (b1 << 8) | b2;
@@ -680,19 +711,24 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_topk_kernel(const bf16_
         sync();
     }
     const uint32_t thr = all ? 0u : uint32_t(sel[2]);
-    // pass 3: arg-max of p_i / q_i over the kept logits (first index wins ties, like torch.argmax on this path)
+    // pass 3: arg-max of p_i / q_i over the kept logits (the lowest index wins ties)
     float best = -1.f;
     int besti = 0x7fffffff;
-    for (int i = t; i < V; i += SAMPLE_THREADS) {
-        const bf16_t b = logits[i];
+    auto consider = [&](bf16_t b, int i) {
         if (bf16_order_key(b) >= thr) {
             const float s = expf((bf2f(b) - mx) * inv_temp) / q[i];
-            if (s > best) {  // (strictly greater: indices come in increasing order within a thread)
+            if (s > best || (s == best && i < besti)) {
                 best = s;
                 besti = i;
             }
         }
+    };
+    for (int c = t; c < nch; c += SAMPLE_THREADS) {
+        const u32x4 v = ld16(logits + (long long)c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) consider(bf16_t(e & 1 ? v[e >> 1] >> 16 : v[e >> 1] & 0xffffu), c * 8 + e);
     }
+    for (int i = nch * 8 + t; i < V; i += SAMPLE_THREADS) consider(logits[i], i);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const float ov = shfl_xor(best, d);
@@ -708,7 +744,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_topk_kernel(const bf16_
     }
     sync();
     if (t == 0) {
-        for (int i = 1; i < SAMPLE_THREADS / 64; ++i)
+        for (int i = 1; i < NWV; ++i)
             if (red_v[i] > best || (red_v[i] == best && red_i[i] < besti)) {
                 best = red_v[i];
                 besti = red_i[i];
@@ -945,6 +981,7 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
 int aria_sample_topk(const void* logits, const float* q, int64_t V, int64_t top_k, float temperature, int32_t* out, void* stream) {
     if (!logits || !q || !out || V <= 0) return ARIA_ERR_INVALID;
     if (V >= (1ll << 31)) return ARIA_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(logits) & 15) return ARIA_ERR_ALIGN;  // 16-byte loads
     const float t = temperature > 1e-5f ? temperature : 1e-5f;  // (gptfast/generate.py:47: max(temperature, 1e-5))
     const int k = (top_k <= 0 || top_k >= V) ? int(V) : int(top_k);
     ARIA_LAUNCH(sample_topk_kernel, dim3(1), dim3(SAMPLE_THREADS), 0, stream, static_cast<const bf16_t*>(logits), q, int(V), k, 1.0f / t, out);
