@@ -464,11 +464,13 @@ struct DecodeAttn {
         const long long col = (long long)head * HD + sub * 8;
         const u32x4 f = ld16(fc + (long long)ps * HD + sub * 8);
         const u32x4 qr = rope(ld16(qkv + col), f);
-        if (writes_new && w == 0 && grp == 0) {  // this head's slice of the new key / value goes into the cache first; it is read back below
-            st16(k_cache + (long long)ps * D + col, rope(ld16(qkv + D + col), f));
-            st16(v_cache + (long long)ps * D + col, ld16(qkv + 2 * D + col));
+        // the new token's rotated key / value slice, in EVERY lane group: the pass that covers position ps takes it from these registers, so
+        // nobody waits for the cache write below to become visible (it was: store, barrier, read back -- ~2 us in front of the first K / V load)
+        const u32x4 knew = rope(ld16(qkv + D + col), f), vnew = ld16(qkv + 2 * D + col);
+        if (writes_new && w == 0 && grp == 0) {
+            st16(k_cache + (long long)ps * D + col, knew);
+            st16(v_cache + (long long)ps * D + col, vnew);
         }
-        sync();
         const float scale2 = scale * 1.4426950408889634f;
         m = -INFINITY, lsum = 0.f;
 #pragma unroll
@@ -485,6 +487,10 @@ struct DecodeAttn {
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                if (key[u] == ps) {  // (the row being written by this very workgroup)
+                    kx[u] = knew;
+                    vx[u] = vnew;
+                }
                 float sc = 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sc = dot2bf(kx[u][q], qr[q], sc);
