@@ -9,8 +9,14 @@
 //   * RMSNorm is folded into the consumer GEMV (each wave re-normalises the 2560-vector it needs anyway, with the same lane <-> chunk
 //     mapping and reduction order as rmsnorm_fwd_kernel: identical rstd), residual adds into the GEMV epilogue, SwiGLU into the
 //     up-projection pair, RoPE + KV-cache write into one kernel, the six routed experts are indexed on the device (no gather of weights);
-//   * ONE C call walks all layers and enqueues 7 launches per layer back to back (no Python, no allocation, no host sync): the
-//     position lives on the device, so the same enqueue sequence is valid for every token.
+//   * ONE C call walks all layers and enqueues 6 launches per layer back to back (no Python, no allocation, no host sync): the
+//     position lives on the device, so the same enqueue sequence is valid for every token.  Per layer: qkv | attention (RoPE + cache
+//     write inside) | wo + residual | router logits + shared up-projection | routed up-projection (top-k inside) | every
+//     down-projection + combine + residual;
+//   * what a kernel does in front of its first weight byte is kept short: rows are requested before the activation vector is fetched and
+//     normalised, and the wave reductions on the way (routing maximum, per-key score, row sums) run on DPP instead of LDS round trips --
+//     at ~6 TB/s of streaming a layer's 258 MB take 43 us, and every microsecond of fixed cost per kernel is 2 % of that;
+//   * sampling (gptfast/generate.py:35-58) is one launch as well (aria_sample_topk).
 // Rounding points mirror the tile path (GEMM outputs, norm, SwiGLU, residual adds are each rounded to bf16 where the reference
 // materialises a bf16 tensor); only the fp32 summation ORDER inside a dot product differs from the MFMA kernels.
 #include "aria_device.h"

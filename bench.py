@@ -9,7 +9,7 @@ per-GPU shape (per_device_train_batch_size 8 x max_seq_length 2048, recipes/conf
 Aria-25.3B MoE decoder (28 layers, 64 experts top-6, vocab 100352, random-init bf16 weights N(0,0.02)), shifted masked
 cross-entropy, full backward incl. router aux-loss gradients; data-parallel gradient all-reduce overlapped with backward
 when N > 1 (weak scaling: per-GPU work fixed).  Inputs are resident in HBM before the timed region.
-Prints ONE JSON line (rank 0) with the driver's contract fields + `roofline` (dominant kernel: the fc1 grouped expert GEMM (gemm2.hip),
+Prints ONE JSON line (rank 0) with the driver's contract fields + `roofline` (dominant kernel: the fc1 grouped expert GEMM with its SwiGLU epilogue, gemm3.hip,
 timed live with HIP events on the launch stream) + `cpu_baseline` (the CPU oracle timed on the host cores, N=1 only).
 """
 from __future__ import annotations
