@@ -181,7 +181,7 @@ def test_gemm_swiglu_split(force_gemm_v3, counts, K, I, T):
     C.case_gemm_swiglu_split(DEV, counts, K, I, T)
 
 
-@pytest.mark.parametrize("counts,K,I,T", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300), ([130, 520], 192, 384, 72)])
+@pytest.mark.parametrize("counts,K,I,T", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300), ([130, 520], 192, 384, 72), ([0, 0, 257], 64, 256, 1)])
 def test_gemm_dswiglu_fused(force_gemm_v3, counts, K, I, T):
     C.case_gemm_dswiglu_fused(DEV, counts, K, I, T)
 
@@ -191,7 +191,26 @@ def test_sample_topk_matches_the_tensor_path(V, top_k, temperature):
     C.case_sample_topk(DEV, V, top_k, temperature)
 
 
-@pytest.mark.parametrize("E,k", [(64, 6), (8, 3), (200, 8), (256, 2)])
+def test_sample_topk_degenerate_rows():
+    """Every logit equal (the whole vocabulary ties at the threshold: all kept, the draw decides), masked (-inf) entries (never chosen),
+    and a vocabulary smaller than one 16-byte chunk."""
+    from aria_amd import gptfast as G
+    from aria_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    for V, fill in ((1000, "const"), (1000, "masked"), (5, "rand")):
+        logits = {"const": torch.full((V,), 0.75), "masked": torch.randn(V, generator=g), "rand": torch.randn(V, generator=g)}[fill].to(torch.bfloat16)
+        if fill == "masked":
+            logits[::2] = -float("inf")
+        for _ in range(4):
+            q = torch.empty(V).exponential_(1, generator=g)
+            want = int(torch.argmax(G.logits_to_probs(logits, 0.8, 50) / q))
+            got = int(ops.sample_topk(logits.clone(), q, 0.8, 50))
+            assert got == want, (fill, got, want)
+            assert fill != "masked" or got % 2 == 1
+
+
+@pytest.mark.parametrize("E,k", [(64, 6), (8, 3), (200, 8), (256, 2), (64, 1)])
 def test_decode_route_matches_the_batched_router(E, k):
     C.case_decode_route(DEV, E, k)
 
