@@ -39,3 +39,20 @@ def test_dispatch_any_shape(T, E, k, D8):
        K8=st.integers(1, 12), N8=st.integers(1, 20))
 def test_grouped_gemm_any_counts(counts, K8, N8):
     C.case_grouped_gemm(DEV, counts, K=8 * K8, N=8 * N8)
+
+
+@settings(max_examples=10, **COMMON)
+@given(counts=st.lists(st.one_of(st.just(0), st.integers(1, 70), st.integers(120, 520)), min_size=1, max_size=6).filter(lambda c: sum(c) > 0),
+       K64=st.integers(1, 3), I128=st.integers(1, 3), T=st.integers(1, 300))
+def test_fused_glu_launches_any_counts(counts, K64, I128, T, monkeypatch):
+    """round 3: the SwiGLU-backward epilogue (gemm3_kernel<.., .., 5>) and the split gate / up launch (<false, false, 6>) on ragged / empty
+    experts, partial column tiles and single-row dense problems: equal to their two-step chains bit for bit."""
+    monkeypatch.setenv("ARIA_GEMM_FORCE", "3")
+    C.case_gemm_dswiglu_fused(DEV, counts, 64 * K64, 128 * I128, T)
+    C.case_gemm_swiglu_split(DEV, counts, 64 * K64, 128 * I128, T)
+
+
+@settings(max_examples=12, **COMMON)
+@given(V=st.integers(1, 3000), kfrac=st.floats(0.0, 1.2), temp=st.sampled_from([1e-6, 0.5, 0.8, 1.0, 2.0]), seed=st.integers(0, 5))
+def test_sample_topk_any_vocabulary(V, kfrac, temp, seed):
+    C.case_sample_topk(DEV, V, max(1, int(kfrac * V)) if kfrac <= 1.0 else None, temp, seed)
