@@ -182,6 +182,41 @@ class AttnBlockFn(torch.autograd.Function):
 
 _LAYER_KEYS = ("ln1", "wq", "wk", "wv", "wo", "ln2", "router", "fc1", "fc2", "gate", "up", "down")
 
+RECOMPUTE_LEVELS = ("moe", "layer")
+
+
+def recompute_kept_bytes(level: str, tokens: int, hidden: int, shared_inter: int, n_layers: int) -> int:
+    """What ``DecoderLayerFn`` keeps between forward and backward over the whole stack, bf16: "moe" = every token-sized tensor of a layer
+    (x, normed x, q|k|v, o, h, normed h, the shared expert's gate|up and activation, router logits and routing metadata: ~(8 D + 3 Is) values
+    per token = 61 KB at Aria's width, 4.1 GB per layer at 64K tokens); "layer" = the layer input and the flash kernel's (o, lse)."""
+    per_token = (8 * hidden + 3 * shared_inter + 256) * 2 if level == "moe" else (2 * hidden + 64) * 2
+    return int(tokens) * per_token * int(n_layers)
+
+
+def choose_recompute_level(tokens: int, hidden: int, shared_inter: int, expert_rows_per_token: int, expert_inter: int, n_layers: int,
+                           pending_grad_bytes: int = 0, device=None, requested: str = "auto") -> str:
+    """The recompute level of the recipe's ``gradient_checkpointing`` (level "moe" keeps ~115 GB at 64K tokens x 28 layers -- fine
+    next to weights and gradients on 288 GB, not next to everything a long-sequence fine-tune may hold).  ``ARIA_RECOMPUTE_LEVEL`` or the
+    config's ``recompute_level`` ("moe" / "layer") force a level; "auto" takes "moe" when what it keeps, plus the gradients still to be
+    allocated, plus one layer's complete backward state and the loss buffers, fits in 85 % of the memory that is free NOW on the device,
+    and the reference's own form ("layer": layer inputs only, recipes/config_full.yaml:17) otherwise.  Without a GPU (emulator): "moe"."""
+    level = os.environ.get("ARIA_RECOMPUTE_LEVEL") or requested or "auto"
+    if level in RECOMPUTE_LEVELS:
+        return level
+    if level != "auto":
+        raise ValueError(f"recompute level {level!r}: expected one of {RECOMPUTE_LEVELS + ('auto',)}")
+    if device is None or torch.device(device).type != "cuda" or not torch.cuda.is_available():
+        return "moe"
+    free, _total = torch.cuda.mem_get_info(device)
+    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)     # the caching allocator's idle blocks are ours too
+    keep = recompute_kept_bytes("moe", tokens, hidden, shared_inter, n_layers)
+    # one layer's full backward state (the kept part + the four expert-row tensors + as much again for the gradients flowing through it)
+    # and lm_head logits / dlogits rows for a quarter of the positions at a 100K vocabulary
+    one_layer = 2 * (keep // max(n_layers, 1) + tokens * expert_rows_per_token * (2 * hidden + 3 * expert_inter) * 2)
+    loss = tokens // 4 * 100352 * 2 * 2
+    return "moe" if keep + pending_grad_bytes + one_layer + loss <= 0.85 * free else "layer"
+
+
 
 class DecoderLayerFn(torch.autograd.Function):
     """One MoEDecoderLayer (moe_lm.py:580-602) as a single autograd node with a hand-written backward.
@@ -189,13 +224,16 @@ class DecoderLayerFn(torch.autograd.Function):
     layer's backward needs, 24 KB are the four expert-row tensors of the MoE block (perm, fc1 output, its activation, fc2 output: 6 rows
     per token each); the default level ("moe") keeps everything else and rebuilds those four in the backward -- a row gather and the two
     routed-expert GEMMs, 60 % of the layer's forward GEMM flops, none of its attention.  At 64K tokens that is 4.1 GB per layer kept
-    instead of 12 (115 GB for 28 layers next to 101 GB of weights and gradients).  ARIA_RECOMPUTE_LEVEL=layer: keep only the layer
-    input and the flash kernel's (o, lse) and run the whole layer again (round 2's form: 1.0 GB per layer at 64K)."""
+    instead of 12 (115 GB for 28 layers next to 101 GB of weights and gradients).  Level "layer": keep only the layer input and the flash
+    kernel's (o, lse) and run the whole layer again (round 2's form, the reference recipe's: 1.0 GB per layer at 64K).  The model picks the
+    level once per forward from the memory that is free (``choose_recompute_level``); ARIA_RECOMPUTE_LEVEL / config.recompute_level force it."""
 
     @staticmethod
     def forward(ctx, x, cos, sin, B, S, acfg, mcfg, eps, kv_len, recompute, *params):
         p = dict(zip(_LAYER_KEYS, params))
-        level = os.environ.get("ARIA_RECOMPUTE_LEVEL", "moe") if recompute else None
+        # recompute: False / None, True (= "moe", or what ARIA_RECOMPUTE_LEVEL says) or the level itself (the model picks it once per forward)
+        level = (recompute if recompute in RECOMPUTE_LEVELS else os.environ.get("ARIA_RECOMPUTE_LEVEL", "moe")) if recompute else None
+        recompute = bool(recompute)
         if level == "moe":  # keep the layer's token-sized tensors, rebuild the four expert-row tensors (perm, h1, act, eo) in the backward
             out, c = Fn.decoder_layer_fwd(x, p, cos, sin, B, S, acfg, mcfg, eps, kv_len, save="lean")
         else:               # "layer": keep only the flash kernel's (o, lse), run the whole layer again

@@ -86,9 +86,17 @@ def adjacent_pair(p1: nn.Parameter, p2: nn.Parameter) -> bool:
 def _glu_pair_ready(w_gate: nn.Parameter, w_up: nn.Parameter) -> bool:
     """True when the fused gate / up launch can take the pair (re-homing it once if only the layout is in the way)."""
     I, K = w_gate.shape[-2], w_gate.shape[-1]
-    if I % 128 or K % 64 or K < 64 or not ops.swiglu_fusion_enabled():
+    if I % 128 or K % 64 or K < 64 or not ops.swiglu_fusion_enabled() or getattr(w_gate, "_glu_pair_rejected", False):
         return False
-    return ops.glu_split_fusable(w_gate, w_up) or (adjacent_pair(w_gate, w_up) and ops.glu_split_fusable(w_gate, w_up))
+    if ops.glu_split_fusable(w_gate, w_up):
+        return True
+    # re-home the pair only when the adjacent layout WOULD be taken (the kernel's size limits first: a rejected pair must not cost a 2 x
+    # tensor-size copy on every forward -- ADVICE r3) and remember a rejection on the parameter
+    if (w_gate.shape == w_up.shape and ops.glu_split_offset_ok(2 * w_gate.numel(), I, K, w_gate.numel()) and adjacent_pair(w_gate, w_up)
+            and ops.glu_split_fusable(w_gate, w_up)):
+        return True
+    w_gate._glu_pair_rejected = True
+    return False
 
 
 class RMSNorm(nn.Module):
@@ -237,7 +245,14 @@ class Transformer(nn.Module):
     def setup_caches(self, max_batch_size, max_seq_length, training: bool = False, **_):
         """gptfast/model.py:113-166 (no S x S mask is ever built: the attention kernel masks in-register)."""
         dev = self.output.weight.device
-        self.max_batch_size, self.max_seq_length = max_batch_size, (max_seq_length + 7) // 8 * 8
+        rounded = (max_seq_length + 7) // 8 * 8
+        c0 = self.layers[0].attention.kv_cache
+        if (not training and c0 is not None and (self.max_batch_size, self.max_seq_length) == (max_batch_size, rounded)
+                and c0.k.device == dev and self.freqs_cis is not None and self.freqs_cis.device == dev):
+            return   # same geometry: the buffers are re-used as they are (positions beyond the cursor are never read; gptfast/model.py:67-93
+            #          overwrites rows in place as well) and the decode engine's pointer table stays valid
+        self.max_batch_size, self.max_seq_length = max_batch_size, rounded
+        self._engine = None   # it holds raw addresses of the tensors replaced below
         for b in self.layers:
             b.attention.kv_cache = None if training else KVCache(max_batch_size, self.max_seq_length, self.config.n_head,
                                                                  b.attention.hdp, dev)
@@ -303,12 +318,7 @@ class DecodeEngine:
         self.x_in = torch.zeros(c.dim, dtype=bf16, device=dev)
         self.logits = torch.zeros(c.vocab_size, dtype=bf16, device=dev)
         self.eps = float(c.norm_eps)
-        tensors = [model.freqs_cis, model.norm.weight, model.output.weight, self.scratch, self.pos, self.x_in, self.logits, self.pos]
-        for blk in model.layers:
-            a, f = blk.attention, blk.feed_forward
-            tensors += [blk.attention_norm.weight, a.wqkv.weight, a.wo.weight, blk.ffn_norm.weight, f.gate.weight, f.cond_ffn.w1,
-                        f.cond_ffn.w3, f.cond_ffn.w2, f.shared_ffn.w1.weight, f.shared_ffn.w3.weight, f.shared_ffn.w2.weight,
-                        a.kv_cache.k, a.kv_cache.v]
+        tensors = self._table(model)
         for t in tensors:
             assert t.is_contiguous() and t.device == dev
         self._keep = tensors  # the table holds raw addresses: keep the tensors alive and detect re-allocation
@@ -324,8 +334,23 @@ class DecodeEngine:
         except Exception:
             pass
 
+    def _table(self, model: "Transformer"):
+        """The pointer table of aria_decode_token, read from the MODEL's current tensors (weights, freqs_cis, KV cache) + the engine's own."""
+        tensors = [model.freqs_cis, model.norm.weight, model.output.weight, self.scratch, self.pos, self.x_in, self.logits, self.pos]
+        for blk in model.layers:
+            a, f = blk.attention, blk.feed_forward
+            tensors += [blk.attention_norm.weight, a.wqkv.weight, a.wo.weight, blk.ffn_norm.weight, f.gate.weight, f.cond_ffn.w1,
+                        f.cond_ffn.w3, f.cond_ffn.w2, f.shared_ffn.w1.weight, f.shared_ffn.w3.weight, f.shared_ffn.w2.weight,
+                        a.kv_cache.k, a.kv_cache.v]
+        return tensors
+
     def valid_for(self, model: "Transformer") -> bool:
-        return all(t.data_ptr() == a for t, a in zip(self._keep, self._addr)) and int(self.dims[9]) == model.max_seq_length
+        """The recorded addresses against what the model holds NOW: ``setup_caches`` allocates new K/V tensors and a fresh ``freqs_cis``,
+        ``module.to`` / ``load_state_dict(assign=True)`` re-home weights -- the engine's own references stay alive and would never differ from themselves
+        (a second cached generate() kept attending over the previous call's cache)."""
+        if int(self.dims[9]) != model.max_seq_length or model.layers[0].attention.kv_cache is None:
+            return False
+        return [t.data_ptr() for t in self._table(model)] == self._addr
 
     def step(self, x_embed: torch.Tensor, input_pos: torch.Tensor) -> torch.Tensor:
         """x_embed [1,1,D] (embedding of the new token), input_pos: device tensor with the cursor -> logits [1,1,V] (a view of the

@@ -33,7 +33,7 @@ class AriaMoELMConfig:
                  hidden_size: int = 2560, num_hidden_layers: int = 28, num_attention_heads: int = 20,
                  num_key_value_heads: Optional[int] = None, vocab_size: int = 100352, rms_norm_eps: float = 1e-6,
                  rope_theta: float = 5_000_000.0, max_position_embeddings: int = 65536, pad_token_id: Optional[int] = None,
-                 gradient_checkpointing: bool = False, **kwargs):
+                 gradient_checkpointing: bool = False, recompute_level: str = "auto", **kwargs):
         self.moe_intermediate_size = moe_intermediate_size
         self.moe_num_experts = moe_num_experts
         self.moe_topk = moe_topk
@@ -50,6 +50,7 @@ class AriaMoELMConfig:
         self.max_position_embeddings = max_position_embeddings
         self.pad_token_id = pad_token_id
         self.gradient_checkpointing = gradient_checkpointing
+        self.recompute_level = recompute_level   # "auto" (by free memory) / "moe" / "layer": autograd.choose_recompute_level
         self.extra = kwargs
 
     @property
@@ -331,7 +332,7 @@ class MoEDecoderLayer(nn.Module):
                 m.shared_experts.gate_proj.weight, m.shared_experts.up_proj.weight, m.shared_experts.down_proj.weight)
 
     def forward(self, hidden_states: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
-                kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+                kv_len: Optional[torch.Tensor] = None, recompute_level: Optional[str] = None) -> torch.Tensor:
         B, S, D = hidden_states.shape
         a = self.self_attn
         if self.mlp.ep_enabled or self.mlp.has_adapter() or not _plain_linears(a.q_proj, a.k_proj, a.v_proj, a.o_proj):
@@ -351,6 +352,8 @@ class MoEDecoderLayer(nn.Module):
         x = hidden_states.reshape(B * S, D)
         x = x if x.is_contiguous() else x.contiguous()
         recompute = bool(self.config.gradient_checkpointing and self.training and torch.is_grad_enabled())
+        if recompute and recompute_level in AG.RECOMPUTE_LEVELS:
+            recompute = recompute_level
         out = AG.DecoderLayerFn.apply(x, cos, sin, B, S, self.self_attn.attn_config(), self.mlp.moe_config(),
                                       self.config.rms_norm_eps, kv_len, recompute, *self.layer_params())
         return out.view(B, S, D)
@@ -400,9 +403,23 @@ class AriaMoELMModel(nn.Module):
         B, S, _ = h.shape
         cos, sin = self.rope(S, h.device)
         kv_len = self.kv_len_from_mask(attention_mask)
+        level = self.recompute_level_for(B * S, h.device)
         for layer in self.layers:
-            h = layer(h, cos, sin, kv_len)
+            h = layer(h, cos, sin, kv_len, level)
         return self.norm(h)
+
+    def recompute_level_for(self, tokens: int, device) -> Optional[str]:
+        """The level of the recipe's gradient checkpointing for THIS forward (None: off), decided once for all layers from the memory that is
+        free now and the gradients that are still to be allocated; recorded in ``last_recompute_level`` (bench.py / train.py report it)."""
+        c = self.config
+        if not (c.gradient_checkpointing and self.training and torch.is_grad_enabled()):
+            self.last_recompute_level = None
+            return None
+        pending = sum(p.numel() * p.element_size() for p in self.parameters() if p.requires_grad and p.grad is None)
+        self.last_recompute_level = AG.choose_recompute_level(
+            tokens, c.hidden_size, c.moe_intermediate_size * c.moe_num_shared_experts, c.moe_topk, c.moe_intermediate_size, len(self.layers),
+            pending_grad_bytes=pending, device=device, requested=getattr(c, "recompute_level", "auto"))
+        return self.last_recompute_level
 
 
 class AriaMoELMForCausalLM(nn.Module):

@@ -165,10 +165,17 @@ def glu_split_fusable(w_gate: torch.Tensor, w_up: torch.Tensor) -> bool:
     if not swiglu_fusion_enabled() or w_gate.shape != w_up.shape or not (w_gate.is_contiguous() and w_up.is_contiguous()):
         return False
     I, K = w_gate.shape[-2], w_gate.shape[-1]
-    diff = w_up.data_ptr() - w_gate.data_ptr()
     same_storage = w_gate.untyped_storage().data_ptr() == w_up.untyped_storage().data_ptr()
-    return bool(same_storage and I % 128 == 0 and K % 64 == 0 and K >= 64 and diff >= 2 * K * w_gate.numel() // K and diff % (2 * K) == 0
-                and diff + 2 * (I + 128) * K < (1 << 32))
+    return bool(same_storage and glu_split_offset_ok(w_up.data_ptr() - w_gate.data_ptr(), I, K, w_gate.numel()))
+
+
+def glu_split_offset_ok(diff_bytes: int, I: int, K: int, numel: int) -> bool:
+    """The limits of csrc/gemm.hip ``glu_split_rows`` on the byte distance between the gate and the up tensor, mirrored exactly (per-lane DMA
+    offsets are 32-bit, the row index goes through a 24-bit multiply) + a margin of one 128-row tile on the byte limit."""
+    if I % 128 or K % 64 or K < 64 or diff_bytes < 2 * numel or diff_bytes % (2 * K):
+        return False
+    rows = diff_bytes // (2 * K)
+    return rows >= I and rows + I < (1 << 24) and (rows + I + 128) * 2 * K < (1 << 32)
 
 
 def grouped_gemm_swiglu_split(a: torch.Tensor, w_gate: torch.Tensor, w_up: torch.Tensor, offsets: torch.Tensor, want_h: bool = False):
@@ -220,7 +227,9 @@ def decode_route(logits: torch.Tensor, k: int):
 
 def dglu_fusable(I: int, K: int) -> bool:
     """Shapes the fused input-gradient + SwiGLU-backward launches take (128-column blocks of I are all-or-nothing, the v3 K loop wants
-    K % 64 == 0; ARIA_FUSE_DSWIGLU=0 switches the fusion off: the two-step chain, bit-identical)."""
+    K % 64 == 0; ARIA_FUSE_DSWIGLU=0 switches the fusion off: the two-step chain -- bit-identical for the grouped launches and for dense
+    ones whose two-step GEMM does not select split-K; where it does (a partly filled last round with a workspace) the two agree to the GEMM
+    tolerance only, last assertion of ``tests/kernel_cases.py::case_gemm_dswiglu_fused``)."""
     import os
 
     return os.environ.get("ARIA_FUSE_DSWIGLU", "1") != "0" and I % 128 == 0 and K >= 64 and K % 64 == 0

@@ -54,6 +54,12 @@ def parse():
                     "target shape -- one 65 536-token image+text sequence, gradient checkpointing on -- after the main measurement)")
     ap.add_argument("--long64k-seq", type=int, default=65536, help="debug only (CPU dry run of the sub-record's code path)")
     ap.add_argument("--long64k-images", type=int, default=8, help="debug only")
+    ap.add_argument("--no-inference-records", action="store_true", help="skip the `generate_config2` / `prefill_config4` sub-records (N = 1 only: "
+                    "BASELINE configs #2 and #4 on the gptfast surface of the SAME weights, after the training measurement)")
+    ap.add_argument("--gen-new", type=int, default=200, help="debug only (config #2 protocol: 200 new tokens)")
+    ap.add_argument("--gen-image", type=int, default=1, help="debug only (config #2: one 980px image)")
+    ap.add_argument("--prefill-seq", type=int, default=53248, help="debug only (config #4: 32 x 128 frame tokens + 49 152 text tokens)")
+    ap.add_argument("--prefill-frames", type=int, default=32, help="debug only (config #4: 32 frames at 490px)")
     ap.add_argument("--ep", action="store_true", help="BASELINE config #5 instead of #3: routed experts sharded over the N ranks (all-to-all "
                                                       "dispatch over xGMI), everything else data-parallel; not what the driver runs")
     args = ap.parse_args()
@@ -197,13 +203,111 @@ def long64k_record(model, cfg, make_inputs, ops, steps=3, warmup=1, S=65536, n_i
     avg = sum(durs) / max(1, len(durs))
     flops = 2.5 * 4.0 * (S * S / 2.0) * hd * H
     return {"workload": f"north_star target shape: Aria-25.3B random-init, ONE {S}-token sequence ({n_img} x 980px images + text), frozen ViT fwd -> "
-                        "projector -> 28-layer MoE decoder fwd+bwd, gradient checkpointing on (selective: flash (o, lse) kept)",
+                        "projector -> 28-layer MoE decoder fwd+bwd, gradient checkpointing on (level in `recompute_level`: 'moe' keeps a layer's "
+                        "token-sized tensors and rebuilds the expert-row tensors, 'layer' keeps layer inputs + flash (o, lse))",
+            "recompute_level": getattr(model.language_model.model, "last_recompute_level", None),
             "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 1), "value": round(S * steps / dt, 1), "unit": "tokens/s",
             "loss": round(float(loss), 4), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
             "roofline": {"kernel": f"attention backward (aria_attn_bwd: delta + dK/dV/dQ), causal S={S}, {H} x {hd}", "bound": "mfma",
                          "achieved": round(flops / avg / 1e12, 1) if durs else None, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(flops / avg / 2.5e15, 4) if durs else None, "launches_timed": len(durs),
                          "avg_call_ms": round(avg * 1e3, 3), "algorithmic_flops_per_call": flops}}
+
+
+def decode_weight_bytes(t) -> int:
+    """Bytes of bf16 weights one decoded token streams (7.716 GB at Aria's shape): per layer the k routed experts' three
+    matrices, the shared expert, the router and the four attention projections; + lm_head."""
+    D, I, Is = t.hidden_size, t.moe_intermediate_size, t.moe_intermediate_size * t.moe_num_shared_experts
+    per_layer = t.moe_topk * 3 * D * I + 3 * D * Is + t.moe_num_experts * D + 4 * D * D
+    return (t.num_hidden_layers * per_layer + t.vocab_size * D) * 2
+
+
+def generate_config2_record(twin, tcfg, new_tokens=200, runs=5, warmup=2, n_img=1, img_px=980, qtok=256, img_token=9):
+    """BASELINE config #2 by the reference's protocol (gptfast/benchmark.py:10-48): one 980px image (256 image tokens) + a short prompt =
+    280 positions, max_new_tokens 200, top-k 200, temperature 0.8, 2 warm-up + 5 timed whole generates (ViT + prefill + decode + sampling),
+    tok/s = mean(#new tokens) / mean(latency); then 50 decode steps alone for the per-token figure its HBM roofline is quoted on."""
+    from aria_amd import gptfast as G
+
+    dev = twin.llm.output.weight.device
+    g = torch.Generator(device="cuda").manual_seed(2)
+    T = 24 + n_img * qtok
+    ids = torch.randint(10, tcfg.vocab_size, (1, T), generator=g, device=dev)
+    pv = pm = None
+    if n_img:
+        ids[:, 8:8 + n_img * qtok] = img_token
+        pv = torch.randn((n_img, 3, img_px, img_px), generator=g, device=dev).clamp_(-1, 1).to(bf16)
+        pm = torch.ones((n_img, img_px, img_px), dtype=torch.bool, device=dev)
+    twin.setup_caches(1, T + new_tokens)
+    decoder, lat, ntok = None, [], []
+    with torch.no_grad():
+        for i in range(warmup + runs):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out, decoder = G.generate(twin, ids, new_tokens, pixel_values=pv, pixel_mask=pm, temperature=0.8, top_k=200, decoder=decoder)
+            torch.cuda.synchronize()
+            if i >= warmup:
+                lat.append(time.perf_counter() - t0)
+                ntok.append(out.numel() - ids.numel())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        emb = twin.prepare_embeddings(ids, pv, pm)
+        twin(None, torch.arange(T, device=dev), emb, last_only=True)
+        torch.cuda.synchronize()
+        t_prefill = time.perf_counter() - t0
+        pos = torch.tensor([T], device=dev, dtype=torch.int32)
+        tok = torch.tensor([[11]], device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            decoder(tok, pos)
+        torch.cuda.synchronize()
+        t_dec = (time.perf_counter() - t0) / 50
+    wbytes = decode_weight_bytes(tcfg)
+    return {"workload": f"config#2 (gptfast/benchmark.py protocol): {n_img} x {img_px}px image + prompt = {T} positions, {new_tokens} new tokens, top-k 200, "
+                        f"T 0.8, {warmup} warm-up + {runs} timed whole generates (ViT + prefill + decode + sampling); same random-init weights",
+            "value": round(sum(ntok) / sum(lat), 2), "unit": "tokens/s", "runs": runs, "warmup": warmup, "new_tokens": new_tokens,
+            "mean_latency_s": round(sum(lat) / len(lat), 4), "published_h100": {"eager": 25.2, "compile": 130.0},
+            "prefill_ms_incl_vit": round(t_prefill * 1e3, 2), "decode_ms_per_token": round(t_dec * 1e3, 3),
+            "decode_engine": bool(twin.llm._engine is not None),
+            "roofline": {"kernel": "decode step incl. sampling (aria_decode_token + aria_sample_topk)", "bound": "hbm",
+                         "achieved": round(wbytes / t_dec / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(wbytes / t_dec / 8e12, 4),
+                         "algorithmic_bytes_per_token": wbytes, "traffic": None}}
+
+
+def prefill_config4_record(twin, tcfg, S=53248, frames=32, runs=2, img_px=490, qtok=128, img_token=9, vit_tf_per_frame=1.19e12):
+    """BASELINE config #4: ONE long-context prefill (32 frames at 490px = 4096 image tokens + 49 152 text tokens) through the gptfast
+    surface with a bf16 KV cache, last-position logits; 1 warm-up + `runs` timed.  Roofline: bf16 MFMA on the algorithmic flops
+    (7.716 GF/token of GEMMs, 28 * 4 * D * S/2 per token of causal attention, 1.19 TF per 490px frame of ViT)."""
+    dev = twin.llm.output.weight.device
+    g = torch.Generator(device="cuda").manual_seed(4)
+    ids = torch.randint(10, tcfg.vocab_size, (1, S), generator=g, device=dev)
+    pv = pm = None
+    if frames:
+        ids[:, 16:16 + qtok * frames] = img_token
+        pv = torch.randn((frames, 3, img_px, img_px), generator=g, device=dev).clamp_(-1, 1).to(bf16)
+        pm = torch.ones((frames, img_px, img_px), dtype=torch.bool, device=dev)
+    twin.setup_caches(1, S)
+    torch.cuda.reset_peak_memory_stats()
+    ts = []
+    with torch.no_grad():
+        for i in range(runs + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            emb = twin.prepare_embeddings(ids, pv, pm)
+            lg = twin(None, torch.arange(S, device=dev), emb, last_only=True)
+            torch.cuda.synchronize()
+            if i:
+                ts.append(time.perf_counter() - t0)
+    t = sum(ts) / len(ts)
+    D, L = tcfg.hidden_size, tcfg.num_hidden_layers
+    gemm_per_token = decode_weight_bytes(tcfg)          # 2 flops per weight of the token's path = bytes of bf16 weights
+    flops = S * gemm_per_token + L * 4.0 * D * (S / 2.0) * S + frames * vit_tf_per_frame
+    return {"workload": f"config#4: ONE {S}-position prefill ({frames} x {img_px}px frames = {frames * qtok} image tokens + text) on the gptfast surface, "
+                        f"bf16 KV cache, last-position logits; 1 warm-up + {runs} timed; same random-init weights",
+            "value": round(S / t, 1), "unit": "tokens/s", "seconds": round(t, 4), "runs": runs, "finite_logits": bool(torch.isfinite(lg.float()).all()),
+            "kv_cache_GB": round(L * 2 * S * D * 2 / 1e9, 1), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+            "roofline": {"kernel": "whole prefill (GEMMs + causal attention + ViT)", "bound": "mfma", "achieved": round(flops / t / 1e12, 1),
+                         "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / t / 2.5e15, 4), "algorithmic_flops": flops, "traffic": None}}
 
 
 def self_launch(args):
@@ -415,7 +519,8 @@ def main():
                                     "config#3 per-GPU shape (recipes/config_full.yaml): Aria-25.3B random-init, per GPU 8 samples x ") +
                                    f"({n_img} x 980px images + text) padded to S={S}; frozen 27-layer ViT fwd (4900 patches/img) -> "
                                    "trainable projector (256 tok/img) -> 28-layer MoE decoder (64 experts top-6, D=2560, V=100352) "
-                                   "fwd+bwd incl. lm_head+CE and router aux-loss grads",
+                                   "fwd+bwd incl. lm_head+CE and router aux-loss grads; recipe gradient checkpointing: " +
+                                   ("ON" if args.recompute else "OFF (288 GB holds every activation; the recipe-as-written number is `recipe_grad_checkpointing`)"),
                        "layers": args.layers, "vit_layers": args.vit_layers, "images_per_sample": n_img, "global_batch": world * B, "seq_len": S,
                        "parallelism": (f"dp{world}+ep{world}" if args.ep else f"dp{world}") if world > 1 else ("single+ep1" if args.ep else "single"),
                        "grad_exchange": None if world == 1 else ("all_reduce" if args.allreduce else "reduce_scatter (ZeRO-2)"), "grad_checkpointing": bool(args.recompute),
@@ -447,8 +552,10 @@ def main():
                 dtr = (time.perf_counter() - t0) / 3
                 cfg.gradient_checkpointing = False
                 res["recipe_grad_checkpointing"] = {"ms_per_step": round(dtr * 1e3, 1), "value": round(B * S / dtr, 1), "unit": "tokens/s", "steps": 3,
-                                                    "warmup": 1, "note": "config #3 step with recipes/config_full.yaml:17 gradient_checkpointing on "
-                                                                         "(per decoder layer, selective: the flash kernel's (o, lse) are kept)"}
+                                                    "warmup": 1, "recompute_level": getattr(model.language_model.model, "last_recompute_level", None),
+                                                    "note": "config #3 step with recipes/config_full.yaml:17 gradient_checkpointing on (per decoder layer; "
+                                                            "level 'moe': token-sized tensors kept, the four expert-row tensors rebuilt in the backward; "
+                                                            "level 'layer': layer inputs + the flash kernel's (o, lse) kept, the layer re-run)"}
             if world == 1 and not args.long and not args.no_long64k and (full_depth or args.long64k_seq != 65536):
                 res["long64k"] = long64k_record(model, cfg, make_inputs, ops, steps=3, warmup=1, S=args.long64k_seq, n_img=args.long64k_images)
                 if not full_depth or args.long64k_seq != 65536:
@@ -456,6 +563,29 @@ def main():
         except Exception as ex:  # noqa: BLE001
             res["sub_records_error"] = f"{type(ex).__name__}: {ex}"[:400]
             cfg.gradient_checkpointing = bool(args.recompute)
+        try:
+            if world == 1 and not args.long and not args.ep and not args.no_inference_records:
+                # BASELINE configs #2 (generate) and #4 (long prefill) on the gptfast surface of the SAME weights (the reference's own
+                # checkpoint conversion, on the device), so that every published inference number is timed by whoever runs this file
+                model.zero_grad(set_to_none=True)
+                batch = None
+                torch.cuda.empty_cache()
+                model.eval()
+                t0 = time.perf_counter()
+                twin = model.to_gptfast()
+                torch.cuda.synchronize()
+                t_conv = time.perf_counter() - t0
+                debug = not full_depth or args.gen_new != 200 or args.gen_image != 1 or args.prefill_seq != 53248 or args.prefill_frames != 32
+                img_px = model.config.vision_config.image_size
+                res["generate_config2"] = generate_config2_record(twin, cfg, new_tokens=args.gen_new, n_img=args.gen_image, img_px=img_px,
+                                                                  qtok=acfg.projector_patch_to_query_dict.get((img_px // 14) ** 2, QTOK), img_token=IMG_TOKEN)
+                res["generate_config2"]["hf_to_gptfast_s"] = round(t_conv, 2)
+                res["prefill_config4"] = prefill_config4_record(twin, cfg, S=args.prefill_seq, frames=args.prefill_frames, img_token=IMG_TOKEN)
+                if debug:
+                    res["generate_config2"]["INVALID"] = res["prefill_config4"]["INVALID"] = "debug run (reduced depth / lengths)"
+                del twin
+        except Exception as ex:  # noqa: BLE001
+            res["inference_records_error"] = f"{type(ex).__name__}: {ex}"[:400]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(cfg_kwargs)

@@ -105,7 +105,9 @@ int aria_gemm_swiglu_split_bf16(const void* A, const void* Bg, const void* Bu, v
 int aria_grouped_gemm_dswiglu_bf16(const void* dY, const void* B, const void* H, void* DH, const int32_t* offsets, int64_t E, int64_t M_total,
                                    int64_t I, int64_t K, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldh, int64_t lddh, void* stream);
 /* The dense counterpart (SharedExpertMLP's down_proj input gradient + act backward): d_act = dY * W with W [K, I] row-major
- * (down_proj.weight, b_oc = 1 form) or, b_oc = 0, W [I, K]. */
+ * (down_proj.weight, b_oc = 1 form) or, b_oc = 0, W [I, K].  Bit-identical to the two-step chain through the SAME kernel family; the dense
+ * two-step entry (aria_gemm_bf16_ws) may pick split-K for a partly filled last round of tiles, which sums the reduction in a different
+ * order -- against that path the results agree to the GEMM tolerance, not bit for bit. */
 int aria_gemm_dswiglu_bf16(const void* dY, const void* B, const void* H, void* DH, int64_t M, int64_t I, int64_t K, int b_oc, int64_t lda,
                            int64_t ldb, int64_t ldh, int64_t lddh, void* stream);
 

@@ -33,5 +33,13 @@ def test_bench_line_carries_the_contract(world):
         assert {"ms_per_step", "value", "unit", "steps", "roofline"} <= set(sub) and sub["steps"] == 3 and sub["value"] > 0
         assert sub["roofline"]["bound"] == "mfma" and sub["roofline"]["launches_timed"] == 3 * 2 and "INVALID" in sub
         assert res["recipe_grad_checkpointing"]["steps"] == 3 and res["recipe_grad_checkpointing"]["value"] > 0
+        # BASELINE configs #2 / #4 ride in the same line too (gptfast surface of the same weights; toy lengths here)
+        assert "inference_records_error" not in res and "sub_records_error" not in res, res
+        gen, pre = res["generate_config2"], res["prefill_config4"]
+        assert gen["value"] > 0 and gen["new_tokens"] == 6 and gen["runs"] == 5 and gen["warmup"] == 2 and gen["decode_engine"] is True
+        assert gen["roofline"]["bound"] == "hbm" and gen["roofline"]["frac"] >= 0 and "INVALID" in gen
+        assert pre["value"] > 0 and pre["finite_logits"] is True and pre["roofline"]["bound"] == "mfma" and "INVALID" in pre
+        assert res["long64k"]["recompute_level"] == "moe" and res["recipe_grad_checkpointing"]["recompute_level"] == "moe"
+        assert "recipe gradient checkpointing: OFF" in res["config"]["workload"]
     else:
-        assert "long64k" not in res
+        assert "long64k" not in res and "generate_config2" not in res

@@ -134,6 +134,36 @@ def test_hf_generate_with_the_static_kv_cache_is_linear_and_equal():
     assert s1.shape == (1, 16) and torch.equal(s1[:, :12], ids)
 
 
+def test_repeated_cached_generate_with_different_prompts_of_equal_length():
+    """a second cached generate() with the same rounded cache length must not attend over the previous call's K/V (the
+    decode engine records raw addresses: they are checked against the model's CURRENT tensors, and an unchanged geometry re-uses the
+    buffers).  Two different 12-token prompts, cached == cache-free for both, in both orders; then a different length."""
+    _, m = tiny()
+    m.eval()
+    ids, pv = batch()
+    g = torch.Generator().manual_seed(7)
+    ids2 = torch.randint(10, 512, (1, 12), generator=g)
+    ids2[0, 2:6] = 9
+    pv2 = torch.randn((1, 3, 56, 56), generator=g).to(bf16)
+    want1 = m.generate(input_ids=ids, pixel_values=pv, max_new_tokens=5, do_sample=False, use_cache=False)
+    want2 = m.generate(input_ids=ids2, pixel_values=pv2, max_new_tokens=5, do_sample=False, use_cache=False)
+    assert not torch.equal(want1[:, 12:], want2[:, 12:])                       # the prompts really lead somewhere else
+    for _ in range(2):
+        assert torch.equal(m.generate(input_ids=ids, pixel_values=pv, max_new_tokens=5, do_sample=False), want1)
+        assert torch.equal(m.generate(input_ids=ids2, pixel_values=pv2, max_new_tokens=5, do_sample=False), want2)
+    twin = m._twin()
+    eng = twin.llm._engine
+    assert eng is not None and eng.valid_for(twin.llm)
+    k0 = twin.llm.layers[0].attention.kv_cache.k
+    m.generate(input_ids=ids, pixel_values=pv, max_new_tokens=5, do_sample=False)
+    assert twin.llm.layers[0].attention.kv_cache.k is k0 and twin.llm._engine is eng   # same geometry: buffers and engine re-used
+    long = m.generate(input_ids=ids2, pixel_values=pv2, max_new_tokens=14, do_sample=False)  # another cache length: new buffers, new engine
+    assert torch.equal(long[:, :17], want2)
+    assert twin.llm.layers[0].attention.kv_cache.k is not k0 and not eng.valid_for(twin.llm)
+    twin.llm.layers[0].attention.kv_cache.k = torch.zeros_like(twin.llm.layers[0].attention.kv_cache.k)   # a cache swapped behind the engine's back
+    assert not twin.llm._engine.valid_for(twin.llm)
+
+
 def test_two_steps_under_transformers_trainer():
     transformers = pytest.importorskip("transformers")
     pytest.importorskip("accelerate")

@@ -40,7 +40,7 @@ class TorchProxy(types.ModuleType):
         super().__init__("torch")
         self.cuda = types.SimpleNamespace(is_available=lambda: True, set_device=lambda i: None, synchronize=lambda *a: None, Event=FakeEvent,
                                           get_device_name=lambda *a: "cpu (dry run)", empty_cache=lambda: None,
-                                          max_memory_allocated=lambda *a: 0)
+                                          max_memory_allocated=lambda *a: 0, reset_peak_memory_stats=lambda *a: None)
 
     def __getattr__(self, name):
         return getattr(torch, name)
@@ -74,7 +74,7 @@ def run(world: int, rank: int, ep: bool):
 
     moe_lm.AriaMoELMConfig, vision.AriaVisionConfig = tiny_lm, tiny_vis
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--layers", "2", "--vit-layers", "1", "--images", "0",
-                "--batch", "2", "--seq", "64", "--no-cpu-baseline", "--long64k-seq", "96", "--long64k-images", "0"] + (["--ep"] if ep else []) + (["--time-grouped"] if world == 1 else [])
+                "--batch", "2", "--seq", "64", "--no-cpu-baseline", "--long64k-seq", "96", "--long64k-images", "0", "--gen-new", "6", "--gen-image", "0", "--prefill-seq", "96", "--prefill-frames", "0"] + (["--ep"] if ep else []) + (["--time-grouped"] if world == 1 else [])
     try:
         bench.main()
     finally:
