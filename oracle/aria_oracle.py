@@ -20,6 +20,11 @@ below against those fixtures, and ``tests/test_oracle_vs_reference.py`` checks
 them against the live reference on fresh random inputs whenever
 ``/root/reference`` is present.
 
+The language-model functions follow the DEVICE of their inputs.  On the CPU they are the oracle.  The two long-sequence parity cases
+(one decoder layer at 65 536 tokens, the 53 248-token prefill: 17 + 5 minutes of host fp32) evaluate this same fp32 code with torch's own
+fp32 kernels on the GPU -- never the product library -- and only after the same test has pinned device-fp32 == host-fp32 on a
+full-width layer at T = 4096 (``tests/fullwidth_cases.py::oracle_device_pin``), so the device does not vouch for itself.
+
 Weights are passed as a flat ``dict[str, Tensor]`` using the reference's own
 state-dict key names, so the same dict drives the
 reference, this oracle and ``aria_amd``.
@@ -133,7 +138,7 @@ def router_routing(logits: Tensor, topk: int, num_experts: int) -> Tuple[Tensor,
     if _FORCED_ROUTING is not None:
         if not _FORCED_ROUTING:  # a router call the caller supplied no ids for: never fall back to the oracle's own top-k silently
             raise AssertionError("forced_routing: more router calls than index tensors supplied")
-        top_indices = _FORCED_ROUTING.pop(0).to(torch.int64).reshape(logits.shape[0], topk)
+        top_indices = _FORCED_ROUTING.pop(0).to(device=logits.device, dtype=torch.int64).reshape(logits.shape[0], topk)
         top_logits = torch.gather(logits, 1, top_indices)
     else:
         top_logits, top_indices = topk_lowest_index(logits, topk)
@@ -194,7 +199,7 @@ def token_permutation(hidden: Tensor, indices: Tensor, topk: int) -> Tuple[Tenso
 
 def token_unpermutation(expert_out: Tensor, scores: Tensor, sorted_indices: Tensor, topk: int, out_shape) -> Tensor:
     """moe_lm.py:336-365: scatter back, weight by scores (in scores' dtype), sum over k."""
-    buf = torch.zeros((scores.numel(), expert_out.size(1)), dtype=expert_out.dtype)
+    buf = torch.zeros((scores.numel(), expert_out.size(1)), dtype=expert_out.dtype, device=expert_out.device)
     buf.index_copy_(0, sorted_indices, expert_out)
     buf = buf.reshape(-1, topk, expert_out.size(1))
     buf = buf * scores.unsqueeze(-1)
@@ -202,10 +207,11 @@ def token_unpermutation(expert_out: Tensor, scores: Tensor, sorted_indices: Tens
 
 
 def _sequential_gemm_loop(inp: Tensor, weight: Tensor, tokens_per_expert: Tensor) -> Tensor:
-    out = torch.zeros(inp.shape[0], weight.shape[-1], dtype=inp.dtype)
+    out = torch.zeros(inp.shape[0], weight.shape[-1], dtype=inp.dtype, device=inp.device)
     start = 0
+    counts = [int(n) for n in tokens_per_expert.tolist()]   # one host read, not one per expert (the counts may live on a device)
     for e in range(weight.shape[0]):
-        n = int(tokens_per_expert[e])
+        n = counts[e]
         if n:
             out[start : start + n] = inp[start : start + n] @ weight[e]
         start += n
@@ -220,7 +226,7 @@ class _SequentialGemm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inp, weight, tokens_per_expert):
         ctx.save_for_backward(inp, weight)
-        ctx.tpe = [int(n) for n in tokens_per_expert]
+        ctx.tpe = [int(n) for n in tokens_per_expert.tolist()]
         return _sequential_gemm_loop(inp, weight, tokens_per_expert)
 
     @staticmethod
@@ -322,7 +328,7 @@ def rms_norm(x: Tensor, weight: Tensor, eps: float) -> Tensor:
 def rope_cos_sin(position_ids: Tensor, head_dim: int, theta: float, dtype: torch.dtype) -> Tuple[Tensor, Tensor]:
     """LlamaRotaryEmbedding.forward (transformers/.../modeling_llama.py:96-127): fp32 angles,
     emb = cat(freqs, freqs), cos/sin cast to the activation dtype.  [B, S, head_dim]."""
-    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64, device=position_ids.device).float() / head_dim))
     freqs = position_ids[:, :, None].float() * inv_freq[None, None, :]
     emb = torch.cat((freqs, freqs), dim=-1)
     return emb.cos().to(dtype), emb.sin().to(dtype)
@@ -346,7 +352,7 @@ def attention_eager(q: Tensor, k: Tensor, v: Tensor, scale: float, causal: bool,
     att = (q @ k.transpose(2, 3)) * scale
     sq, sk = q.shape[2], k.shape[2]
     if causal:
-        m = torch.full((sq, sk), torch.finfo(att.dtype).min, dtype=att.dtype).triu(1 + sk - sq)
+        m = torch.full((sq, sk), torch.finfo(att.dtype).min, dtype=att.dtype, device=att.device).triu(1 + sk - sq)
         att = att + m
     if key_padding is not None:
         att = att + key_padding[:, None, None, :].to(att.dtype) * torch.finfo(att.dtype).min
@@ -367,7 +373,7 @@ class _StreamedCausalAttention(torch.autograd.Function):
     def forward(ctx, q, k, v, scale, block):
         B, H, S, hd = q.shape
         o = torch.empty_like(q)
-        tri = torch.ones(min(block, S), min(block, S), dtype=torch.bool).triu(1)  # key j > query i inside the diagonal block
+        tri = torch.ones(min(block, S), min(block, S), dtype=torch.bool, device=q.device).triu(1)  # key j > query i inside the diagonal block
         for b in range(B):
             for h in range(H):
                 for q0 in range(0, S, block):
@@ -385,7 +391,7 @@ class _StreamedCausalAttention(torch.autograd.Function):
         scale, block = ctx.scale, ctx.block
         B, H, S, hd = q.shape
         dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
-        tri = torch.ones(min(block, S), min(block, S), dtype=torch.bool).triu(1)
+        tri = torch.ones(min(block, S), min(block, S), dtype=torch.bool, device=q.device).triu(1)
         for b in range(B):
             for h in range(H):
                 for q0 in range(0, S, block):
@@ -468,7 +474,7 @@ def lm_forward(inputs_embeds: Tensor, w: Dict[str, Tensor], cfg: LMConfig, prefi
     """AriaMoELMForCausalLM forward on embeddings: 28x layer, final RMSNorm, lm_head
     (moe_lm.py:605-661; LlamaModel/LlamaForCausalLM.forward)."""
     B, S, _ = inputs_embeds.shape
-    position_ids = torch.arange(S)[None, :].expand(B, S)
+    position_ids = torch.arange(S, device=inputs_embeds.device)[None, :].expand(B, S)
     h = inputs_embeds
     for i in range(cfg.num_hidden_layers):
         h = decoder_layer(h, w, f"{prefix}model.layers.{i}.", cfg, position_ids, attention_mask, training)

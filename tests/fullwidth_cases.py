@@ -166,11 +166,78 @@ def router_parity(case, layer, dev_idx, dev_logits, logits, k, min_same=0.9):
     assert float(same_set.float().mean()) >= min_same, (case, layer, float(same_set.float().mean()))
 
 
+_PINNED = {}
+
+
+def oracle_device_pin(odev, *, hidden=2560, heads=20, experts=64, topk=6, inter=1664, vocab=2048, S=4096, seed=41, tol=2e-4):
+    """The fp32 oracle evaluated by torch's fp32 kernels on ``odev`` == the same oracle on the host: one full-width decoder layer inside a
+    1-layer LM at T = 4096, training mode (aux losses), block-wise attention, routing forced to the HOST oracle's own top-k (fp32 GEMMs in
+    another summation order may flip an exact tie); logits, loss and every gradient to ``tol`` (relative L2 and max-abs / max-abs).  The
+    long cases below run their oracle on the device only after this has passed in the same process (once per process and device)."""
+    key = (str(odev), hidden, heads, experts, topk, inter)
+    if _PINNED.get(key):
+        return
+    ocfg = O.LMConfig(hidden_size=hidden, num_hidden_layers=1, num_attention_heads=heads, num_key_value_heads=heads, vocab_size=vocab,
+                      moe_intermediate_size=inter, moe_num_experts=experts, moe_topk=topk)
+    w = lm_weights(ocfg, seed)
+    ids = torch.randint(0, vocab, (1, S), generator=torch.Generator().manual_seed(seed + 1))
+    results = []
+    host_idx = None
+    for d in ("cpu", odev):
+        wf = {k: v.float().to(d).requires_grad_(True) for k, v in w.items()}
+        idd = ids.to(d)
+        with _OracleIds() as oi, (O.forced_routing(host_idx) if host_idx is not None else _null()), O.streamed_attention(1024):
+            lg = O.lm_forward(wf["model.embed_tokens.weight"][idd], wf, ocfg, training=True)
+        if host_idx is None:
+            host_idx = [t.cpu() for t in oi.idx]
+        loss = torch.nn.functional.cross_entropy(lg[:, :-1].reshape(-1, vocab), idd[:, 1:].reshape(-1))
+        loss.backward()
+        results.append((lg.detach().cpu(), float(loss.detach()), {k: v.grad.detach().cpu() for k, v in wf.items()}))
+        del wf, lg, loss
+    (lg0, l0, g0), (lg1, l1, g1) = results
+    case = f"oracle_device_pin_{odev}"
+    check(case, "logits", lg1, lg0, tol, tol)
+    assert abs(l0 - l1) <= 1e-5 * abs(l0), (l0, l1)
+    for k in g0:
+        check(case, "grad " + k, g1[k], g0[k], tol, 10 * tol)
+    _PINNED[key] = True
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+class _OracleIds:
+    """Records the expert ids the oracle's router returns (its own top-k unless routing is forced)."""
+
+    def __enter__(self):
+        self.idx = []
+        self._orig = O.router_routing
+
+        def rr(logits, topk, num_experts):
+            r = self._orig(logits, topk, num_experts)
+            self.idx.append(r[1].detach().clone())
+            return r
+
+        O.router_routing = rr
+        return self
+
+    def __exit__(self, *exc):
+        O.router_routing = self._orig
+        return False
+
+
 def case_lm(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, B, S, expect_big_gemm, seed=5,
-            act_tol=(2e-2, 4e-2), grad_tol=(3e-2, 6e-2), recompute=False, eval_pass=True, stream_block=None):
+            act_tol=(2e-2, 4e-2), grad_tol=(3e-2, 6e-2), recompute=False, eval_pass=True, stream_block=None, oracle_device=None):
     """L-layer AriaMoELMForCausalLM at the given width: eval logits, training loss and EVERY gradient (aux losses on).
-    ``recompute``: the recipe's gradient checkpointing (selective: the flash kernel's (o, lse) are kept -- what the 64K benchmark line
-    runs); ``stream_block``: the oracle evaluates attention block-wise (O.streamed_attention) -- needed beyond S ~ 16 K."""
+    ``recompute``: the recipe's gradient checkpointing (True: the level the model picks; "moe" / "layer": forced);
+    ``stream_block``: the oracle evaluates attention block-wise (O.streamed_attention) -- needed beyond S ~ 16 K; ``oracle_device``: the
+    SAME fp32 oracle code evaluated by torch's fp32 kernels on that device (``oracle_device_pin`` first) -- the 64K case is 17 minutes of
+    host fp32 otherwise."""
     import contextlib
 
     from aria_amd.moe_lm import AriaMoELMConfig, AriaMoELMForCausalLM, load_reference_state_dict
@@ -184,12 +251,17 @@ def case_lm(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, B,
     cfg = AriaMoELMConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, vocab_size=vocab,
                           moe_intermediate_size=inter, moe_num_experts=experts, moe_topk=topk, moe_num_shared_experts=2,
                           rms_norm_eps=ocfg.rms_norm_eps, rope_theta=ocfg.rope_theta, moe_z_loss_coeff=ocfg.moe_z_loss_coeff,
-                          moe_aux_loss_coeff=ocfg.moe_aux_loss_coeff, gradient_checkpointing=recompute)
+                          moe_aux_loss_coeff=ocfg.moe_aux_loss_coeff, gradient_checkpointing=bool(recompute),
+                          recompute_level=recompute if isinstance(recompute, str) else "auto")
+    od = oracle_device or "cpu"
+    if oracle_device:
+        oracle_device_pin(oracle_device, hidden=hidden, heads=heads, experts=experts, topk=topk, inter=inter)
     lm = AriaMoELMForCausalLM(cfg)
     load_reference_state_dict(lm, w)
     lm = lm.to(dev)
     ids = torch.randint(0, vocab, (B, S), generator=torch.Generator().manual_seed(seed + 1))
-    wf = {k: v.float().requires_grad_(True) for k, v in w.items()}
+    wf = {k: v.float().to(od).requires_grad_(True) for k, v in w.items()}
+    ids_o = ids.to(od)
 
     # ---- eval: logits
     if eval_pass:
@@ -203,9 +275,9 @@ def case_lm(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, B,
             assert rec.fused == layers, (rec.fused, layers)
         REPORT.setdefault(case, {})["grouped_gemm_variants"] = sorted(set(rec.variants))
         with _OracleLogits() as ol, O.forced_routing(rec.idx), oracle_ctx(), torch.no_grad():
-            want = O.lm_forward(wf["model.embed_tokens.weight"][ids], wf, ocfg)
+            want = O.lm_forward(wf["model.embed_tokens.weight"][ids_o], wf, ocfg)
         for i in range(layers):
-            router_parity(case, i, rec.idx[i], rec.logits[i], ol.logits[i], topk)
+            router_parity(case, i, rec.idx[i], rec.logits[i], ol.logits[i].cpu(), topk)
         check(case, "logits", got, want, *act_tol)
 
     # ---- training: loss and gradients with the router's aux losses
@@ -222,14 +294,16 @@ def case_lm(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, B,
     if expect_big_gemm:
         assert rec.variants and min(rec.variants) >= 2, rec.variants
     with _OracleLogits() as ol, O.forced_routing(rec.idx), oracle_ctx():
-        lgo = O.lm_forward(wf["model.embed_tokens.weight"][ids], wf, ocfg, training=True)
+        lgo = O.lm_forward(wf["model.embed_tokens.weight"][ids_o], wf, ocfg, training=True)
     if not eval_pass:
         for i in range(layers):
-            router_parity(case, i, rec.idx[i], rec.logits[i], ol.logits[i].detach(), topk)
-    loss_o = torch.nn.functional.cross_entropy(lgo[:, :-1].reshape(-1, vocab), ids[:, 1:].reshape(-1))
+            router_parity(case, i, rec.idx[i], rec.logits[i], ol.logits[i].detach().cpu(), topk)
+    loss_o = torch.nn.functional.cross_entropy(lgo[:, :-1].reshape(-1, vocab), ids_o[:, 1:].reshape(-1))
     loss_o.backward()
     rel = abs(float(out.loss.detach()) - float(loss_o.detach())) / abs(float(loss_o.detach()))
     REPORT[case]["loss"] = {"got": float(out.loss.detach()), "want": float(loss_o.detach()), "rel": round(rel, 6)}
+    REPORT[case]["oracle_device"] = str(od)
+    REPORT[case]["recompute_level"] = getattr(lm.model, "last_recompute_level", None)
     assert rel <= 5e-3, REPORT[case]["loss"]
     n = 0
     for name, p in lm.named_parameters():
@@ -439,7 +513,7 @@ def case_vit_attention_bwd(dev, case, *, S, H, hd=72, B=2, seed=23, tol=(6e-3, 2
 
 # ------------------------------------------------------------------------------------------------------------ config #4 prefill
 def case_prefill_gptfast(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, S, seed=31, tol=(3e-2, 6e-2), stream_block=4096,
-                         expect_big_gemm=True):
+                         expect_big_gemm=True, oracle_device=None):
     """BASELINE config #4's code path at its sequence length: the gptfast surface (aria_amd.gptfast.Transformer, model.pth wire format
     converted from the HF layout exactly as gptfast/scripts/convert_hf_checkpoint.py:90-162 does) prefills S tokens into its static bf16
     KV cache and returns the LAST position's logits (gptfast/model.py:178-234, 413-447); oracle = O.lm_forward (HF layout: the two
@@ -466,12 +540,17 @@ def case_prefill_gptfast(dev, case, *, hidden, heads, experts, topk, inter, voca
     with _Recorder() as rec, torch.no_grad():
         got = tf(ids.to(dev), torch.arange(S, device=dev), last_only=True).float().cpu()
     assert len(rec.idx) == layers and rec.variants and (not expect_big_gemm or min(rec.variants) >= 2), (len(rec.idx), rec.variants)
-    wf = {k: v.float() for k, v in w.items()}
+    od = oracle_device or "cpu"
+    if oracle_device:   # the same fp32 oracle code on the device's fp32 kernels, pinned on the host oracle first (see oracle_device_pin)
+        oracle_device_pin(oracle_device, hidden=hidden, heads=heads, experts=experts, topk=topk, inter=inter)
+    wf = {k: v.float().to(od) for k, v in w.items()}
     with _OracleLogits() as ol, O.forced_routing(rec.idx), O.streamed_attention(stream_block), torch.no_grad():
-        h = O.lm_forward(wf["model.embed_tokens.weight"][ids], wf, ocfg, return_hidden=True)
-        want = torch.nn.functional.linear(h[:, -1:], wf["lm_head.weight"])
+        h = O.lm_forward(wf["model.embed_tokens.weight"][ids.to(od)], wf, ocfg, return_hidden=True)
+        want = torch.nn.functional.linear(h[:, -1:], wf["lm_head.weight"]).cpu()
+    wf = {k: v.cpu() for k, v in wf.items()}
+    REPORT.setdefault(case, {})["oracle_device"] = str(od)
     for i in range(layers):
-        router_parity(case, i, rec.idx[i], rec.logits[i], ol.logits[i], topk)
+        router_parity(case, i, rec.idx[i], rec.logits[i], ol.logits[i].cpu(), topk)
     check(case, "last-position logits", got, want, *tol)
     # the static KV cache of layer 0 (gptfast/model.py:67-93): V rows are v_proj(RMSNorm(embedding)) -- layout-independent -- at both ends
     rows = torch.tensor([0, 1, S // 2, S - 2, S - 1])
@@ -479,3 +558,98 @@ def case_prefill_gptfast(dev, case, *, hidden, heads, experts, topk, inter, voca
     check(case, "layer-0 V cache rows", tf.layers[0].attention.kv_cache.v[0, rows.to(dev)].float().cpu(),
           torch.nn.functional.linear(x0, wf["model.layers.0.self_attn.v_proj.weight"]), 1e-2, 3e-2)
     assert int(got.argmax()) == int(want.argmax()) or float(want.flatten().topk(2).values.diff().abs()) < 4e-2 * float(want.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------------------ operands beyond 2^31 bytes
+def case_grouped_gemm_beyond_2g(dev, case, *, rows=430080, K=2560, I=1664, E=64, seed=51, expect_v3=True):
+    """The three fused grouped launches of the 64K-token step on operands whose byte offsets pass 2^31 (393 216 expert rows x 2560 x 2 B =
+    2.01 GB; here 430 080 rows so that A, H, ACT and DH all cross the boundary): ``gemm3_kernel<.., .., 3>`` (fc1 + SwiGLU, moe_lm.py:505-525),
+    ``<.., .., 5>`` (fc2 input gradient + SwiGLU backward) and ``<.., .., 6>`` (gptfast w1 / w3 split form, gptfast/model.py:278-325).
+    Two checks per launch: (1) the rows of chosen experts -- the first, the ones straddling 2^31 bytes of every operand, the last -- are
+    BIT-IDENTICAL to the same kernel run on that expert alone at low addresses (same tiles, same k order: only the addressing differs);
+    (2) sampled rows against the fp32 oracle (sequential_gemm + glu, and autograd through glu) on the host."""
+    from aria_amd import hip, ops
+
+    g = torch.Generator(device=dev).manual_seed(seed)
+    gc = torch.Generator().manual_seed(seed)
+    # ragged counts: a few empty experts, a few tiny ones, the rest uneven; sum = rows
+    wts = torch.rand(E, generator=gc) + 0.25
+    wts[[3, min(17, E - 1)]] = 0.0
+    counts = torch.floor(wts / wts.sum() * (rows - 7)).long()
+    counts[5] += 7 + (rows - 7 - int(counts.sum()))
+    assert int(counts.sum()) == rows and int(counts.min()) == 0
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(counts, 0)
+    offd = off.to(dev)
+
+    def rn(*shape, scale=1.0):
+        return (torch.randn(shape, generator=g, device=dev) * scale).to(bf16)
+
+    a = rn(rows, K)
+    w1 = rn(E, K, 2 * I, scale=0.02)                       # experts.fc1.weight [E, K, 2I]
+    lib = hip.get_lib().cdll
+
+    def experts_at(byte_marks, row_bytes):
+        """experts holding the rows at the given byte offsets of an operand with ``row_bytes`` per row"""
+        out = set()
+        for m in byte_marks:
+            r = min(rows - 1, m // row_bytes)
+            out.add(int(torch.searchsorted(off[1:].long(), torch.tensor(r), right=True)))
+        return out
+
+    marks = [1 << 31, (1 << 31) - 4096, (1 << 31) + 4096]
+    chosen = {int((counts > 0).nonzero()[0]), int((counts > 0).nonzero()[-1])}
+    for rb in (2 * K, 2 * 2 * I, 2 * I):
+        chosen |= experts_at(marks, rb)
+    chosen = sorted(e for e in chosen if counts[e] > 0)
+    sample = torch.cat([torch.arange(0, 64), torch.arange(rows - 64, rows)] +
+                       [torch.arange(max(0, min(rows, (1 << 31) // rb) - 32), min(rows, (1 << 31) // rb + 32)) for rb in (2 * K, 4 * I, 2 * I)]).unique()
+    sample_e = torch.searchsorted(off[1:].long(), sample, right=True)
+
+    def one_expert_offsets(n):
+        return torch.tensor([0, n], dtype=torch.int32, device=dev)
+
+    # ---- <3>: fc1 + SwiGLU
+    h, act = ops.grouped_gemm_swiglu(a, w1, offd, want_h=True)
+    assert lib.aria_last_gemm_variant() == 3 or not expect_v3
+    for e in chosen:
+        s0, s1 = int(off[e]), int(off[e + 1])
+        h1, act1 = ops.grouped_gemm_swiglu(a[s0:s1].clone(), w1[e:e + 1].clone(), one_expert_offsets(s1 - s0), want_h=True)
+        assert torch.equal(h[s0:s1], h1) and torch.equal(act[s0:s1], act1), f"<3> expert {e} rows {s0}:{s1} differ from the low-address run"
+    hs = torch.stack([a[r].float().cpu() @ w1[e].float().cpu() for r, e in zip(sample.tolist(), sample_e.tolist())])
+    check(case, "<3> h sampled rows", h[sample.to(dev)], hs, 1e-2, 3e-2)
+    check(case, "<3> act sampled rows", act[sample.to(dev)], O.glu(hs.to(bf16).float()), 1.5e-2, 4e-2)
+
+    # ---- <5>: fc2 input gradient + SwiGLU backward (dy [rows, K], fc2.weight [E, I, K], h from above)
+    dy = rn(rows, K)
+    w2 = rn(E, I, K, scale=0.02)
+    dh = ops.grouped_gemm_dswiglu(dy, w2, offd, h)
+    assert lib.aria_last_gemm_variant() == 3 or not expect_v3
+    for e in chosen:
+        s0, s1 = int(off[e]), int(off[e + 1])
+        dh1 = ops.grouped_gemm_dswiglu(dy[s0:s1].clone(), w2[e:e + 1].clone(), one_expert_offsets(s1 - s0), h[s0:s1].clone())
+        assert torch.equal(dh[s0:s1], dh1), f"<5> expert {e} rows {s0}:{s1} differ from the low-address run"
+    dact = torch.stack([dy[r].float().cpu() @ w2[e].float().cpu().t() for r, e in zip(sample.tolist(), sample_e.tolist())]).to(bf16).float()
+    hf = h[sample.to(dev)].float().cpu().requires_grad_(True)
+    (O.glu(hf) * dact).sum().backward()
+    check(case, "<5> dh sampled rows", dh[sample.to(dev)], hf.grad, 2e-2, 5e-2)
+    del dh, dy, w2
+
+    # ---- <6>: gate / up weights as two [E, I, K] tensors of one allocation (gptfast wire format)
+    pair = torch.empty((2, E, I, K), dtype=bf16, device=dev)
+    pair[0].copy_(w1[:, :, :I].transpose(1, 2))
+    pair[1].copy_(w1[:, :, I:].transpose(1, 2))
+    assert ops.glu_split_fusable(pair[0], pair[1])
+    h6, act6 = ops.grouped_gemm_swiglu_split(a, pair[0], pair[1], offd, want_h=True)
+    assert lib.aria_last_gemm_variant() == 3 or not expect_v3
+    for e in chosen:
+        s0, s1 = int(off[e]), int(off[e + 1])
+        sub = torch.empty((2, 1, I, K), dtype=bf16, device=dev)
+        sub[0, 0].copy_(pair[0, e]), sub[1, 0].copy_(pair[1, e])
+        h1, act1 = ops.grouped_gemm_swiglu_split(a[s0:s1].clone(), sub[0], sub[1], one_expert_offsets(s1 - s0), want_h=True)
+        assert torch.equal(h6[s0:s1], h1) and torch.equal(act6[s0:s1], act1), f"<6> expert {e} rows {s0}:{s1} differ from the low-address run"
+    check(case, "<6> h sampled rows", h6[sample.to(dev)], hs, 1e-2, 3e-2)
+    check(case, "<6> act sampled rows", act6[sample.to(dev)], O.glu(hs.to(bf16).float()), 1.5e-2, 4e-2)
+    REPORT[case]["rows"] = rows
+    REPORT[case]["experts_compared_bitwise"] = chosen
+    REPORT[case]["bytes_A_H_ACT"] = [rows * 2 * K, rows * 4 * I, rows * 2 * I]

@@ -58,3 +58,21 @@ def test_lm_case_small_recompute_streamed(level, monkeypatch):
 def test_prefill_gptfast_case_small():
     F.case_prefill_gptfast("cpu", "emu_prefill", hidden=128, heads=2, experts=8, topk=2, inter=128, vocab=160, layers=2, S=72,
                            tol=(5e-2, 1.5e-1), stream_block=32, expect_big_gemm=False)
+
+
+def test_lm_case_small_oracle_device_path():
+    """The always-on 64K case's code path at toy size: recompute level forced through the case's argument, the oracle evaluated on an
+    explicit device behind ``oracle_device_pin`` (here the host against itself: the plumbing, not the claim)."""
+    F._PINNED.clear()
+    F.case_lm("cpu", "emu_lm_oracle_device", hidden=128, heads=2, experts=8, topk=2, inter=128, vocab=160, layers=1, B=1, S=40,
+              expect_big_gemm=False, act_tol=(3e-2, 8e-2), grad_tol=(8e-2, 2e-1), recompute="layer", eval_pass=False, stream_block=16,
+              oracle_device="cpu")
+    rep = F.REPORT["emu_lm_oracle_device"]
+    assert rep["oracle_device"] == "cpu" and rep["recompute_level"] == "layer" and F.REPORT["oracle_device_pin_cpu"]["logits"]["rel_l2"] == 0.0
+    F.case_prefill_gptfast("cpu", "emu_prefill_oracle_device", hidden=128, heads=2, experts=8, topk=2, inter=128, vocab=160, layers=1, S=40,
+                           tol=(5e-2, 1.5e-1), stream_block=16, expect_big_gemm=False, oracle_device="cpu")
+
+
+def test_grouped_gemm_beyond_2g_case_small():
+    """The > 2^31-byte grouped-GEMM case's own logic (expert choice, single-expert bitwise reruns, sampled oracle rows) at toy size."""
+    F.case_grouped_gemm_beyond_2g("cpu", "emu_beyond_2g", rows=900, K=64, I=128, E=8, expect_v3=False)
