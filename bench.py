@@ -82,12 +82,13 @@ def init_params(model, seed):
                     flat[o:o + chunk].normal_(0.0, 0.02, generator=g)
 
 
-KERNEL_REV = "r02b"   # bumped with every change of the v3 K loop / epilogues: a PMC pass of an older build does not describe this one
-PMC_KERNEL_TAG = "gemm3_kernel<rc,oc,3>+wide_store+expert_major+swiglu@r02b"   # the fc1 launch the committed PMC pass profiled
+PMC_FILE = "r04_pmc_fc1.json"
+KERNEL_REV = "r04a"   # bumped with every change of the v3 K loop / epilogues: a PMC pass of an older build does not describe this one
+PMC_KERNEL_TAG = "gemm3_kernel<rc,oc,3>+wide_store+expert_major+swiglu@r04a"   # the fc1 launch the committed PMC pass profiled
 
 
 def fc1_kernel_tag(variant):
-    """What the default path launched for experts.fc1 in THIS run, spelled like profiles/r02_pmc_fc1.json's kernel_tag."""
+    """What the default path launched for experts.fc1 in THIS run, spelled like profiles/r04_pmc_fc1.json's kernel_tag."""
     if variant != 3:
         return f"gemm{variant}_kernel<rc,oc>"
     wide = os.environ.get("ARIA_GEMM_WIDE_STORE", "1") != "0"
@@ -100,7 +101,7 @@ def pmc_traffic(variant=3):
     tools/gemm_pmc_target.py = the same shape and the same fused launch; gfx950 FETCH_SIZE x2 correction applied) -- counters cannot be read inside the timed run.
     None unless the pass profiled exactly the kernel / epilogue / tile order this run launched."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_fc1.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             d = json.load(f)
         return round(d["hbm_bytes_per_launch"]) if d["kernel_tag"] == fc1_kernel_tag(variant) else None
     except Exception:
