@@ -234,9 +234,13 @@ class Transformer(nn.Module):
         #                                   enqueue on ROCm 7.2: 6.2 vs 4.8 ms/token -- graph kernel nodes cost more than stream launches)
         self._engine: Optional["DecodeEngine"] = None
 
+    def _engine_capable(self) -> bool:
+        """The one-call-per-token engine serves this model's shape (native head dims of the decode attention kernel)."""
+        return self.layers[0].attention.hdp == self.config.head_dim and self.config.head_dim in (64, 128)
+
     def _engine_ok(self) -> bool:
         att = self.layers[0].attention
-        if att.kv_cache is None or att.hdp != self.config.head_dim or self.config.head_dim not in (64, 128):
+        if att.kv_cache is None or not self._engine_capable():
             return False
         if self._engine is None or not self._engine.valid_for(self):
             self._engine = DecodeEngine(self)

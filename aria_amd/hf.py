@@ -14,9 +14,12 @@ so checkpoints written by either class load into the other and into the referenc
 KV cache (modeling_aria.py:43-58, 337-365): HF ``generate()`` runs WITH a cache.  ``past_key_values`` is an ``AriaStaticKVCache`` -- the
 static bf16 cache ``[1, S_max, H * hd]`` per layer of the model's gptfast twin (gptfast/model.py:67-93) with the one-call-per-token decode
 engine (csrc/decode.hip) behind it: the first forward prefills the prompt (ViT + projector run ONCE, tile kernels), every later forward
-decodes the new token against the cache -- linear time, any ``GenerationConfig`` sampling option of the HF loop.  Batch 1 without padding
-(what the decode engine serves); other inputs, or ``use_cache=False``, take the cache-free path (every step re-runs the prefix: correct,
-quadratic).  ``.generate_fast`` is the native sampling loop (gptfast/generate.py:112-177) on the same engine.
+decodes the new token against the cache -- linear time, any ``GenerationConfig`` sampling option of the HF loop.  Any batch size: every row
+of a (left-padded) batch owns a row of static caches and a pointer table of the decode engine, is prefilled from its own first real token
+(positions count from 0 there, as HF's ``position_ids = cumsum(attention_mask) - 1`` has it) and decoded by the batch-1 engine -- a batch of B
+rows is B batch-1 generations step for step, token for token; beam search re-orders (copies) rows.  Right-padded or hole-y masks, assisted
+decoding, or ``use_cache=False`` take the cache-free path (every step re-runs the prefix: correct, quadratic).  ``.generate_fast`` is the
+native sampling loop (gptfast/generate.py:112-177) on the same engine.
 """
 from __future__ import annotations
 
@@ -123,17 +126,68 @@ class AriaHFConfig(PreTrainedConfig):
         return self.text_config.hidden_size
 
 
+class _CacheRow:
+    """One sequence of a cached batch: its static K/V tensors per layer and the decode engine whose pointer table names them."""
+
+    def __init__(self, kv, engine=None):
+        self.kv, self.engine, self.pads = kv, engine, 0
+
+
 class AriaStaticKVCache:
     """``past_key_values`` of the native HF class: the gptfast twin's static KV cache (``setup_caches`` gptfast/model.py:113-166, ``KVCache``
     :67-93) and how many positions of it are filled.  Exposes what ``GenerationMixin`` asks of a cache object (``get_seq_length``,
-    ``is_compileable``, ``get_max_cache_shape``); the tensors live in ``twin.llm.layers[i].attention.kv_cache``."""
+    ``is_compileable``, ``get_max_cache_shape``, ``reorder_cache``, ``crop``).  Row 0 is the twin's own cache (``twin.llm.layers[i].attention
+    .kv_cache``); further rows of a batch are added by ``ensure_rows`` (kept on the twin between calls of equal geometry).  ``seen`` counts
+    COLUMNS of ``input_ids`` consumed (left padding included, what HF's ``cache_position`` counts); row r holds ``seen - rows[r].pads``
+    positions."""
 
     is_compileable = False   # the decode step is already one native call per token; there is nothing for torch.compile to capture
     is_sliding = [False]
 
-    def __init__(self, twin, max_len: int):
+    def __init__(self, twin, max_len: int, batch: int = 1):
         self.twin, self.max_len, self.seen = twin, int(max_len), 0
         twin.setup_caches(1, self.max_len)
+        llm = twin.llm
+        pool = getattr(twin, "_hf_cache_rows", None)
+        row0_kv = [b.attention.kv_cache for b in llm.layers]
+        if pool is None or pool[0].kv[0] is not row0_kv[0]:          # new geometry (setup_caches re-allocated): rows of the old one are stale
+            pool = [_CacheRow(row0_kv, llm._engine)]
+            twin._hf_cache_rows = pool
+        self.rows = pool
+        self.ensure_rows(batch)
+        for r in self.rows:
+            r.pads = 0
+
+    def ensure_rows(self, batch: int):
+        from . import gptfast as G
+
+        llm = self.twin.llm
+        c, a0 = llm.config, llm.layers[0].attention
+        dev = llm.output.weight.device
+        while len(self.rows) < batch:
+            self.rows.append(_CacheRow([G.KVCache(1, llm.max_seq_length, c.n_head, a0.hdp, dev) for _ in llm.layers]))
+        self.batch = batch
+
+    def bind(self, r: int):
+        """Context: the twin's attention layers (and its decode engine) point at row ``r``; row 0 is restored on exit."""
+        cache = self
+
+        class _Bind:
+            def __enter__(self_b):
+                cache._attach(cache.rows[r])
+
+            def __exit__(self_b, *exc):
+                cache.rows[r].engine = cache.twin.llm._engine     # (created lazily by the first single-token step of the row)
+                cache._attach(cache.rows[0])
+                return False
+
+        return _Bind()
+
+    def _attach(self, row):
+        llm = self.twin.llm
+        for b, kv in zip(llm.layers, row.kv):
+            b.attention.kv_cache = kv
+        llm._engine = row.engine
 
     def get_seq_length(self, layer_idx: int = 0) -> int:
         return self.seen
@@ -147,7 +201,25 @@ class AriaStaticKVCache:
         return len(self.twin.llm.layers)
 
     def reorder_cache(self, beam_idx):
-        raise NotImplementedError("AriaStaticKVCache: beam search needs batch > 1; the static cache serves batch 1 (use use_cache=False)")
+        """Beam search: row i continues the hypothesis row ``beam_idx[i]`` held -- copy the filled part of the source's K/V (two rows may
+        descend from one parent, so sources are snapshotted before anything is overwritten)."""
+        idx = [int(i) for i in beam_idx.tolist()]
+        if len(idx) != self.batch:
+            raise ValueError(f"reorder_cache: {len(idx)} beams for a cache of {self.batch} rows")
+        moves = [(dst, src) for dst, src in enumerate(idx) if dst != src]
+        if not moves:
+            return
+        snap = {}
+        for _, src in moves:
+            if src not in snap:
+                n = self.seen - self.rows[src].pads
+                snap[src] = (self.rows[src].pads, [(kv.k[:, :n].clone(), kv.v[:, :n].clone()) for kv in self.rows[src].kv])
+        for dst, src in moves:
+            pads, layers = snap[src]
+            self.rows[dst].pads = pads
+            for kv, (k, v) in zip(self.rows[dst].kv, layers):
+                kv.k[:, :k.shape[1]].copy_(k)
+                kv.v[:, :v.shape[1]].copy_(v)
 
     def crop(self, max_length: int):
         """Forget positions >= max_length (assisted decoding rolls back rejected tokens): the rows stay in the buffer and are overwritten."""
@@ -249,26 +321,77 @@ class AriaForConditionalGeneration(AriaPretrainedModel, GenerationMixin):
             object.__setattr__(self, "_twin_stamp", stamp)
         return core._gptfast_twin
 
-    def make_cache(self, max_len: int) -> AriaStaticKVCache:
-        """A fresh ``past_key_values`` object for a sequence of up to ``max_len`` positions (prompt + new tokens)."""
-        return AriaStaticKVCache(self._twin(), max_len)
+    def make_cache(self, max_len: int, batch: int = 1) -> AriaStaticKVCache:
+        """A fresh ``past_key_values`` object for ``batch`` sequences of up to ``max_len`` positions (prompt + new tokens) each."""
+        return AriaStaticKVCache(self._twin(), max_len, batch)
 
-    def _forward_cached(self, cache: AriaStaticKVCache, input_ids, pixel_values, pixel_mask, keep: int) -> torch.Tensor:
-        """One step of cached generation (modeling_aria.py:337-365 + gptfast/generate.py:71-110): the first call prefills the whole prompt
-        (image features merged once), later calls feed only the new token(s)."""
+    @staticmethod
+    def left_pads(attention_mask: Optional[torch.Tensor], B: int, T: int):
+        """Per-row count of leading padding columns, or None when the mask is not left padding (a zero after a one)."""
+        if attention_mask is None:
+            return [0] * B
+        m = attention_mask[:, :T].ne(0)
+        pads = (~m).sum(dim=1)
+        ok = (m.long().cumsum(dim=1) == (torch.arange(T, device=m.device)[None, :] + 1 - pads[:, None]).clamp(min=0)).all()
+        return [int(p) for p in pads.tolist()] if bool(ok) else None
+
+    def _forward_cached(self, cache: AriaStaticKVCache, input_ids, pixel_values, pixel_mask, keep: int, attention_mask=None) -> torch.Tensor:
+        """One step of cached generation (modeling_aria.py:337-365 + gptfast/generate.py:71-110): the first call prefills every row's prompt
+        (image features merged once; a row identical to the one before it -- beams, ``num_return_sequences`` -- is copied, not recomputed),
+        later calls feed the new token of every row to the decode engine."""
         twin = cache.twin
-        if input_ids is None or input_ids.dim() != 2 or input_ids.shape[0] != 1:
-            raise NotImplementedError("cached generation serves batch 1 (input_ids [1, T]); pass use_cache=False for other shapes")
-        T = input_ids.shape[1]
+        if input_ids is None or input_ids.dim() != 2:
+            raise NotImplementedError("cached generation takes input_ids [B, T]; pass use_cache=False for other inputs")
+        B, T = input_ids.shape
         if cache.seen + T > cache.max_len:
             raise ValueError(f"AriaStaticKVCache of {cache.max_len} positions cannot take {cache.seen} + {T}")
         dev = input_ids.device
+        V = self.vocab_size
         with torch.no_grad():
-            if cache.seen == 0:                                   # prefill: ViT + projector once, all prompt positions into the cache
-                emb = twin.prepare_embeddings(input_ids, pixel_values, pixel_mask)
-                logits = twin(None, torch.arange(T, device=dev), emb, last_only=(keep == 1))
-            elif T == 1:                                          # decode: the native one-call-per-token engine
-                logits = twin(input_ids, torch.tensor([cache.seen], dtype=torch.int32, device=dev))
+            if cache.seen == 0:                                   # prefill: ViT + projector once per row, its prompt positions into its cache
+                pads = self.left_pads(attention_mask, B, T)
+                if pads is None or max(pads) >= T:
+                    raise NotImplementedError("cached generation serves unpadded or LEFT-padded prompts (HF's convention for decoder-only "
+                                              "generation); pass use_cache=False for other masks")
+                cache.ensure_rows(B)
+                n_img = [0] * B
+                if pixel_values is not None:
+                    side = pixel_values.shape[-1] // self.native_config.vision_config.patch_size
+                    q = self.native_config.projector_patch_to_query_dict[side * side]
+                    n_img = [int(c) // q for c in (input_ids == self.config.image_token_index).sum(dim=1).tolist()]
+                    if sum(n_img) != pixel_values.shape[0]:
+                        raise ValueError("Image features and image tokens do not match")          # modeling_aria.py:267-271
+                rows_logits, first = [], 0
+                for r in range(B):
+                    ids_r = input_ids[r:r + 1, pads[r]:]
+                    pv = pixel_values[first:first + n_img[r]] if n_img[r] else None
+                    pm = pixel_mask[first:first + n_img[r]] if (n_img[r] and pixel_mask is not None) else None
+                    same = (r > 0 and pads[r] == pads[r - 1] and n_img[r] == n_img[r - 1] and torch.equal(ids_r, input_ids[r - 1:r, pads[r - 1]:])
+                            and (pv is None or (torch.equal(pv, pixel_values[first - n_img[r]:first])
+                                                and (pm is None or torch.equal(pm, pixel_mask[first - n_img[r]:first])))))
+                    first += n_img[r]
+                    cache.rows[r].pads = pads[r]
+                    if same:                                      # an expanded copy of the previous row: its cache rows and logits are the same
+                        n = T - pads[r]
+                        for kv, src in zip(cache.rows[r].kv, cache.rows[r - 1].kv):
+                            kv.k[:, :n].copy_(src.k[:, :n]), kv.v[:, :n].copy_(src.v[:, :n])
+                        rows_logits.append(rows_logits[-1])
+                        continue
+                    with cache.bind(r):
+                        emb = twin.prepare_embeddings(ids_r, pv, pm)
+                        lg = twin(None, torch.arange(T - pads[r], device=dev), emb, last_only=(keep == 1))
+                    if keep != 1 and pads[r]:                     # full-length logits: pad columns read zero
+                        lg = torch.cat([lg.new_zeros((1, pads[r], V)), lg], dim=1)
+                    rows_logits.append(lg)
+                logits = torch.cat(rows_logits, dim=0)
+            elif T == 1:                                          # decode: the native one-call-per-token engine, row by row
+                if B != cache.batch:
+                    raise ValueError(f"AriaStaticKVCache holds {cache.batch} rows, input_ids has {B}")
+                out = torch.empty((B, 1, V), dtype=torch.bfloat16, device=dev)
+                for r in range(B):
+                    with cache.bind(r):
+                        out[r] = twin(input_ids[r:r + 1], torch.tensor([cache.seen - cache.rows[r].pads], dtype=torch.int32, device=dev))[0]
+                logits = out
             else:
                 raise NotImplementedError("several new tokens against a filled cache (assisted / speculative decoding): use use_cache=False")
         cache.seen += T
@@ -288,9 +411,7 @@ class AriaForConditionalGeneration(AriaPretrainedModel, GenerationMixin):
         if isinstance(past_key_values, AriaStaticKVCache):
             if labels is not None or inputs_embeds is not None or self.training:
                 raise NotImplementedError("AriaStaticKVCache is an inference cache: no labels / inputs_embeds / training mode")
-            if attention_mask is not None and not bool(attention_mask.ne(0).all()):
-                raise NotImplementedError("cached generation: padded prompts are not supported (batch 1 has nothing to pad)")
-            logits = self._forward_cached(past_key_values, input_ids, pixel_values, pixel_mask, keep)
+            logits = self._forward_cached(past_key_values, input_ids, pixel_values, pixel_mask, keep, attention_mask)
             return CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=past_key_values)
         if past_key_values is not None and not (hasattr(past_key_values, "get_seq_length") and past_key_values.get_seq_length() == 0):
             raise NotImplementedError("aria_amd HF surface: past_key_values must be an AriaStaticKVCache (model.make_cache(max_len))")
@@ -314,22 +435,26 @@ class AriaForConditionalGeneration(AriaPretrainedModel, GenerationMixin):
                 "num_logits_to_keep": 1, "use_cache": False}
 
     def generate(self, *args, **kwargs):
-        """HF ``generate`` with the static KV cache whenever the decode engine can serve the request (batch 1, no padding, eval mode, no
-        beam search); ``use_cache=False`` or any other request runs cache-free."""
+        """HF ``generate`` with the static KV cache whenever the decode engine can serve the request (any batch, unpadded or left-padded
+        prompts, sampling / greedy / beam search, eval mode); ``use_cache=False``, assisted decoding or other masks run cache-free."""
         use_cache = kwargs.pop("use_cache", True)
         input_ids = kwargs.get("input_ids", args[0] if args else kwargs.get("inputs"))
         am = kwargs.get("attention_mask")
         gc = kwargs.get("generation_config") or self.generation_config
         beams = kwargs.get("num_beams", getattr(gc, "num_beams", 1)) or 1
         servable = (use_cache is not False and kwargs.get("past_key_values") is None and torch.is_tensor(input_ids) and input_ids.dim() == 2
-                    and input_ids.shape[0] == 1 and (am is None or bool(am.ne(0).all())) and beams == 1 and not self.training
-                    and kwargs.get("assistant_model") is None and (kwargs.get("num_return_sequences") or 1) == 1)
+                    and input_ids.shape[0] >= 1 and not self.training and kwargs.get("assistant_model") is None)
+        if servable:
+            pads = self.left_pads(am, *input_ids.shape)
+            servable = pads is not None and max(pads) < input_ids.shape[1]
         if servable:
             T = input_ids.shape[1]
+            nret = kwargs.get("num_return_sequences", getattr(gc, "num_return_sequences", 1)) or 1
+            rows = input_ids.shape[0] * max(int(beams), 1) * (int(nret) if int(beams) == 1 else 1)
             max_new = kwargs.get("max_new_tokens", getattr(gc, "max_new_tokens", None))
             max_len = kwargs.get("max_length", getattr(gc, "max_length", None))
             total = T + int(max_new) if max_new is not None else max(int(max_len or 0), T + 1)
-            kwargs["past_key_values"] = self.make_cache(total + 1)
+            kwargs["past_key_values"] = self.make_cache(total + 1, rows)
             kwargs["use_cache"] = True
         elif not isinstance(kwargs.get("past_key_values"), AriaStaticKVCache):
             kwargs["use_cache"] = False

@@ -22,7 +22,7 @@ ALG = {  # algorithmic bytes per launch
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").strip()[:80]
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()[:80]
 
 
 for target in sys.argv[1:]:
