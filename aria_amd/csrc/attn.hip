@@ -121,6 +121,19 @@ inline unsigned attn_grid(long long nblk, long long H, long long B) { return uns
 // read and no VALU repacking), softmax in the log2 domain on v_exp_f32 with the scale folded in, lazy (wave-uniform)
 // rescale, mask arithmetic only on edge / diagonal / padded tiles, native head dims 64 / 72 / 128 (72 = ViT and
 // projector: reduction padded to 80, output tiles 32+32+8).
+// Timing-only ablations of attn_fwd2_kernel (tools/probes/attn_fwd_ablate.py builds the variants; results are garbage by design):
+// 1 no QK MFMAs, 2 no exponentials, 4 no PV MFMAs (nor V reads), 8 V fragments not read (MFMAs stay), 16 K fragments not read, 32 next tile
+// neither loaded nor staged, 64 no barrier, 128 no running-maximum update.  0 in the library: every branch below folds away.
+#ifndef ARIA_ATTN_ABL
+#define ARIA_ATTN_ABL 0
+#endif
+template <typename T>
+__device__ __forceinline__ void abl_keep(const T& v) {
+#ifndef ARIA_EMU
+    asm volatile("" : : "v"(v));
+#endif
+}
+
 template <int HD, int NW = 8>
 struct Cfg2 {
     static constexpr int NT2 = NW * 64;   // threads per block
@@ -229,9 +242,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
         }
     }
     for (int it = 0; it < ntiles; ++it) {
-        sync();  // tile `it` complete in buffer it&1; every wave is done reading the other buffer
+        if (!(ARIA_ATTN_ABL & 64)) sync();  // tile `it` complete in buffer it&1; every wave is done reading the other buffer
         const int cur = it & 1, kv0 = it * 64;
-        const bool more = it + 1 < ntiles;
+        const bool more = it + 1 < ntiles && !(ARIA_ATTN_ABL & 32);
         if (more) {
             tile2_load<HD, NW>(rk, Kb, ldk, kv0 + 64, S, t);
             tile2_load<HD, NW>(rv, Vb, ldv, kv0 + 64, S, t);
@@ -244,10 +257,20 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
             f32x16 st[2];
             st[0] = zero_acc();
             st[1] = zero_acc();
+            if (ARIA_ATTN_ABL & 1) {
 #pragma unroll
-            for (int kk = 0; kk < C::KS; ++kk)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) st[i] = mfma32(*reinterpret_cast<const s16x8*>(cK + (i * 32 + (l & 31)) * C::KP + kk * 16 + h2 * 8), qf[kk], st[i]);
+                    for (int r = 0; r < 16; ++r) st[i][r] = float((it * 7 + r * 3 + i + l) & 31) * 0.03125f;
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < C::KS; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        st[i] = mfma32((ARIA_ATTN_ABL & 16) ? qf[(kk + i) % C::KS]
+                                                            : *reinterpret_cast<const s16x8*>(cK + (i * 32 + (l & 31)) * C::KP + kk * 16 + h2 * 8),
+                                       qf[kk], st[i]);
+            }
             const bool need_mask = (kv0 + 64 > klen) || (causal && kv0 + 63 > q_wmin) || (kmb && !(sFlag[cur] & 1));
             if (need_mask) {
                 const uint8_t* cM = sM + cur * 64;
@@ -263,11 +286,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
                     }
             }
             float mx = st[0][0];
+            if (!(ARIA_ATTN_ABL & 128)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[i][r]);
-            mx = fmaxf(mx, shfl_xor(mx, 32));
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[i][r]);
+                mx = fmaxf(mx, shfl_xor(mx, 32));
+            } else {
+                mx = 8.f;
+            }
             const float m_new = fmaxf(m, mx * scale2);
             const float m_safe = m_new == -INFINITY ? 0.f : m_new;
             if (ballot(m_new > m) != 0ull) {  // wave-uniform lazy rescale: exact (alpha == 1 whenever it is skipped)
@@ -284,7 +311,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = exp2_fast(st[i][r] * scale2 - m_safe);
+                    const float p = (ARIA_ATTN_ABL & 2) ? st[i][r] * scale2 - m_safe : exp2_fast(st[i][r] * scale2 - m_safe);
                     st[i][r] = p;
                     if (!C::ROWSUM_IN_MFMA) ps += p;
                 }
@@ -295,16 +322,24 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const s16x8 pf = pack_frag(st[i], u);
+                    if (ARIA_ATTN_ABL & 4) {
+                        abl_keep(pf);
+                        continue;
+                    }
                     const bf16_t* vrow = cV + (i * 32 + 16 * u + 4 * h2 + ((l & 15) >> 2)) * C::VP + 16 * ((l >> 4) & 1) + 4 * (l & 3);
 #pragma unroll
                     for (int dt = 0; dt < C::DT; ++dt) {
-                        const s16x4 a0 = ds_read_tr16(vrow + 32 * dt);
-                        const s16x4 a1 = ds_read_tr16(vrow + 8 * C::VP + 32 * dt);
                         s16x8 vf;
+                        if (ARIA_ATTN_ABL & 8) {
+                            vf = qf[dt];
+                        } else {
+                            const s16x4 a0 = ds_read_tr16(vrow + 32 * dt);
+                            const s16x4 a1 = ds_read_tr16(vrow + 8 * C::VP + 32 * dt);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            vf[e] = a0[e];
-                            vf[4 + e] = a1[e];
+                            for (int e = 0; e < 4; ++e) {
+                                vf[e] = a0[e];
+                                vf[4 + e] = a1[e];
+                            }
                         }
                         o[dt] = mfma32(vf, pf, o[dt]);
                     }

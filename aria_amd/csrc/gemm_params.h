@@ -102,8 +102,11 @@ __device__ __forceinline__ bool aria_grouped_tile(const P& p, int bid, int l, in
     const int loF = int((long long)TF * xcd / 8), nF = int((long long)TF * (xcd + 1) / 8) - loF;
     const int loR = int((long long)TR * xcd / 8), nR = int((long long)TR * (xcd + 1) / 8) - loR;
     if (idx >= nF + nR) return false;
-    const bool ragged = idx >= nF;
-    const int v = ragged ? loR + idx - nF : loF + idx;
+    // bit 11 (with bit 9): the ragged tiles FIRST -- the short tiles open every XCD's run, where all 32 CUs start
+    // together anyway, and the run ends on full tiles, whose partial last round costs what it always costs
+    const bool rfirst = (p.order >> 11) & 1;
+    const bool ragged = rfirst ? idx < nR : idx >= nF;
+    const int v = ragged ? loR + idx - (rfirst ? 0 : nF) : loF + idx - (rfirst ? nR : 0);
     int base = 0;
     for (int e0 = 0; e0 < p.E; e0 += 64) {
         const int e = e0 + l;

@@ -23,7 +23,7 @@ cases = {
     "fc1 dgrad": (f1, lambda i: ops.grouped_gemm(dy1[i % 2], w1[i % 3], offd, w_is_kn=False, out=din)),
 }
 for rep in range(2):
-    for order in ("4", "516"):
+    for order in ("4", "516", "2564"):   # default; ragged-last (bit 9); ragged-first (bits 9 + 11)
         os.environ["ARIA_GEMM_ORDER"] = order
         for name, (fl, fn) in cases.items():
             it = [0]
