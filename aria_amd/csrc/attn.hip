@@ -1097,6 +1097,309 @@ __global__ __launch_bounds__(512) void attn_bwd5_dq_kernel(const bf16_t* Q, cons
 }
 
 
+// =========================================================================================== forward v3 (hd 128 / 72): software-pipelined
+// Round 4.  An ablation of attn_fwd2 (profiles/r04_attn_fwd_ablate.json) showed what a key tile's time is made of: the vector ALU alone
+// (scaling, v_exp_f32 at quarter rate, packing) needs 1.22 ms of the ViT launch's 2.26, the matrix pipe with its fragment reads alone 1.6 --
+// their SUM, not their maximum, is what the kernel took (hd 128 at 64K: 9.2 + 15.6 against 23.2), and staging the next tile through
+// registers + ds_write_b128 (13 LDS cycles per wave-instruction) another 15-20 %.  A wave's own chain QK -> softmax -> PV leaves nothing
+// for the other pipe to do, and the tile barrier puts both waves of a SIMD into the same phase.  Here:
+//   * the score tile of key tile t + 1 is computed INSIDE the block that runs the softmax and P V of tile t (S^T double-buffered in
+//     registers, loop unrolled by two so no copies): 16 + 16 (hd 72: 10 + 12) MFMAs and the tile's ~100 vector instructions are
+//     independent work in ONE basic block for the scheduler to interleave -- every wave feeds both pipes all the time;
+//   * K runs one tile ahead of V in LDS; both arrive by LDS-DMA (no staging registers, no ds_write pass), one barrier per tile;
+//   * hd 128: the backward kernels' tile image (256-byte rows, chunk swizzle swz3: conflict-free for the row fragments and the
+//     transposing reads).  hd 72: K rows of 144 bytes as they are (36 dwords: the 16 rows of a ds_read_b128 lane group hit 16 different
+//     bank quads; the reduction's 8 pad columns read the next row's first chunk against Q's zero pad); V rows of 160 bytes = 9 data chunks
+//     + one constant chunk [1, 0 x 7] fetched from a device constant (the "ones" column that puts the softmax denominator on the matrix
+//     pipe, as in v2), key j stored at row rho(j) = 8 (j >> 3) + 2 (j & 3) + ((j >> 2) & 1) so that the four keys of a transposing read lie
+//     16 banks apart.
+// Same arithmetic in the same order as v2: results are bit-identical (tests compare the two).
+__device__ const uint32_t aria_ones_chunk[4] = {0x00003F80u, 0u, 0u, 0u};  // bf16 {1, 0, 0, 0, 0, 0, 0, 0}
+
+template <int HD>
+struct FwdFmt;
+template <>
+struct FwdFmt<128> {
+    static constexpr int KS = 8, DT = 4, KTILE = 16384, VTILE = 16384;
+    static constexpr bool ROWSUM_IN_MFMA = false;
+    int dummy;
+    __device__ __forceinline__ void init(int, int) {}
+    __device__ __forceinline__ void dma_k(const bf16_t* base, long long ld, int row0, int row_last, char* s, int w, int l) const {
+        tile_dma3<128>(base, int(ld), row0, row_last, s, w, l);
+    }
+    __device__ __forceinline__ void dma_v(const bf16_t* base, long long ld, int row0, int row_last, char* s, int w, int l) const {
+        tile_dma3<128>(base, int(ld), row0, row_last, s, w, l);
+    }
+    static __device__ __forceinline__ s16x8 kfrag(const char* s, int row, int kk, int l) { return frag_rc3<128>(s, row, kk, l); }
+    static __device__ __forceinline__ s16x8 vfrag(const char* s, int rb, int d0, int l) { return frag_tr3<128>(s, rb, d0, l); }
+};
+template <>
+struct FwdFmt<72> {
+    static constexpr int KS = 5, DT = 3, KROW = 144, VROW = 160;
+    static constexpr int KTILE = 64 * KROW + 16, VTILE = 64 * VROW + 32;  // (+ what the last row's pad-column reads touch)
+    static constexpr bool ROWSUM_IN_MFMA = true;
+    // per-lane constants of the DMA pieces: K piece p holds image chunks 64 p + l = (row, chunk) = (q / 9, q % 9); V piece p the chunks
+    // (LDS row R, chunk) = (q / 10, q % 10), LDS row R holding key 8 (R >> 3) + 4 (R & 1) + ((R >> 1) & 3)
+    int krow[2], kcol[2], vkey[2], vcol[2];
+    __device__ __forceinline__ void init(int w, int l) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = i == 0 ? w : 8 + w;  // second pieces: K has one (wave 0), V two (waves 0, 1)
+            const int qk = 64 * p + l, qv = 64 * p + l;
+            krow[i] = qk / 9, kcol[i] = (qk % 9) * 8;
+            const int R = qv / 10;
+            vkey[i] = 8 * (R >> 3) + 4 * (R & 1) + ((R >> 1) & 3), vcol[i] = (qv % 10) * 8;
+        }
+    }
+    __device__ __forceinline__ void dma_k(const bf16_t* base, long long ld, int row0, int row_last, char* s, int w, int l) const {
+        glds16_raw(base + (long long)min(row0 + krow[0], row_last) * ld + kcol[0], s + w * 1024);
+        if (w == 0) glds16_raw(base + (long long)min(row0 + krow[1], row_last) * ld + kcol[1], s + 8 * 1024);
+    }
+    __device__ __forceinline__ void dma_v(const bf16_t* base, long long ld, int row0, int row_last, char* s, int w, int l) const {
+        const bf16_t* ones = reinterpret_cast<const bf16_t*>(aria_ones_chunk);
+        glds16_raw(vcol[0] < 72 ? base + (long long)min(row0 + vkey[0], row_last) * ld + vcol[0] : ones, s + w * 1024);
+        if (w < 2) glds16_raw(vcol[1] < 72 ? base + (long long)min(row0 + vkey[1], row_last) * ld + vcol[1] : ones, s + (8 + w) * 1024);
+    }
+    static __device__ __forceinline__ s16x8 kfrag(const char* s, int row, int kk, int l) {
+        return *reinterpret_cast<const s16x8*>(s + row * KROW + kk * 32 + (l >> 5) * 16);
+    }
+    // fragment of feature columns d0 .. d0 + 31 whose 8 k-slots are keys rb + 4 h + (e & 3) + 8 (e >> 2); rb % 16 == 0
+    static __device__ __forceinline__ s16x8 vfrag(const char* s, int rb, int d0, int l) {
+        const int R0 = rb + 2 * ((l & 15) >> 2) + (l >> 5);  // rho(rb + 4 h + c) = rb + 2 c + h;  rho(.. + 8) = R0 + 8
+        const int col = d0 + 16 * ((l >> 4) & 1) + 4 * (l & 3);
+        const s16x4 a0 = ds_read_tr16(reinterpret_cast<const bf16_t*>(s + R0 * VROW + col * 2));
+        const s16x4 a1 = ds_read_tr16(reinterpret_cast<const bf16_t*>(s + (R0 + 8) * VROW + col * 2));
+        s16x8 f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[e] = a0[e];
+            f[4 + e] = a1[e];
+        }
+        return f;
+    }
+};
+
+template <int HD>
+struct Fwd3Smem {
+    using F = FwdFmt<HD>;
+    static constexpr int K0 = 0, V0 = 2 * F::KTILE, M0 = V0 + 2 * F::VTILE, FLAG0 = M0 + 3 * 64, BYTES = FLAG0 + 16;
+};
+
+// S^T tile of one key tile: rows = keys (two sub-tiles of 32), cols = this wave's 32 queries
+template <int HD>
+__device__ __forceinline__ void fwd3_qk(f32x16 (&st)[2], const char* cK, const s16x8 (&qf)[FwdFmt<HD>::KS], int l) {
+    st[0] = zero_acc();
+    st[1] = zero_acc();
+#pragma unroll
+    for (int kk = 0; kk < FwdFmt<HD>::KS; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) st[i] = mfma32(FwdFmt<HD>::kfrag(cK, i * 32 + (l & 31), kk, l), qf[kk], st[i]);
+}
+
+// key-mask / length / causal mask of one score tile (edge, diagonal and padded tiles only)
+__device__ __forceinline__ void fwd3_mask(f32x16 (&st)[2], const uint8_t* cM, bool use_km, int kv0, int klen, int causal, int q_abs, int l) {
+    hold(l);  // (the 32 row indices below are loop invariants: hoisted out of the tile loop they would sit in 32+ VGPRs across the hot block)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kvl = i * 32 + acc_row(r, l);
+            const int kv = kv0 + kvl;
+            bool dead = kv >= klen || (causal && kv > q_abs);
+            if (use_km) dead = dead || !cM[kvl];
+            if (dead) st[i][r] = -INFINITY;
+        }
+}
+
+// One key tile of the pipelined loop: softmax + P V of the tile whose (masked) scores are in `st`, and the scores of the following tile
+// into `sn` (ALWAYS: behind a wave's last tile the image it reads is a stale or never-written buffer and the result is dropped -- one code
+// path keeps the accumulators in place; every extra variant of this block cost a second register copy of O^T at the merge points).  After the running-maximum update the tile is cut into FOUR sub-steps, one per 16-key group (i, u) of the P V product:
+//     a quarter of the next tile's score MFMAs | the group's 8 exponentials + packing | the group's P V MFMAs (one per 32 features)
+// -- independent matrix and vector work side by side in every sub-step; scheduling fences between the sub-steps keep the compiler from
+// hoisting all fragment reads of the tile to the top (256 VGPRs and spills without them).
+template <int HD>
+__device__ __forceinline__ void fwd3_step(f32x16 (&st)[2], f32x16 (&sn)[2], f32x16 (&o)[FwdFmt<HD>::DT], float& m, float& lsum,
+                                          const s16x8 (&qf)[FwdFmt<HD>::KS], const char* cV, const char* nK, float scale2, int l) {
+    using F = FwdFmt<HD>;
+    constexpr int KS = F::KS;
+    float mx = st[0][0];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[i][r]);
+    mx = fmaxf(mx, shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx * scale2);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    if (ballot(m_new > m) != 0ull) {  // wave-uniform lazy rescale: exact (alpha == 1 whenever it is skipped)
+        const float alpha = exp2_fast(m - m_safe);
+        if (!F::ROWSUM_IN_MFMA) lsum *= alpha;
+#pragma unroll
+        for (int i = 0; i < F::DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        m = m_new;
+    }
+    sn[0] = zero_acc();
+    sn[1] = zero_acc();
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = j >> 1, u = j & 1;
+        sched_fence();
+        // k-steps [KS j / 4, KS (j + 1) / 4) of the next tile's scores (hd 128: 2 of 8; hd 72: 1, 1, 1, 2 of 5)
+#pragma unroll
+        for (int kk = KS * j / 4; kk < KS * (j + 1) / 4; ++kk)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) sn[ii] = mfma32(F::kfrag(nK, ii * 32 + (l & 31), kk, l), qf[kk], sn[ii]);
+#pragma unroll
+        for (int r = 8 * u; r < 8 * u + 8; ++r) {
+            const float p = exp2_fast(st[i][r] * scale2 - m_safe);
+            st[i][r] = p;
+            if (!F::ROWSUM_IN_MFMA) ps += p;
+        }
+        const s16x8 pf = pack_frag(st[i], u);
+#pragma unroll
+        for (int dt = 0; dt < F::DT; ++dt) o[dt] = mfma32(F::vfrag(cV, i * 32 + 16 * u, 32 * dt, l), pf, o[dt]);
+    }
+    sched_fence();
+    if (!F::ROWSUM_IN_MFMA) lsum += ps;
+}
+
+template <int HD>
+__global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE,
+                                                        const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
+                                                        long long ldq, long long ldk, long long ldv, long long ldo, float scale,
+                                                        int causal, int nbatch) {
+    using F = FwdFmt<HD>;
+    using L = Fwd3Smem<HD>;
+    constexpr int KS = F::KS, DT = F::DT;
+    ARIA_DYN_SMEM(smem);
+    char* sK = smem + L::K0;
+    char* sV = smem + L::V0;
+    uint8_t* sM = reinterpret_cast<uint8_t*>(smem + L::M0);   // [3][64]: the key-mask bytes of tiles t, t + 1, t + 2
+    int* sFlag = reinterpret_cast<int*>(smem + L::FLAG0);     // [3]: bit 0 every key of the tile valid, bit 1 none
+    const int t = threadIdx.x, l = t & 63, w = first_lane(t >> 6), h2 = l >> 5;
+    int qblk, head, b;
+    if (!attn_block_coords((Sq + 255) / 256, H, nbatch, causal, true, qblk, head, b)) return;
+    const int q0 = qblk * 256;
+    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
+    const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
+    const bf16_t* Kb = K + tok0 * ldk + head * HD;
+    const bf16_t* Vb = V + tok0 * ldv + head * HD;
+    const uint8_t* kmb = key_mask ? key_mask + tok0 : nullptr;
+    const int q_wmin = q0 + 32 * w, q_abs = q_wmin + (l & 31);
+    const int klen = kv_len ? min(S, kv_len[b]) : S;
+    const float scale2 = scale * 1.4426950408889634f;
+    F fmt;
+    fmt.init(w, l);
+
+    s16x8 qf[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        u32x4 v = zero16();
+        const int col = kk * 16 + h2 * 8;
+        if (q_abs < Sq && col < HD) v = ld16(Qb + (long long)q_abs * ldq + col);
+        qf[kk] = __builtin_bit_cast(s16x8, v);
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] = zero_acc();
+    float m = -INFINITY, lsum = 0.f;
+    int kv_end = klen;
+    if (causal) kv_end = min(kv_end, q0 + 256);
+    const int ntiles = (kv_end + 63) / 64;
+
+    // key-mask bytes of one tile -> ring slot tile % 3 (threads 0..63: wave 0)
+    auto mask_fetch = [&](int tile) __attribute__((always_inline)) -> uint8_t { return (tile * 64 + t < S) ? kmb[tile * 64 + t] : uint8_t(0); };
+    auto mask_park = [&](int tile, uint8_t mv) __attribute__((always_inline)) {
+        sM[(tile % 3) * 64 + t] = mv;
+        const unsigned long long all = ballot(mv != 0);
+        if (t == 0) sFlag[tile % 3] = int(all == ~0ull) | (int(all == 0ull) << 1);
+    };
+    if (ntiles > 0) {
+        if (HD == 72) {  // what the pad-column reads behind the last rows touch must hold finite values (0 x NaN = NaN)
+            if (t < 2) st16(sK + t * F::KTILE + F::KTILE - 16, zero16());
+            if (t >= 64 && t < 68) st16(sV + ((t - 64) >> 1) * F::VTILE + F::VTILE - 32 + 16 * (t & 1), zero16());
+        }
+        fmt.dma_k(Kb, ldk, 0, S - 1, sK, w, l);
+        fmt.dma_v(Vb, ldv, 0, S - 1, sV, w, l);
+        if (ntiles > 1) fmt.dma_k(Kb, ldk, 64, S - 1, sK + F::KTILE, w, l);
+        if (kmb && t < 64) {
+            mask_park(0, mask_fetch(0));
+            if (ntiles > 1) mask_park(1, mask_fetch(1));
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) settle(qf[kk]);
+    // tiles this wave works on: the causal diagonal ends its run early (the workgroup's later tiles hold no key it may see); a tile
+    // WITHOUT a valid key (padded image rows) is worked on like any other -- every probability is exp2(-inf) = 0 and the running maximum
+    // does not move, so it contributes exactly nothing (v2 skipped it; same bits)
+    const int nmine = causal ? min(ntiles, (q_wmin + 31) / 64 + 1) : ntiles;
+    auto tile_masked = [&](int tile) __attribute__((always_inline)) -> bool {
+        return (tile * 64 + 64 > klen) || (causal && tile * 64 + 63 > q_wmin) || (kmb && !(sFlag[tile % 3] & 1));
+    };
+    // the part of an iteration every wave owes the workgroup: the tile barrier, its DMA pieces of K(it + 2) / V(it + 1), the mask bytes
+    uint8_t mv = 0;
+    auto duties = [&](int it) __attribute__((always_inline)) {
+        wait_vm<0>();  // this wave's pieces of K(it + 1) and V(it) have landed
+        sync();        // ... everybody's; every wave is done with K(it) and V(it - 1)
+        if (it + 2 < ntiles) fmt.dma_k(Kb, ldk, (it + 2) * 64, S - 1, sK + (it & 1) * F::KTILE, w, l);
+        if (it + 1 < ntiles) fmt.dma_v(Vb, ldv, (it + 1) * 64, S - 1, sV + ((it + 1) & 1) * F::VTILE, w, l);
+        if (kmb && t < 64 && it + 2 < ntiles) mv = mask_fetch(it + 2);
+    };
+    auto park = [&](int it) __attribute__((always_inline)) {
+        if (kmb && t < 64 && it + 2 < ntiles) mask_park(it + 2, mv);
+    };
+    f32x16 sa[2], sb[2];
+    if (ntiles > 0) {
+        wait_vm<0>();
+        sync();
+        if (nmine > 0) fwd3_qk<HD>(sa, sK, qf, l);
+    }
+    // one iteration: tile `it` (scores in `cur`) -> softmax + P V; tile it + 1 -> scores into `nxt`
+    auto iterate = [&](int it, f32x16 (&cur)[2], f32x16 (&nxt)[2]) __attribute__((always_inline)) {
+        duties(it);
+        if (tile_masked(it)) fwd3_mask(cur, sM + (it % 3) * 64, kmb != nullptr, it * 64, klen, causal, q_abs, l);
+        fwd3_step<HD>(cur, nxt, o, m, lsum, qf, sV + (it & 1) * F::VTILE, sK + ((it + 1) & 1) * F::KTILE, scale2, l);
+        park(it);
+    };
+    int it = 0;
+    for (; it + 1 < nmine; it += 2) {
+        iterate(it, sa, sb);
+        iterate(it + 1, sb, sa);
+    }
+    if (it < nmine) {
+        iterate(it, sa, sb);
+        ++it;
+    }
+    for (; it < ntiles; ++it) {  // the workgroup's remaining tiles (other waves' diagonals): barriers and staging only
+        duties(it);
+        park(it);
+    }
+    // ROWSUM_IN_MFMA: feature row HD = 32 (DT-1) + 8 sits in accumulator register 4 of the lanes with h2 == 0
+    const float ltot = F::ROWSUM_IN_MFMA ? shfl(o[DT - 1][4], l & 31) : lsum + shfl_xor(lsum, 32);
+    const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+    if (q_abs < Sq) {
+        if (h2 == 0 && LSE)
+            LSE[((long long)b * H + head) * Sq + q_abs] = (ltot > 0.f) ? (m + log2f(ltot)) * 0.6931471805599453f : -INFINITY;
+        bf16_t* orow = O + (tokq0 + q_abs) * ldo + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d0 = 32 * dt + 8 * rg + 4 * h2;
+                if (d0 < HD) {
+                    u32x2 v;
+                    v[0] = pack2bf(o[dt][4 * rg] * inv, o[dt][4 * rg + 1] * inv);
+                    v[1] = pack2bf(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
+                    *reinterpret_cast<u32x2*>(orow + d0) = v;
+                }
+            }
+    }
+}
+
+
+thread_local int g_last_fwd_variant = 0;  // 2: attn_fwd2 (staged through registers), 3: attn_fwd3 (software-pipelined, LDS-DMA)
 thread_local int g_last_bwd_variant = 0;  // 2: the padded-tile pair (hd 64 / 72), 5: role-split dK/dV + dQ v5 (hd 128) -- tests assert which ran
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -1115,7 +1418,18 @@ int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     if (B == 0 || Sq == 0) return ARIA_OK;
     const bf16_t *Q = static_cast<const bf16_t*>(q), *K = static_cast<const bf16_t*>(k), *V = static_cast<const bf16_t*>(v);
     const char* nw72 = std::getenv("ARIA_ATTN_HD72_WAVES");  // "8": the two-waves-per-SIMD variant (A/B measurements)
-    if (hd == 128)
+    const char* fwdv = std::getenv("ARIA_ATTN_FWD");          // "2": the round-1..3 kernels (A/B measurements, bit-identity tests)
+    const bool v3 = !(fwdv && fwdv[0] == '2') && (hd == 128 || hd == 72) && Skv > 0;
+    g_last_fwd_variant = v3 ? 3 : 2;
+    if (v3 && hd == 128)
+        ARIA_LAUNCH((attn_fwd3_kernel<128>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Fwd3Smem<128>::BYTES), stream, Q, K, V,
+                    static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
+                    (long long)ldv, (long long)ldo, scale, causal, int(B));
+    else if (v3)
+        ARIA_LAUNCH((attn_fwd3_kernel<72>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Fwd3Smem<72>::BYTES), stream, Q, K, V,
+                    static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
+                    (long long)ldv, (long long)ldo, scale, causal, int(B));
+    else if (hd == 128)
         ARIA_LAUNCH((attn_fwd2_kernel<128, 8>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Cfg2<128>::SMEM), stream, Q, K, V,
                     static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
                     (long long)ldv, (long long)ldo, scale, causal, int(B));
@@ -1135,6 +1449,7 @@ int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
 }
 
 int aria_last_attn_bwd_variant(void) { return g_last_bwd_variant; }
+int aria_last_attn_fwd_variant(void) { return g_last_fwd_variant; }
 
 int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
                   void* dq, void* dk, void* dv, const int32_t* kv_len, const uint8_t* key_mask, int64_t B, int64_t Sq, int64_t Skv,

@@ -31,6 +31,7 @@ SIGNATURES = {
     "aria_abi_version": [],
     "aria_last_gemm_variant": [],
     "aria_last_attn_bwd_variant": [],
+    "aria_last_attn_fwd_variant": [],
     "aria_decode_scratch_bytes": [P],
     "aria_decode_token": [P, P, F32, P],
     "aria_decode_route": [P, I64, I64, P, P, P],

@@ -230,6 +230,9 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
 
 /* which backward the calling thread's last aria_attn_bwd ran: 2 = padded-tile pair (hd 64 / 72), 5 = role-split dK/dV + dQ v5 (hd 128) */
 int aria_last_attn_bwd_variant(void);
+/* which forward the calling thread's last aria_attn_fwd launched: 3 = attn_fwd3 (hd 128 / 72: software-pipelined score tiles, K / V by
+ * LDS-DMA), 2 = attn_fwd2 (hd 64; or ARIA_ATTN_FWD=2: the round-3 kernels for A/B runs and the bit-identity tests) */
+int aria_last_attn_fwd_variant(void);
 
 /* ------------------------------------------------------------------------------------------------
  * ViT / projector support (vit.hip)
