@@ -793,6 +793,12 @@ __device__ __forceinline__ s16x8 frag_tr3(const char* s, int rb, int d0, int l) 
     return f;
 }
 
+// Timing-only ablations of attn_bwd3_dkdv_kernel (tools/probes/build_attn_abl.sh with -DARIA_DKDV_ABL; results are garbage by design):
+// 1 no first GEMM (S / dP), 2 no exponentials, 4 no second GEMM (dV / dK), 8 no P exchange through LDS, 16 no mid-tile barrier,
+// 32 next tile not staged, 64 no tile barrier, 128 role B's dS arithmetic off.
+#ifndef ARIA_DKDV_ABL
+#define ARIA_DKDV_ABL 0
+#endif
 // grid (H, B, ceil(S/128)), 512 threads: wave pair (g, g + 4) owns keys kv0 + 32 g + (l & 31); loop over 64-query tiles
 template <int HD>
 __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
@@ -855,9 +861,9 @@ __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, co
     }
     for (int it = 0; it < ntiles; ++it) {
         wait_vm<0>();  // this wave's LDS-DMA pieces of tile `it` have landed
-        sync();  // tile `it` is complete in buffer it & 1; the other buffer and the P exchange are free
+        if (!(ARIA_DKDV_ABL & 64)) sync();  // tile `it` is complete in buffer it & 1; the other buffer and the P exchange are free
         const int cur = it & 1, qt0 = q_begin + it * 64;
-        const bool more = it + 1 < ntiles;
+        const bool more = it + 1 < ntiles && !(ARIA_DKDV_ABL & 32);
         // next tile straight into the other buffer by LDS-DMA (its last readers finished before the barrier): no staging registers, no
         // ds_write pass; issued as the kernel's own instruction so that the compiler does not drain it in front of the next LDS read
         float lse_n = 0.f, del_n = 0.f;
@@ -879,10 +885,17 @@ __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, co
         if (active) {
             sc[0] = zero_acc();
             sc[1] = zero_acc();
+            if (ARIA_DKDV_ABL & 1) {
 #pragma unroll
-            for (int kk = 0; kk < C::KS; ++kk)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) sc[i] = mfma32(frag_rc3<HD>(first, i * 32 + (l & 31), kk, l), of[kk], sc[i]);
+                    for (int r = 0; r < 16; ++r) sc[i][r] = float((it * 5 + r * 3 + i + l) & 31) * 0.03125f;
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < C::KS; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) sc[i] = mfma32(frag_rc3<HD>(first, i * 32 + (l & 31), kk, l), of[kk], sc[i]);
+            }
             if (role == 0) {
                 const float* cL = sLse + cur * 64;
                 const bool need_mask = !all_keys_ok || (qt0 + 64 > Sq) || (causal && kv_wmin + 31 > qt0);
@@ -894,7 +907,7 @@ __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, co
                         f32x4 pv;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float p = exp2_fast(sc[i][4 * rg + e] * scale2 - ls[e]);
+                            float p = (ARIA_DKDV_ABL & 2) ? sc[i][4 * rg + e] * scale2 - ls[e] : exp2_fast(sc[i][4 * rg + e] * scale2 - ls[e]);
                             if (need_mask) {
                                 const int q = qt0 + i * 32 + 8 * rg + 4 * h2 + e;
                                 if (!(q < Sq && key_ok && !(causal && kv_abs > q))) p = 0.f;
@@ -902,19 +915,19 @@ __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, co
                             sc[i][4 * rg + e] = p;
                             pv[e] = p;
                         }
-                        *reinterpret_cast<f32x4*>(myP + (i * 4 + rg) * 1024) = pv;
+                        if (!(ARIA_DKDV_ABL & 8)) *reinterpret_cast<f32x4*>(myP + (i * 4 + rg) * 1024) = pv;
                     }
             }
         }
-        sync();  // P published
+        if (!(ARIA_DKDV_ABL & 16)) sync();  // P published
         if (active) {
-            if (role == 1) {
+            if (role == 1 && !(ARIA_DKDV_ABL & 128)) {
                 const float* cD = sDel + cur * 64;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
-                        const f32x4 pv = *reinterpret_cast<const f32x4*>(myP + (i * 4 + rg) * 1024);
+                        const f32x4 pv = (ARIA_DKDV_ABL & 8) ? f32x4{0.5f, 0.25f, 0.125f, 1.f} : *reinterpret_cast<const f32x4*>(myP + (i * 4 + rg) * 1024);
                         const f32x4 dl = *reinterpret_cast<const f32x4*>(cD + i * 32 + 8 * rg + 4 * h2);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) sc[i][4 * rg + e] = pv[e] * (sc[i][4 * rg + e] - dl[e]) * scale;
@@ -925,6 +938,10 @@ __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, co
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const s16x8 pf = pack_frag(sc[i], u);
+                    if (ARIA_DKDV_ABL & 4) {
+                        abl_keep(pf);
+                        continue;
+                    }
 #pragma unroll
                     for (int dt = 0; dt < C::DT; ++dt) acc[dt] = mfma32(pf, frag_tr3<HD>(second, i * 32 + 16 * u, 32 * dt, l), acc[dt]);
                 }
@@ -1123,7 +1140,7 @@ struct FwdFmt<128> {
     static constexpr int KS = 8, DT = 4, KTILE = 16384, VTILE = 16384;
     static constexpr bool ROWSUM_IN_MFMA = false;
     int dummy;
-    __device__ __forceinline__ void init(int, int) {}
+    __device__ __forceinline__ void init(int, int, int) {}  // (tile_dma3: 8 waves x 2 pieces)
     __device__ __forceinline__ void dma_k(const bf16_t* base, long long ld, int row0, int row_last, char* s, int w, int l) const {
         tile_dma3<128>(base, int(ld), row0, row_last, s, w, l);
     }
@@ -1140,11 +1157,14 @@ struct FwdFmt<72> {
     static constexpr bool ROWSUM_IN_MFMA = true;
     // per-lane constants of the DMA pieces: K piece p holds image chunks 64 p + l = (row, chunk) = (q / 9, q % 9); V piece p the chunks
     // (LDS row R, chunk) = (q / 10, q % 10), LDS row R holding key 8 (R >> 3) + 4 (R & 1) + ((R >> 1) & 3)
-    int krow[2], kcol[2], vkey[2], vcol[2];
-    __device__ __forceinline__ void init(int w, int l) {
+    // (wave w issues pieces w and w + nw: with 8 waves K's ninth piece falls to wave 0 and V's ninth / tenth to waves 0 / 1; with 12 waves
+    // every wave has at most one piece of each)
+    int krow[2], kcol[2], vkey[2], vcol[2], nw;
+    __device__ __forceinline__ void init(int w, int l, int nwaves) {
+        nw = nwaves;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int p = i == 0 ? w : 8 + w;  // second pieces: K has one (wave 0), V two (waves 0, 1)
+            const int p = w + nwaves * i;
             const int qk = 64 * p + l, qv = 64 * p + l;
             krow[i] = qk / 9, kcol[i] = (qk % 9) * 8;
             const int R = qv / 10;
@@ -1152,13 +1172,13 @@ struct FwdFmt<72> {
         }
     }
     __device__ __forceinline__ void dma_k(const bf16_t* base, long long ld, int row0, int row_last, char* s, int w, int l) const {
-        glds16_raw(base + (long long)min(row0 + krow[0], row_last) * ld + kcol[0], s + w * 1024);
-        if (w == 0) glds16_raw(base + (long long)min(row0 + krow[1], row_last) * ld + kcol[1], s + 8 * 1024);
+        if (w < 9) glds16_raw(base + (long long)min(row0 + krow[0], row_last) * ld + kcol[0], s + w * 1024);
+        if (w + nw < 9) glds16_raw(base + (long long)min(row0 + krow[1], row_last) * ld + kcol[1], s + (w + nw) * 1024);
     }
     __device__ __forceinline__ void dma_v(const bf16_t* base, long long ld, int row0, int row_last, char* s, int w, int l) const {
         const bf16_t* ones = reinterpret_cast<const bf16_t*>(aria_ones_chunk);
-        glds16_raw(vcol[0] < 72 ? base + (long long)min(row0 + vkey[0], row_last) * ld + vcol[0] : ones, s + w * 1024);
-        if (w < 2) glds16_raw(vcol[1] < 72 ? base + (long long)min(row0 + vkey[1], row_last) * ld + vcol[1] : ones, s + (8 + w) * 1024);
+        if (w < 10) glds16_raw(vcol[0] < 72 ? base + (long long)min(row0 + vkey[0], row_last) * ld + vcol[0] : ones, s + w * 1024);
+        if (w + nw < 10) glds16_raw(vcol[1] < 72 ? base + (long long)min(row0 + vkey[1], row_last) * ld + vcol[1] : ones, s + (w + nw) * 1024);
     }
     static __device__ __forceinline__ s16x8 kfrag(const char* s, int row, int kk, int l) {
         return *reinterpret_cast<const s16x8*>(s + row * KROW + kk * 32 + (l >> 5) * 16);
@@ -1217,7 +1237,7 @@ __device__ __forceinline__ void fwd3_mask(f32x16 (&st)[2], const uint8_t* cM, bo
 //     a quarter of the next tile's score MFMAs | the group's 8 exponentials + packing | the group's P V MFMAs (one per 32 features)
 // -- independent matrix and vector work side by side in every sub-step; scheduling fences between the sub-steps keep the compiler from
 // hoisting all fragment reads of the tile to the top (256 VGPRs and spills without them).
-template <int HD>
+template <int HD, bool PIPE>
 __device__ __forceinline__ void fwd3_step(f32x16 (&st)[2], f32x16 (&sn)[2], f32x16 (&o)[FwdFmt<HD>::DT], float& m, float& lsum,
                                           const s16x8 (&qf)[FwdFmt<HD>::KS], const char* cV, const char* nK, float scale2, int l) {
     using F = FwdFmt<HD>;
@@ -1239,18 +1259,22 @@ __device__ __forceinline__ void fwd3_step(f32x16 (&st)[2], f32x16 (&sn)[2], f32x
             for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
         m = m_new;
     }
-    sn[0] = zero_acc();
-    sn[1] = zero_acc();
+    if (PIPE) {
+        sn[0] = zero_acc();
+        sn[1] = zero_acc();
+    }
     float ps = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = j >> 1, u = j & 1;
-        sched_fence();
-        // k-steps [KS j / 4, KS (j + 1) / 4) of the next tile's scores (hd 128: 2 of 8; hd 72: 1, 1, 1, 2 of 5)
+        if (PIPE) {
+            sched_fence();
+            // k-steps [KS j / 4, KS (j + 1) / 4) of the next tile's scores (hd 128: 2 of 8; hd 72: 1, 1, 1, 2 of 5)
 #pragma unroll
-        for (int kk = KS * j / 4; kk < KS * (j + 1) / 4; ++kk)
+            for (int kk = KS * j / 4; kk < KS * (j + 1) / 4; ++kk)
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) sn[ii] = mfma32(F::kfrag(nK, ii * 32 + (l & 31), kk, l), qf[kk], sn[ii]);
+                for (int ii = 0; ii < 2; ++ii) sn[ii] = mfma32(F::kfrag(nK, ii * 32 + (l & 31), kk, l), qf[kk], sn[ii]);
+        }
 #pragma unroll
         for (int r = 8 * u; r < 8 * u + 8; ++r) {
             const float p = exp2_fast(st[i][r] * scale2 - m_safe);
@@ -1261,12 +1285,15 @@ __device__ __forceinline__ void fwd3_step(f32x16 (&st)[2], f32x16 (&sn)[2], f32x
 #pragma unroll
         for (int dt = 0; dt < F::DT; ++dt) o[dt] = mfma32(F::vfrag(cV, i * 32 + 16 * u, 32 * dt, l), pf, o[dt]);
     }
-    sched_fence();
+    if (PIPE) sched_fence();
     if (!F::ROWSUM_IN_MFMA) lsum += ps;
 }
 
-template <int HD>
-__global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE,
+// PIPE: the next tile's scores inside the current tile's block (S^T double-buffered: ~190 / 242 VGPRs, two waves per SIMD) -- the hd 128
+// form.  !PIPE: scores at the top of the tile's own iteration as in v2, K and V tiles in step (hd 72 with NW = 12: ~160 VGPRs, THREE waves
+// per SIMD -- measured: for the ViT's shape the third wave is worth more than the in-wave overlap, profiles/r04_attn_fwd3_ab.json).
+template <int HD, int NW, bool PIPE>
+__global__ __launch_bounds__(NW * 64) void attn_fwd3_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE,
                                                         const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
                                                         long long ldq, long long ldk, long long ldv, long long ldo, float scale,
                                                         int causal, int nbatch) {
@@ -1280,8 +1307,10 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* Q, const b
     int* sFlag = reinterpret_cast<int*>(smem + L::FLAG0);     // [3]: bit 0 every key of the tile valid, bit 1 none
     const int t = threadIdx.x, l = t & 63, w = first_lane(t >> 6), h2 = l >> 5;
     int qblk, head, b;
-    if (!attn_block_coords((Sq + 255) / 256, H, nbatch, causal, true, qblk, head, b)) return;
-    const int q0 = qblk * 256;
+    constexpr int QB = NW * 32, KA = PIPE ? 1 : 0;  // queries per workgroup; how many tiles K runs ahead of V in LDS
+    static_assert(HD != 128 || NW == 8, "tile_dma3 deals a tile's 16 pieces to 8 waves");
+    if (!attn_block_coords((Sq + QB - 1) / QB, H, nbatch, causal, true, qblk, head, b)) return;
+    const int q0 = qblk * QB;
     const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
     const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
     const bf16_t* Kb = K + tok0 * ldk + head * HD;
@@ -1291,7 +1320,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* Q, const b
     const int klen = kv_len ? min(S, kv_len[b]) : S;
     const float scale2 = scale * 1.4426950408889634f;
     F fmt;
-    fmt.init(w, l);
+    fmt.init(w, l, NW);
 
     s16x8 qf[KS];
 #pragma unroll
@@ -1306,7 +1335,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* Q, const b
     for (int i = 0; i < DT; ++i) o[i] = zero_acc();
     float m = -INFINITY, lsum = 0.f;
     int kv_end = klen;
-    if (causal) kv_end = min(kv_end, q0 + 256);
+    if (causal) kv_end = min(kv_end, q0 + QB);
     const int ntiles = (kv_end + 63) / 64;
 
     // key-mask bytes of one tile -> ring slot tile % 3 (threads 0..63: wave 0)
@@ -1323,7 +1352,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* Q, const b
         }
         fmt.dma_k(Kb, ldk, 0, S - 1, sK, w, l);
         fmt.dma_v(Vb, ldv, 0, S - 1, sV, w, l);
-        if (ntiles > 1) fmt.dma_k(Kb, ldk, 64, S - 1, sK + F::KTILE, w, l);
+        if (PIPE && ntiles > 1) fmt.dma_k(Kb, ldk, 64, S - 1, sK + F::KTILE, w, l);
         if (kmb && t < 64) {
             mask_park(0, mask_fetch(0));
             if (ntiles > 1) mask_park(1, mask_fetch(1));
@@ -1341,9 +1370,9 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* Q, const b
     // the part of an iteration every wave owes the workgroup: the tile barrier, its DMA pieces of K(it + 2) / V(it + 1), the mask bytes
     uint8_t mv = 0;
     auto duties = [&](int it) __attribute__((always_inline)) {
-        wait_vm<0>();  // this wave's pieces of K(it + 1) and V(it) have landed
-        sync();        // ... everybody's; every wave is done with K(it) and V(it - 1)
-        if (it + 2 < ntiles) fmt.dma_k(Kb, ldk, (it + 2) * 64, S - 1, sK + (it & 1) * F::KTILE, w, l);
+        wait_vm<0>();  // this wave's pieces of K(it + KA) and V(it) have landed
+        sync();        // ... everybody's; every wave is done with K(it + KA - 1) and V(it - 1)
+        if (it + KA + 1 < ntiles) fmt.dma_k(Kb, ldk, (it + KA + 1) * 64, S - 1, sK + ((it + KA + 1) & 1) * F::KTILE, w, l);
         if (it + 1 < ntiles) fmt.dma_v(Vb, ldv, (it + 1) * 64, S - 1, sV + ((it + 1) & 1) * F::VTILE, w, l);
         if (kmb && t < 64 && it + 2 < ntiles) mv = mask_fetch(it + 2);
     };
@@ -1351,26 +1380,31 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* Q, const b
         if (kmb && t < 64 && it + 2 < ntiles) mask_park(it + 2, mv);
     };
     f32x16 sa[2], sb[2];
-    if (ntiles > 0) {
+    if (PIPE && ntiles > 0) {
         wait_vm<0>();
         sync();
         if (nmine > 0) fwd3_qk<HD>(sa, sK, qf, l);
     }
-    // one iteration: tile `it` (scores in `cur`) -> softmax + P V; tile it + 1 -> scores into `nxt`
+    // one iteration: tile `it` (PIPE: its scores are in `cur`) -> softmax + P V; PIPE: tile it + 1 -> scores into `nxt`
     auto iterate = [&](int it, f32x16 (&cur)[2], f32x16 (&nxt)[2]) __attribute__((always_inline)) {
         duties(it);
+        if (!PIPE) fwd3_qk<HD>(cur, sK + (it & 1) * F::KTILE, qf, l);
         if (tile_masked(it)) fwd3_mask(cur, sM + (it % 3) * 64, kmb != nullptr, it * 64, klen, causal, q_abs, l);
-        fwd3_step<HD>(cur, nxt, o, m, lsum, qf, sV + (it & 1) * F::VTILE, sK + ((it + 1) & 1) * F::KTILE, scale2, l);
+        fwd3_step<HD, PIPE>(cur, nxt, o, m, lsum, qf, sV + (it & 1) * F::VTILE, sK + ((it + 1) & 1) * F::KTILE, scale2, l);
         park(it);
     };
     int it = 0;
-    for (; it + 1 < nmine; it += 2) {
-        iterate(it, sa, sb);
-        iterate(it + 1, sb, sa);
-    }
-    if (it < nmine) {
-        iterate(it, sa, sb);
-        ++it;
+    if (PIPE) {
+        for (; it + 1 < nmine; it += 2) {
+            iterate(it, sa, sb);
+            iterate(it + 1, sb, sa);
+        }
+        if (it < nmine) {
+            iterate(it, sa, sb);
+            ++it;
+        }
+    } else {
+        for (; it < nmine; ++it) iterate(it, sa, sb);
     }
     for (; it < ntiles; ++it) {  // the workgroup's remaining tiles (other waves' diagonals): barriers and staging only
         duties(it);
@@ -1419,14 +1453,20 @@ int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     const bf16_t *Q = static_cast<const bf16_t*>(q), *K = static_cast<const bf16_t*>(k), *V = static_cast<const bf16_t*>(v);
     const char* nw72 = std::getenv("ARIA_ATTN_HD72_WAVES");  // "8": the two-waves-per-SIMD variant (A/B measurements)
     const char* fwdv = std::getenv("ARIA_ATTN_FWD");          // "2": the round-1..3 kernels (A/B measurements, bit-identity tests)
+    // default: hd 128 -> v3 pipelined; hd 72 -> v3 with 12 waves, K / V by LDS-DMA, scores in step ("3p": the pipelined 8-wave form)
     const bool v3 = !(fwdv && fwdv[0] == '2') && (hd == 128 || hd == 72) && Skv > 0;
+    const bool pipe72 = fwdv && fwdv[0] == '3' && fwdv[1] == 'p';
     g_last_fwd_variant = v3 ? 3 : 2;
     if (v3 && hd == 128)
-        ARIA_LAUNCH((attn_fwd3_kernel<128>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Fwd3Smem<128>::BYTES), stream, Q, K, V,
+        ARIA_LAUNCH((attn_fwd3_kernel<128, 8, true>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Fwd3Smem<128>::BYTES), stream, Q, K, V,
+                    static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
+                    (long long)ldv, (long long)ldo, scale, causal, int(B));
+    else if (v3 && pipe72)
+        ARIA_LAUNCH((attn_fwd3_kernel<72, 8, true>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Fwd3Smem<72>::BYTES), stream, Q, K, V,
                     static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
                     (long long)ldv, (long long)ldo, scale, causal, int(B));
     else if (v3)
-        ARIA_LAUNCH((attn_fwd3_kernel<72>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Fwd3Smem<72>::BYTES), stream, Q, K, V,
+        ARIA_LAUNCH((attn_fwd3_kernel<72, 12, false>), dim3(attn_grid((Sq + 383) / 384, H, B)), dim3(768), size_t(Fwd3Smem<72>::BYTES), stream, Q, K, V,
                     static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
                     (long long)ldv, (long long)ldo, scale, causal, int(B));
     else if (hd == 128)

@@ -29,13 +29,14 @@ for name, (B, Sq, Skv, H, hd, causal, masked, iters) in SHAPES.items():
         km = torch.ones(B, Skv, dtype=torch.uint8, device=dev)
         km[0, Skv * 3 // 4:] = 0
     fl = 4.0 * B * H * Sq * Skv * hd * (0.5 if causal else 1.0)
-    out, times = {}, {"2": [], "3": []}
+    vers = ("2", "3", "3p") if hd == 72 else ("2", "3")   # hd 72: "3" = 12 waves, LDS-DMA, scores in step; "3p" = 8 waves, pipelined
+    out, times = {}, {v: [] for v in vers}
     for rep in range(2):
-        for ver in ("2", "3"):
+        for ver in vers:
             os.environ["ARIA_ATTN_FWD"] = ver
             f = lambda: ops.attention_fwd(q, kv[:, :D], kv[:, D:], B, Sq, H, hd, hd ** -0.5, causal, key_mask=km, Skv=Skv)
             o, lse = f()
-            assert hip.get_lib().cdll.aria_last_attn_fwd_variant() == int(ver)
+            assert hip.get_lib().cdll.aria_last_attn_fwd_variant() == int(ver[0])
             out[ver] = (o, lse)
             f()
             torch.cuda.synchronize()
@@ -46,8 +47,8 @@ for name, (B, Sq, Skv, H, hd, causal, masked, iters) in SHAPES.items():
             e.record()
             torch.cuda.synchronize()
             times[ver].append(round(s.elapsed_time(e) / iters, 4))
-    same = bool(torch.equal(out["2"][0], out["3"][0]) and torch.equal(out["2"][1], out["3"][1]))
-    res[name] = {"v2_ms": times["2"], "v3_ms": times["3"], "v2_TF_s": round(fl / min(times["2"]) / 1e9, 1), "v3_TF_s": round(fl / min(times["3"]) / 1e9, 1),
+    same = all(bool(torch.equal(out["2"][0], out[v][0]) and torch.equal(out["2"][1], out[v][1])) for v in vers)
+    res[name] = {**{f"v{v}_ms": times[v] for v in vers}, **{f"v{v}_TF_s": round(fl / min(times[v]) / 1e9, 1) for v in vers},
                  "bit_identical": same, "finite": bool(torch.isfinite(out["3"][0].float()).all())}
     del q, kv, out
 os.environ.pop("ARIA_ATTN_FWD", None)
