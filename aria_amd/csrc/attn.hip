@@ -1290,8 +1290,10 @@ __device__ __forceinline__ void fwd3_step(f32x16 (&st)[2], f32x16 (&sn)[2], f32x
 }
 
 // PIPE: the next tile's scores inside the current tile's block (S^T double-buffered: ~190 / 242 VGPRs, two waves per SIMD) -- the hd 128
-// form.  !PIPE: scores at the top of the tile's own iteration as in v2, K and V tiles in step (hd 72 with NW = 12: ~160 VGPRs, THREE waves
-// per SIMD -- measured: for the ViT's shape the third wave is worth more than the in-wave overlap, profiles/r04_attn_fwd3_ab.json).
+// form and the default there.  !PIPE: scores at the top of the tile's own iteration as in v2, K and V tiles in step (hd 72 with NW = 12:
+// 145 VGPRs, THREE waves per SIMD).  Measured for the ViT's shape (profiles/r04_attn_fwd3_ab.json): the third wave is worth more than the
+// in-wave overlap, and with it LDS-DMA staging into the conflict-free images (SQ_LDS_BANK_CONFLICT 0, was 8 % of the LDS cycles) is level
+// with v2's register staging -- so hd 72 stays on v2 by default and both v3 forms are kept selectable (ARIA_ATTN_FWD) as measurements.
 template <int HD, int NW, bool PIPE>
 __global__ __launch_bounds__(NW * 64) void attn_fwd3_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE,
                                                         const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
@@ -1453,9 +1455,12 @@ int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     const bf16_t *Q = static_cast<const bf16_t*>(q), *K = static_cast<const bf16_t*>(k), *V = static_cast<const bf16_t*>(v);
     const char* nw72 = std::getenv("ARIA_ATTN_HD72_WAVES");  // "8": the two-waves-per-SIMD variant (A/B measurements)
     const char* fwdv = std::getenv("ARIA_ATTN_FWD");          // "2": the round-1..3 kernels (A/B measurements, bit-identity tests)
-    // default: hd 128 -> v3 pipelined; hd 72 -> v3 with 12 waves, K / V by LDS-DMA, scores in step ("3p": the pipelined 8-wave form)
-    const bool v3 = !(fwdv && fwdv[0] == '2') && (hd == 128 || hd == 72) && Skv > 0;
-    const bool pipe72 = fwdv && fwdv[0] == '3' && fwdv[1] == 'p';
+    // default: hd 128 -> v3 pipelined (+4..8 % over v2 from 2K to 64K tokens); hd 72 -> v2 with 12 waves (measured, same box: v2 2.23-2.46 ms,
+    // v3 with 12 waves + LDS-DMA 2.38-2.45, v3 pipelined with 8 waves 2.78-2.81 per ViT launch: profiles/r04_attn_fwd3_ab.json).
+    // ARIA_ATTN_FWD = "2": v2 everywhere; "3": v3 for hd 72 too (12 waves, scores in step); "3p": hd 72 pipelined with 8 waves.
+    const bool want3 = fwdv && fwdv[0] == '3';
+    const bool v3 = !(fwdv && fwdv[0] == '2') && (hd == 128 || (hd == 72 && want3)) && Skv > 0;
+    const bool pipe72 = want3 && fwdv[1] == 'p';
     g_last_fwd_variant = v3 ? 3 : 2;
     if (v3 && hd == 128)
         ARIA_LAUNCH((attn_fwd3_kernel<128, 8, true>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Fwd3Smem<128>::BYTES), stream, Q, K, V,

@@ -65,6 +65,19 @@ __device__ __forceinline__ void load_vector(u32x4 (&xv)[NC], const bf16_t* x, co
             xv[i][q] = pack2bf(bflo(wv[i][q]) * rbf(bflo(xv[i][q]) * r), bfhi(wv[i][q]) * rbf(bfhi(xv[i][q]) * r));
 }
 
+// 16 bytes of a WEIGHT stream: every byte is read once per token by one CU, so the load is marked non-temporal (it does not displace
+// what the L2 / MALL hold for re-use: the guide's "nt-weights" row -- issued -> landed -18 % on this chip's decode GEMVs).
+// -DARIA_DECODE_NT=0: plain loads (A/B builds, tools/gpu_r4_s5.sh).
+#ifndef ARIA_DECODE_NT
+#define ARIA_DECODE_NT 1
+#endif
+__device__ __forceinline__ u32x4 ldw16(const bf16_t* p) {
+#if defined(ARIA_EMU) || !ARIA_DECODE_NT
+    return ld16(p);
+#else
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#endif
+}
 // R consecutive weight rows as 16-byte chunks c = l + 64 i per lane.  Rows past the end are clamped (their results are never stored), no
 // branches: all R * NC loads of a wave are in flight together.  Kernels issue these BEFORE they fetch and normalise the vector: the vector
 // (L2 hits + a wave reduction + rsqrt, ~1.5 us of dependent latency) then hides under the HBM latency of the rows instead of in front of it.
@@ -75,7 +88,7 @@ __device__ __forceinline__ void load_rows(u32x4 (&a)[R][NC], const bf16_t* w, lo
     for (int r = 0; r < R; ++r) {
         const bf16_t* row = w + (long long)min(row0 + r, nrows - 1) * ldw;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) a[r][i] = ld16(row + min(l + 64 * i, nch - 1) * 8);
+        for (int i = 0; i < NC; ++i) a[r][i] = ldw16(row + min(l + 64 * i, nch - 1) * 8);
     }
 }
 // dot products of the loaded rows with the lane-distributed vector (chunks past K read as zeros there); every lane returns the full sums
@@ -274,14 +287,14 @@ __global__ __launch_bounds__(256) void expert_down_combine_kernel(const bf16_t* 
     {
         const bf16_t* row = S2 + (long long)nn * ns * I;
 #pragma unroll
-        for (int i = 0; i < NCS; ++i) ws[i] = ld16(row + min(l + 64 * i, nchS - 1) * 8);
+        for (int i = 0; i < NCS; ++i) ws[i] = ldw16(row + min(l + 64 * i, nchS - 1) * 8);
     }
 #pragma unroll
     for (int j = 0; j < DOWN_KMAX; ++j)
         if (j < k) {
             const bf16_t* row = W2 + ((long long)e[j] * N + nn) * I;
 #pragma unroll
-            for (int i = 0; i < NCI; ++i) wr[j][i] = ld16(row + min(l + 64 * i, nchI - 1) * 8);
+            for (int i = 0; i < NCI; ++i) wr[j][i] = ldw16(row + min(l + 64 * i, nchI - 1) * 8);
         }
     wait_vm<0>();  // this wave's image pieces have landed (the weight rows with them: they are needed next anyway)
     sync();

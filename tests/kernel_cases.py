@@ -571,6 +571,63 @@ def case_attention_masked_tiles(dev, hd, H, B=2, S=330):
     assert float(dk.float().cpu()[dead].abs().max()) == 0.0 and float(dv.float().cpu()[dead].abs().max()) == 0.0
 
 
+def case_attention_forward_variants(dev, B, Sq, Skv, H, hd, causal, masked, use_len):
+    """Round 4: ``attn_fwd3`` (the next key tile's score MFMAs inside the current tile's softmax / P V block, K one tile ahead of V, both
+    by LDS-DMA; hd 128 default) performs v2's arithmetic in v2's order -- every selectable form (ARIA_ATTN_FWD: "2" = v2; "3" = v3, for
+    hd 72 with 12 waves and the scores in step; "3p" = hd 72 pipelined with 8 waves) gives the same bits, and those bits are within the
+    attention tolerance of the fp32 eager oracle (modeling_llama.py:192-215; key padding vision_encoder.py:147-152)."""
+    import os
+
+    from aria_amd import hip, ops
+
+    D = H * hd
+    g = torch.Generator().manual_seed(B * 1000 + Sq + Skv + hd)
+    q = torch.randn(B * Sq, D, generator=g).to(bf16)
+    kv = torch.randn(B * Skv, 2 * D, generator=g).to(bf16)
+    km = kl = None
+    if masked:
+        km = (torch.rand(B, Skv, generator=g) > 0.3).to(torch.uint8)
+        km[:, 0] = 1
+        if Skv > 130:
+            km[0, 64:128] = 0          # a whole tile without a valid key: v2 skips it, v3 works through it (exp2(-inf) = 0)
+        if Skv > 200:
+            km[0, Skv - Skv // 4:] = 0
+    if use_len:
+        kl = torch.randint(1, Skv + 1, (B,), generator=g).to(torch.int32)
+    want_variant = {"2": 2, "3": 3, "3p": 3}
+    vers = ("2", "3", "3p") if hd == 72 else ("2", "3")
+    prev = os.environ.get("ARIA_ATTN_FWD")
+    got = {}
+    try:
+        for ver in vers:
+            os.environ["ARIA_ATTN_FWD"] = ver
+            o, lse = ops.attention_fwd(q.to(dev), kv[:, :D].to(dev), kv[:, D:].to(dev), B, Sq, H, hd, hd ** -0.5, causal,
+                                       kv_len=None if kl is None else kl.to(dev), key_mask=None if km is None else km.to(dev), Skv=Skv)
+            assert hip.get_lib().cdll.aria_last_attn_fwd_variant() == want_variant[ver]
+            got[ver] = (o.cpu(), lse.cpu())
+        os.environ.pop("ARIA_ATTN_FWD")
+        ops.attention_fwd(q.to(dev), kv[:, :D].to(dev), kv[:, D:].to(dev), B, Sq, H, hd, hd ** -0.5, causal, Skv=Skv)
+        assert hip.get_lib().cdll.aria_last_attn_fwd_variant() == (3 if hd == 128 else 2)    # the defaults
+    finally:
+        if prev is None:
+            os.environ.pop("ARIA_ATTN_FWD", None)
+        else:
+            os.environ["ARIA_ATTN_FWD"] = prev
+    for ver in vers[1:]:
+        assert torch.equal(got["2"][0], got[ver][0]) and torch.equal(got["2"][1], got[ver][1]), (ver, float((got["2"][0].float() - got[ver][0].float()).abs().max()))
+    pad = None
+    if km is not None or kl is not None:
+        pad = torch.zeros(B, Skv, dtype=torch.bool)
+        if km is not None:
+            pad |= km == 0
+        if kl is not None:
+            pad |= torch.arange(Skv)[None, :] >= kl[:, None].long()
+    qq = q.float().view(B, Sq, H, hd).transpose(1, 2)
+    kk, vv = (kv[:, i * D:(i + 1) * D].float().view(B, Skv, H, hd).transpose(1, 2) for i in range(2))
+    want = O.attention_eager(qq, kk, vv, hd ** -0.5, causal, key_padding=pad)
+    close(got["3"][0], want.transpose(1, 2).reshape(B * Sq, D), 2e-2, 2e-2)
+
+
 # ------------------------------------------------------------------------------------------ single-query decode attention
 def case_decode_attention(dev, H, hd, pos, splits, S_max=None):
     """aria_decode_attn (RoPE of q / k with freqs_cis[pos], cache write at row pos, softmax over rows 0..pos) against fp32 torch on the same

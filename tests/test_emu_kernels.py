@@ -104,6 +104,16 @@ def test_attention_hd72_forward(B, Sq, Skv, H, masked):
     C.case_attention_hd72_forward(DEV, B, Sq, Skv, H, masked)
 
 
+@pytest.mark.parametrize("B,Sq,Skv,H,hd,causal,masked,use_len", [
+    (1, 64, 64, 1, 128, True, False, False), (2, 200, 200, 2, 128, True, False, False), (1, 330, 330, 1, 128, False, True, False),
+    (2, 150, 150, 1, 128, False, False, True), (1, 513, 513, 1, 128, True, False, True), (1, 16, 200, 2, 128, False, False, False),
+    (1, 64, 64, 1, 72, False, False, False), (2, 300, 300, 2, 72, False, True, False), (1, 385, 385, 1, 72, False, False, True),
+    (1, 129, 129, 1, 72, True, False, False), (2, 40, 330, 1, 72, False, True, False),
+])
+def test_attention_forward_variants_give_the_same_bits(B, Sq, Skv, H, hd, causal, masked, use_len):
+    C.case_attention_forward_variants(DEV, B, Sq, Skv, H, hd, causal, masked, use_len)
+
+
 @pytest.mark.parametrize("force", ["1", "2", "3", None])
 @pytest.mark.parametrize("M,N,K", [(40, 72, 64), (264, 136, 192), (72, 520, 128)])
 def test_gemm_fused_gelu(monkeypatch, force, M, N, K):
