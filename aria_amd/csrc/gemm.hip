@@ -498,6 +498,62 @@ int aria_gemm_swiglu_split_bf16(const void* A, const void* Bg, const void* Bu, v
     return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int((M + 255) / 256), stream);
 }
 
+// K2: the two fused SwiGLU launches over grouped rows with the dispatcher's gather folded into the A loader.  X is the un-permuted token
+// matrix [T, K]; rows[r] (int32, device, r < M_total) is the token row permuted row r would hold.
+int aria_grouped_gemm_swiglu_gather_bf16(const void* X, const int32_t* rows, int64_t T, const void* B, void* H, void* ACT, const int32_t* offsets,
+                                         int64_t E, int64_t M_total, int64_t N2, int64_t K, int64_t ldx, int64_t ldb, int64_t strideB, int64_t ldh,
+                                         int64_t ldact, void* stream) {
+    if (!offsets || !rows || E <= 0 || T <= 0) return ARIA_ERR_INVALID;
+    const int rc = glu_check(X, B, H, ACT, M_total, N2, K, ldx, ldb, ldh, ldact);
+    if (rc != ARIA_OK) return rc;
+    if (strideB & 7) return ARIA_ERR_ALIGN;
+    if ((K % 64) || 2 * T * ldx >= (1ll << 32) || T >= (1ll << 24) || 2 * K * ldb >= (1ll << 32)) return ARIA_ERR_UNSUPPORTED;
+    if (M_total == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(X);
+    p.B = static_cast<const bf16_t*>(B);
+    p.C = H;
+    p.C2 = ACT;
+    p.lda = ldx, p.ldb = ldb, p.ldc = ldh, p.ldc2 = ldact;
+    p.M = int(M_total), p.N = int(N2), p.K = int(K);
+    p.mode = 1;
+    p.offsets = offsets;
+    p.E = int(E);
+    p.strideB = strideB;
+    p.glu = 1;
+    p.gather_rows = rows;
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, 1, int(M_total / 256 + E), stream);
+}
+
+int aria_grouped_gemm_swiglu_split_gather_bf16(const void* X, const int32_t* rows, int64_t T, const void* Bg, const void* Bu, void* H, void* ACT,
+                                               const int32_t* offsets, int64_t E, int64_t M_total, int64_t I, int64_t K, int64_t ldx, int64_t ldb,
+                                               int64_t strideB, int64_t ldh, int64_t ldact, void* stream) {
+    if (!offsets || !rows || E <= 0 || !Bu || T <= 0) return ARIA_ERR_INVALID;
+    int rc = glu_check(X, Bg, H, ACT, M_total, 2 * I, K, ldx, ldb, ldh, ldact);
+    if (rc != ARIA_OK) return rc;
+    if ((strideB & 7) || !aligned16(Bu)) return ARIA_ERR_ALIGN;
+    if ((K % 64) || 2 * T * ldx >= (1ll << 32) || T >= (1ll << 24)) return ARIA_ERR_UNSUPPORTED;
+    int up_rows = 0;
+    rc = glu_split_rows(Bg, Bu, I, ldb, 0, &up_rows);
+    if (rc != ARIA_OK) return rc;
+    if (M_total == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(X);
+    p.B = static_cast<const bf16_t*>(Bg);
+    p.C = H;
+    p.C2 = ACT;
+    p.lda = ldx, p.ldb = ldb, p.ldc = ldh, p.ldc2 = ldact;
+    p.M = int(M_total), p.N = int(2 * I), p.K = int(K);
+    p.mode = 1;
+    p.offsets = offsets;
+    p.E = int(E);
+    p.strideB = strideB;
+    p.glu = 1;
+    p.glu_up_rows = up_rows;
+    p.gather_rows = rows;
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int(M_total / 256 + E), stream);
+}
+
 // shared validation of the fused input-gradient + SwiGLU-backward entries (gemm3_kernel<.., .., 5>)
 static int dglu_check(const void* A, const void* B, const void* H, const void* DH, int64_t M, int64_t I, int64_t K, int64_t lda, int64_t ldb,
                       int64_t ldh, int64_t lddh) {

@@ -197,10 +197,15 @@ struct Stage {  // everything a wave needs to issue its two DMA pieces of any ha
     const char* gB;
     // per lane, tile-independent
     int la_a, la_b, lb_a, lb_b;
+    // GATHER (K2: fc1's A rows are token rows reached through the dispatcher's index, moe_lm.py:326-334 without the permuted copy): byte
+    // offsets of this lane's four A rows of the tile (half x piece) from the operand base at k = 0, chunk term included -- looked up ONCE per
+    // tile (the rows of a tile do not change along k); dead fields in every other instantiation
+    uint32_t ga[2][2];
 };
 
-template <bool A_OC, bool B_OC, int OPERAND, int HALF, int BUF, bool TAIL = true>
+template <bool A_OC, bool B_OC, int OPERAND, int HALF, int BUF, bool TAIL = true, bool GATHER = false>
 __device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
+    static_assert(!GATHER || !A_OC, "gathered A rows are k-contiguous token rows");
     constexpr bool OC = OPERAND == 0 ? A_OC : B_OC;
     const int tile = gtile - st.g0;
     const char* g = (OPERAND == 0 ? st.gA + tile * st.kstepA : st.gB + tile * st.kstepB);
@@ -210,8 +215,8 @@ __device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
     ls.b = OPERAND == 0 ? st.la_b : st.lb_b;
     const int first = OPERAND == 0 ? st.m0 + HALF * 128 : st.n0 + HALF * st.bhalf, limit = OPERAND == 0 ? st.limA : st.limB;
     const uint32_t ld2 = OPERAND == 0 ? st.ldA2 : st.ldB2;
-    const char* s0 = g + ls.offset(0, first, limit, ld2);
-    const char* s1 = g + ls.offset(1, first, limit, ld2);
+    const char* s0 = (GATHER && OPERAND == 0) ? g + st.ga[HALF][0] : g + ls.offset(0, first, limit, ld2);
+    const char* s1 = (GATHER && OPERAND == 0) ? g + st.ga[HALF][1] : g + ls.offset(1, first, limit, ld2);
     if (TAIL && st.tail_k < BK && tile == st.nk - 1) {  // wave-uniform: the ragged end of the reduction -> granules past it read zeros
         // first reduction index (inside the tile) of this lane's 16 bytes, pieces 0 and 1
         const int k0 = OC ? ls.a : ls.b >> 1, k1 = OC ? ls.a + 4 : (ls.b ^ 64) >> 1;
@@ -253,7 +258,7 @@ __device__ __forceinline__ void stage_init(Stage& st, const P& p, int w, int l, 
 // are in flight behind every wait -- the phase is straight-line code (the general form spends two scalar branches, a handful of selects
 // and a chain of compares per phase on conditions that only change in a tile's last three K-tiles).
 template <bool A_OC, bool B_OC, int QA, int QB, bool LOAD_A, bool LOAD_B, int BUF, int SO, int SH, int SB, int WAIT, bool EDGE,
-          bool STEADY = false>
+          bool STEADY = false, bool GATHER = false>
 __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                       const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int stage_tile, bool do_stage,
                                       bool more_in_flight, int rows_left, int cols_left) {
@@ -281,9 +286,9 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
     constexpr bool LATE = true;
     if (!LATE) {
         if (STEADY)
-            stage_half<A_OC, B_OC, SO, SH, SB, false>(st, stage_tile);
+            stage_half<A_OC, B_OC, SO, SH, SB, false, GATHER>(st, stage_tile);
         else if (do_stage)
-            stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
+            stage_half<A_OC, B_OC, SO, SH, SB, true, GATHER>(st, stage_tile);
     }
     if (!(ARIA_ABL & 32) && WAIT == 1) {  // phase 1: B1 and A1 of THIS tile must have landed; newer = A0, B0 (and, early placement, A1) of the next tile
         if (STEADY || more_in_flight)
@@ -312,14 +317,14 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
                 if (ARIA_ABL & 4) {
                     // (timing experiment: no DMA)
                 } else if (STEADY)
-                    stage_half<A_OC, B_OC, SO, SH, SB, false>(st, stage_tile);
+                    stage_half<A_OC, B_OC, SO, SH, SB, false, GATHER>(st, stage_tile);
                 else if (do_stage)
-                    stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
+                    stage_half<A_OC, B_OC, SO, SH, SB, true, GATHER>(st, stage_tile);
                 sched_fence();
             }
         }
     } else {
-        if (LATE && do_stage) stage_half<A_OC, B_OC, SO, SH, SB>(st, stage_tile);
+        if (LATE && do_stage) stage_half<A_OC, B_OC, SO, SH, SB, true, GATHER>(st, stage_tile);
         if (col_ok) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -333,17 +338,17 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
     if (!(ARIA_ABL & 8)) raw_barrier();
 }
 
-template <bool A_OC, bool B_OC, int BUF, bool EDGE, bool STEADY = false>
+template <bool A_OC, bool B_OC, int BUF, bool EDGE, bool STEADY = false, bool GATHER = false>
 __device__ __forceinline__ void k_tile(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                        const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int t, int nk, int rl, int cl) {
     const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-    phase<A_OC, B_OC, 0, 0, true, true, BUF, 0, 1, BUF ^ 1, 1, EDGE, STEADY>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, n1, rl, cl);
-    phase<A_OC, B_OC, 0, 1, false, true, BUF, 1, 1, BUF ^ 1, 0, EDGE, STEADY>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
-    phase<A_OC, B_OC, 1, 1, true, false, BUF, 0, 0, BUF, 0, EDGE, STEADY>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, false, rl, cl);
-    phase<A_OC, B_OC, 1, 0, false, false, BUF, 1, 0, BUF, 4, EDGE, STEADY>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, n2, rl, cl);
+    phase<A_OC, B_OC, 0, 0, true, true, BUF, 0, 1, BUF ^ 1, 1, EDGE, STEADY, GATHER>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, n1, rl, cl);
+    phase<A_OC, B_OC, 0, 1, false, true, BUF, 1, 1, BUF ^ 1, 0, EDGE, STEADY, GATHER>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
+    phase<A_OC, B_OC, 1, 1, true, false, BUF, 0, 0, BUF, 0, EDGE, STEADY, GATHER>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, false, rl, cl);
+    phase<A_OC, B_OC, 1, 0, false, false, BUF, 1, 0, BUF, 4, EDGE, STEADY, GATHER>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, n2, rl, cl);
 }
 
-template <bool A_OC, bool B_OC, bool EDGE>
+template <bool A_OC, bool B_OC, bool EDGE, bool GATHER = false>
 __device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                         const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int nk, int rl, int cl) {
     int kt = 0;
@@ -351,15 +356,15 @@ __device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4
         // steady part: K-tile t stages tiles t + 1 and t + 2, both of which must exist and be full -- t + 2 <= last full tile
         const int last_full = st.tail_k < BK ? nk - 2 : nk - 1;
         for (; kt + 1 <= last_full - 2; kt += 2) {
-            k_tile<A_OC, B_OC, 0, false, true>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
-            k_tile<A_OC, B_OC, 1, false, true>(acc, fa, fb, aa, ab, smem, st, kt + 1, nk, rl, cl);
+            k_tile<A_OC, B_OC, 0, false, true, GATHER>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
+            k_tile<A_OC, B_OC, 1, false, true, GATHER>(acc, fa, fb, aa, ab, smem, st, kt + 1, nk, rl, cl);
         }
     }
     for (; kt + 1 < nk; kt += 2) {
-        k_tile<A_OC, B_OC, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
-        k_tile<A_OC, B_OC, 1, EDGE>(acc, fa, fb, aa, ab, smem, st, kt + 1, nk, rl, cl);
+        k_tile<A_OC, B_OC, 0, EDGE, false, GATHER>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
+        k_tile<A_OC, B_OC, 1, EDGE, false, GATHER>(acc, fa, fb, aa, ab, smem, st, kt + 1, nk, rl, cl);
     }
-    if (kt < nk) k_tile<A_OC, B_OC, 0, EDGE>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
+    if (kt < nk) k_tile<A_OC, B_OC, 0, EDGE, false, GATHER>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
 }
 
 template <int ACT, class P>
@@ -706,8 +711,19 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     // order bit 10 (experiment, measured 8-10 % SLOWER, profiles/r02_gemm_tile_timeline.md section 8): the two wave groups run IN STEP instead of
     // one barrier apart -- both waves of a SIMD in their MFMA sections together, fragment reads exposed
     const bool stagger_groups = !((p.order >> 10) & 1);
+    // VER 8 / 9: the fused SwiGLU launches ([gate | up] weights / the gptfast two-tensor form) with GATHERED A rows
+    constexpr bool GATHER = VER == 8 || VER == 9;
     Stage st;
-    stage_init<A_OC, B_OC, VER == 6>(st, p, w, l, smem);
+    stage_init<A_OC, B_OC, VER == 6 || VER == 9>(st, p, w, l, smem);
+    if (GATHER) {  // this lane's four A rows of the tile -> token rows (one index load each, ONCE per tile; rows past the end clamped)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const int row = min(m0 + hh * 128 + st.la_a + 8 * ss, p.M - 1);
+                st.ga[hh][ss] = mul24(uint32_t(p.gather_rows[row]), st.ldA2) + uint32_t(st.la_b ^ (64 * ss));
+            }
+    }
     st.gA = reinterpret_cast<const char*>(p.A) + (A_OC ? 2 * k_begin * p.lda : 2 * (long long)k_begin) + kt_first * st.kstepA;
     st.gB = reinterpret_cast<const char*>(p.B + b_off) + (B_OC ? 2 * k_begin * p.ldb : 2 * (long long)k_begin) + kt_first * st.kstepB;
     st.g0 = 0;
@@ -740,13 +756,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         // ---- prologue: tile 0 completely, A0 and B0 of tile 1 (phases 1 and 2 of tile 0 issue its A1 and B1) -- the steady-state
         // queue shape
         if (nk > 0) {
-            stage_half<A_OC, B_OC, 0, 0, 0>(st, 0);
+            stage_half<A_OC, B_OC, 0, 0, 0, true, GATHER>(st, 0);
             stage_half<A_OC, B_OC, 1, 0, 0>(st, 0);
             stage_half<A_OC, B_OC, 1, 1, 0>(st, 0);
-            stage_half<A_OC, B_OC, 0, 1, 0>(st, 0);
+            stage_half<A_OC, B_OC, 0, 1, 0, true, GATHER>(st, 0);
         }
         if (nk > 1) {
-            stage_half<A_OC, B_OC, 0, 0, 1>(st, 1);
+            stage_half<A_OC, B_OC, 0, 0, 1, true, GATHER>(st, 1);
             stage_half<A_OC, B_OC, 1, 0, 1>(st, 1);
             wait_vm<4>();
         } else {
@@ -756,9 +772,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         ts_mark(1);
         if (wm == 1 && stagger_groups) raw_barrier();  // waves 4-7 run one barrier behind waves 0-3
         if (interior)
-            k_loop3<A_OC, B_OC, false>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
+            k_loop3<A_OC, B_OC, false, GATHER>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
         else
-            k_loop3<A_OC, B_OC, true>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
+            k_loop3<A_OC, B_OC, true, GATHER>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
     }
     if (wm == 0 && stagger_groups) raw_barrier();  // balance the barrier count of the two groups
     ts_mark(2);
@@ -890,6 +906,14 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     if (ntn * ntm <= 0) return ARIA_OK;
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
     dim3 grid(unsigned(aria_tile_grid(q)), grid_y), block(512);
+    if (p.gather_rows) {  // gathered A rows (K2): the two fused SwiGLU launches over grouped rows only
+        if (a_oc || !p.glu || p.mode != 1 || (p.glu_up_rows > 0 && b_oc) || (p.glu_up_rows == 0 && !b_oc)) return ARIA_ERR_INVALID;
+        if (p.glu_up_rows > 0)
+            ARIA_LAUNCH((gemm3_kernel<false, false, 9>), grid, block, shmem, stream, q);
+        else
+            ARIA_LAUNCH((gemm3_kernel<false, true, 8>), grid, block, shmem, stream, q);
+        return aria_check_launch();
+    }
     if (p.glu && p.glu_up_rows > 0) {  // fused SwiGLU with gate / up weights in two tensors ([N, K] form): its own instantiation
         if (a_oc || b_oc || p.mode == 2) return ARIA_ERR_INVALID;
         ARIA_LAUNCH((gemm3_kernel<false, false, 6>), grid, block, shmem, stream, q);

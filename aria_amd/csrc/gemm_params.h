@@ -40,6 +40,9 @@ struct GemmParams {
     // fused SwiGLU epilogue with gate and up weights in TWO tensors of one allocation (gptfast: cond_ffn.w1 / w3 [E, I, D], shared_ffn.w1 /
     // w3 [Is, D]): the up rows of an expert start `glu_up_rows` rows of the B operand behind its gate rows (0: the [gate | up] layout, N / 2)
     int glu_up_rows;
+    // K2 (fused SwiGLU launches over grouped rows only): A is the UN-permuted token matrix [T, K] and gather_rows[r] the token row that
+    // permuted row r would hold (TokenDispatcher.token_permutation's index_select, moe_lm.py:326-334, folded into the A loader)
+    const int* gather_rows;
 };
 // (the device helpers below are templates on the block's type so that a kernel may also hand them the block where it lies in the
 // kernarg segment -- a reference into the constant address space: scalar loads at the point of use instead of registers held live)

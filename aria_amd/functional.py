@@ -65,12 +65,19 @@ def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save=Tr
     logits = ops.gemm(x, router_w)                                   # TopKRouter.gating  moe_lm.py:190-201
     scores, idx, counts = ops.moe_route(logits, k)                   # routing :261-269 (device-side histogram)
     offsets, sorted_src, inv = ops.moe_sort(idx, counts)             # token_permutation :326-334 (stable)
-    perm = ops.moe_permute(x, sorted_src, k)
-    if ops.glu_fusable(fc1.shape[1], fc1.shape[2]):                  # experts.fc1 :522 + glu :505-507 in ONE launch (no D2H sync)
-        h1, act = ops.grouped_gemm_swiglu(perm, fc1, offsets, want_h=bool(save) and not lean)   # (h1 is only kept for the backward of glu)
+    fused = ops.glu_fusable(fc1.shape[1], fc1.shape[2])
+    if fused and (lean or not save) and ops.gather_fusable(fc1.shape[1]):
+        # K2: no backward will read `perm` out of THIS forward (inference, or the forward pass of a checkpointed step -- the backward
+        # rebuilds the expert-row tensors): the row gather rides in fc1's A loader, the [6T, D] copy is neither written nor read
+        perm = h1 = None
+        act = ops.grouped_gemm_swiglu_gather(x, ops.permuted_token_rows(sorted_src, k), fc1, offsets, want_h=False)[1]
     else:
-        h1 = ops.grouped_gemm(perm, fc1, offsets)
-        act = ops.swiglu(h1)
+        perm = ops.moe_permute(x, sorted_src, k)
+        if fused:                                                    # experts.fc1 :522 + glu :505-507 in ONE launch (no D2H sync)
+            h1, act = ops.grouped_gemm_swiglu(perm, fc1, offsets, want_h=bool(save) and not lean)   # (h1 is only kept for the backward of glu)
+        else:
+            h1 = ops.grouped_gemm(perm, fc1, offsets)
+            act = ops.swiglu(h1)
     eo = ops.grouped_gemm(act, fc2, offsets)                         # experts.fc2 :524
     T = x.shape[0]
     I2 = gate_w.shape[0]

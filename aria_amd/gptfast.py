@@ -179,11 +179,15 @@ class MOEFeedForward(nn.Module):
         logits = ops.gemm(x2d, self.gate.weight)
         scores, idx, counts = ops.moe_route(logits, k)                 # topk + softmax (model.py:359-363)
         offsets, sorted_src, inv = ops.moe_sort(idx, counts)           # token_permutation (:243-254)
-        perm = ops.moe_permute(x2d, sorted_src, k)
         cf = self.cond_ffn
-        if _glu_pair_ready(cf.w1, cf.w3):   # w1 / w3 GEMMs + SwiGLU in ONE launch (no h1 / h3 round trip: 2 x [6T, I] written and read)
-            act = ops.grouped_gemm_swiglu_split(perm, cf.w1, cf.w3, offsets)[1]
+        if _glu_pair_ready(cf.w1, cf.w3) and ops.gather_fusable(x2d.shape[1]):
+            # K2 + K3: the dispatcher's row gather (model.py:243-254) in the A loader of the fused w1 / w3 / SwiGLU launch -- no permuted copy
+            # of the tokens ([6T, D]: 1.6 GB written and read per layer of a 53 K-token prefill), no h1 / h3 round trip
+            act = ops.grouped_gemm_swiglu_split_gather(x2d, ops.permuted_token_rows(sorted_src, k), cf.w1, cf.w3, offsets)[1]
+        elif _glu_pair_ready(cf.w1, cf.w3):   # w1 / w3 GEMMs + SwiGLU in ONE launch (no h1 / h3 round trip: 2 x [6T, I] written and read)
+            act = ops.grouped_gemm_swiglu_split(ops.moe_permute(x2d, sorted_src, k), cf.w1, cf.w3, offsets)[1]
         else:
+            perm = ops.moe_permute(x2d, sorted_src, k)
             h1 = ops.grouped_gemm(perm, cf.w1, offsets, w_is_kn=False)     # sequential_gemm(w1) (:278-297): w1[e] is [I, D] = rc form
             h3 = ops.grouped_gemm(perm, cf.w3, offsets, w_is_kn=False)
             act = ops.swiglu(h1, h3)

@@ -191,6 +191,48 @@ def grouped_gemm_swiglu_split(a: torch.Tensor, w_gate: torch.Tensor, w_up: torch
     return h, act
 
 
+def gather_fusable(K: int) -> bool:
+    """The fused fc1 + SwiGLU launches can take the UN-permuted tokens and the dispatcher's row index (K2); ARIA_FUSE_GATHER=0 switches it
+    off (the permuted copy is built and the un-gathered launch runs: bit-identical)."""
+    import os
+
+    return K % 64 == 0 and K >= 64 and os.environ.get("ARIA_FUSE_GATHER", "1") != "0"
+
+
+def permuted_token_rows(sorted_src: torch.Tensor, k: int) -> torch.Tensor:
+    """Token row of every permuted row (``sorted_indices // topk``, moe_lm.py:330): int32 [T * k]."""
+    return torch.div(sorted_src, k, rounding_mode="floor").to(torch.int32)
+
+
+def grouped_gemm_swiglu_gather(x: torch.Tensor, rows: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, want_h: bool = False):
+    """``grouped_gemm_swiglu(moe_permute(x, ..), w, offsets)`` without the permuted copy: x [T, K] tokens, rows int32 [M] (token row per
+    permuted row), w [E, K, 2I].  -> (h [M, 2I] or None, act [M, I]); bit-identical to the two-step form."""
+    _chk(x, name="x"), _chk(w, name="w"), _chk(offsets, torch.int32, "offsets"), _chk(rows, torch.int32, "rows")
+    if w.dim() != 3 or not w.is_contiguous() or w.shape[1] != x.shape[1] or not rows.is_contiguous():
+        raise ValueError("grouped_gemm_swiglu_gather: w must be a contiguous [E, K, 2I] tensor, rows contiguous int32")
+    T, K = x.shape
+    M = rows.numel()
+    E, _, N2 = w.shape
+    h = torch.empty((M, N2), dtype=bf16, device=x.device) if want_h else None
+    act = torch.empty((M, N2 // 2), dtype=bf16, device=x.device)
+    hip.get_lib().call("aria_grouped_gemm_swiglu_gather_bf16", _p(x), _p(rows), T, _p(w), _p(h) if want_h else None, _p(act), _p(offsets), E, M,
+                       N2, K, _rowmajor_2d(x, "x"), N2, K * N2, N2, N2 // 2, _stream(x))
+    return h, act
+
+
+def grouped_gemm_swiglu_split_gather(x: torch.Tensor, rows: torch.Tensor, w_gate: torch.Tensor, w_up: torch.Tensor, offsets: torch.Tensor,
+                                     want_h: bool = False):
+    """The gptfast form (w_gate / w_up [E, I, K], ``glu_split_fusable``) of ``grouped_gemm_swiglu_gather``."""
+    _chk(x, name="x"), _chk(w_gate, name="w_gate"), _chk(w_up, name="w_up"), _chk(offsets, torch.int32, "offsets"), _chk(rows, torch.int32, "rows")
+    E, I, K = w_gate.shape
+    T, M = x.shape[0], rows.numel()
+    h = torch.empty((M, 2 * I), dtype=bf16, device=x.device) if want_h else None
+    act = torch.empty((M, I), dtype=bf16, device=x.device)
+    hip.get_lib().call("aria_grouped_gemm_swiglu_split_gather_bf16", _p(x), _p(rows), T, _p(w_gate), _p(w_up), _p(h) if want_h else None, _p(act),
+                       _p(offsets), E, M, I, K, _rowmajor_2d(x, "x"), K, I * K, 2 * I, I, _stream(x))
+    return h, act
+
+
 def gemm_swiglu_split(x: torch.Tensor, w_gate: torch.Tensor, w_up: torch.Tensor, want_h: bool = False):
     """silu(x @ w_gate^T) * (x @ w_up^T) in one launch (gptfast FeedForward): w_gate / w_up [I, K] as in ``grouped_gemm_swiglu_split``."""
     _chk(x, name="x"), _chk(w_gate, name="w_gate"), _chk(w_up, name="w_up")

@@ -93,6 +93,19 @@ int aria_gemm_swiglu_bf16(const void* A, const void* B, void* H, void* ACT, int6
 int aria_grouped_gemm_swiglu_split_bf16(const void* A, const void* Bg, const void* Bu, void* H, void* ACT, const int32_t* offsets, int64_t E,
                                         int64_t M_total, int64_t I, int64_t K, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldh,
                                         int64_t ldact, void* stream);
+
+/* K2: TokenDispatcher.token_permutation's row gather (moe_lm.py:326-334; gptfast/model.py:243-254) folded into the A loader of
+ * the fused fc1 + SwiGLU launches: X is the UN-permuted token matrix [T, K] and rows[r] (int32 on the device, r < M_total) the token row
+ * that permuted row r would hold (= sorted_src[r] / topk); each lane looks its four rows up once per tile.  The [M_total, K] permuted copy is
+ * neither written nor read.  Same results, bit for bit, as aria_moe_permute followed by the un-gathered launch.  For paths that need no
+ * weight gradient of fc1 afterwards (inference prefill, the forward pass of a checkpointed step): the weight gradient's loader wants the
+ * permuted rows as a tensor.  K % 64 == 0, T < 2^24, 2 T ldx < 2^32. */
+int aria_grouped_gemm_swiglu_gather_bf16(const void* X, const int32_t* rows, int64_t T, const void* B, void* H, void* ACT, const int32_t* offsets,
+                                         int64_t E, int64_t M_total, int64_t N2, int64_t K, int64_t ldx, int64_t ldb, int64_t strideB, int64_t ldh,
+                                         int64_t ldact, void* stream);
+int aria_grouped_gemm_swiglu_split_gather_bf16(const void* X, const int32_t* rows, int64_t T, const void* Bg, const void* Bu, void* H, void* ACT,
+                                               const int32_t* offsets, int64_t E, int64_t M_total, int64_t I, int64_t K, int64_t ldx, int64_t ldb,
+                                               int64_t strideB, int64_t ldh, int64_t ldact, void* stream);
 int aria_gemm_swiglu_split_bf16(const void* A, const void* Bg, const void* Bu, void* H, void* ACT, int64_t M, int64_t I, int64_t K, int64_t lda,
                                 int64_t ldb, int64_t ldh, int64_t ldact, void* stream);
 

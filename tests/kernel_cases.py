@@ -187,6 +187,40 @@ def case_gemm_swiglu_split(dev, counts, K, I, T_dense):
     assert torch.equal(ops.gemm_swiglu_split(x, s1, s3)[1].cpu(), ref.cpu())
 
 
+def case_gemm_swiglu_gather(dev, T, E, k, K, I, seed=91):
+    """K2: the fused fc1 + SwiGLU launches with the dispatcher's row gather in the A loader (``gemm3_kernel<.., .., 8 / 9>``: token matrix +
+    row index instead of the permuted copy; moe_lm.py:326-334, 505-525; gptfast/model.py:243-254, 278-325) == permute followed by the
+    un-gathered launch, bit for bit -- both weight forms, ragged / empty experts from a real routing, a column edge tile (I = 128 mod 256)."""
+    from aria_amd import ops
+
+    g = torch.Generator().manual_seed(seed)
+    x = rnd(T, K, seed=seed).to(dev)
+    logits = torch.randn(T, E, generator=g)
+    logits[:, 1] = -50.0                                   # an expert nobody routes to
+    scores, idx, counts = ops.moe_route(logits.to(bf16).to(dev), k)
+    offsets, sorted_src, inv = ops.moe_sort(idx, counts)
+    rows = ops.permuted_token_rows(sorted_src, k)
+    assert rows.dtype == torch.int32 and rows.numel() == T * k and int(counts.cpu()[1]) == 0
+    perm = ops.moe_permute(x, sorted_src, k)
+    assert torch.equal(perm.cpu(), x.cpu()[rows.cpu().long()])
+    w = rnd(E, K, 2 * I, seed=seed + 1, scale=0.2).to(dev)
+    assert ops.glu_fusable(K, 2 * I) and ops.gather_fusable(K)
+    h_ref, act_ref = ops.grouped_gemm_swiglu(perm, w, offsets, want_h=True)
+    h, act = ops.grouped_gemm_swiglu_gather(x, rows, w, offsets, want_h=True)
+    assert torch.equal(h.cpu(), h_ref.cpu()) and torch.equal(act.cpu(), act_ref.cpu())
+    assert ops.grouped_gemm_swiglu_gather(x, rows, w, offsets, want_h=False)[0] is None
+    pair = torch.empty((2, E, I, K), dtype=bf16, device=dev)
+    pair[0].copy_(w[:, :, :I].transpose(1, 2))
+    pair[1].copy_(w[:, :, I:].transpose(1, 2))
+    assert ops.glu_split_fusable(pair[0], pair[1])
+    h6_ref, act6_ref = ops.grouped_gemm_swiglu_split(perm, pair[0], pair[1], offsets, want_h=True)
+    h6, act6 = ops.grouped_gemm_swiglu_split_gather(x, rows, pair[0], pair[1], offsets, want_h=True)
+    assert torch.equal(h6.cpu(), h6_ref.cpu()) and torch.equal(act6.cpu(), act6_ref.cpu())
+    # the oracle's own chain on the gathered rows (sequential_gemm + glu), with the usual GEMM tolerance
+    want = O.glu(O.sequential_gemm(x.cpu().float()[rows.cpu().long()], w.cpu().float(), counts.cpu().long()).to(bf16).float())
+    close(act, want, 3e-2, 3e-2)
+
+
 def case_gemm_dswiglu_fused(dev, counts, K, I, T_dense):
     """experts.fc2's input gradient + the backward of glu in one launch (aria_grouped_gemm_dswiglu_bf16 / aria_gemm_dswiglu_bf16,
     gemm3_kernel<.., .., 5>) == the two-step chain (grouped GEMM with [N, K] weights, then aria_swiglu_bwd), bit for bit; ragged / empty

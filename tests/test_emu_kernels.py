@@ -229,3 +229,8 @@ def test_decode_route_matches_the_batched_router(E, k):
                                              (2, 128, 1500, 32), (3, 64, 127, 2), (2, 64, 128, 2), (2, 64, 1000, 5)])
 def test_decode_attention_split_kv(H, hd, pos, splits):
     C.case_decode_attention(DEV, H, hd, pos, splits)
+
+
+@pytest.mark.parametrize("T,E,k,K,I", [(70, 8, 2, 64, 128), (300, 8, 3, 128, 384)])
+def test_fused_swiglu_with_the_row_gather_in_the_loader(T, E, k, K, I):
+    C.case_gemm_swiglu_gather(DEV, T, E, k, K, I)

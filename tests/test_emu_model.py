@@ -105,13 +105,19 @@ def test_gptfast_gate_up_pairs_share_an_allocation_and_fuse(monkeypatch):
     assert ops.glu_split_fusable(ff.cond_ffn.w1, ff.cond_ffn.w3) and ops.glu_split_fusable(ff.shared_ffn.w1.weight, ff.shared_ffn.w3.weight)
     assert list(m.state_dict()) == keys_before and all(torch.equal(v, ref_sd[k]) for k, v in m.state_dict().items())
     calls = []
-    og, od = ops.grouped_gemm_swiglu_split, ops.gemm_swiglu_split
+    og, od, ogg = ops.grouped_gemm_swiglu_split, ops.gemm_swiglu_split, ops.grouped_gemm_swiglu_split_gather
     monkeypatch.setattr(ops, "grouped_gemm_swiglu_split", lambda *a, **k: (calls.append("g"), og(*a, **k))[1])
     monkeypatch.setattr(ops, "gemm_swiglu_split", lambda *a, **k: (calls.append("d"), od(*a, **k))[1])
+    monkeypatch.setattr(ops, "grouped_gemm_swiglu_split_gather", lambda *a, **k: (calls.append("G"), ogg(*a, **k))[1])
     ids = torch.randint(1, 136, (1, 24), generator=torch.Generator().manual_seed(2))
     with torch.no_grad():
         fused = m(ids, torch.arange(24)).float().clone()
-        assert calls == ["g", "d"] * 2
+        assert calls == ["G", "d"] * 2                      # r04: the routed launch also carries the dispatcher's row gather (K2)
+        calls.clear()
+        monkeypatch.setenv("ARIA_FUSE_GATHER", "0")         # ... and equals permute + the un-gathered launch bit for bit
+        ungathered = m(ids, torch.arange(24)).float().clone()
+        monkeypatch.delenv("ARIA_FUSE_GATHER")
+        assert calls == ["g", "d"] * 2 and torch.equal(fused, ungathered)
         step = m(torch.tensor([[7]]), torch.tensor([24], dtype=torch.int32)).float().clone()   # decode engine on the re-homed parameters
         assert m._engine is not None
         monkeypatch.setenv("ARIA_FUSE_SWIGLU", "0")
@@ -126,7 +132,7 @@ def test_gptfast_gate_up_pairs_share_an_allocation_and_fuse(monkeypatch):
         assert not ops.glu_split_fusable(ff.cond_ffn.w1, ff.cond_ffn.w3)
         calls.clear()
         again = m(ids, torch.arange(24)).float()
-        assert calls == ["g", "d"] * 2 and torch.equal(again, fused) and ops.glu_split_fusable(ff.cond_ffn.w1, ff.cond_ffn.w3)
+        assert calls == ["G", "d"] * 2 and torch.equal(again, fused) and ops.glu_split_fusable(ff.cond_ffn.w1, ff.cond_ffn.w3)
 
 
 def test_vit_projector_golden(golden):

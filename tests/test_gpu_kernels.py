@@ -228,3 +228,8 @@ def test_decode_route_matches_the_batched_router(E, k):
 def test_decode_attention_split_kv(H, hd, pos, splits):
     """split-KV decode attention (the default beyond 2048 cache slots) against the fp32 reference and the single-workgroup form, on hardware"""
     C.case_decode_attention(DEV, H, hd, pos, splits)
+
+
+@pytest.mark.parametrize("T,E,k,K,I", [(70, 8, 2, 64, 128), (300, 8, 3, 128, 384), (16384, 64, 6, 2560, 1664), (4099, 64, 6, 2560, 1664)])
+def test_fused_swiglu_with_the_row_gather_in_the_loader(T, E, k, K, I):
+    C.case_gemm_swiglu_gather(DEV, T, E, k, K, I)
