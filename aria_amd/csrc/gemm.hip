@@ -554,6 +554,33 @@ int aria_grouped_gemm_swiglu_split_gather_bf16(const void* X, const int32_t* row
     return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int(M_total / 256 + E), stream);
 }
 
+// K7: wqkv projection + interleaved RoPE + KV-cache write in one launch (gptfast/model.py:413-435, 67-93).
+int aria_gemm_qkv_rope_cache_bf16(const void* X, const void* Wqkv, void* Q, void* Kc, void* Vc, const void* freqs_cis, const int32_t* pos,
+                                  int64_t M, int64_t D, int64_t K, int64_t hd, int64_t S, int64_t S_cache, int64_t ldx, int64_t ldw, int64_t ldq,
+                                  int64_t ld_cache, void* stream) {
+    if (!X || !Wqkv || !Q || !Kc || !Vc || !freqs_cis || M < 0 || D <= 0 || K <= 0 || hd <= 0 || S <= 0 || S_cache <= 0) return ARIA_ERR_INVALID;
+    if (!aligned16(X) || !aligned16(Wqkv) || !aligned16(Q) || !aligned16(Kc) || !aligned16(Vc) || !aligned16(freqs_cis) || (ldx & 7) || (ldw & 7) ||
+        (ldq & 7) || (ld_cache & 7))
+        return ARIA_ERR_ALIGN;
+    if ((D % 256) || (K % 64) || K < 64 || (hd & 7) || (D % hd) || 2 * M * ldx >= (1ll << 32) || 2 * 3 * D * ldw >= (1ll << 32) || 2 * ldx >= (1ll << 24) ||
+        2 * ldw >= (1ll << 24))
+        return ARIA_ERR_UNSUPPORTED;
+    if (M == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(X);
+    p.B = static_cast<const bf16_t*>(Wqkv);   // [3 D, K] row-major (q rows, k rows, v rows: gptfast's wqkv)
+    p.C = Q;
+    p.lda = ldx, p.ldb = ldw, p.ldc = ldq;
+    p.M = int(M), p.N = int(3 * D), p.K = int(K);
+    p.mode = 0;
+    p.rope_fc = static_cast<const bf16_t*>(freqs_cis);
+    p.rope_pos = pos;
+    p.rope_hd = int(hd), p.rope_D = int(D), p.rope_S = int(S), p.cache_S = int(S_cache);
+    p.kc = Kc, p.vc = Vc;
+    p.ld_cache = ld_cache;
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int((M + 255) / 256), stream);
+}
+
 // shared validation of the fused input-gradient + SwiGLU-backward entries (gemm3_kernel<.., .., 5>)
 static int dglu_check(const void* A, const void* B, const void* H, const void* DH, int64_t M, int64_t I, int64_t K, int64_t lda, int64_t ldb,
                       int64_t ldh, int64_t lddh) {

@@ -504,6 +504,59 @@ __device__ __forceinline__ void store_tile3_rows(const P& p, const f32x16 (&acc)
     }
 }
 
+// Row form of the epilogue for the fused wqkv projection (K7): the parked 256 x 256 tile leaves as complete 512-byte rows like
+// store_tile3_rows; a lane's 16 bytes are four interleaved (x[2i], x[2i+1]) pairs of ONE head, so the rotation is lane-local:
+// one 16-byte load of (cos, sin) x 4 from the bf16 freqs_cis row of the token's position per row piece.
+template <class P>
+__device__ __forceinline__ void store_tile3_rows_rope(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
+                                                      int wm, int wn, char* smem) {
+    const int c = l & 31, h = l >> 5, odd = l & 1;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    const float v0 = acc[a][i][b][2 * rp], v1 = acc[a][i][b][2 * rp + 1];
+                    const int r = 2 * rp;
+                    const int row = a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;  // inside the tile
+                    const float got = xor1(odd ? v0 : v1);
+                    const float lo = odd ? got : v0, hi = odd ? v1 : got;
+                    *reinterpret_cast<uint32_t*>(smem + row * ROWP3 + (b * 128 + wn * 32 + (c & ~1)) * 2) = pack2bf(lo, hi);
+                }
+    sync();
+    const int region = n0 / p.rope_D;                 // 0 q, 1 k, 2 v (tile-uniform)
+    const int col0 = n0 - region * p.rope_D;          // first column of the tile inside its block
+    const int rr = l >> 5, cc = (l & 31) * 8;
+    const int fcol = (col0 + cc) % p.rope_hd;         // position of the lane's 8 columns inside their head
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+        const int row = w * 32 + s2 * 2 + rr;
+        u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * ROWP3 + cc * 2);
+        const int m = m0 + row;
+        if (m < m_end) {
+            const int seq = m / p.rope_S;
+            const int ps = p.rope_pos ? p.rope_pos[m] : m - seq * p.rope_S;
+            if (region < 2) {
+                const u32x4 f = ld16(p.rope_fc + (long long)ps * p.rope_hd + fcol);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x0 = bflo(v[q]), x1 = bfhi(v[q]), cs = bflo(f[q]), sn = bfhi(f[q]);
+                    v[q] = pack2bf(x0 * cs - x1 * sn, x1 * cs + x0 * sn);
+                }
+            }
+            bf16_t* dst;
+            if (region == 0)
+                dst = reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + col0 + cc;
+            else
+                dst = static_cast<bf16_t*>(region == 1 ? p.kc : p.vc) + ((long long)seq * p.cache_S + ps) * p.ld_cache + col0 + cc;
+            *reinterpret_cast<u32x4*>(dst) = v;
+        }
+    }
+}
+
 template <int ACT, class P>
 __device__ __forceinline__ void store_any3(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w, int wm,
                                            int wn, char* smem) {
@@ -798,6 +851,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         store_tile3_dglu(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
         return;
     }
+    if (VER == 7) {  // fused wqkv projection: RoPE + KV-cache write epilogue
+        store_tile3_rows_rope(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
+        return;
+    }
     if (p.glu)
         store_tile3_glu(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
     else if (p.act == 1)  // (one wave-uniform branch here instead of one per value inside the unrolled epilogues)
@@ -906,6 +963,11 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     if (ntn * ntm <= 0) return ARIA_OK;
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
     dim3 grid(unsigned(aria_tile_grid(q)), grid_y), block(512);
+    if (p.rope_fc) {  // fused wqkv projection (K7): dense, both operands k-contiguous, whole column tiles
+        if (a_oc || b_oc || p.mode != 0 || p.glu || p.dglu || p.c_f32 || p.accumulate || p.bias || p.act || (p.N % BN) || (p.rope_D % BN)) return ARIA_ERR_INVALID;
+        ARIA_LAUNCH((gemm3_kernel<false, false, 7>), grid, block, shmem, stream, q);
+        return aria_check_launch();
+    }
     if (p.gather_rows) {  // gathered A rows (K2): the two fused SwiGLU launches over grouped rows only
         if (a_oc || !p.glu || p.mode != 1 || (p.glu_up_rows > 0 && b_oc) || (p.glu_up_rows == 0 && !b_oc)) return ARIA_ERR_INVALID;
         if (p.glu_up_rows > 0)

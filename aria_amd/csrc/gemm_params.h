@@ -43,6 +43,17 @@ struct GemmParams {
     // K2 (fused SwiGLU launches over grouped rows only): A is the UN-permuted token matrix [T, K] and gather_rows[r] the token row that
     // permuted row r would hold (TokenDispatcher.token_permutation's index_select, moe_lm.py:326-334, folded into the A loader)
     const int* gather_rows;
+    // K7 (gemm3_kernel<false, false, 7>, dense): the fused wqkv projection of gptfast's Attention.forward (gptfast/model.py:413-435) with
+    // the interleaved RoPE and the KV-cache write as its epilogue.  N = 3 D; a 256-column tile lies wholly in the q, k or v block
+    // (D % 256 == 0).  q columns: rotated, written to C [M, ldc]; k columns: rotated, written to kc; v columns: written to vc -- both cache
+    // tensors [B, cache_S, D] with row stride ld_cache, row of token t = (t / rope_S) * cache_S + pos(t), pos(t) = rope_pos[t] (or t % rope_S).
+    // The rotation reads the bf16-rounded product, computes in fp32 and rounds once -- the bits of gemm + rope_interleaved + copy.
+    const ad::bf16_t* rope_fc;   // freqs_cis [positions, hd / 2, 2] bf16 (cos, sin)
+    const int* rope_pos;
+    int rope_hd, rope_D, rope_S, cache_S;
+    void* kc;
+    void* vc;
+    long long ld_cache;
 };
 // (the device helpers below are templates on the block's type so that a kernel may also hand them the block where it lies in the
 // kernarg segment -- a reference into the constant address space: scalar loads at the point of use instead of registers held live)

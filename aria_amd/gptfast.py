@@ -129,6 +129,15 @@ class Attention(nn.Module):
     def forward(self, x2d, B, S, freqs_cis, pos32, kv_len, prefill: bool):
         c = self.config
         D, H, hd, hdp = c.dim, c.n_head, c.head_dim, self.hdp
+        if (prefill and self.kv_cache is not None and B == 1 and hdp == hd and x2d.shape[0] == S
+                and ops.qkv_rope_cache_fusable(D, x2d.shape[1], hd)):
+            # K7: projection + interleaved RoPE + KVCache.update (model.py:423-435, 67-93) as ONE launch -- q to its own buffer, rotated k and v
+            # straight into the static cache (prefill positions are arange(S), generate.py:147-150), which the attention kernel then
+            # reads in place: no [T, 3D] product, no rotation pass, no cache copies
+            cache = self.kv_cache
+            q = ops.gemm_qkv_rope_cache(x2d, self.wqkv.weight, freqs_cis, pos32, cache.k, cache.v, S, hd)
+            o, _ = ops.attention_fwd(q, cache.k[0, :S], cache.v[0, :S], 1, S, H, hd, hd ** -0.5, True)
+            return ops.gemm(o, self.wo.weight)
         qkv = ops.gemm(x2d, self.wqkv.weight)
         ops.rope_interleaved_(qkv[:, :2 * D], freqs_cis, 2 * H, hd, pos32)
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]

@@ -191,6 +191,36 @@ def grouped_gemm_swiglu_split(a: torch.Tensor, w_gate: torch.Tensor, w_up: torch
     return h, act
 
 
+def qkv_rope_cache_fusable(D: int, K: int, hd: int) -> bool:
+    """The wqkv projection can carry RoPE and the KV-cache write as its epilogue (K7); ARIA_FUSE_QKV_ROPE=0: the three-step chain."""
+    import os
+
+    return D % 256 == 0 and K % 64 == 0 and K >= 64 and hd % 8 == 0 and D % hd == 0 and os.environ.get("ARIA_FUSE_QKV_ROPE", "1") != "0"
+
+
+def gemm_qkv_rope_cache(x: torch.Tensor, wqkv: torch.Tensor, freqs_cis: torch.Tensor, pos32: Optional[torch.Tensor], k_cache: torch.Tensor,
+                        v_cache: torch.Tensor, S: int, hd: int) -> torch.Tensor:
+    """gptfast Attention.forward up to the attention call (model.py:413-435) in one launch: x [B*S, K], wqkv [3D, K], freqs_cis bf16
+    [positions, hd/2, 2], pos32 int32 [B*S] (or None: t % S), k_cache / v_cache [B_max, S_cache, D] (rows (t // S, pos) are written).
+    -> q [B*S, D] rotated.  Bit-identical to ``gemm`` + ``rope_interleaved_`` + the cache copies."""
+    _chk(x, name="x"), _chk(wqkv, name="wqkv"), _chk(freqs_cis, name="freqs_cis"), _chk(k_cache, name="k_cache"), _chk(v_cache, name="v_cache")
+    M, K = x.shape
+    D = wqkv.shape[0] // 3
+    if wqkv.shape != (3 * D, K) or k_cache.dim() != 3 or k_cache.shape != v_cache.shape or k_cache.shape[2] != D:
+        raise ValueError("gemm_qkv_rope_cache: wqkv [3D, K], caches [B, S_cache, D]")
+    if not (k_cache.is_contiguous() and v_cache.is_contiguous() and freqs_cis.is_contiguous()):
+        raise ValueError("gemm_qkv_rope_cache: caches and freqs_cis must be contiguous")
+    if M % S or M // S > k_cache.shape[0]:
+        raise ValueError("gemm_qkv_rope_cache: rows must be whole sequences that fit the cache's batch")
+    if pos32 is not None:
+        _chk(pos32, torch.int32, "pos32")
+        assert pos32.is_contiguous() and pos32.numel() == M
+    q = torch.empty((M, D), dtype=bf16, device=x.device)
+    hip.get_lib().call("aria_gemm_qkv_rope_cache_bf16", _p(x), _p(wqkv), _p(q), _p(k_cache), _p(v_cache), _p(freqs_cis), _p(pos32), M, D, K, hd, S,
+                       k_cache.shape[1], _rowmajor_2d(x, "x"), _rowmajor_2d(wqkv, "wqkv"), D, D, _stream(x))
+    return q
+
+
 def gather_fusable(K: int) -> bool:
     """The fused fc1 + SwiGLU launches can take the UN-permuted tokens and the dispatcher's row index (K2); ARIA_FUSE_GATHER=0 switches it
     off (the permuted copy is built and the un-gathered launch runs: bit-identical)."""

@@ -106,6 +106,16 @@ int aria_grouped_gemm_swiglu_gather_bf16(const void* X, const int32_t* rows, int
 int aria_grouped_gemm_swiglu_split_gather_bf16(const void* X, const int32_t* rows, int64_t T, const void* Bg, const void* Bu, void* H, void* ACT,
                                                const int32_t* offsets, int64_t E, int64_t M_total, int64_t I, int64_t K, int64_t ldx, int64_t ldb,
                                                int64_t strideB, int64_t ldh, int64_t ldact, void* stream);
+
+/* K7: gptfast's Attention.forward up to the attention call (gptfast/model.py:413-435) as ONE launch: the fused wqkv projection
+ * X [M, K] x Wqkv^T ([3 D, K]: q rows, k rows, v rows), the interleaved-pair RoPE of q and k (apply_rotary_emb :519-531: fp32 arithmetic on
+ * the bf16-rounded product with the bf16 freqs_cis table [positions, hd / 2, 2], one rounding) and KVCache.update (:67-93) as the GEMM's
+ * epilogue: q -> Q [M, ldq]; rotated k and v -> the static caches Kc / Vc [B, S_cache, D] (row stride ld_cache) at row
+ * (t / S) * S_cache + pos[t] (pos int32 per token row on the device, or NULL: t % S).  The [M, 3 D] product never visits HBM.
+ * Bit-identical to aria_gemm_bf16 + aria_rope_interleaved_inplace + row copies.  D % 256 == 0, K % 64 == 0, hd % 8 == 0. */
+int aria_gemm_qkv_rope_cache_bf16(const void* X, const void* Wqkv, void* Q, void* Kc, void* Vc, const void* freqs_cis, const int32_t* pos,
+                                  int64_t M, int64_t D, int64_t K, int64_t hd, int64_t S, int64_t S_cache, int64_t ldx, int64_t ldw, int64_t ldq,
+                                  int64_t ld_cache, void* stream);
 int aria_gemm_swiglu_split_bf16(const void* A, const void* Bg, const void* Bu, void* H, void* ACT, int64_t M, int64_t I, int64_t K, int64_t lda,
                                 int64_t ldb, int64_t ldh, int64_t ldact, void* stream);
 

@@ -187,6 +187,53 @@ def case_gemm_swiglu_split(dev, counts, K, I, T_dense):
     assert torch.equal(ops.gemm_swiglu_split(x, s1, s3)[1].cpu(), ref.cpu())
 
 
+def case_gemm_qkv_rope_cache(dev, B, S, D, hd, K, S_cache, shuffled_pos=False):
+    """K7: wqkv projection + interleaved RoPE + KV-cache write in one launch (``gemm3_kernel<false, false, 7>``; gptfast/model.py:413-435,
+    67-93, 519-531) == the chain gemm (v3, no split-K) -> rope_interleaved_ -> row copies, bit for bit: q, and the cache rows at the tokens'
+    positions (rows nobody wrote keep their sentinel); then against the oracle's fp32 interleaved rotation."""
+    import os
+
+    from aria_amd import ops
+
+    M = B * S
+    x = rnd(M, K, seed=95).to(dev)
+    w = rnd(3 * D, K, seed=96, scale=0.2).to(dev)
+    n_pos = max(S, S_cache)
+    ang = torch.outer(torch.arange(n_pos).float(), 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd)))
+    fc = torch.stack([ang.cos(), ang.sin()], dim=-1).to(bf16).contiguous()          # [n_pos, hd/2, 2] (precompute_freqs_cis :500-516)
+    if shuffled_pos:
+        pos = torch.stack([torch.randperm(S_cache, generator=torch.Generator().manual_seed(97 + b))[:S] for b in range(B)]).reshape(-1).to(torch.int32)
+    else:
+        pos = torch.arange(S, dtype=torch.int32).repeat(B)
+    assert ops.qkv_rope_cache_fusable(D, K, hd)
+    kc = torch.full((B, S_cache, D), 7.0, dtype=bf16, device=dev)
+    vc = torch.full((B, S_cache, D), 7.0, dtype=bf16, device=dev)
+    q = ops.gemm_qkv_rope_cache(x, w, fc.to(dev), pos.to(dev), kc, vc, S, hd)
+    prev, ops.GEMM_SPLIT_K = os.environ.get("ARIA_GEMM_FORCE"), False
+    os.environ["ARIA_GEMM_FORCE"] = "3"
+    try:
+        qkv = ops.gemm(x, w)
+    finally:
+        ops.GEMM_SPLIT_K = True
+        if prev is None:
+            os.environ.pop("ARIA_GEMM_FORCE")
+        else:
+            os.environ["ARIA_GEMM_FORCE"] = prev
+    raw = qkv.clone()
+    ops.rope_interleaved_(qkv[:, :2 * D], fc.to(dev), 2 * D // hd, hd, pos.to(dev))
+    assert torch.equal(q.cpu(), qkv[:, :D].cpu())
+    rows = (torch.arange(M) // S) * S_cache + pos.long()
+    assert torch.equal(kc.view(-1, D).cpu()[rows], qkv[:, D:2 * D].cpu()) and torch.equal(vc.view(-1, D).cpu()[rows], qkv[:, 2 * D:].cpu())
+    untouched = torch.ones(B * S_cache, dtype=torch.bool)
+    untouched[rows] = False
+    assert bool((kc.view(-1, D).cpu()[untouched] == 7.0).all()) and bool((vc.view(-1, D).cpu()[untouched] == 7.0).all())
+    # oracle: interleaved pairs rotated in fp32 with the bf16 table (gptfast/model.py:519-531)
+    xq = raw[:, :D].cpu().float().view(M, D // hd, hd // 2, 2)
+    f = fc[pos.long()].float().view(M, 1, hd // 2, 2)
+    want = torch.stack([xq[..., 0] * f[..., 0] - xq[..., 1] * f[..., 1], xq[..., 1] * f[..., 0] + xq[..., 0] * f[..., 1]], dim=-1).reshape(M, D)
+    same(q, want.to(bf16), str(dev) == "cpu")   # (hardware: the compiler contracts x0 cs - x1 sn into an fma)
+
+
 def case_gemm_swiglu_gather(dev, T, E, k, K, I, seed=91):
     """K2: the fused fc1 + SwiGLU launches with the dispatcher's row gather in the A loader (``gemm3_kernel<.., .., 8 / 9>``: token matrix +
     row index instead of the permuted copy; moe_lm.py:326-334, 505-525; gptfast/model.py:243-254, 278-325) == permute followed by the

@@ -76,3 +76,24 @@ def test_lm_case_small_oracle_device_path():
 def test_grouped_gemm_beyond_2g_case_small():
     """The > 2^31-byte grouped-GEMM case's own logic (expert choice, single-expert bitwise reruns, sampled oracle rows) at toy size."""
     F.case_grouped_gemm_beyond_2g("cpu", "emu_beyond_2g", rows=900, K=64, I=128, E=8, expect_v3=False)
+
+
+def test_prefill_gptfast_case_small_with_the_fused_qkv_epilogue(monkeypatch):
+    """Width 256 / head dim 128: the prefill's wqkv projection carries RoPE and the cache write (K7) and the routed fc1 the row gather (K2);
+    same case, same tolerances -- and the same logits, bit for bit, with both fusions switched off."""
+    from aria_amd import ops
+
+    calls = []
+    f7, f2 = ops.gemm_qkv_rope_cache, ops.grouped_gemm_swiglu_split_gather
+    monkeypatch.setattr(ops, "gemm_qkv_rope_cache", lambda *a, **k: (calls.append("k7"), f7(*a, **k))[1])
+    monkeypatch.setattr(ops, "grouped_gemm_swiglu_split_gather", lambda *a, **k: (calls.append("k2"), f2(*a, **k))[1])
+    kw = dict(hidden=256, heads=2, experts=8, topk=2, inter=128, vocab=160, layers=2, S=72, tol=(5e-2, 1.5e-1), stream_block=32, expect_big_gemm=False)
+    F.case_prefill_gptfast("cpu", "emu_prefill_k7", **kw)
+    assert calls == ["k7", "k2"] * 2, calls
+    fused = dict(F.REPORT["emu_prefill_k7"]["last-position logits"])
+    monkeypatch.setenv("ARIA_FUSE_QKV_ROPE", "0")
+    monkeypatch.setenv("ARIA_FUSE_GATHER", "0")
+    monkeypatch.setenv("ARIA_GEMM_FORCE", "3")   # (the un-fused projection through the same kernel family: same k order per accumulator)
+    calls.clear()
+    F.case_prefill_gptfast("cpu", "emu_prefill_k7_off", **kw)
+    assert calls == [] and F.REPORT["emu_prefill_k7_off"]["last-position logits"] == fused

@@ -234,3 +234,8 @@ def test_decode_attention_split_kv(H, hd, pos, splits):
 @pytest.mark.parametrize("T,E,k,K,I", [(70, 8, 2, 64, 128), (300, 8, 3, 128, 384)])
 def test_fused_swiglu_with_the_row_gather_in_the_loader(T, E, k, K, I):
     C.case_gemm_swiglu_gather(DEV, T, E, k, K, I)
+
+
+@pytest.mark.parametrize("B,S,D,hd,K,S_cache,shuffled", [(1, 70, 256, 64, 64, 96, False), (2, 33, 256, 128, 128, 40, True)])
+def test_qkv_projection_with_rope_and_cache_write_epilogue(B, S, D, hd, K, S_cache, shuffled):
+    C.case_gemm_qkv_rope_cache(DEV, B, S, D, hd, K, S_cache, shuffled)
