@@ -954,6 +954,10 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     // bit 8 = DMA pieces inside the MFMA section: measured +4..6 % with two k-contiguous operands, -5 % when an operand goes through
     // the transposing reads (profiles/r01_gemm_tuning.md)
     q.order = ord ? std::atoi(ord) : 4;  // groups of 4 row tiles (dense); bit 9 = ragged-last (grouped rows, gemm_params.h)
+    // r04: the fused fc1 + SwiGLU launches over grouped rows run ragged-last by default -- measured on the same box
+    // (profiles/r04_grouped_order_ab.json, r04_pmc_grouped_orders_and_clocks.json): fabric-side fetches 7.0 -> 3.9 GB per launch, L2 hit rate
+    // 49 -> 69 %, TF/s level (975 / 1023 vs 1012 / 993); the plain grouped launches lose 1-2 % under it and keep the expert-major order
+    if (!ord && p.glu && p.mode == 1) q.order |= 512;
     // wide epilogue: every 8-column piece of a C row must be 16-byte aligned.  ARIA_GEMM_WIDE_STORE=0 switches it off (A/B measurements).
     const char* wsd = std::getenv("ARIA_GEMM_WIDE_STORE");
     q.wide_store = !(wsd && wsd[0] == '0') && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.ldc & 7) == 0 && (p.strideC & 7) == 0;

@@ -83,8 +83,8 @@ def init_params(model, seed):
 
 
 PMC_FILE = "r04_pmc_fc1.json"
-KERNEL_REV = "r04a"   # bumped with every change of the v3 K loop / epilogues: a PMC pass of an older build does not describe this one
-PMC_KERNEL_TAG = "gemm3_kernel<rc,oc,3>+wide_store+expert_major+swiglu@r04a"   # the fc1 launch the committed PMC pass profiled
+KERNEL_REV = "r04b"   # bumped with every change of the v3 K loop / epilogues: a PMC pass of an older build does not describe this one
+PMC_KERNEL_TAG = "gemm3_kernel<rc,oc,3>+wide_store+ragged_last+swiglu@r04b"   # the fc1 launch the committed PMC pass profiled
 
 
 def fc1_kernel_tag(variant):
@@ -93,7 +93,10 @@ def fc1_kernel_tag(variant):
         return f"gemm{variant}_kernel<rc,oc>"
     wide = os.environ.get("ARIA_GEMM_WIDE_STORE", "1") != "0"
     fused = os.environ.get("ARIA_FUSE_SWIGLU", "1") != "0"
-    return "gemm3_kernel<rc,oc,3>" + ("+wide_store" if wide else "") + "+expert_major" + ("+swiglu" if fused else "") + "@" + KERNEL_REV
+    order = os.environ.get("ARIA_GEMM_ORDER")
+    ragged_last = fused if order is None else bool(int(order) & 512)   # the fused launch's default tile order since r04b
+    return ("gemm3_kernel<rc,oc,3>" + ("+wide_store" if wide else "") + ("+ragged_last" if ragged_last else "+expert_major") +
+            ("+swiglu" if fused else "") + "@" + KERNEL_REV)
 
 
 def pmc_traffic(variant=3):
