@@ -663,20 +663,29 @@ __global__ __launch_bounds__(NT) void attn_bwd2_dq_kernel(const bf16_t* Q, const
                 }
             const bool need_mask = !all_q_ok || (kv0 + 64 > klen) || (causal && kv0 + 63 > q_wmin) || (kmb && !(sFlag[cur] & 1));
             const uint8_t* cM = sM + cur * 64;
+            // (r04: the mask test outside the element loops -- as one loop the compiler kept a scalar branch per element, ~100 per tile)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float p = exp2_fast(st[i][r] * scale2 - lse2);
-                    if (need_mask) {
-                        const int kvl = i * 32 + acc_row(r, l);
+                for (int r = 0; r < 16; ++r) st[i][r] = exp2_fast(st[i][r] * scale2 - lse2);
+            if (need_mask) {
+                int ll = l;
+                hold(ll);  // (keeps the 32 row indices from being hoisted out of the tile loop into 32 VGPRs)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kvl = i * 32 + acc_row(r, ll);
                         const int kv = kv0 + kvl;
                         bool ok = q_abs < Sq && kv < klen && !(causal && kv > q_abs);
                         if (kmb) ok = ok && cM[kvl];
-                        if (!ok) p = 0.f;
+                        if (!ok) st[i][r] = 0.f;
                     }
-                    dpt[i][r] = p * (dpt[i][r] - del) * scale;
-                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dpt[i][r] = st[i][r] * (dpt[i][r] - del) * scale;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -891,32 +900,55 @@ __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, co
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sc[i][r] = float((it * 5 + r * 3 + i + l) & 31) * 0.03125f;
             } else {
+                // r04: the row fragments of k-step kk + 1 are requested BEFORE the two MFMAs of k-step kk are issued (the scheduler, short of
+                // registers, had sunk every read to just in front of its MFMA: read, wait out the LDS latency, multiply -- sixteen times)
+                s16x8 fr[2][2];
+                fr[0][0] = frag_rc3<HD>(first, (l & 31), 0, l);
+                fr[0][1] = frag_rc3<HD>(first, 32 + (l & 31), 0, l);
 #pragma unroll
-                for (int kk = 0; kk < C::KS; ++kk)
+                for (int kk = 0; kk < C::KS; ++kk) {
+                    if (kk + 1 < C::KS) {
+                        fr[(kk + 1) & 1][0] = frag_rc3<HD>(first, (l & 31), kk + 1, l);
+                        fr[(kk + 1) & 1][1] = frag_rc3<HD>(first, 32 + (l & 31), kk + 1, l);
+                    }
+                    sched_fence();
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) sc[i] = mfma32(frag_rc3<HD>(first, i * 32 + (l & 31), kk, l), of[kk], sc[i]);
+                    for (int i = 0; i < 2; ++i) sc[i] = mfma32(fr[kk & 1][i], of[kk], sc[i]);
+                    sched_fence();
+                }
             }
             if (role == 0) {
                 const float* cL = sLse + cur * 64;
                 const bool need_mask = !all_keys_ok || (qt0 + 64 > Sq) || (causal && kv_wmin + 31 > qt0);
+                // r04: the tile's 32 log-sum-exp values first, all eight reads in flight together (the loop used to fetch one f32x4, wait,
+                // use it, fetch the next: eight exposed LDS round trips per tile), and the mask test OUTSIDE the element loop (the compiler
+                // had turned the wave-uniform `if (need_mask)` into one scalar branch per element: 32 per tile)
+                f32x4 ls[2][4];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const f32x4 ls = *reinterpret_cast<const f32x4*>(cL + i * 32 + 8 * rg + 4 * h2);
-                        f32x4 pv;
+                    for (int rg = 0; rg < 4; ++rg) ls[i][rg] = *reinterpret_cast<const f32x4*>(cL + i * 32 + 8 * rg + 4 * h2);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float p = (ARIA_DKDV_ABL & 2) ? sc[i][4 * rg + e] * scale2 - ls[e] : exp2_fast(sc[i][4 * rg + e] * scale2 - ls[e]);
-                            if (need_mask) {
-                                const int q = qt0 + i * 32 + 8 * rg + 4 * h2 + e;
-                                if (!(q < Sq && key_ok && !(causal && kv_abs > q))) p = 0.f;
-                            }
-                            sc[i][4 * rg + e] = p;
-                            pv[e] = p;
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sc[i][r] = (ARIA_DKDV_ABL & 2) ? sc[i][r] * scale2 - ls[i][r >> 2][r & 3] : exp2_fast(sc[i][r] * scale2 - ls[i][r >> 2][r & 3]);
+                if (need_mask) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int q = qt0 + i * 32 + 8 * (r >> 2) + 4 * h2 + (r & 3);
+                            if (!(q < Sq && key_ok && !(causal && kv_abs > q))) sc[i][r] = 0.f;
                         }
-                        if (!(ARIA_DKDV_ABL & 8)) *reinterpret_cast<f32x4*>(myP + (i * 4 + rg) * 1024) = pv;
-                    }
+                }
+                if (!(ARIA_DKDV_ABL & 8)) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg)
+                            *reinterpret_cast<f32x4*>(myP + (i * 4 + rg) * 1024) = f32x4{sc[i][4 * rg], sc[i][4 * rg + 1], sc[i][4 * rg + 2], sc[i][4 * rg + 3]};
+                }
             }
         }
         if (!(ARIA_DKDV_ABL & 16)) sync();  // P published
@@ -1058,6 +1090,7 @@ __global__ __launch_bounds__(512) void attn_bwd5_dq_kernel(const bf16_t* Q, cons
                 st[i] = zero_acc();
                 dpt[i] = zero_acc();
             }
+            // (an explicit one-step fragment prefetch as in the dK/dV kernel spills here: 252 VGPRs already)
 #pragma unroll
             for (int kk = 0; kk < C::KS; ++kk)
 #pragma unroll
