@@ -263,13 +263,26 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
 #pragma unroll
                     for (int r = 0; r < 16; ++r) st[i][r] = float((it * 7 + r * 3 + i + l) & 31) * 0.03125f;
             } else {
+                // r04: the K fragments of k-step kk + 1 are requested before the two MFMAs of k-step kk are issued -- left to itself the
+                // scheduler sank every read to just in front of its MFMA (read, lgkmcnt(0), multiply: ten exposed LDS round trips per tile)
+                auto kf = [&](int i, int kk) __attribute__((always_inline)) -> s16x8 {
+                    return (ARIA_ATTN_ABL & 16) ? qf[(kk + i) % C::KS]
+                                                : *reinterpret_cast<const s16x8*>(cK + (i * 32 + (l & 31)) * C::KP + kk * 16 + h2 * 8);
+                };
+                s16x8 fr[2][2];
+                fr[0][0] = kf(0, 0);
+                fr[0][1] = kf(1, 0);
 #pragma unroll
-                for (int kk = 0; kk < C::KS; ++kk)
+                for (int kk = 0; kk < C::KS; ++kk) {
+                    if (kk + 1 < C::KS) {
+                        fr[(kk + 1) & 1][0] = kf(0, kk + 1);
+                        fr[(kk + 1) & 1][1] = kf(1, kk + 1);
+                    }
+                    sched_fence();
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        st[i] = mfma32((ARIA_ATTN_ABL & 16) ? qf[(kk + i) % C::KS]
-                                                            : *reinterpret_cast<const s16x8*>(cK + (i * 32 + (l & 31)) * C::KP + kk * 16 + h2 * 8),
-                                       qf[kk], st[i]);
+                    for (int i = 0; i < 2; ++i) st[i] = mfma32(fr[kk & 1][i], qf[kk], st[i]);
+                    sched_fence();
+                }
             }
             const bool need_mask = (kv0 + 64 > klen) || (causal && kv0 + 63 > q_wmin) || (kmb && !(sFlag[cur] & 1));
             if (need_mask) {
