@@ -81,6 +81,15 @@ __device__ __forceinline__ s16x8 pack_frag(const f32x16& p, int u) {
 
 __device__ __forceinline__ int acc_row(int r, int l) { return (r & 3) + 8 * (r >> 2) + 4 * (l >> 5); }
 
+// (a0 * b + c, a1 * b + c) as ONE v_pk_fma_f32 (two fp32 lanes per instruction at the plain-VALU rate; each lane is a fused multiply-add,
+// the same rounding as two v_fma_f32): the softmax's score scaling is 32 of a key tile's ~100 vector instructions in the forward kernels,
+// which are vector-ALU-bound as much as matrix-bound (profiles/r04_attn_fwd_ablate.json)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(float a0, float a1, float b, float c) {
+    const f32x2 a = {a0, a1}, bb = {b, b}, cc = {c, c};
+    return __builtin_elementwise_fma(a, bb, cc);
+}
+
 __device__ __forceinline__ f32x16 zero_acc() {
     f32x16 z;
 #pragma unroll
@@ -323,10 +332,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = (ARIA_ATTN_ABL & 2) ? st[i][r] * scale2 - m_safe : exp2_fast(st[i][r] * scale2 - m_safe);
-                    st[i][r] = p;
-                    if (!C::ROWSUM_IN_MFMA) ps += p;
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 x = fma2(st[i][r], st[i][r + 1], scale2, -m_safe);
+#pragma unroll
+                    for (int z = 0; z < 2; ++z) {
+                        const float p = (ARIA_ATTN_ABL & 2) ? x[z] : exp2_fast(x[z]);
+                        st[i][r + z] = p;
+                        if (!C::ROWSUM_IN_MFMA) ps += p;
+                    }
                 }
             if (!C::ROWSUM_IN_MFMA) lsum += ps;
             // O^T += V^T P^T
@@ -1322,10 +1335,14 @@ __device__ __forceinline__ void fwd3_step(f32x16 (&st)[2], f32x16 (&sn)[2], f32x
                 for (int ii = 0; ii < 2; ++ii) sn[ii] = mfma32(F::kfrag(nK, ii * 32 + (l & 31), kk, l), qf[kk], sn[ii]);
         }
 #pragma unroll
-        for (int r = 8 * u; r < 8 * u + 8; ++r) {
-            const float p = exp2_fast(st[i][r] * scale2 - m_safe);
-            st[i][r] = p;
-            if (!F::ROWSUM_IN_MFMA) ps += p;
+        for (int r = 8 * u; r < 8 * u + 8; r += 2) {
+            const f32x2 x = fma2(st[i][r], st[i][r + 1], scale2, -m_safe);
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                const float p = exp2_fast(x[z]);
+                st[i][r + z] = p;
+                if (!F::ROWSUM_IN_MFMA) ps += p;
+            }
         }
         const s16x8 pf = pack_frag(st[i], u);
 #pragma unroll
