@@ -122,6 +122,43 @@ class ExpertsGluFn(torch.autograd.Function):
         return dx, dw, None
 
 
+class ExpertsGemmSegFn(torch.autograd.Function):
+    """``ExpertsGemmFn`` over the SEGMENTS of an expert-parallel exchange: rows ordered (source rank, local expert), offsets int32
+    [ranks * E_local + 1]; segment g uses weight[g % E_local] (``ops.grouped_gemm_seg``) -- the all-to-all's output is consumed in arrival
+    order, forward and backward; the weight gradient sums the source ranks' segments of an expert (fp32 when there are several)."""
+
+    @staticmethod
+    def forward(ctx, inp, weight, offsets):
+        ctx.save_for_backward(inp, weight, offsets)
+        return ops.grouped_gemm_seg(inp, weight, offsets)
+
+    @staticmethod
+    def backward(ctx, dy):
+        inp, weight, offsets = ctx.saved_tensors
+        dy = _c(dy)
+        dx = ops.grouped_gemm_seg(dy, weight, offsets, w_is_kn=False) if ctx.needs_input_grad[0] else None
+        dw = ops.grouped_gemm_wgrad_seg(inp, dy, offsets, weight.shape[0]) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+class ExpertsGluSegFn(torch.autograd.Function):
+    """``ExpertsGluFn`` over segments (fc1 + SwiGLU in one launch on the exchange's output as it arrived)."""
+
+    @staticmethod
+    def forward(ctx, inp, weight, offsets):
+        h, act = ops.grouped_gemm_swiglu_seg(inp, weight, offsets, want_h=True)
+        ctx.save_for_backward(inp, weight, offsets, h)
+        return act
+
+    @staticmethod
+    def backward(ctx, dact):
+        inp, weight, offsets, h = ctx.saved_tensors
+        dh = ops.swiglu_bwd(h, _c(dact))
+        dx = ops.grouped_gemm_seg(dh, weight, offsets, w_is_kn=False) if ctx.needs_input_grad[0] else None
+        dw = ops.grouped_gemm_wgrad_seg(inp, dh, offsets, weight.shape[0]) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
 class SharedGluFn(torch.autograd.Function):
     """silu(gate_proj(x)) * up_proj(x) of SharedExpertMLP (moe_lm.py:368-395) as ONE GEMM over the row-wise concatenation of the two
     weights with the SwiGLU epilogue; the input gradient is one GEMM with the long reduction, the two weight gradients one wide GEMM."""

@@ -498,6 +498,57 @@ int aria_gemm_swiglu_split_bf16(const void* A, const void* Bg, const void* Bu, v
     return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int((M + 255) / 256), stream);
 }
 
+// Expert parallelism: grouped launches over the SEGMENTS of an all-to-all's output (ordered (source rank, local expert)): segment g uses
+// the weight of local expert g % n_local.  v3 kernels only (ARIA_ERR_UNSUPPORTED otherwise: the caller re-orders and takes the plain entry).
+int aria_grouped_gemm_seg_bf16(const void* A, const void* B, void* C, const int32_t* offsets, int64_t n_seg, int64_t n_local, int64_t M_total,
+                               int64_t N, int64_t K, int b_oc, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldc, void* stream) {
+    if (!A || !B || !C || !offsets || n_seg <= 0 || n_local <= 0 || (n_seg % n_local) || M_total < 0 || N <= 0 || K <= 0) return ARIA_ERR_INVALID;
+    if (!aligned16(A) || !aligned16(B) || (lda & 7) || (ldb & 7) || (strideB & 7) || (K & 7) || (b_oc && (N & 7)) || (ldc & 1) ||
+        (reinterpret_cast<uintptr_t>(C) & 3))
+        return ARIA_ERR_ALIGN;
+    if ((K % 64) || K < 64 || 2 * M_total * lda >= (1ll << 32) || 2 * (b_oc ? K : N) * ldb >= (1ll << 32) || 2 * lda >= (1ll << 24) || 2 * ldb >= (1ll << 24) ||
+        N < 8)
+        return ARIA_ERR_UNSUPPORTED;
+    if (M_total == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A);
+    p.B = static_cast<const bf16_t*>(B);
+    p.C = C;
+    p.lda = lda, p.ldb = ldb, p.ldc = ldc;
+    p.M = int(M_total), p.N = int(N), p.K = int(K);
+    p.mode = 1;
+    p.offsets = offsets;
+    p.E = int(n_seg);
+    p.strideB = strideB;
+    p.expert_mod = int(n_local);
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, b_oc, int(M_total / 256 + n_seg), stream);
+}
+
+int aria_grouped_gemm_swiglu_seg_bf16(const void* A, const void* B, void* H, void* ACT, const int32_t* offsets, int64_t n_seg, int64_t n_local,
+                                      int64_t M_total, int64_t N2, int64_t K, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldh, int64_t ldact,
+                                      void* stream) {
+    if (!offsets || n_seg <= 0 || n_local <= 0 || (n_seg % n_local)) return ARIA_ERR_INVALID;
+    const int rc = glu_check(A, B, H, ACT, M_total, N2, K, lda, ldb, ldh, ldact);
+    if (rc != ARIA_OK) return rc;
+    if (strideB & 7) return ARIA_ERR_ALIGN;
+    if ((K % 64) || 2 * M_total * lda >= (1ll << 32) || 2 * K * ldb >= (1ll << 32)) return ARIA_ERR_UNSUPPORTED;
+    if (M_total == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A);
+    p.B = static_cast<const bf16_t*>(B);
+    p.C = H;
+    p.C2 = ACT;
+    p.lda = lda, p.ldb = ldb, p.ldc = ldh, p.ldc2 = ldact;
+    p.M = int(M_total), p.N = int(N2), p.K = int(K);
+    p.mode = 1;
+    p.offsets = offsets;
+    p.E = int(n_seg);
+    p.strideB = strideB;
+    p.glu = 1;
+    p.expert_mod = int(n_local);
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, 1, int(M_total / 256 + n_seg), stream);
+}
+
 // K2: the two fused SwiGLU launches over grouped rows with the dispatcher's gather folded into the A loader.  X is the un-permuted token
 // matrix [T, K]; rows[r] (int32, device, r < M_total) is the token row permuted row r would hold.
 int aria_grouped_gemm_swiglu_gather_bf16(const void* X, const int32_t* rows, int64_t T, const void* B, void* H, void* ACT, const int32_t* offsets,

@@ -751,7 +751,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         int expert = 0;
         if (!aria_grouped_tile(p, blockIdx.x, l, expert, m0, m_end, tn)) return;
         n0 = tn * bn_step;
-        b_off = (long long)expert * p.strideB;
+        b_off = (long long)(p.expert_mod > 0 ? expert % p.expert_mod : expert) * p.strideB;
     }
     char* C = static_cast<char*>(p.C) + c_off * (p.c_f32 ? 4 : 2);
     int nk = (k_len + BK - 1) / BK, kt_first = 0;

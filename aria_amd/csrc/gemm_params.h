@@ -54,6 +54,9 @@ struct GemmParams {
     void* kc;
     void* vc;
     long long ld_cache;
+    // grouped rows whose groups are SEGMENTS of an expert-parallel exchange (rows arrive ordered (source rank, local expert)): group g uses
+    // the weight of expert g % expert_mod (0: group g uses weight g).  The all-to-all's output is consumed in arrival order, no re-order pass.
+    int expert_mod;
 };
 // (the device helpers below are templates on the block's type so that a kernel may also hand them the block where it lies in the
 // kernarg segment -- a reference into the constant address space: scalar loads at the point of use instead of registers held live)

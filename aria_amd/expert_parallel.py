@@ -185,7 +185,23 @@ def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w
         both = both_dev.cpu()
     send_splits, recv_splits = both[0].sum(1).tolist(), both[1].sum(1).tolist()
     rows = AllToAllRowsFn.apply(perm, send_splits, recv_splits, group)             # ordered (source rank, local expert)
-    # reorder to local-expert-major for the grouped GEMM: destination segment (e, s) takes source segment (s, e)
+    K = fc1_local.shape[1]
+    if ops.segments_supported(K) and ops.segments_supported(fc2_local.shape[1]) and ops.glu_fusable(K, fc1_local.shape[2]):
+        # r04: the grouped launches take the exchange's output AS IT ARRIVED -- W * El segments ordered (source rank, local expert), segment
+        # g multiplying with local expert g % El -- so no row passes over [6T, D] in front of fc1 or behind fc2, forward or backward
+        seg_off = torch.zeros(W * El + 1, dtype=torch.int32, device=x.device)
+        seg_off[1:] = torch.cumsum(recv_counts.reshape(-1), 0).to(torch.int32)
+        act = AG.ExpertsGluSegFn.apply(rows, fc1_local, seg_off)
+        eo_local = AG.ExpertsGemmSegFn.apply(act, fc2_local, seg_off)
+        eo = AllToAllRowsFn.apply(eo_local, recv_splits, send_splits, group)       # my rows, original expert-major order
+        if sh is None:
+            sh = _shared_expert(x, gate_w, up_w, down_w)
+        else:
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            sh.record_stream(torch.cuda.current_stream(x.device))
+            x.record_stream(side)
+        return UnpermuteFn.apply(eo, inv, scores, sh, k)
+    # (widths the segment launches do not take: reorder to local-expert-major -- destination segment (e, s) takes source segment (s, e))
     R = rows.shape[0]
     rcd = recv_counts.long()                                                       # [source rank, local expert] on the device
     src_start = (torch.cumsum(rcd.reshape(-1), 0) - rcd.reshape(-1)).view(W, El)   # where segment (s, e) starts in `rows`

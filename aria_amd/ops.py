@@ -191,6 +191,58 @@ def grouped_gemm_swiglu_split(a: torch.Tensor, w_gate: torch.Tensor, w_up: torch
     return h, act
 
 
+def segments_supported(K: int) -> bool:
+    """Grouped launches over the segments of an expert-parallel exchange (``expert_mod``): v3 kernels only; ARIA_EP_SEGMENTS=0 switches the
+    expert-parallel layer back to re-ordering the received rows."""
+    import os
+
+    return K % 64 == 0 and K >= 64 and os.environ.get("ARIA_EP_SEGMENTS", "1") != "0"
+
+
+def grouped_gemm_seg(a: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, *, w_is_kn: bool = True) -> torch.Tensor:
+    """``grouped_gemm`` over segments: offsets int32 [n_seg + 1], n_seg a multiple of w.shape[0]; segment g uses w[g % w.shape[0]]."""
+    _chk(a, name="a"), _chk(w, name="w"), _chk(offsets, torch.int32, "offsets")
+    if w.dim() != 3 or not w.is_contiguous():
+        raise ValueError("grouped_gemm_seg: w must be a contiguous [E_local, ., .] tensor")
+    M, K = a.shape
+    El, n_seg = w.shape[0], offsets.numel() - 1
+    N = w.shape[2] if w_is_kn else w.shape[1]
+    if (w.shape[1] if w_is_kn else w.shape[2]) != K or n_seg % El:
+        raise ValueError("grouped_gemm_seg: reduction sizes differ or the segment count is not a multiple of the local experts")
+    out = torch.empty((M, N), dtype=bf16, device=a.device)
+    hip.get_lib().call("aria_grouped_gemm_seg_bf16", _p(a), _p(w), _p(out), _p(offsets), n_seg, El, M, N, K, int(w_is_kn), _rowmajor_2d(a, "a"),
+                       w.shape[2], w.shape[1] * w.shape[2], N, _stream(a))
+    return out
+
+
+def grouped_gemm_swiglu_seg(a: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, want_h: bool = True):
+    """``grouped_gemm_swiglu`` over segments (see ``grouped_gemm_seg``)."""
+    _chk(a, name="a"), _chk(w, name="w"), _chk(offsets, torch.int32, "offsets")
+    M, K = a.shape
+    El, _, N2 = w.shape
+    n_seg = offsets.numel() - 1
+    if w.shape[1] != K or n_seg % El or not w.is_contiguous():
+        raise ValueError("grouped_gemm_swiglu_seg: w must be a contiguous [E_local, K, 2I] tensor and the segments a multiple of E_local")
+    h = torch.empty((M, N2), dtype=bf16, device=a.device) if want_h else None
+    act = torch.empty((M, N2 // 2), dtype=bf16, device=a.device)
+    hip.get_lib().call("aria_grouped_gemm_swiglu_seg_bf16", _p(a), _p(w), _p(h) if want_h else None, _p(act), _p(offsets), n_seg, El, M, N2, K,
+                       _rowmajor_2d(a, "a"), N2, K * N2, N2, N2 // 2, _stream(a))
+    return h, act
+
+
+def grouped_gemm_wgrad_seg(a: torch.Tensor, dy: torch.Tensor, offsets: torch.Tensor, El: int) -> torch.Tensor:
+    """dW[e] = sum over source ranks s of a[seg(s, e)]^T dy[seg(s, e)]: one grouped-K launch per source rank on that rank's El + 1 offsets;
+    several ranks accumulate in fp32 and round once."""
+    n_seg = offsets.numel() - 1
+    W = n_seg // El
+    if W == 1:
+        return grouped_gemm_wgrad(a, dy, offsets, El)
+    out = torch.empty((El, a.shape[1], dy.shape[1]), dtype=torch.float32, device=a.device)
+    for src in range(W):
+        grouped_gemm_wgrad(a, dy, offsets[src * El: (src + 1) * El + 1], El, out=out, accumulate=src > 0)
+    return out.to(bf16)
+
+
 def qkv_rope_cache_fusable(D: int, K: int, hd: int) -> bool:
     """The wqkv projection can carry RoPE and the KV-cache write as its epilogue (K7); ARIA_FUSE_QKV_ROPE=0: the three-step chain."""
     import os

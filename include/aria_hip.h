@@ -116,6 +116,19 @@ int aria_grouped_gemm_swiglu_split_gather_bf16(const void* X, const int32_t* row
 int aria_gemm_qkv_rope_cache_bf16(const void* X, const void* Wqkv, void* Q, void* Kc, void* Vc, const void* freqs_cis, const int32_t* pos,
                                   int64_t M, int64_t D, int64_t K, int64_t hd, int64_t S, int64_t S_cache, int64_t ldx, int64_t ldw, int64_t ldq,
                                   int64_t ld_cache, void* stream);
+
+/* Expert parallelism (BASELINE config #5; the reference's dispatcher is local, moe_lm.py:313-365): the grouped GEMM and the fused fc1 + glu
+ * launch over the SEGMENTS of an all-to-all's output.  Rows arrive ordered (source rank s, local expert e); offsets int32 [n_seg + 1] bound the
+ * n_seg = ranks x n_local segments in that order, and segment g multiplies with the weight of local expert g % n_local (B + (g % n_local) *
+ * strideB) -- the exchange's output is consumed where it lands, no re-order pass in front of the GEMM or behind it.  Everything else as
+ * aria_grouped_gemm_bf16 / aria_grouped_gemm_swiglu_bf16.  K % 64 == 0 (ARIA_ERR_UNSUPPORTED otherwise: re-order and use the plain entries).
+ * The weight gradient needs no entry of its own: aria_grouped_gemm_wgrad_bf16 once per source rank on that rank's n_local + 1 offsets,
+ * accumulating. */
+int aria_grouped_gemm_seg_bf16(const void* A, const void* B, void* C, const int32_t* offsets, int64_t n_seg, int64_t n_local, int64_t M_total,
+                               int64_t N, int64_t K, int b_oc, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldc, void* stream);
+int aria_grouped_gemm_swiglu_seg_bf16(const void* A, const void* B, void* H, void* ACT, const int32_t* offsets, int64_t n_seg, int64_t n_local,
+                                      int64_t M_total, int64_t N2, int64_t K, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldh, int64_t ldact,
+                                      void* stream);
 int aria_gemm_swiglu_split_bf16(const void* A, const void* Bg, const void* Bu, void* H, void* ACT, int64_t M, int64_t I, int64_t K, int64_t lda,
                                 int64_t ldb, int64_t ldh, int64_t ldact, void* stream);
 

@@ -162,23 +162,39 @@ def _ep_inputs(rank, D):
     return torch.randn(21 + 4 * rank, D, generator=g).to(bf16), torch.randn(21 + 4 * rank, D, generator=g).to(bf16)
 
 
-def _ep_params(dev):
-    g = torch.load(GOLDEN_MOE, map_location="cpu", weights_only=False)
-    w = {k: v.to(bf16).to(dev) for k, v in g["weights"].items()}
+def _ep_params(dev, width=None):
+    """The golden MoE layer (D 64, I 32: the re-ordering form of the EP layer), or -- ``width`` = (D, I, E, k) -- random weights at a width
+    the segment launches take (K % 64 == 0, I % 128 == 0: the exchange's output consumed in arrival order)."""
     from aria_amd.functional import MoEConfig
 
+    if width is not None:
+        D, I, E, k = width
+        gen = torch.Generator().manual_seed(4242)
+
+        def r(*shape):
+            return (torch.randn(shape, generator=gen) * 0.08).to(bf16).to(dev)
+
+        cfg = MoEConfig(topk=k, num_experts=E, z_loss_coeff=1e-3, aux_loss_coeff=1e-2, aux_scale=1.0)
+        return [r(E, D), r(E, D, 2 * I), r(E, I, D), r(2 * I, D), r(2 * I, D), r(D, 2 * I)], cfg
+    g = torch.load(GOLDEN_MOE, map_location="cpu", weights_only=False)
+    w = {k: v.to(bf16).to(dev) for k, v in g["weights"].items()}
     cfg = MoEConfig(topk=g["cfg"]["moe_topk"], num_experts=g["cfg"]["moe_num_experts"], z_loss_coeff=1e-3, aux_loss_coeff=1e-2, aux_scale=1.0)
     return [w["router.weight"], w["experts.fc1.weight"], w["experts.fc2.weight"], w["shared_experts.gate_proj.weight"],
             w["shared_experts.up_proj.weight"], w["shared_experts.down_proj.weight"]], cfg
 
 
-def _ep_worker(rank, world, port, outdir, backend):
+def _ep_worker(rank, world, port, outdir, backend, width):
     dev = _setup(rank, world, port, backend)
     import torch.distributed as dist
 
+    from aria_amd import ops
     from aria_amd.expert_parallel import ep_moe_forward, shard_expert_weights
 
-    (router, fc1, fc2, gate, up, down), cfg = _ep_params(dev)
+    (router, fc1, fc2, gate, up, down), cfg = _ep_params(dev, width)
+    seg_calls = []
+    if width is not None:   # the segment launches must be what runs at this width
+        orig = ops.grouped_gemm_swiglu_seg
+        ops.grouped_gemm_swiglu_seg = lambda *a, **k: (seg_calls.append(1), orig(*a, **k))[1]
     f1, f2 = shard_expert_weights(fc1, fc2, rank, world)
     ps = [t.clone().requires_grad_(True) for t in (router, f1, f2, gate, up, down)]
     x, gy = (t.to(dev) for t in _ep_inputs(rank, router.shape[1]))
@@ -191,22 +207,23 @@ def _ep_worker(rank, world, port, outdir, backend):
         out.backward(gy)
     if dev.type == "cuda":
         torch.cuda.synchronize()
+    assert width is None or len(seg_calls) == 2, seg_calls
     torch.save(dict(out=out.detach().float().cpu(), dx=x.grad.float().cpu(), grads=[p.grad.float().cpu() for p in ps]),
                os.path.join(outdir, f"ep{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def run_ep_layer(backend: str, world: int):
+def run_ep_layer(backend: str, world: int, width=None):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_ep_worker, args=(world, free_port(), d, backend), nprocs=world, join=True)
+        mp.spawn(_ep_worker, args=(world, free_port(), d, backend, width), nprocs=world, join=True)
         got = [torch.load(os.path.join(d, f"ep{r}.pt")) for r in range(world)]
     dev = _local_device(backend)
     from aria_amd import autograd as AG
 
     ref = []
     for r in range(world):
-        params, cfg = _ep_params(dev)
+        params, cfg = _ep_params(dev, width)
         ps = [t.clone().requires_grad_(True) for t in params]
         x, gy = (t.to(dev) for t in _ep_inputs(r, ps[0].shape[1]))
         x = x.requires_grad_(True)

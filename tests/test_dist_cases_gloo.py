@@ -20,3 +20,9 @@ def test_dp_lm_exchange_norm_and_sharded_adamw(mode, overlap):
 
 def test_ep_layer_two_ranks():
     D.run_ep_layer("gloo", 2)
+
+
+def test_ep_layer_consumes_the_exchange_in_arrival_order():
+    """Width the segment launches take (D 128, I 128, 8 experts top-2): fc1 + glu and fc2 run over (source rank, local expert) segments with
+    weight index = segment mod local experts -- no row re-order around the grouped GEMMs; weight gradients summed over the source ranks."""
+    D.run_ep_layer("gloo", 2, width=(128, 128, 8, 2))

@@ -21,6 +21,7 @@ def test_dp_lm_exchange_norm_and_sharded_adamw_rccl(mode, overlap):
 @need2
 def test_ep_layer_two_ranks_rccl():
     D.run_ep_layer("nccl", 2)
+    D.run_ep_layer("nccl", 2, width=(2560, 1664, 64, 6))     # Aria's width: the segment launches
 
 
 @pytest.mark.skipif(N_GPU < 4, reason="needs >= 4 GPUs")
