@@ -2,6 +2,7 @@
 // ballots for the stable sort, no host round trips).  Reference: aria/model/moe_lm.py:243-365, 505-507.
 #include "aria_device.h"
 #include "aria_hip.h"
+#include <cstdlib>
 #include <algorithm>
 
 namespace {
@@ -178,7 +179,129 @@ __global__ __launch_bounds__(256) void permute_kernel(const bf16_t* x, const int
     }
 }
 
+// Row width known at compile time (D = 512 NC: Aria's 2560 is NC = 5): every 16-byte load of a row is issued before the first store, and
+// the NEXT row's index is fetched while the current row moves -- the generic kernel above has one load per lane in flight (index load,
+// then chunk after chunk), ~32 KB per CU against the ~64 KB that 8 TB/s x ~2 us of latency need (r04; it ran at 3.5-3.8 TB/s).
+template <int NC>
+__global__ __launch_bounds__(256) void permute_rows_kernel(const bf16_t* x, const int32_t* sorted_src, bf16_t* out, int M, int k, long long ldx) {
+    const int l = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    constexpr int D = NC * 512;
+    int p = wave;
+    int src = p < M ? sorted_src[p] : 0;
+    while (p < M) {
+        const int pn = p + nwaves;
+        const int src_n = pn < M ? sorted_src[pn] : 0;
+        const bf16_t* row = x + (long long)(src / k) * ldx;
+        u32x4 v[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) v[i] = ld16(row + (l + 64 * i) * 8);
+        bf16_t* dst = out + (long long)p * D;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) st16(dst + (l + 64 * i) * 8, v[i]);
+        p = pn;
+        src = src_n;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- unpermute (+ shared add)
+// (compile-time row width, see permute_rows_kernel: the k rows of a token x NC chunks + the shared expert's chunks are all in flight together;
+// same arithmetic in the same order as unpermute_kernel -- bit-identical)
+template <int NC, int K>
+__global__ __launch_bounds__(256) void unpermute_rows_kernel(const bf16_t* eo, const int32_t* inv, const bf16_t* scores, const bf16_t* add,
+                                                             bf16_t* out, int T) {
+    const int l = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    constexpr int D = NC * 512;
+    for (int t = wave; t < T; t += nwaves) {
+        int rows[K];
+        float sc[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            rows[j] = inv[(long long)t * K + j];
+            sc[j] = scores ? bf2f(scores[(long long)t * K + j]) : 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = l + 64 * i;
+            u32x4 v[K], a = zero16();
+#pragma unroll
+            for (int j = 0; j < K; ++j) v[j] = ld16(eo + (long long)rows[j] * D + c * 8);
+            if (add) a = ld16(add + (long long)t * D + c * 8);
+            float acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (scores) {  // product materialised in bf16 by the reference (moe_lm.py:362)
+                        acc[2 * q] += rbf(bflo(v[j][q]) * sc[j]);
+                        acc[2 * q + 1] += rbf(bfhi(v[j][q]) * sc[j]);
+                    } else {
+                        acc[2 * q] += bflo(v[j][q]);
+                        acc[2 * q + 1] += bfhi(v[j][q]);
+                    }
+                }
+            u32x4 o;
+            if (add) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = pack2bf(rbf(acc[2 * q]) + bflo(a[q]), rbf(acc[2 * q + 1]) + bfhi(a[q]));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = pack2bf(acc[2 * q], acc[2 * q + 1]);
+            }
+            st16(out + (long long)t * D + c * 8, o);
+        }
+    }
+}
+
+// backward of unpermute with a compile-time row width: dout's chunks are fetched ONCE per token (the generic kernel re-reads them for each of
+// the k rows), a row's NC chunks are in flight together, and the dot product's wave sum runs on the DPP ladder instead of six ds_bpermute
+// round trips per row.  d_eo is bit-identical to the generic kernel's; dscores differs from it in the order of the 64-lane sum only (the
+// per-lane partial sums are formed in the same order), within the rounding of the bf16 it is stored in.
+template <int NC, int K>
+__global__ __launch_bounds__(256) void unpermute_bwd_rows_kernel(const bf16_t* dout, const bf16_t* eo, const int32_t* inv, const bf16_t* scores,
+                                                                 bf16_t* d_eo, bf16_t* dscores, int T) {
+    const int l = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    constexpr int D = NC * 512;
+    for (int t = wave; t < T; t += nwaves) {
+        u32x4 g[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) g[i] = ld16(dout + (long long)t * D + (l + 64 * i) * 8);
+        int rows[K];
+        float sc[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            rows[j] = inv[(long long)t * K + j];
+            sc[j] = bf2f(scores[(long long)t * K + j]);
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            u32x4 v[NC];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) v[i] = ld16(eo + (long long)rows[j] * D + (l + 64 * i) * 8);
+            float dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                u32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    dot += bflo(g[i][q]) * bflo(v[i][q]) + bfhi(g[i][q]) * bfhi(v[i][q]);
+                    o[q] = pack2bf(bflo(g[i][q]) * sc[j], bfhi(g[i][q]) * sc[j]);
+                }
+                st16(d_eo + (long long)rows[j] * D + (l + 64 * i) * 8, o);
+            }
+            dot = wave_sum_bcast(dot);
+            if (l == 0) dscores[(long long)t * K + j] = f2bf(dot);
+        }
+    }
+}
+
 template <int K_MAX>
 __global__ __launch_bounds__(256) void unpermute_kernel(const bf16_t* eo, const int32_t* inv, const bf16_t* scores,
                                                         const bf16_t* add, bf16_t* out, int T, int D, int k) {
@@ -390,6 +513,12 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const bf16_t* dy, co
     }
 }
 
+// ARIA_MOE_GENERIC_DISPATCH=1: the generic-width permute / unpermute kernels everywhere (A/B measurements, bit-identity tests)
+bool generic_dispatch_kernels() {
+    const char* e = std::getenv("ARIA_MOE_GENERIC_DISPATCH");
+    return e && e[0] == '1';
+}
+
 int grid_for_waves(long long n_items, int waves_per_block = 4) {
     long long g = (n_items + waves_per_block - 1) / waves_per_block;
     if (g < 1) g = 1;
@@ -444,8 +573,15 @@ int aria_moe_permute(const void* x, const int32_t* sorted_src, void* permuted, i
     if (!x || !sorted_src || !permuted || M < 0 || D <= 0 || k <= 0) return ARIA_ERR_INVALID;
     if ((D & 7) || (ldx & 7)) return ARIA_ERR_ALIGN;
     if (M == 0) return ARIA_OK;
-    ARIA_LAUNCH(permute_kernel, dim3(grid_for_waves(M)), dim3(256), 0, stream, static_cast<const bf16_t*>(x), sorted_src,
-                static_cast<bf16_t*>(permuted), int(M), int(D), int(k), (long long)ldx);
+    if (D == 2560 && !generic_dispatch_kernels())
+        ARIA_LAUNCH((permute_rows_kernel<5>), dim3(grid_for_waves(M)), dim3(256), 0, stream, static_cast<const bf16_t*>(x), sorted_src,
+                    static_cast<bf16_t*>(permuted), int(M), int(k), (long long)ldx);
+    else if (D == 512 && !generic_dispatch_kernels())
+        ARIA_LAUNCH((permute_rows_kernel<1>), dim3(grid_for_waves(M)), dim3(256), 0, stream, static_cast<const bf16_t*>(x), sorted_src,
+                    static_cast<bf16_t*>(permuted), int(M), int(k), (long long)ldx);
+    else
+        ARIA_LAUNCH(permute_kernel, dim3(grid_for_waves(M)), dim3(256), 0, stream, static_cast<const bf16_t*>(x), sorted_src,
+                    static_cast<bf16_t*>(permuted), int(M), int(D), int(k), (long long)ldx);
     return aria_check_launch();
 }
 
@@ -455,9 +591,14 @@ int aria_moe_unpermute(const void* expert_out, const int32_t* inv, const void* s
     if (D & 7) return ARIA_ERR_ALIGN;
     if (k > 8) return ARIA_ERR_UNSUPPORTED;
     if (T == 0) return ARIA_OK;
-    ARIA_LAUNCH((unpermute_kernel<8>), dim3(grid_for_waves(T)), dim3(256), 0, stream, static_cast<const bf16_t*>(expert_out), inv,
-                static_cast<const bf16_t*>(scores), static_cast<const bf16_t*>(add), static_cast<bf16_t*>(out), int(T), int(D),
-                int(k));
+    const bf16_t *eo = static_cast<const bf16_t*>(expert_out), *sc = static_cast<const bf16_t*>(scores), *ad = static_cast<const bf16_t*>(add);
+    if (D == 2560 && k == 6 && !generic_dispatch_kernels())   // Aria's width and top-k: compile-time row width, everything in flight together
+        ARIA_LAUNCH((unpermute_rows_kernel<5, 6>), dim3(grid_for_waves(T)), dim3(256), 0, stream, eo, inv, sc, ad, static_cast<bf16_t*>(out), int(T));
+    else if (D == 512 && k == 2 && !generic_dispatch_kernels())   // (the same template at a width the CPU suite runs)
+        ARIA_LAUNCH((unpermute_rows_kernel<1, 2>), dim3(grid_for_waves(T)), dim3(256), 0, stream, eo, inv, sc, ad, static_cast<bf16_t*>(out), int(T));
+    else
+        ARIA_LAUNCH((unpermute_kernel<8>), dim3(grid_for_waves(T)), dim3(256), 0, stream, eo, inv, sc, ad, static_cast<bf16_t*>(out), int(T), int(D),
+                    int(k));
     return aria_check_launch();
 }
 
@@ -466,9 +607,16 @@ int aria_moe_unpermute_bwd(const void* dout, const void* expert_out, const int32
     if (!dout || !expert_out || !inv || !scores || !d_expert_out || !dscores || T < 0 || D <= 0 || k <= 0) return ARIA_ERR_INVALID;
     if (D & 7) return ARIA_ERR_ALIGN;
     if (T == 0) return ARIA_OK;
-    ARIA_LAUNCH(unpermute_bwd_kernel, dim3(grid_for_waves(T)), dim3(256), 0, stream, static_cast<const bf16_t*>(dout),
-                static_cast<const bf16_t*>(expert_out), inv, static_cast<const bf16_t*>(scores),
-                static_cast<bf16_t*>(d_expert_out), static_cast<bf16_t*>(dscores), int(T), int(D), int(k));
+    const bf16_t *g = static_cast<const bf16_t*>(dout), *eo = static_cast<const bf16_t*>(expert_out), *sc = static_cast<const bf16_t*>(scores);
+    if (D == 2560 && k == 6 && !generic_dispatch_kernels())
+        ARIA_LAUNCH((unpermute_bwd_rows_kernel<5, 6>), dim3(grid_for_waves(T)), dim3(256), 0, stream, g, eo, inv, sc, static_cast<bf16_t*>(d_expert_out),
+                    static_cast<bf16_t*>(dscores), int(T));
+    else if (D == 512 && k == 2 && !generic_dispatch_kernels())
+        ARIA_LAUNCH((unpermute_bwd_rows_kernel<1, 2>), dim3(grid_for_waves(T)), dim3(256), 0, stream, g, eo, inv, sc, static_cast<bf16_t*>(d_expert_out),
+                    static_cast<bf16_t*>(dscores), int(T));
+    else
+        ARIA_LAUNCH(unpermute_bwd_kernel, dim3(grid_for_waves(T)), dim3(256), 0, stream, g, eo, inv, sc, static_cast<bf16_t*>(d_expert_out),
+                    static_cast<bf16_t*>(dscores), int(T), int(D), int(k));
     return aria_check_launch();
 }
 

@@ -402,6 +402,45 @@ def case_dispatch(dev, T, E, k, exact, D=72):
     close(gsum, torch.zeros(T * k, D).index_copy_(0, want_sorted, eo.float()).view(T, k, D).sum(1).to(bf16), 1e-2, 1e-2)
 
 
+def case_dispatch_fixed_width(dev, T, E, k, D):
+    """r04: the permute / unpermute / unpermute-backward kernels with a compile-time row width (every chunk of a row in flight together, the
+    gradient row fetched once per token, the dot product's wave sum on DPP) against the generic-width kernels (ARIA_MOE_GENERIC_DISPATCH=1):
+    rows bit-identical; dscores identical up to the order of the 64-lane sum; and against the oracle (moe_lm.py:313-365)."""
+    import os
+
+    from aria_amd import ops
+
+    g = torch.Generator().manual_seed(T + D)
+    logits = torch.randn(T, E, generator=g).to(bf16)
+    scores, idx, counts = ops.moe_route(logits.to(dev), k)
+    off, sorted_src, inv = ops.moe_sort(idx, counts)
+    x, eo, shared, dout = rnd(T, D, seed=9), rnd(T * k, D, seed=10), rnd(T, D, seed=11), rnd(T, D, seed=12)
+
+    def run():
+        perm = ops.moe_permute(x.to(dev), sorted_src, k)
+        comb = ops.moe_unpermute(eo.to(dev), inv, scores, k, add=shared.to(dev))
+        plain = ops.moe_unpermute(eo.to(dev), inv, None, k)
+        d_eo, dsc = ops.moe_unpermute_bwd(dout.to(dev), eo.to(dev), inv, scores, k)
+        return [t.cpu() for t in (perm, comb, plain, d_eo, dsc)]
+
+    fast = run()
+    os.environ["ARIA_MOE_GENERIC_DISPATCH"] = "1"
+    try:
+        generic = run()
+    finally:
+        os.environ.pop("ARIA_MOE_GENERIC_DISPATCH")
+    for a, b, what in zip(fast[:4], generic[:4], ("permute", "unpermute + shared", "unpermute", "d_eo")):
+        assert torch.equal(a, b), what
+    close(fast[4], generic[4].float(), 1e-2, 1e-2)                      # dscores: another order of the 64-lane sum
+    want_perm, want_sorted = O.token_permutation(x, idx.cpu().long(), k)
+    assert torch.equal(fast[0], want_perm)
+    assert torch.equal(fast[1], O.token_unpermutation(eo, scores.cpu(), want_sorted, k, (T, D)) + shared)
+    eof, sf = eo.float().requires_grad_(True), scores.cpu().float().requires_grad_(True)
+    O.token_unpermutation(eof, sf, want_sorted, k, (T, D)).backward(dout.float())
+    close(fast[3], eof.grad, 1e-2, 1e-2)
+    close(fast[4], sf.grad, 2e-2, 5e-2)
+
+
 def case_moe_backward_pieces(dev):
     from aria_amd import ops
 

@@ -239,3 +239,8 @@ def test_fused_swiglu_with_the_row_gather_in_the_loader(T, E, k, K, I):
 @pytest.mark.parametrize("B,S,D,hd,K,S_cache,shuffled", [(1, 70, 256, 64, 64, 96, False), (2, 33, 256, 128, 128, 40, True)])
 def test_qkv_projection_with_rope_and_cache_write_epilogue(B, S, D, hd, K, S_cache, shuffled):
     C.case_gemm_qkv_rope_cache(DEV, B, S, D, hd, K, S_cache, shuffled)
+
+
+@pytest.mark.parametrize("T,E,k,D", [(70, 8, 2, 512), (37, 64, 6, 2560)])
+def test_dispatch_kernels_with_a_compile_time_row_width(T, E, k, D):
+    C.case_dispatch_fixed_width(DEV, T, E, k, D)
