@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* x, const
                 }
             }
         }
-        ss = wave_sum(ss);
+        ss = wave_sum_bcast(ss);
         const float r = rsqrtf(ss / float(D) + eps);
         if (l == 0 && rstd) rstd[t] = r;
 #pragma unroll
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, cons
                 }
             }
         }
-        dot = wave_sum(dot) / float(D);
+        dot = wave_sum_bcast(dot) / float(D);
 #pragma unroll
         for (int i = 0; i < MAX_CPL; ++i) {
             const int c = l + 64 * i;

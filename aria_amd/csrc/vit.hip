@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* x, con
                 }
             }
         }
-        const float mu = wave_sum(s) / float(D);
+        const float mu = wave_sum_bcast(s) / float(D);
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < MAX_CPL; ++i) {
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* x, con
                     ss += d * d;
                 }
         }
-        const float r = rsqrtf(wave_sum(ss) / float(D) + eps);
+        const float r = rsqrtf(wave_sum_bcast(ss) / float(D) + eps);
         if (l == 0) {
             if (mean) mean[t] = mu;
             if (rstd) rstd[t] = r;
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* dy, co
                     }
             }
         }
-        sg = wave_sum(sg) / float(D);
-        sgx = wave_sum(sgx) / float(D);
+        sg = wave_sum_bcast(sg) / float(D);
+        sgx = wave_sum_bcast(sgx) / float(D);
 #pragma unroll
         for (int i = 0; i < MAX_CPL; ++i) {
             const int c = l + 64 * i;
