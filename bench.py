@@ -334,6 +334,12 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)  # does not return
+    # stdout carries the contract line and NOTHING else: RCCL (version banner, flushed from libc's buffer when the process exits, i.e.
+    # AFTER the JSON line) and gloo ("Rank 0 is connected ...") write to fd 1 themselves.  The JSON goes to a private duplicate of the
+    # original stdout; fd 1 itself points at stderr from here on.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -596,7 +602,8 @@ def main():
             except Exception as ex:  # keep the bench line even if the host is too small for the sample
                 res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
                                        "sample": f"failed: {type(ex).__name__}: {ex}"}
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=json_out, flush=True)
+    json_out.close()
     if world > 1 or args.ep:
         import torch.distributed as dist
 
