@@ -625,6 +625,12 @@ __device__ __forceinline__ void store_tile3_glu(const P& p, const f32x16 (&acc)[
             }
         }
     }
+    if (ARIA_ABL & 512) {  // (timing build: marks 3 / 4 = stores issued, 5 = stores acknowledged)
+        ts_mark(3);
+        ts_mark(4);
+        wait_vm<0>();
+        ts_mark(5);
+    }
 }
 
 // Fused SwiGLU-backward epilogue (gemm3_kernel<.., .., 5>; GroupedMLP's glu backward moe_lm.py:505-507 behind experts.fc2's input
