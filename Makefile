@@ -21,9 +21,14 @@ tests/emu/libaria_emu.so: $(SRC) $(HDR) tests/emu/hip_emu.cpp tests/emu/hip_emu.
 	$(HOSTCXX) -x c++ -std=c++17 -O3 -g -fPIC -shared -DARIA_EMU -Wno-unknown-attributes -Wno-unused-value -Wno-psabi \
 	    -Iinclude -Iaria_amd/csrc -Itests/emu $(SRC) tests/emu/hip_emu.cpp -o $@
 
+# test infrastructure: hardware-semantics probes (lane layout of ds_read_b64_tr_b16, fp32 atomic rates) -- their own shared object
+probes: tests/probes/libaria_probe.so
+tests/probes/libaria_probe.so: tests/probes/probe.hip
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $< -o $@
+
 oracle_c:
 	$(MAKE) -C oracle
 
 clean:
 	rm -rf build aria_amd/libaria_hip.so tests/emu/libaria_emu.so
-.PHONY: all emu clean oracle_c
+.PHONY: all emu probes clean oracle_c

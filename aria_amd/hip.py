@@ -87,8 +87,6 @@ SIGNATURES = {
     "aria_gather_add_rows": [P, P, P, I64, I64, P],
     "aria_colsum_bf16": [P, P, I64, I64, I64, I64, P],
     "aria_cross_entropy": [P, P, P, P, P, F32, P, I64, I64, I64, P],
-    "aria_probe_tr16": [P, I32, P],
-    "aria_probe_atomic": [P, P, I64, I64, I32, I32, I32, I32, P],
 }
 
 

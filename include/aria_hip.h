@@ -310,12 +310,6 @@ int aria_cross_entropy(const void* logits, const int32_t* labels, float* loss_su
                        float grad_scale, const int32_t* count_in /* device, or NULL: scale = grad_scale / max(1,*count_in) */,
                        int64_t T, int64_t V, int64_t ld, void* stream);
 
-/* hardware-semantics probe (ds_read_b64_tr_b16 lane mapping); test-only, see csrc/probe.hip */
-int aria_probe_tr16(void* out /* u16[256] */, int mode, void* stream);
-/* hardware probe: rate and scope semantics of global_atomic_add_f32 without / with sc1 (see csrc/probe.hip); test / measurement only */
-int aria_probe_atomic(float* buf, int* xcc, int64_t nblocks, int64_t region_floats, int region_mode, int scope, int iters,
-                      int row_stride, void* stream);
-
 /* ------------------------------------------------------------------------------------------------
  * Single-token decode engine (decode.hip) -- gptfast/model.py:178-234 (Transformer.forward, one new token, batch 1),
  * :318-366 (MOEFeedForward, T < 50 path), :67-93 (KVCache.update), :413-447 (Attention with the static cache).

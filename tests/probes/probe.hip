@@ -1,7 +1,13 @@
-// Hardware-semantics probes (used by tests/test_gpu_probes.py to re-verify on a real MI355X the lane layouts
-// that tests/emu/hip_emu.h assumes).  Not on the hot path.
-#include "aria_device.h"
-#include "aria_hip.h"
+// Hardware-semantics probes -- TEST INFRASTRUCTURE, built into tests/probes/libaria_probe.so (never into the product library: round 3 had
+// them in libaria_hip.so's ABI).  tests/test_gpu_probes.py re-verifies on a real MI355X the lane layouts tests/emu/hip_emu.h assumes;
+// tools/probes/l2_atomics.py measures fp32 atomic rates.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#define ARIA_OK 0
+#define ARIA_ERR_INVALID 1
+#define ARIA_ERR_UNSUPPORTED 3
+#define ARIA_ERR_LAUNCH 4
+static int aria_check_launch() { return hipGetLastError() == hipSuccess ? ARIA_OK : ARIA_ERR_LAUNCH; }
 
 #ifndef ARIA_EMU
 namespace {

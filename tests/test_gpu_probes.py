@@ -7,13 +7,21 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_ds_read_tr16_b64_semantics_dump():
-    from aria_amd import hip
+def probe_lib():
+    """tests/probes/libaria_probe.so (make probes; built by __graft_entry__.build()): test infrastructure, not part of the product ABI."""
+    import os
 
-    lib = hip.get_lib()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libaria_probe.so")
+    lib = ctypes.CDLL(path)
+    lib.aria_probe_tr16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    return lib
+
+
+def test_ds_read_tr16_b64_semantics_dump():
+    lib = probe_lib()
     for mode in (0, 1):
         out = torch.zeros(256, dtype=torch.int16, device="cuda")
-        lib.call("aria_probe_tr16", out.data_ptr(), mode, torch.cuda.current_stream().cuda_stream)
+        assert lib.aria_probe_tr16(out.data_ptr(), mode, torch.cuda.current_stream().cuda_stream) == 0
         torch.cuda.synchronize()
         v = out.cpu().view(64, 4).tolist()
         print(f"tr16 mode {mode}:", v[:20], "...", v[32:36])

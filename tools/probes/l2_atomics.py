@@ -6,9 +6,21 @@ Writes gpurun_out/l2_atomics.json."""
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from aria_amd import hip
+import ctypes
 
-lib = hip.get_lib()
+# test infrastructure, not the product library: tests/probes/libaria_probe.so (make probes)
+_cdll = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "probes", "libaria_probe.so"))
+_cdll.aria_probe_atomic.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+
+
+class _Lib:
+    @staticmethod
+    def call(name, *a):
+        rc = getattr(_cdll, name)(*a)
+        assert rc == 0, (name, rc)
+
+
+lib = _Lib()
 dev = torch.device("cuda")
 st = torch.cuda.current_stream().cuda_stream
 out = {}
