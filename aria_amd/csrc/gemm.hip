@@ -280,8 +280,6 @@ bool use_v3(long long tiles256, long long K, long long bytesA, long long bytesB,
     if (K < 64 || bytesA >= (1ll << 32) || bytesB >= (1ll << 32) || extentA < 8 || extentB < 8) return false;
     const char* force = std::getenv("ARIA_GEMM_FORCE");
     if (force) return force[0] == '3';
-    const char* v3 = std::getenv("ARIA_GEMM_V3");  // "0" switches the default off (A/B measurements)
-    if (v3 && v3[0] == '0') return false;
     return tiles256 >= 192;
 }
 

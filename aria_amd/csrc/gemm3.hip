@@ -714,16 +714,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     ARIA_DYN_SMEM(smem);
     const int t = threadIdx.x, l = t & 63, w = first_lane(t >> 6), wm = w >> 2, wn = w & 3;
     ts_mark(0);
-#ifndef ARIA_EMU
-    // Start-up stagger (ARIA_GEMM_STAGGER, experiment; measured: no gain): a tile's ~11 us of fixed cost is NOT write-burst contention
-    // between lock-stepped CUs -- ONE tile alone on the chip already takes 10.5 us at K = 64 (tools/probes/tiles_vs_latency.py) -- but the serial chain
-    // inside a CU (store issue, write latency, workgroup turnover, first fetch), which only a second resident workgroup could hide.
-    // The first workgroup of every CU (ids < 256) waits (its slot inside the XCD) x p.stagger / 32 sleep units.
-    if (p.stagger > 0 && blockIdx.x < 256) {
-        const int n = int((blockIdx.x >> 3) * p.stagger) >> 5;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
+    // (round 2's start-up stagger experiment -- first-round workgroups sleeping up to their slot inside the XCD -- measured no gain and left
+    // the kernel in round 4: a tile's fixed cost is the serial chain inside a CU, not write-burst contention between lock-stepped CUs)
 
     // XCD-aware bijective remap of the workgroup id + grouped tile order (same scheme as v2)
     int tn = 0, tmi = 0, slab = -1, ks = 0;  // slab >= 0: this workgroup computes one K range of a split tile into ws
@@ -968,8 +960,6 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     const char* wsd = std::getenv("ARIA_GEMM_WIDE_STORE");
     q.wide_store = !(wsd && wsd[0] == '0') && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.ldc & 7) == 0 && (p.strideC & 7) == 0;
     if (q.wide_store && !(wsd && wsd[0] == '1')) q.wide_store = 2;  // row form (whole tile parked, complete 512-byte rows per store): +0.6..2.9 % over the per-wave form (=1)
-    const char* stg = std::getenv("ARIA_GEMM_STAGGER");
-    q.stagger = stg ? std::atoi(stg) : 0;
     if (ntn * ntm <= 0) return ARIA_OK;
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
     dim3 grid(unsigned(aria_tile_grid(q)), grid_y), block(512);

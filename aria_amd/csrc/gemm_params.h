@@ -27,7 +27,7 @@ struct GemmParams {
     int glu;
     void* C2;
     long long ldc2;
-    int stagger;     // v3 experiment: first-round workgroups start up to this many s_sleep(127) units (~4 us each) apart, see gemm3.hip
+    int reserved0;   // (was the round-2 start-up stagger experiment; the field keeps the kernarg offsets of what follows)
     int wide_store;  // v3: C rows are 16-byte aligned at every 8th column (pointer, ldc, strideC): full-width column tiles take the wide epilogue
     int order;     // tile-order variant (tuning knob): 0 = XCD-contiguous row-major, 1 = plain, >= 2 = groups of `order` row tiles
     // (appended: the fields above keep their kernarg offsets, the default kernels' ISA does not move)
