@@ -476,10 +476,12 @@ struct DecodeAttn {
         m = mm;
     }
 
-    static __device__ __forceinline__ void run(const bf16_t* qkv, const bf16_t* fc, int ps, bf16_t* k_cache, bf16_t* v_cache, int D,
-                                               float scale, int head, int kbeg, int kend, bool writes_new, float (&red)[NWV][LPK][10],
-                                               float& m, float& lsum, float (&o)[8]) {
-        const int l = threadIdx.x & 63, w = threadIdx.x >> 6, sub = l % LPK, grp = l / LPK;
+    // One wave's share of the range: wave `w` of NWV (the streamed schedule spreads the NWV waves of a head over several workgroups and
+    // passes the wave's index within the HEAD).  On return every lane group of the wave holds the wave's unnormalised state.
+    static __device__ __forceinline__ void wave_state(const bf16_t* qkv, const bf16_t* fc, int ps, bf16_t* k_cache, bf16_t* v_cache, int D,
+                                                      float scale, int head, int kbeg, int kend, bool writes_new, int w, float& m,
+                                                      float& lsum, float (&o)[8]) {
+        const int l = threadIdx.x & 63, sub = l % LPK, grp = l / LPK;
         const long long col = (long long)head * HD + sub * 8;
         const u32x4 f = ld16(fc + (long long)ps * HD + sub * 8);
         const u32x4 qr = rope(ld16(qkv + col), f);
@@ -536,35 +538,56 @@ struct DecodeAttn {
             for (int e = 0; e < 8; ++e) o2[e] = shfl_xor(o[e], d);
             merge(m, lsum, o, m2, l2, o2);
         }
+    }
+    // lane group 0 of a wave leaves the wave's state in red[w] (LDS in the one-workgroup form, global scratch in the streamed one)
+    static __device__ __forceinline__ void publish(float (*red)[LPK][10], int w, float m, float lsum, const float (&o)[8]) {
+        const int l = threadIdx.x & 63, sub = l % LPK, grp = l / LPK;
         if (grp == 0) {
             red[w][sub][0] = m;
             red[w][sub][1] = lsum;
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[w][sub][2 + e] = o[e];
         }
-        sync();
-        if (w == 0) {  // the NWV wave states as a tree: lane group g folds waves g, g + NG, ..., then the groups merge by butterfly
-            constexpr int NG = 64 / LPK;
-            if (grp > 0) {  // (group 0 starts from wave 0's own state, which every lane group of the wave holds after the butterfly above)
-                m = -INFINITY, lsum = 0.f;
+    }
+    // The NWV wave states as a tree, run by ONE wave: lane group g folds waves g, g + NG, ..., then the groups merge by butterfly.
+    // OWN0: the wave IS wave 0 and lane group 0 starts from its registers (which hold exactly what it published in red[0]); otherwise
+    // group 0 reads red[0] back -- the same bits, so whichever wave folds, the result is the same.
+    template <bool OWN0>
+    static __device__ __forceinline__ void fold(const float (*red)[LPK][10], float& m, float& lsum, float (&o)[8]) {
+        const int l = threadIdx.x & 63, sub = l % LPK, grp = l / LPK;
+        constexpr int NG = 64 / LPK;
+        if (grp > 0) {
+            m = -INFINITY, lsum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = 0.f;
-            }
-            for (int ww = grp ? grp : NG; ww < NWV; ww += NG) {
-                float o2[8];
+            for (int e = 0; e < 8; ++e) o[e] = 0.f;
+        } else if (!OWN0) {
+            m = red[0][sub][0], lsum = red[0][sub][1];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o2[e] = red[ww][sub][2 + e];
-                merge(m, lsum, o, red[ww][sub][0], red[ww][sub][1], o2);
-            }
-#pragma unroll
-            for (int d = LPK; d < 64; d <<= 1) {
-                float o2[8];
-                const float m2 = shfl_xor(m, d), l2 = shfl_xor(lsum, d);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o2[e] = shfl_xor(o[e], d);
-                merge(m, lsum, o, m2, l2, o2);
-            }
+            for (int e = 0; e < 8; ++e) o[e] = red[0][sub][2 + e];
         }
+        for (int ww = grp ? grp : NG; ww < NWV; ww += NG) {
+            float o2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o2[e] = red[ww][sub][2 + e];
+            merge(m, lsum, o, red[ww][sub][0], red[ww][sub][1], o2);
+        }
+#pragma unroll
+        for (int d = LPK; d < 64; d <<= 1) {
+            float o2[8];
+            const float m2 = shfl_xor(m, d), l2 = shfl_xor(lsum, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o2[e] = shfl_xor(o[e], d);
+            merge(m, lsum, o, m2, l2, o2);
+        }
+    }
+    static __device__ __forceinline__ void run(const bf16_t* qkv, const bf16_t* fc, int ps, bf16_t* k_cache, bf16_t* v_cache, int D,
+                                               float scale, int head, int kbeg, int kend, bool writes_new, float (&red)[NWV][LPK][10],
+                                               float& m, float& lsum, float (&o)[8]) {
+        const int w = threadIdx.x >> 6;
+        wave_state(qkv, fc, ps, k_cache, v_cache, D, scale, head, kbeg, kend, writes_new, w, m, lsum, o);
+        publish(red, w, m, lsum, o);
+        sync();
+        if (w == 0) fold<true>(red, m, lsum, o);
     }
 };
 
@@ -634,6 +657,379 @@ __global__ void decode_attn_merge_kernel(const float* part, bf16_t* out, int NS,
     }
     const float r = lsum > 0.f ? acc * (1.f / lsum) : 0.f;
     out[(long long)head * HD + f] = f2bf(r);
+}
+
+struct Scratch {
+    bf16_t *xa, *xb, *qkv, *ao, *rl, *scores, *act, *eo;
+    int32_t *idx, *kv_len;
+    float* part;  // split-KV attention states: H * DECODE_MAX_SPLITS * (hd + 2) floats
+    int32_t* sync;  // streamed schedule: ticket, error word, per-layer stage counters, per-layer per-head counters
+    float* ared;    // streamed schedule: the attention stage's wave states
+    size_t bytes;
+};
+
+// ---- streamed schedule: the whole token as ONE launch (ARIA_DECODE_STREAM) ---------------------------------------------------------
+// The launch schedule above is a chain of 6 x L + 1 short kernels (5-22 us each at Aria's widths); their sum IS the token, and each
+// spends its first microseconds ramping up and its last ones draining: the kernel trace shows 2.6-4.6 TB/s per GEMV where streaming
+// alone would run near 6.  What a stage needs from its predecessor is a 5 KB activation vector; the WEIGHTS it is going to stream depend
+// on nothing (except the routed experts', on the router logits).  So the stages become workgroups of one grid:
+//   * a workgroup takes a TICKET (one atomic add) and derives (layer, stage, block-in-stage) from it -- tickets, not blockIdx, so the order
+//     in which work is handed out IS the order in which workgroups became resident;
+//   * it requests its weight rows (non-temporal 16-byte loads into registers, exactly the rows / lanes / chunks the launch schedule's
+//     kernel of that stage gives the same wave), THEN waits until the producing stage's completion counter has reached its block count,
+//     then fetches the activation vector and finishes as the launch kernel does -- same dot-product order, same rounding points, so the
+//     hidden state, the KV cache and the logits equal the 6-launch schedule's bit for bit (tests/model_cases.py::case_decode_engine_streamed);
+//   * a finished workgroup releases its writes (agent scope) and bumps its stage's counter.
+// No grid barrier: while a stage's last workgroups finish, the next stages' rows are already landing in the registers of the workgroups
+// behind them; HBM never sees the launch boundary.  Forward progress: a workgroup only ever waits for stages whose tickets are all SMALLER
+// than its own, i.e. were handed to workgroups that are already resident -- the lowest unfinished ticket never waits, by induction nobody
+// waits forever (the scheme of a decoupled look-back scan).  A waiting wave sleeps between polls; only wave 0 of a workgroup polls, the
+// others stand at a bare s_barrier (which does not drain the row loads in flight).  A poll that has not succeeded after ~0.3 s sets the
+// sticky error word and falls through (wrong logits, surfaced by aria_decode_stream_status -- never a hung GPU).
+// Attention: the 16 waves the one-workgroup-per-head kernel gives a head are 4 workgroups here (wave index within the head = 4 * part + w,
+// same keys per wave and pass); each wave leaves its state in global scratch, the LAST of the four to arrive (a per-head counter) folds
+// the 16 states with DecodeAttn::fold -- the same tree on the same bits.
+constexpr int STREAM_MAXL = 28;            // layers whose pointers fit the kernel-argument block (Aria: 28)
+constexpr int STREAM_SYNC_HEADER = 4;      // sync[0] ticket, [1] sticky error, [2], [3] spare; then 8 words per layer, then L * H head counters
+constexpr int STREAM_SPIN_LIMIT = 1 << 18;
+#ifndef ARIA_STREAM_ACQ_FENCE
+#define ARIA_STREAM_ACQ_FENCE 0  // 1: the compiler's acquire fence (drains every load in flight before it invalidates); 0: bare buffer_inv sc1
+#endif
+
+struct StreamArgs {
+    const void* hdr[ARIA_DECODE_HEADER_PTRS];
+    const void* lp[STREAM_MAXL * ARIA_DECODE_LAYER_PTRS];
+    Scratch s;
+    int32_t* sync;  // = s.sync
+    float* ared;    // = s.ared: [H][DECODE_ATTN_WAVES][hd / 8][10] wave states of the attention stage
+    int L, D, H, E, k, I, Is, ns, V;
+    float eps, scale;
+    int nb[6];  // workgroups per stage: qkv | attention | wo | router + shared up | routed up | down + combine
+    int nbl, nbv, total;
+    int r0, r2, ru, rv;  // rows per wave (2 | 4) of the qkv, wo, routed-up and output GEMVs: what launch_gemv / aria_decode_token choose
+    int nrb, nbx;        // router workgroups of stage 3; workgroups per expert of stage 4
+};
+static_assert(sizeof(StreamArgs) <= 3840, "kernel arguments: 4 KB limit");
+
+__device__ __forceinline__ int stream_poll(const int32_t* p) {
+#ifdef ARIA_EMU
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void stream_acquire() {  // what other workgroups wrote before the counter value just observed is visible to the loads that follow
+#ifndef ARIA_EMU
+#if ARIA_STREAM_ACQ_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("buffer_inv sc1" ::: "memory");
+#pragma clang diagnostic pop
+#endif
+#endif
+}
+// Wait until *cnt >= target.  `seen` = a poll wave 0 issued BEFORE its row loads (loads return in order: a poll issued after them would only
+// come back behind them).  cnt == nullptr: nothing to wait for.  Every wave of the workgroup calls this (one bare barrier inside).
+__device__ __forceinline__ void stream_wait(const int32_t* cnt, int target, int seen, int32_t* sync) {
+    if (!cnt) return;
+#ifdef ARIA_EMU
+    if (*cnt < target) sync[1] = 2;  // the emulator runs workgroups in ticket order: an unmet dependency here is a bug in the stage tables
+    emu::syncthreads();
+#else
+    if ((threadIdx.x >> 6) == 0) {
+        int c = seen, spins = 0;
+        while (c < target) {
+            __builtin_amdgcn_s_sleep(16);
+            c = stream_poll(cnt);
+            if (++spins > STREAM_SPIN_LIMIT || ((spins & 255) == 0 && stream_poll(sync + 1) != 0)) {
+                if (threadIdx.x == 0) __hip_atomic_store(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    wait_lds();  // (thread 0's LDS notes for the workgroup are written before anybody passes the barrier)
+    raw_barrier();
+    stream_acquire();
+#endif
+}
+// This workgroup's writes become visible (agent scope), then its stage counter moves; returns the counter's previous value to every thread
+__device__ __forceinline__ int stream_signal(int32_t* cnt, int* bcast) {
+#ifdef ARIA_EMU
+    emu::syncthreads();
+    if (threadIdx.x == 0) {
+        *bcast = *cnt;
+        *cnt += 1;
+    }
+    emu::syncthreads();
+    return *bcast;
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every wave: its own stores (buffer_wbl2 sc1 + wait)
+    raw_barrier();
+    if (threadIdx.x == 0) *bcast = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return *bcast;
+#endif
+}
+
+// y = W . norm(x) (+ residual): gemv_kernel's wave, rows requested before the wait
+template <int R, int NC>
+__device__ __forceinline__ void stream_gemv(int blk, const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w, float eps, int K,
+                                            int N, const bf16_t* residual, bf16_t* y, const int32_t* dep, int target, int32_t* sync) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row0 = (blk * 4 + w) * R;
+    const int seen = (dep && w == 0) ? stream_poll(dep) : 0;
+    u32x4 xv[NC], a[R][NC];
+    float acc[R];
+    load_rows<R, NC>(a, W, ldw, min(row0, N - 1), N, K, l);
+    stream_wait(dep, target, seen, sync);
+    load_vector<NC>(xv, x, norm_w, eps, K, l);
+    dot_loaded<R, NC>(acc, a, xv);
+    if (l == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (row0 + r < N) y[row0 + r] = residual ? f2bf(bf2f(residual[row0 + r]) + rbf(acc[r])) : f2bf(acc[r]);
+    }
+}
+template <int NC>
+__device__ __forceinline__ void stream_gemv_r(int rows, int blk, const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w,
+                                              float eps, int K, int N, const bf16_t* residual, bf16_t* y, const int32_t* dep, int target,
+                                              int32_t* sync) {
+    if (rows == 4)
+        stream_gemv<4, NC>(blk, W, ldw, x, norm_w, eps, K, N, residual, y, dep, target, sync);
+    else
+        stream_gemv<2, NC>(blk, W, ldw, x, norm_w, eps, K, N, residual, y, dep, target, sync);
+}
+
+// routed up-projection pair + SwiGLU of expert slot j: expert_up_kernel's wave (the vector is normalised while the router stage still runs)
+template <int R, int NC>
+__device__ __forceinline__ void stream_expert_up(int bx, int j, const StreamArgs& a, const bf16_t* W1, const bf16_t* W3, const bf16_t* h,
+                                                 const bf16_t* norm_w, const int32_t* dep_h, int target_h, const int32_t* dep_r, int target_r) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int K = a.D, I = a.I, row0 = (bx * 4 + w) * R;
+    const int seen_h = w == 0 ? stream_poll(dep_h) : 0, seen_r = w == 0 ? stream_poll(dep_r) : 0;
+    u32x4 xv[NC];
+    stream_wait(dep_h, target_h, seen_h, a.sync);
+    load_vector<NC>(xv, h, norm_w, a.eps, K, l);
+    stream_wait(dep_r, target_r, seen_r, a.sync);
+    float my_score;
+    int my_idx;
+    const int e = route_one_token(a.s.rl, a.E, a.k, l, j, my_score, my_idx);
+    if (bx == 0 && j == 0 && w == 0 && l < a.k) {
+        a.s.scores[l] = f2bf(my_score);
+        a.s.idx[l] = my_idx;
+    }
+    const long long stride = (long long)I * K;
+    float a1[R], a3[R];
+    dot_rows<R, NC>(a1, W1 + (long long)e * stride, K, min(row0, I - 1), I, xv, K, l);
+    dot_rows<R, NC>(a3, W3 + (long long)e * stride, K, min(row0, I - 1), I, xv, K, l);
+    if (l == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (row0 + r < I) a.s.act[(long long)j * I + row0 + r] = f2bf(rbf(silu(rbf(a1[r]))) * rbf(a3[r]));
+    }
+}
+
+template <int NCD, int NCI, int NCS, int HD>
+__global__ __launch_bounds__(256) void decode_stream_kernel(const StreamArgs a) {
+    ARIA_DYN_SMEM(smem);
+    ARIA_SMEM_STATIC int s_b[4];  // [0] ticket, [1] a stage counter's previous value, [2] "the routed activations are complete already"
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    if (t == 0) {
+#ifdef ARIA_EMU
+        s_b[0] = a.sync[0];
+        a.sync[0] += 1;
+#else
+        s_b[0] = __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
+    sync();
+    const int tk = s_b[0];
+    if (tk >= a.total) return;
+    const bf16_t* x_in = static_cast<const bf16_t*>(a.hdr[5]);
+    const int layer = tk / a.nbl;
+    if (layer >= a.L) {  // output projection on the final norm
+        const int32_t* dep = a.sync + STREAM_SYNC_HEADER + 8 * (a.L - 1) + 5;
+        stream_gemv_r<NCD>(a.rv, tk - a.L * a.nbl, static_cast<const bf16_t*>(a.hdr[2]), a.D, a.L ? a.s.xb : x_in,
+                           static_cast<const bf16_t*>(a.hdr[1]), a.eps, a.D, a.V, nullptr, static_cast<bf16_t*>(const_cast<void*>(a.hdr[6])), dep,
+                           a.nb[5], a.sync);
+        return;  // (the kernel boundary publishes the logits)
+    }
+    int r = tk - layer * a.nbl;
+    int32_t* done = a.sync + STREAM_SYNC_HEADER + 8 * layer;
+    const void* const* lp = a.lp + ARIA_DECODE_LAYER_PTRS * layer;
+    const bf16_t *attn_norm = static_cast<const bf16_t*>(lp[0]), *wqkv = static_cast<const bf16_t*>(lp[1]),
+                 *wo = static_cast<const bf16_t*>(lp[2]), *ffn_norm = static_cast<const bf16_t*>(lp[3]),
+                 *gate = static_cast<const bf16_t*>(lp[4]), *w1 = static_cast<const bf16_t*>(lp[5]), *w3 = static_cast<const bf16_t*>(lp[6]),
+                 *w2 = static_cast<const bf16_t*>(lp[7]), *sw1 = static_cast<const bf16_t*>(lp[8]), *sw3 = static_cast<const bf16_t*>(lp[9]),
+                 *sw2 = static_cast<const bf16_t*>(lp[10]);
+    const bf16_t* x = layer ? a.s.xb : x_in;
+    bf16_t* h = a.s.xa;
+    const int D = a.D;
+    if (r < a.nb[0]) {  // ---- qkv = wqkv . norm(x)
+        stream_gemv_r<NCD>(a.r0, r, wqkv, D, x, attn_norm, a.eps, D, 3 * D, nullptr, a.s.qkv, layer ? done - 8 + 5 : nullptr, a.nb[5], a.sync);
+        stream_signal(done + 0, &s_b[1]);
+        return;
+    }
+    r -= a.nb[0];
+    if (r < a.nb[1]) {  // ---- attention: 4 waves of a head's DECODE_ATTN_WAVES
+        using A = DecodeAttn<HD, DECODE_ATTN_WAVES>;
+        constexpr int PARTS = DECODE_ATTN_WAVES / 4;
+        const int head = r / PARTS, part = r % PARTS, sub = l % A::LPK, grp = l / A::LPK;
+        bf16_t *kc = static_cast<bf16_t*>(const_cast<void*>(lp[11])), *vc = static_cast<bf16_t*>(const_cast<void*>(lp[12]));
+        float(*red)[A::LPK][10] = reinterpret_cast<float(*)[A::LPK][10]>(a.ared) + (long long)head * DECODE_ATTN_WAVES;
+        const int seen = w == 0 ? stream_poll(done + 0) : 0;
+        stream_wait(done + 0, a.nb[0], seen, a.sync);
+        const int ps = static_cast<const int32_t*>(a.hdr[4])[0];
+        float m, lsum, o[8];
+        A::wave_state(a.s.qkv, static_cast<const bf16_t*>(a.hdr[0]), ps, kc, vc, D, a.scale, head, 0, ps + 1, true, part * 4 + w, m, lsum, o);
+        A::publish(red, part * 4 + w, m, lsum, o);
+        int32_t* hc = a.sync + STREAM_SYNC_HEADER + 8 * a.L + layer * a.H + head;
+        if (stream_signal(hc, &s_b[1]) == PARTS - 1) {  // the last workgroup of the head: fold the wave states, normalise, write the head's output
+            stream_acquire();
+            if (w == 0) {
+                A::template fold<false>(red, m, lsum, o);
+                if (grp == 0) {
+                    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+                    u32x4 rr;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rr[q] = pack2bf(o[2 * q] * inv, o[2 * q + 1] * inv);
+                    st16(a.s.ao + (long long)head * HD + sub * 8, rr);
+                }
+            }
+        }
+        stream_signal(done + 1, &s_b[1]);
+        return;
+    }
+    r -= a.nb[1];
+    if (r < a.nb[2]) {  // ---- h = x + wo . attention
+        stream_gemv_r<NCD>(a.r2, r, wo, D, a.s.ao, nullptr, 0.f, D, D, x, h, done + 1, a.nb[1], a.sync);
+        stream_signal(done + 2, &s_b[1]);
+        return;
+    }
+    r -= a.nb[2];
+    if (r < a.nb[3]) {  // ---- router logits | shared up-projection pair + SwiGLU on norm(h): router_shared_up_kernel's waves
+        if (r < a.nrb) {
+            stream_gemv<2, NCD>(r, gate, D, h, ffn_norm, a.eps, D, a.E, nullptr, a.s.rl, done + 2, a.nb[2], a.sync);
+        } else {
+            const int row0 = ((r - a.nrb) * 4 + w) * 2, rows_s = a.Is;
+            const int seen = w == 0 ? stream_poll(done + 2) : 0;
+            float a1[2], a3[2];
+            u32x4 xv[NCD], r1[2][NCD], r3[2][NCD];
+            load_rows<2, NCD>(r1, sw1, D, min(row0, rows_s - 1), rows_s, D, l);
+            load_rows<2, NCD>(r3, sw3, D, min(row0, rows_s - 1), rows_s, D, l);
+            stream_wait(done + 2, a.nb[2], seen, a.sync);
+            load_vector<NCD>(xv, h, ffn_norm, a.eps, D, l);
+            dot_loaded<2, NCD>(a1, r1, xv);
+            dot_loaded<2, NCD>(a3, r3, xv);
+            if (l == 0) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+                    if (row0 + rr < rows_s) a.s.act[(long long)a.k * a.I + row0 + rr] = f2bf(rbf(silu(rbf(a1[rr]))) * rbf(a3[rr]));
+            }
+        }
+        stream_signal(done + 3, &s_b[1]);
+        return;
+    }
+    r -= a.nb[3];
+    if (r < a.nb[4]) {  // ---- routed up-projection pairs + SwiGLU (routing inside)
+        const int j = r / a.nbx, bx = r % a.nbx;
+        if (a.ru == 4)
+            stream_expert_up<4, NCD>(bx, j, a, w1, w3, h, ffn_norm, done + 2, a.nb[2], done + 3, a.nb[3]);
+        else
+            stream_expert_up<2, NCD>(bx, j, a, w1, w3, h, ffn_norm, done + 2, a.nb[2], done + 3, a.nb[3]);
+        stream_signal(done + 4, &s_b[1]);
+        return;
+    }
+    r -= a.nb[4];
+    {  // ---- every down-projection of one output row per wave + combine + residual: expert_down_combine_kernel's waves.  The routing is
+       // derived HERE from the logits (route_one_token: the function the up-projection runs, so the same ids / scores), which lets the
+       // rows be requested while the up-projection is still running; the activation images follow once it has finished.
+        u32x4* sa = reinterpret_cast<u32x4*>(smem);
+        const int k = a.k, ns = a.ns, I = a.I, N = D;
+        const int nchI = I >> 3, nchS = (ns * I) >> 3;
+        const int n = r * 4 + w, nn = min(n, N - 1);
+        const int ninstr = k * NCI + NCS;
+        const bf16_t* act = a.s.act;
+        auto images = [&]() {
+            for (int g = w; g < ninstr; g += 4) {
+                const bf16_t* src;
+                if (g < k * NCI) {
+                    const int j = g / NCI, cc = (g % NCI) * 64 + l;
+                    src = cc < nchI ? act + (long long)j * I + cc * 8 : reinterpret_cast<const bf16_t*>(decode_zero_page) + 8 * (l & 15);
+                } else {
+                    const int cc = (g - k * NCI) * 64 + l;
+                    src = cc < nchS ? act + (long long)k * I + cc * 8 : reinterpret_cast<const bf16_t*>(decode_zero_page) + 8 * (l & 15);
+                }
+                glds16(src, sa + 64 * g);
+            }
+        };
+        const int seen_r = w == 0 ? stream_poll(done + 3) : 0, seen_u = w == 0 ? stream_poll(done + 4) : 0;
+        if (t == 0) s_b[2] = seen_u >= a.nb[4];
+        stream_wait(done + 3, a.nb[3], seen_r, a.sync);  // (its barrier also publishes s_b[2])
+        const bool up_done = s_b[2] != 0;                // workgroup-uniform
+        if (up_done) images();
+        float my_score;
+        int my_idx;
+        route_one_token(a.s.rl, a.E, k, l, 0, my_score, my_idx);
+        const int my_sc = int(uint32_t(f2bf(my_score)) << 16);
+        int e[DOWN_KMAX];
+        float sc[DOWN_KMAX];
+#pragma unroll
+        for (int j = 0; j < DOWN_KMAX; ++j) {
+            e[j] = read_lane(my_idx, j);
+            sc[j] = __builtin_bit_cast(float, read_lane(my_sc, j));
+        }
+        u32x4 wr[DOWN_KMAX][NCI], ws[NCS];
+        {
+            const bf16_t* row = sw2 + (long long)nn * ns * I;
+#pragma unroll
+            for (int i = 0; i < NCS; ++i) ws[i] = ldw16(row + min(l + 64 * i, nchS - 1) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < DOWN_KMAX; ++j)
+            if (j < k) {
+                const bf16_t* row = w2 + ((long long)(e[j] < 0 ? 0 : e[j]) * N + nn) * I;
+#pragma unroll
+                for (int i = 0; i < NCI; ++i) wr[j][i] = ldw16(row + min(l + 64 * i, nchI - 1) * 8);
+            }
+        if (!up_done) {
+            stream_wait(done + 4, a.nb[4], 0, a.sync);
+            images();
+        }
+        wait_vm<0>();
+        sync();
+        float accs = 0.f;
+#pragma unroll
+        for (int j = 0; j < DOWN_KMAX; ++j)
+            if (j < k) {
+                float sj = 0.f;
+#pragma unroll
+                for (int i = 0; i < NCI; ++i) {
+                    const u32x4 xv = sa[j * NCI * 64 + l + 64 * i];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sj = dot2bf(wr[j][i][q], xv[q], sj);
+                }
+                sj = wave_sum_bcast(sj);
+                accs += rbf(rbf(sj) * sc[j]);
+            }
+        float sh = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCS; ++i) {
+            const u32x4 xv = sa[k * NCI * 64 + l + 64 * i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sh = dot2bf(ws[i][q], xv[q], sh);
+        }
+        sh = wave_sum_bcast(sh);
+        if (l == 0 && n < N) a.s.xb[n] = f2bf(bf2f(h[n]) + rbf(rbf(accs) + rbf(sh)));
+        stream_signal(done + 5, &s_b[1]);
+    }
+}
+
+__global__ void decode_stream_reset_kernel(int32_t* sync, int n) {  // every word but the sticky error
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && i != 1) sync[i] = 0;
 }
 
 // ---- sampling (gptfast/generate.py:35-58: logits_to_probs + multinomial_sample_one_no_sync) -------------------------------------------
@@ -851,14 +1247,9 @@ int launch_gemv(int N, void* stream, const bf16_t* W, long long ldw, const bf16_
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
-struct Scratch {
-    bf16_t *xa, *xb, *qkv, *ao, *rl, *scores, *act, *eo;
-    int32_t *idx, *kv_len;
-    float* part;  // split-KV attention states: H * DECODE_MAX_SPLITS * (hd + 2) floats
-    size_t bytes;
-};
+inline size_t stream_sync_words(int64_t L, int64_t H) { return size_t(STREAM_SYNC_HEADER + 8 * L + L * H); }
 
-Scratch carve(char* base, int64_t D, int64_t H, int64_t hd, int64_t E, int64_t k, int64_t I, int64_t Is) {
+Scratch carve(char* base, int64_t L, int64_t D, int64_t H, int64_t hd, int64_t E, int64_t k, int64_t I, int64_t Is) {
     Scratch s{};
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -877,17 +1268,90 @@ Scratch carve(char* base, int64_t D, int64_t H, int64_t hd, int64_t E, int64_t k
     s.idx = reinterpret_cast<int32_t*>(take(k * 4));
     s.kv_len = reinterpret_cast<int32_t*>(take(4));
     s.part = reinterpret_cast<float*>(take(size_t(H) * DECODE_MAX_SPLITS * size_t(hd + 2) * 4));
+    s.sync = reinterpret_cast<int32_t*>(take(stream_sync_words(L, H) * 4));
+    s.ared = reinterpret_cast<float*>(take(size_t(H) * DECODE_ATTN_WAVES * size_t(hd / 8) * 10 * 4));
     s.bytes = off;
     return s;
+}
+
+// ARIA_DECODE_STREAM: "1" = the streamed schedule (one launch per token, decode_stream_kernel) where it has an instantiation; unset / "0" =
+// the launch schedule.  Read per call, like the other decode switches.
+bool decode_stream_enabled() {
+    const char* e = std::getenv("ARIA_DECODE_STREAM");
+    return e && atoi(e) != 0;
+}
+
+// The streamed schedule covers the widths decode_stream_kernel is instantiated for, the 6-launch schedule's fused forms (its waves are what the
+// stages reproduce) and the one-workgroup-per-head attention (no split-KV: caches up to 2048 slots, or up to 16 384 with ARIA_DECODE_SPLIT_KV=0).
+int stream_variant(int64_t L, int64_t D, int64_t hd, int64_t E, int64_t k, int64_t I, int64_t Is, int64_t Smax) {
+    if (L > STREAM_MAXL || k > DOWN_KMAX || E > 256 || !decode_fuse_enabled()) return 0;
+    if (Smax > 16384 || decode_splits_for(Smax) > 1) return 0;
+    const int ncD = chunks_per_lane(D), ncI = chunks_per_lane(I), ncS = chunks_per_lane(Is);
+    if (ncD == 5 && ncI == 4 && ncS == 7 && hd == 128) return 1;  // Aria
+    if (ncD == 1 && ncI == 1 && ncS == 1 && hd == 64) return 2;   // the test suite's toy widths
+    if (ncD == 1 && ncI == 1 && ncS == 1 && hd == 128) return 3;
+    return 0;
+}
+
+int launch_stream(int variant, const void* const* ptrs, const Scratch& s, int64_t L, int64_t D, int64_t H, int64_t hd, int64_t E, int64_t k,
+                  int64_t I, int64_t Is, int64_t V, float eps, void* stream) {
+    StreamArgs a{};
+    for (int i = 0; i < ARIA_DECODE_HEADER_PTRS; ++i) a.hdr[i] = ptrs[i];
+    for (int i = 0; i < ARIA_DECODE_LAYER_PTRS * L; ++i) a.lp[i] = ptrs[ARIA_DECODE_HEADER_PTRS + i];
+    a.s = s;
+    a.sync = s.sync;
+    a.ared = s.ared;
+    a.L = int(L), a.D = int(D), a.H = int(H), a.E = int(E), a.k = int(k), a.I = int(I), a.Is = int(Is), a.ns = int(Is / I), a.V = int(V);
+    a.eps = eps;
+    a.scale = 1.0f / sqrtf(float(hd));
+    auto cdiv = [](int64_t x, int64_t y) { return int((x + y - 1) / y); };
+    a.r0 = 3 * D >= 4096 ? 4 : 2;  // (launch_gemv's choice)
+    a.r2 = D >= 4096 ? 4 : 2;
+    a.rv = V >= 4096 ? 4 : 2;
+    a.ru = I * (k + a.ns) >= 8192 ? 4 : 2;  // (aria_decode_token's choice for expert_up_kernel)
+    a.nrb = cdiv(E, 8);
+    a.nbx = cdiv(I, 4 * a.ru);
+    a.nb[0] = cdiv(3 * D, 4 * a.r0);
+    a.nb[1] = int(H) * (DECODE_ATTN_WAVES / 4);
+    a.nb[2] = cdiv(D, 4 * a.r2);
+    a.nb[3] = a.nrb + cdiv(Is, 8);
+    a.nb[4] = a.nbx * int(k);
+    a.nb[5] = cdiv(D, 4);
+    a.nbl = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4] + a.nb[5];
+    a.nbv = cdiv(V, 4 * a.rv);
+    a.total = int(L) * a.nbl + a.nbv;
+    const int nsync = int(stream_sync_words(L, H));
+    ARIA_LAUNCH(decode_stream_reset_kernel, dim3(unsigned((nsync + 255) / 256)), dim3(256), 0, stream, s.sync, nsync);
+    const int ncI = chunks_per_lane(I), ncS = chunks_per_lane(Is);
+    const size_t lds = size_t(k * ncI + ncS) * 1024;
+    if (variant == 1)
+        ARIA_LAUNCH((decode_stream_kernel<5, 4, 7, 128>), dim3(unsigned(a.total)), dim3(256), lds, stream, a);
+    else if (variant == 2)
+        ARIA_LAUNCH((decode_stream_kernel<1, 1, 1, 64>), dim3(unsigned(a.total)), dim3(256), lds, stream, a);
+    else
+        ARIA_LAUNCH((decode_stream_kernel<1, 1, 1, 128>), dim3(unsigned(a.total)), dim3(256), lds, stream, a);
+    return aria_check_launch();
 }
 
 }  // namespace
 
 extern "C" {
 
+int aria_decode_stream_supported(const int64_t* dims) {
+    if (!dims) return 0;
+    return stream_variant(dims[0], dims[1], dims[3], dims[4], dims[5], dims[6], dims[7], dims[9]) != 0 && dims[7] % dims[6] == 0;
+}
+
+int64_t aria_decode_stream_sync_offset(const int64_t* dims) {
+    if (!dims) return -1;
+    char* const base = reinterpret_cast<char*>(uintptr_t(1) << 20);  // (never dereferenced: carve only does address arithmetic)
+    const Scratch s = carve(base, dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], dims[6], dims[7]);
+    return int64_t(reinterpret_cast<char*>(s.sync) - base);
+}
+
 int64_t aria_decode_scratch_bytes(const int64_t* dims) {
     if (!dims) return 0;
-    return int64_t(carve(nullptr, dims[1], dims[2], dims[3], dims[4], dims[5], dims[6], dims[7]).bytes);
+    return int64_t(carve(nullptr, dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], dims[6], dims[7]).bytes);
 }
 
 int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, void* stream) {
@@ -904,7 +1368,7 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
     const bf16_t* freqs = static_cast<const bf16_t*>(ptrs[0]);
     const bf16_t* final_norm = static_cast<const bf16_t*>(ptrs[1]);
     const bf16_t* out_w = static_cast<const bf16_t*>(ptrs[2]);
-    const Scratch s = carve(static_cast<char*>(const_cast<void*>(ptrs[3])), D, H, hd, E, k, I, Is);
+    const Scratch s = carve(static_cast<char*>(const_cast<void*>(ptrs[3])), L, D, H, hd, E, k, I, Is);
     const int32_t* pos = static_cast<const int32_t*>(ptrs[4]);
     const bf16_t* x = static_cast<const bf16_t*>(ptrs[5]);
     bf16_t* logits = static_cast<bf16_t*>(const_cast<void*>(ptrs[6]));
@@ -915,6 +1379,10 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
         if (rc != ARIA_OK) return rc; \
     } while (0)
     const bool fuse = decode_fuse_enabled();
+    if (decode_stream_enabled()) {
+        const int variant = stream_variant(L, D, hd, E, k, I, Is, Smax);
+        if (variant) return launch_stream(variant, ptrs, s, L, D, H, hd, E, k, I, Is, V, eps, stream);
+    }
     for (int64_t li = 0; li < L; ++li) {
         const void* const* lp = ptrs + ARIA_DECODE_HEADER_PTRS + ARIA_DECODE_LAYER_PTRS * li;
         const bf16_t *attn_norm = static_cast<const bf16_t*>(lp[0]), *wqkv = static_cast<const bf16_t*>(lp[1]),

@@ -369,6 +369,17 @@ class DecodeEngine:
             return False
         return [t.data_ptr() for t in self._table(model)] == self._addr
 
+    def streamed(self) -> bool:
+        """Whether aria_decode_token runs this model as ONE launch per token (ARIA_DECODE_STREAM=1 and widths the streamed kernel covers)."""
+        import os
+
+        return os.environ.get("ARIA_DECODE_STREAM", "0") not in ("", "0") and bool(self._lib.cdll.aria_decode_stream_supported(self._dims_p))
+
+    def stream_status(self) -> int:
+        """The streamed schedule's sticky error word (0 = every dependency wait of every token so far was met; a host sync)."""
+        off = int(self._lib.cdll.aria_decode_stream_sync_offset(self._dims_p))
+        return int(self.scratch[off + 4:off + 8].view(torch.int32).item())
+
     def step(self, x_embed: torch.Tensor, input_pos: torch.Tensor) -> torch.Tensor:
         """x_embed [1,1,D] (embedding of the new token), input_pos: device tensor with the cursor -> logits [1,1,V] (a view of the
         engine's buffer: consume it before the next step)."""

@@ -267,12 +267,16 @@ def generate_config2_record(twin, tcfg, new_tokens=200, runs=5, warmup=2, n_img=
         torch.cuda.synchronize()
         t_dec = (time.perf_counter() - t0) / 50
     wbytes = decode_weight_bytes(tcfg)
+    eng = twin.llm._engine
+    streamed = bool(eng is not None and eng.streamed())
     return {"workload": f"config#2 (gptfast/benchmark.py protocol): {n_img} x {img_px}px image + prompt = {T} positions, {new_tokens} new tokens, top-k 200, "
                         f"T 0.8, {warmup} warm-up + {runs} timed whole generates (ViT + prefill + decode + sampling); same random-init weights",
             "value": round(sum(ntok) / sum(lat), 2), "unit": "tokens/s", "runs": runs, "warmup": warmup, "new_tokens": new_tokens,
             "mean_latency_s": round(sum(lat) / len(lat), 4), "published_h100": {"eager": 25.2, "compile": 130.0},
             "prefill_ms_incl_vit": round(t_prefill * 1e3, 2), "decode_ms_per_token": round(t_dec * 1e3, 3),
-            "decode_engine": bool(twin.llm._engine is not None),
+            "decode_engine": bool(eng is not None),
+            "decode_schedule": "streamed: one launch per token (ARIA_DECODE_STREAM=1)" if streamed else "6 launches per layer",
+            "streamed_schedule_error_word": int(eng.stream_status()) if streamed else None,
             "roofline": {"kernel": "decode step incl. sampling (aria_decode_token + aria_sample_topk)", "bound": "hbm",
                          "achieved": round(wbytes / t_dec / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(wbytes / t_dec / 8e12, 4),
                          "algorithmic_bytes_per_token": wbytes, "traffic": None}}
