@@ -308,6 +308,15 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
 #endif
 }
+// glds16 at agent scope (sc1): the source was written by another workgroup of the same launch, possibly on another XCD
+__device__ __forceinline__ void glds16_agent(const void* g, void* lds_wave_base) {
+#ifdef ARIA_EMU
+    emu::glds(g, static_cast<char*>(lds_wave_base) + 16 * emu::lane());
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 16 /* sc1 */);
+#endif
+}
 // The same DMA issued as the kernel's OWN instruction (inline assembly): hipcc cannot tell a later LDS read from the piece's pending LDS
 // write and puts `s_waitcnt vmcnt(0)` in front of every LDS read that follows a __builtin_amdgcn_global_load_lds -- a complete drain of
 // the prefetch at its first consumer.  Invisible to the compiler's counters, the piece stays in flight until the caller's wait_vm<N>().

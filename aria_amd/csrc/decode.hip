@@ -29,10 +29,56 @@ using namespace ad;
 
 __device__ __forceinline__ float silu(float a) { return silu_fast(a); }
 
+// Agent-scope ("sc1") accesses for values that one workgroup of the streamed schedule writes and another one, possibly on another XCD, reads
+// within the SAME launch: an sc1 store is written through to where every XCD's L2 sees it, an sc1 load does not return a line another
+// XCD may have changed -- single words, so no cache-wide write-back / invalidate is needed (round 4 measured what those cost when every
+// workgroup of a 78 000-workgroup grid issues them: profiles/r04_stream_sync_costs.json).  COH = false: the plain forms (launch schedule).
+template <bool COH>
+__device__ __forceinline__ u32x4 ld16c(const void* p) {
+#ifndef ARIA_EMU
+    if (COH) {
+        const uint64_t* q = static_cast<const uint64_t*>(p);
+        const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return u32x4{uint32_t(a), uint32_t(a >> 32), uint32_t(b), uint32_t(b >> 32)};
+    }
+#endif
+    return ld16(p);
+}
+template <bool COH>
+__device__ __forceinline__ void st16c(void* p, u32x4 v) {
+#ifndef ARIA_EMU
+    if (COH) {
+        uint64_t* q = static_cast<uint64_t*>(p);
+        __hip_atomic_store(q, uint64_t(v[0]) | (uint64_t(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, uint64_t(v[2]) | (uint64_t(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+#endif
+    st16(p, v);
+}
+template <bool COH, class T>
+__device__ __forceinline__ T ldc(const T* p) {
+#ifndef ARIA_EMU
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    return *p;
+}
+template <bool COH, class T>
+__device__ __forceinline__ void stc(T* p, T v) {
+#ifndef ARIA_EMU
+    if (COH) {
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+#endif
+    *p = v;
+}
+
 // x[K] (bf16) -> this lane's chunks c = l + 64 i (i < NC) as packed bf16 pairs, optionally RMS-normalised exactly like
 // rmsnorm_fwd_kernel (norm.hip: same lane <-> chunk mapping and reduction order, so the same rstd).  Chunks past K read as zeros;
 // no branches, so all loads are in flight together.
-template <int NC>
+template <int NC, bool COH = false>
 __device__ __forceinline__ void load_vector(u32x4 (&xv)[NC], const bf16_t* x, const bf16_t* norm_w, float eps, int K, int l) {
     const int nch = K >> 3;
     u32x4 wv[NC];
@@ -40,8 +86,8 @@ __device__ __forceinline__ void load_vector(u32x4 (&xv)[NC], const bf16_t* x, co
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int cc = min(l + 64 * i, nch - 1);
-        xv[i] = ld16(x + cc * 8);
-        wv[i] = ld16(nw + cc * 8);
+        xv[i] = ld16c<COH>(x + cc * 8);
+        wv[i] = ld16(nw + cc * 8);  // (the norm weights are constants: plain loads even when x needs agent-scope ones)
     }
 #pragma unroll
     for (int i = 0; i < NC; ++i)
@@ -131,6 +177,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* W, long long ld
     }
 }
 
+template <bool COH = false>
 __device__ __forceinline__ int route_one_token(const bf16_t* logits, int E, int k, int l, int want, float& my_score, int& my_idx);
 
 // Up-projection pair + SwiGLU for the k routed experts (e_j = idx[j]) AND the shared expert in one launch: grid.y = k + ns, the shared
@@ -327,10 +374,11 @@ __global__ __launch_bounds__(256) void expert_down_combine_kernel(const bf16_t* 
 // id, softmax over the selected logits in fp32, scores cast to bf16.  One wave; the logits come from a regular (multi-workgroup) GEMV --
 // a single workgroup reading the whole 320 KB gate matrix cost 16 us per layer.
 // returns the expert id of slot `want` (wave-uniform); lanes < k also get (score, id) of their own slot
+template <bool COH>
 __device__ __forceinline__ int route_one_token(const bf16_t* logits, int E, int k, int l, int want, float& my_score, int& my_idx) {
     float val[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) val[i] = (l + 64 * i < E) ? bf2f(logits[l + 64 * i]) : -INFINITY;
+    for (int i = 0; i < 4; ++i) val[i] = (l + 64 * i < E) ? bf2f(ldc<COH>(logits + l + 64 * i)) : -INFINITY;
     float top[8];
     int topi = -1, wanted = 0;
 #pragma unroll
@@ -478,16 +526,17 @@ struct DecodeAttn {
 
     // One wave's share of the range: wave `w` of NWV (the streamed schedule spreads the NWV waves of a head over several workgroups and
     // passes the wave's index within the HEAD).  On return every lane group of the wave holds the wave's unnormalised state.
+    template <bool COH = false>  // COH: q | k | v of the new token were written by other workgroups of this launch (streamed schedule)
     static __device__ __forceinline__ void wave_state(const bf16_t* qkv, const bf16_t* fc, int ps, bf16_t* k_cache, bf16_t* v_cache, int D,
                                                       float scale, int head, int kbeg, int kend, bool writes_new, int w, float& m,
                                                       float& lsum, float (&o)[8]) {
         const int l = threadIdx.x & 63, sub = l % LPK, grp = l / LPK;
         const long long col = (long long)head * HD + sub * 8;
         const u32x4 f = ld16(fc + (long long)ps * HD + sub * 8);
-        const u32x4 qr = rope(ld16(qkv + col), f);
+        const u32x4 qr = rope(ld16c<COH>(qkv + col), f);
         // the new token's rotated key / value slice, in EVERY lane group: the pass that covers position ps takes it from these registers, so
         // nobody waits for the cache write below to become visible (it was: store, barrier, read back -- ~2 us in front of the first K / V load)
-        const u32x4 knew = rope(ld16(qkv + D + col), f), vnew = ld16(qkv + 2 * D + col);
+        const u32x4 knew = rope(ld16c<COH>(qkv + D + col), f), vnew = ld16c<COH>(qkv + 2 * D + col);
         if (writes_new && w == 0 && grp == 0) {
             st16(k_cache + (long long)ps * D + col, knew);
             st16(v_cache + (long long)ps * D + col, vnew);
@@ -540,19 +589,20 @@ struct DecodeAttn {
         }
     }
     // lane group 0 of a wave leaves the wave's state in red[w] (LDS in the one-workgroup form, global scratch in the streamed one)
+    template <bool COH = false>
     static __device__ __forceinline__ void publish(float (*red)[LPK][10], int w, float m, float lsum, const float (&o)[8]) {
         const int l = threadIdx.x & 63, sub = l % LPK, grp = l / LPK;
         if (grp == 0) {
-            red[w][sub][0] = m;
-            red[w][sub][1] = lsum;
+            stc<COH>(&red[w][sub][0], m);
+            stc<COH>(&red[w][sub][1], lsum);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[w][sub][2 + e] = o[e];
+            for (int e = 0; e < 8; ++e) stc<COH>(&red[w][sub][2 + e], o[e]);
         }
     }
     // The NWV wave states as a tree, run by ONE wave: lane group g folds waves g, g + NG, ..., then the groups merge by butterfly.
     // OWN0: the wave IS wave 0 and lane group 0 starts from its registers (which hold exactly what it published in red[0]); otherwise
     // group 0 reads red[0] back -- the same bits, so whichever wave folds, the result is the same.
-    template <bool OWN0>
+    template <bool OWN0, bool COH = false>
     static __device__ __forceinline__ void fold(const float (*red)[LPK][10], float& m, float& lsum, float (&o)[8]) {
         const int l = threadIdx.x & 63, sub = l % LPK, grp = l / LPK;
         constexpr int NG = 64 / LPK;
@@ -561,15 +611,16 @@ struct DecodeAttn {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = 0.f;
         } else if (!OWN0) {
-            m = red[0][sub][0], lsum = red[0][sub][1];
+            m = ldc<COH>(&red[0][sub][0]), lsum = ldc<COH>(&red[0][sub][1]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = red[0][sub][2 + e];
+            for (int e = 0; e < 8; ++e) o[e] = ldc<COH>(&red[0][sub][2 + e]);
         }
         for (int ww = grp ? grp : NG; ww < NWV; ww += NG) {
             float o2[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o2[e] = red[ww][sub][2 + e];
-            merge(m, lsum, o, red[ww][sub][0], red[ww][sub][1], o2);
+            for (int e = 0; e < 8; ++e) o2[e] = ldc<COH>(&red[ww][sub][2 + e]);
+            const float m2 = ldc<COH>(&red[ww][sub][0]), l2 = ldc<COH>(&red[ww][sub][1]);
+            merge(m, lsum, o, m2, l2, o2);
         }
 #pragma unroll
         for (int d = LPK; d < 64; d <<= 1) {
@@ -692,8 +743,20 @@ struct Scratch {
 constexpr int STREAM_MAXL = 28;            // layers whose pointers fit the kernel-argument block (Aria: 28)
 constexpr int STREAM_SYNC_HEADER = 4;      // sync[0] ticket, [1] sticky error, [2], [3] spare; then 8 words per layer, then L * H head counters
 constexpr int STREAM_SPIN_LIMIT = 1 << 18;
-#ifndef ARIA_STREAM_ACQ_FENCE
-#define ARIA_STREAM_ACQ_FENCE 0  // 1: the compiler's acquire fence (drains every load in flight before it invalidates); 0: bare buffer_inv sc1
+// ARIA_STREAM_COH 1 (default): what one workgroup hands another travels in agent-scope (sc1) single-word stores / loads; the producer waits for
+// its stores' acknowledgements before it bumps the counter, the consumer issues its loads after it has seen the counter.  0: plain accesses +
+// buffer_wbl2 sc1 / buffer_inv sc1 per wave (the first build: correct, and 8x slower than the launch schedule -- profiles/r04_decode_stream_ab.json).
+// ARIA_STREAM_TICKET 1 (default): order by an atomic ticket; 0: by blockIdx (assumes in-order dispatch; timing experiments only).
+#ifndef ARIA_STREAM_COH
+#define ARIA_STREAM_COH 1
+#endif
+#ifndef ARIA_STREAM_TICKET
+#define ARIA_STREAM_TICKET 1
+#endif
+constexpr bool SCOH = ARIA_STREAM_COH != 0;
+// ARIA_STREAM_ABL (timing-only builds, wrong results: tools/probes/decode_stream_ab.py --lib=...): 1 = no dependency waits, 2 = no completion atomics
+#ifndef ARIA_STREAM_ABL
+#define ARIA_STREAM_ABL 0
 #endif
 
 struct StreamArgs {
@@ -720,14 +783,14 @@ __device__ __forceinline__ int stream_poll(const int32_t* p) {
 }
 __device__ __forceinline__ void stream_acquire() {  // what other workgroups wrote before the counter value just observed is visible to the loads that follow
 #ifndef ARIA_EMU
-#if ARIA_STREAM_ACQ_FENCE
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#else
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
+#if ARIA_STREAM_COH
+    asm volatile("" ::: "memory");  // (the loads that follow are sc1 loads; nothing cached needs to go)
+#else
     asm volatile("buffer_inv sc1" ::: "memory");
-#pragma clang diagnostic pop
 #endif
+#pragma clang diagnostic pop
 #endif
 }
 // Wait until *cnt >= target.  `seen` = a poll wave 0 issued BEFORE its row loads (loads return in order: a poll issued after them would only
@@ -738,6 +801,7 @@ __device__ __forceinline__ void stream_wait(const int32_t* cnt, int target, int 
     if (*cnt < target) sync[1] = 2;  // the emulator runs workgroups in ticket order: an unmet dependency here is a bug in the stage tables
     emu::syncthreads();
 #else
+    if (ARIA_STREAM_ABL & 1) return;
     if ((threadIdx.x >> 6) == 0) {
         int c = seen, spins = 0;
         while (c < target) {
@@ -765,9 +829,13 @@ __device__ __forceinline__ int stream_signal(int32_t* cnt, int* bcast) {
     emu::syncthreads();
     return *bcast;
 #else
+#if ARIA_STREAM_COH
+    wait_vm<0>();  // every wave: its sc1 stores are acknowledged (written through to where the other XCDs read)
+#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every wave: its own stores (buffer_wbl2 sc1 + wait)
+#endif
     raw_barrier();
-    if (threadIdx.x == 0) *bcast = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) *bcast = (ARIA_STREAM_ABL & 2) ? 0 : __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     return *bcast;
 #endif
@@ -784,12 +852,13 @@ __device__ __forceinline__ void stream_gemv(int blk, const bf16_t* W, long long 
     float acc[R];
     load_rows<R, NC>(a, W, ldw, min(row0, N - 1), N, K, l);
     stream_wait(dep, target, seen, sync);
-    load_vector<NC>(xv, x, norm_w, eps, K, l);
+    load_vector<NC, SCOH>(xv, x, norm_w, eps, K, l);
     dot_loaded<R, NC>(acc, a, xv);
     if (l == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (row0 + r < N) y[row0 + r] = residual ? f2bf(bf2f(residual[row0 + r]) + rbf(acc[r])) : f2bf(acc[r]);
+            if (row0 + r < N)
+                stc<SCOH>(y + row0 + r, residual ? f2bf(bf2f(ldc<SCOH>(residual + row0 + r)) + rbf(acc[r])) : f2bf(acc[r]));
     }
 }
 template <int NC>
@@ -811,11 +880,11 @@ __device__ __forceinline__ void stream_expert_up(int bx, int j, const StreamArgs
     const int seen_h = w == 0 ? stream_poll(dep_h) : 0, seen_r = w == 0 ? stream_poll(dep_r) : 0;
     u32x4 xv[NC];
     stream_wait(dep_h, target_h, seen_h, a.sync);
-    load_vector<NC>(xv, h, norm_w, a.eps, K, l);
+    load_vector<NC, SCOH>(xv, h, norm_w, a.eps, K, l);
     stream_wait(dep_r, target_r, seen_r, a.sync);
     float my_score;
     int my_idx;
-    const int e = route_one_token(a.s.rl, a.E, a.k, l, j, my_score, my_idx);
+    const int e = route_one_token<SCOH>(a.s.rl, a.E, a.k, l, j, my_score, my_idx);
     if (bx == 0 && j == 0 && w == 0 && l < a.k) {
         a.s.scores[l] = f2bf(my_score);
         a.s.idx[l] = my_idx;
@@ -827,7 +896,7 @@ __device__ __forceinline__ void stream_expert_up(int bx, int j, const StreamArgs
     if (l == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (row0 + r < I) a.s.act[(long long)j * I + row0 + r] = f2bf(rbf(silu(rbf(a1[r]))) * rbf(a3[r]));
+            if (row0 + r < I) stc<SCOH>(a.s.act + (long long)j * I + row0 + r, f2bf(rbf(silu(rbf(a1[r]))) * rbf(a3[r])));
     }
 }
 
@@ -840,8 +909,10 @@ __global__ __launch_bounds__(256) void decode_stream_kernel(const StreamArgs a) 
 #ifdef ARIA_EMU
         s_b[0] = a.sync[0];
         a.sync[0] += 1;
-#else
+#elif ARIA_STREAM_TICKET
         s_b[0] = __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        s_b[0] = int(blockIdx.x);
 #endif
     }
     sync();
@@ -883,19 +954,20 @@ __global__ __launch_bounds__(256) void decode_stream_kernel(const StreamArgs a) 
         stream_wait(done + 0, a.nb[0], seen, a.sync);
         const int ps = static_cast<const int32_t*>(a.hdr[4])[0];
         float m, lsum, o[8];
-        A::wave_state(a.s.qkv, static_cast<const bf16_t*>(a.hdr[0]), ps, kc, vc, D, a.scale, head, 0, ps + 1, true, part * 4 + w, m, lsum, o);
-        A::publish(red, part * 4 + w, m, lsum, o);
+        A::template wave_state<SCOH>(a.s.qkv, static_cast<const bf16_t*>(a.hdr[0]), ps, kc, vc, D, a.scale, head, 0, ps + 1, true, part * 4 + w,
+                                     m, lsum, o);
+        A::template publish<SCOH>(red, part * 4 + w, m, lsum, o);
         int32_t* hc = a.sync + STREAM_SYNC_HEADER + 8 * a.L + layer * a.H + head;
         if (stream_signal(hc, &s_b[1]) == PARTS - 1) {  // the last workgroup of the head: fold the wave states, normalise, write the head's output
             stream_acquire();
             if (w == 0) {
-                A::template fold<false>(red, m, lsum, o);
+                A::template fold<false, SCOH>(red, m, lsum, o);
                 if (grp == 0) {
                     const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
                     u32x4 rr;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) rr[q] = pack2bf(o[2 * q] * inv, o[2 * q + 1] * inv);
-                    st16(a.s.ao + (long long)head * HD + sub * 8, rr);
+                    st16c<SCOH>(a.s.ao + (long long)head * HD + sub * 8, rr);
                 }
             }
         }
@@ -920,13 +992,13 @@ __global__ __launch_bounds__(256) void decode_stream_kernel(const StreamArgs a) 
             load_rows<2, NCD>(r1, sw1, D, min(row0, rows_s - 1), rows_s, D, l);
             load_rows<2, NCD>(r3, sw3, D, min(row0, rows_s - 1), rows_s, D, l);
             stream_wait(done + 2, a.nb[2], seen, a.sync);
-            load_vector<NCD>(xv, h, ffn_norm, a.eps, D, l);
+            load_vector<NCD, SCOH>(xv, h, ffn_norm, a.eps, D, l);
             dot_loaded<2, NCD>(a1, r1, xv);
             dot_loaded<2, NCD>(a3, r3, xv);
             if (l == 0) {
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr)
-                    if (row0 + rr < rows_s) a.s.act[(long long)a.k * a.I + row0 + rr] = f2bf(rbf(silu(rbf(a1[rr]))) * rbf(a3[rr]));
+                    if (row0 + rr < rows_s) stc<SCOH>(a.s.act + (long long)a.k * a.I + row0 + rr, f2bf(rbf(silu(rbf(a1[rr]))) * rbf(a3[rr])));
             }
         }
         stream_signal(done + 3, &s_b[1]);
@@ -962,7 +1034,10 @@ __global__ __launch_bounds__(256) void decode_stream_kernel(const StreamArgs a) 
                     const int cc = (g - k * NCI) * 64 + l;
                     src = cc < nchS ? act + (long long)k * I + cc * 8 : reinterpret_cast<const bf16_t*>(decode_zero_page) + 8 * (l & 15);
                 }
-                glds16(src, sa + 64 * g);
+                if (SCOH)
+                    glds16_agent(src, sa + 64 * g);
+                else
+                    glds16(src, sa + 64 * g);
             }
         };
         const int seen_r = w == 0 ? stream_poll(done + 3) : 0, seen_u = w == 0 ? stream_poll(done + 4) : 0;
@@ -972,7 +1047,7 @@ __global__ __launch_bounds__(256) void decode_stream_kernel(const StreamArgs a) 
         if (up_done) images();
         float my_score;
         int my_idx;
-        route_one_token(a.s.rl, a.E, k, l, 0, my_score, my_idx);
+        route_one_token<SCOH>(a.s.rl, a.E, k, l, 0, my_score, my_idx);
         const int my_sc = int(uint32_t(f2bf(my_score)) << 16);
         int e[DOWN_KMAX];
         float sc[DOWN_KMAX];
@@ -1022,7 +1097,7 @@ __global__ __launch_bounds__(256) void decode_stream_kernel(const StreamArgs a) 
             for (int q = 0; q < 4; ++q) sh = dot2bf(ws[i][q], xv[q], sh);
         }
         sh = wave_sum_bcast(sh);
-        if (l == 0 && n < N) a.s.xb[n] = f2bf(bf2f(h[n]) + rbf(rbf(accs) + rbf(sh)));
+        if (l == 0 && n < N) stc<SCOH>(a.s.xb + n, f2bf(bf2f(ldc<SCOH>(h + n)) + rbf(rbf(accs) + rbf(sh))));
         stream_signal(done + 5, &s_b[1]);
     }
 }

@@ -48,8 +48,113 @@ __global__ __launch_bounds__(256) void probe_atomic_kernel(float* buf, int* xcc,
                     asm volatile("global_atomic_add_f32 %0, %1, off sc1" ::"v"(p), "v"(one) : "memory");
             }
 }
+
+// ---- what the cross-workgroup synchronisation of a one-launch decode schedule costs (tools/probes/stream_sync_costs.py) ----------------
+// Every workgroup (256 threads, `nblocks` of them) does only the selected pieces; mode bits:
+//   1  ticket: thread 0, RETURNING atomic add on ONE word, broadcast through LDS + barrier     64: the word is cnt[16 * (b & 7)] (one per XCD)
+//   2  completion: thread 0, atomic add on cnt[1024 + 16 * ((b / 512) & 63)] at the end (a new word every 512 workgroups)   128: non-returning
+//   4  every wave: buffer_wbl2 sc1 + s_waitcnt vmcnt(0)        8  every wave: buffer_inv sc1
+//   16 wave 0: one sc1 poll load of cnt[2048] + wait           32 two bare s_barriers
+//   256 every wave: one 2-byte sc1 store to a private slot of `sink` + s_waitcnt vmcnt(0)
+__global__ __launch_bounds__(256) void probe_sync_kernel(int* cnt, unsigned short* sink, int mode) {
+    __shared__ int s_t;
+    const int b = blockIdx.x, t = threadIdx.x, w = t >> 6;
+    int ticket = b;
+    if (mode & 1) {
+        if (t == 0) s_t = __hip_atomic_fetch_add(cnt + ((mode & 64) ? 16 * (b & 7) : 0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        ticket = s_t;
+    }
+    if ((mode & 16) && w == 0) {
+        const int v = __hip_atomic_load(cnt + 2048, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == 0x7fffffff) sink[0] = 1;
+    }
+    if (mode & 32) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+    }
+    if (mode & 8) asm volatile("buffer_inv sc1" ::: "memory");
+    if (mode & 256) {
+        if ((t & 63) == 0) __hip_atomic_store(sink + 64 + (((long long)ticket * 4 + w) & 0xfffff), (unsigned short)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (mode & 4) asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    if (mode & 2) {
+        __syncthreads();
+        int* c = cnt + 1024 + 16 * ((b / 512) & 63);
+        if (t == 0) {
+            if (mode & 128)
+                __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                s_t = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// Two workgroups (0 and `partner`; everybody else leaves) bounce a word `iters` times: A writes 2i + 1 and waits for 2i + 2, B the reverse.
+// how 0: sc1 store / sc1 load     1: atomic exchange-add / sc1 load     2: plain store + buffer_wbl2 sc1 / buffer_inv sc1 + plain load
+// Polls are bounded (a lost update ends the run with out[1] = 1 instead of hanging the GPU).  out[0] = round trips completed.
+__global__ __launch_bounds__(64) void probe_pingpong_kernel(int* flag, int* out, int iters, int partner, int how) {
+    const int b = blockIdx.x;
+    if ((b != 0 && b != partner) || threadIdx.x != 0) return;
+    const bool A = b == 0;
+    int done = 0;
+    for (int i = 0; i < iters; ++i) {
+        const int mine = A ? 2 * i + 1 : 2 * i + 2, theirs = A ? 2 * i + 2 : 2 * i + 1;
+        for (int phase = 0; phase < 2; ++phase) {
+            if ((phase == 0) == A) {  // A writes first, B waits first
+                if (how == 0)
+                    __hip_atomic_store(flag, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (how == 1)
+                    __hip_atomic_exchange(flag, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else {
+                    *(volatile int*)flag = mine;
+                    asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else {
+                int spins = 0, v;
+                do {
+                    if (how == 2) {
+                        asm volatile("buffer_inv sc1" ::: "memory");
+                        v = *(volatile int*)flag;
+                    } else
+                        v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while (v != theirs && ++spins < (1 << 20));
+                if (v != theirs) {
+                    out[1] = 1;
+                    out[0] = done;
+                    return;
+                }
+            }
+        }
+        ++done;
+    }
+    if (A) out[0] = done;
+}
 }  // namespace
 #endif
+
+extern "C" int aria_probe_sync(int* cnt, unsigned short* sink, int64_t nblocks, int mode, void* stream) {
+#ifdef ARIA_EMU
+    (void)cnt; (void)sink; (void)nblocks; (void)mode; (void)stream;
+    return ARIA_ERR_UNSUPPORTED;
+#else
+    if (!cnt || !sink || nblocks <= 0) return ARIA_ERR_INVALID;
+    hipLaunchKernelGGL(probe_sync_kernel, dim3(unsigned(nblocks)), dim3(256), 0, static_cast<hipStream_t>(stream), cnt, sink, mode);
+    return aria_check_launch();
+#endif
+}
+
+extern "C" int aria_probe_pingpong(int* flag, int* out, int iters, int partner, int how, void* stream) {
+#ifdef ARIA_EMU
+    (void)flag; (void)out; (void)iters; (void)partner; (void)how; (void)stream;
+    return ARIA_ERR_UNSUPPORTED;
+#else
+    if (!flag || !out || iters <= 0 || partner <= 0) return ARIA_ERR_INVALID;
+    hipLaunchKernelGGL(probe_pingpong_kernel, dim3(unsigned(partner + 1)), dim3(64), 0, static_cast<hipStream_t>(stream), flag, out, iters, partner, how);
+    return aria_check_launch();
+#endif
+}
 
 extern "C" int aria_probe_atomic(float* buf, int* xcc, int64_t nblocks, int64_t region_floats, int region_mode, int scope, int iters,
                                  int row_stride, void* stream) {
