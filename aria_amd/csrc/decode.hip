@@ -45,16 +45,43 @@ __device__ __forceinline__ u32x4 ld16c(const void* p) {
 #endif
     return ld16(p);
 }
+// Stores another XCD must see inside the launch travel as ATOMIC EXCHANGES of 4 / 8 bytes (results unused: fire and forget).  Measured on
+// MI355X (profiles/r04_decode_stream_bisect.json): with exchanges every GEMV-type stage of a 28-layer token is bit-exact; plain stores +
+// buffer_wbl2 sc1 per wave are right as well and 8x too slow at 78 000 workgroups; read-modify-write atomics are performed where every
+// XCD looks (the completion counters rely on it).  The one exception is noted at ARIA_STREAM_ST_MASK.
 template <bool COH>
-__device__ __forceinline__ void st16c(void* p, u32x4 v) {
+__device__ __forceinline__ void stx32(void* p, uint32_t v) {
 #ifndef ARIA_EMU
     if (COH) {
-        uint64_t* q = static_cast<uint64_t*>(p);
-        __hip_atomic_store(q, uint64_t(v[0]) | (uint64_t(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(q + 1, uint64_t(v[2]) | (uint64_t(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the RETURNING form: the old value comes back from where the exchange was performed, so the wait for it (stream_release) is a wait
+        // for the exchange itself
+        const uint32_t old = __hip_atomic_exchange(static_cast<uint32_t*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(old));
         return;
     }
 #endif
+    *static_cast<uint32_t*>(p) = v;
+}
+template <bool COH>
+__device__ __forceinline__ void stx64(void* p, uint32_t lo, uint32_t hi) {
+#ifndef ARIA_EMU
+    if (COH) {
+        const unsigned long long old = __hip_atomic_exchange(static_cast<unsigned long long*>(p), (unsigned long long)lo | ((unsigned long long)hi << 32),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(old));
+        return;
+    }
+#endif
+    static_cast<uint32_t*>(p)[0] = lo;
+    static_cast<uint32_t*>(p)[1] = hi;
+}
+template <bool COH>
+__device__ __forceinline__ void st16c(void* p, u32x4 v) {
+    if (COH) {
+        stx64<true>(p, v[0], v[1]);
+        stx64<true>(static_cast<char*>(p) + 8, v[2], v[3]);
+        return;
+    }
     st16(p, v);
 }
 template <bool COH, class T>
@@ -64,15 +91,12 @@ __device__ __forceinline__ T ldc(const T* p) {
 #endif
     return *p;
 }
-template <bool COH, class T>
-__device__ __forceinline__ void stc(T* p, T v) {
-#ifndef ARIA_EMU
-    if (COH) {
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-#endif
-    *p = v;
+template <bool COH>
+__device__ __forceinline__ void stcf(float* p, float v) {  // one fp32 word
+    if (COH)
+        stx32<true>(p, __builtin_bit_cast(uint32_t, v));
+    else
+        *p = v;
 }
 
 // x[K] (bf16) -> this lane's chunks c = l + 64 i (i < NC) as packed bf16 pairs, optionally RMS-normalised exactly like
@@ -593,10 +617,10 @@ struct DecodeAttn {
     static __device__ __forceinline__ void publish(float (*red)[LPK][10], int w, float m, float lsum, const float (&o)[8]) {
         const int l = threadIdx.x & 63, sub = l % LPK, grp = l / LPK;
         if (grp == 0) {
-            stc<COH>(&red[w][sub][0], m);
-            stc<COH>(&red[w][sub][1], lsum);
+            stcf<COH>(&red[w][sub][0], m);
+            stcf<COH>(&red[w][sub][1], lsum);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) stc<COH>(&red[w][sub][2 + e], o[e]);
+            for (int e = 0; e < 8; ++e) stcf<COH>(&red[w][sub][2 + e], o[e]);
         }
     }
     // The NWV wave states as a tree, run by ONE wave: lane group g folds waves g, g + NG, ..., then the groups merge by butterfly.
@@ -719,45 +743,82 @@ struct Scratch {
     size_t bytes;
 };
 
-// ---- streamed schedule: the whole token as ONE launch (ARIA_DECODE_STREAM) ---------------------------------------------------------
-// The launch schedule above is a chain of 6 x L + 1 short kernels (5-22 us each at Aria's widths); their sum IS the token, and each
-// spends its first microseconds ramping up and its last ones draining: the kernel trace shows 2.6-4.6 TB/s per GEMV where streaming
-// alone would run near 6.  What a stage needs from its predecessor is a 5 KB activation vector; the WEIGHTS it is going to stream depend
-// on nothing (except the routed experts', on the router logits).  So the stages become workgroups of one grid:
-//   * a workgroup takes a TICKET (one atomic add) and derives (layer, stage, block-in-stage) from it -- tickets, not blockIdx, so the order
-//     in which work is handed out IS the order in which workgroups became resident;
-//   * it requests its weight rows (non-temporal 16-byte loads into registers, exactly the rows / lanes / chunks the launch schedule's
-//     kernel of that stage gives the same wave), THEN waits until the producing stage's completion counter has reached its block count,
-//     then fetches the activation vector and finishes as the launch kernel does -- same dot-product order, same rounding points, so the
-//     hidden state, the KV cache and the logits equal the 6-launch schedule's bit for bit (tests/model_cases.py::case_decode_engine_streamed);
-//   * a finished workgroup releases its writes (agent scope) and bumps its stage's counter.
+// ---- streamed schedule: the whole token as ONE launch (ARIA_DECODE_STREAM=1; opt-in) ----------------------------------------------------
+// The launch schedule above is a chain of 6 x L + 1 short kernels.  Measured (profiles/r04_xcd_visibility.json, "reread"): a kernel that
+// streams X MB takes ~4.5 us + X / 7.2 TB/s on this chip -- launch, ramp and tail are paid per kernel whatever it reads -- so a layer is
+// 6 x 4.5 + 275 MB / 7.2 TB/s = 65 us of which 27 are boundaries (measured 68-71).  What a stage needs from its predecessor is a 5 KB
+// activation vector; the WEIGHTS it is going to stream depend on nothing (except the routed experts', on the router logits).  So the
+// stages become workgroups of one grid:
+//   * a workgroup derives (layer, stage, block-in-stage) from its index, requests its weight rows (non-temporal 16-byte loads into
+//     registers: the rows / lanes / chunks the launch schedule gives a wave of that stage; rows per wave may differ, which moves rows
+//     between waves, not the arithmetic of a row), THEN waits for the producing stage, then gets the activation vector -- once per
+//     workgroup, into LDS (block_vector) -- and finishes as the launch kernel does: same dot-product order, same rounding points, so
+//     hidden state, KV cache and logits equal the 6-launch schedule's bit for bit (tests/model_cases.py::case_decode_engine_streamed,
+//     and the 28-layer model in tools/probes/decode_stream_ab.py);
+//   * a finished workgroup makes its few output words visible and counts itself done (stream_count: 8 + 1 counter lines and 64 flag
+//     lines per stage, so that nobody polls or increments a word everybody else is using).
 // No grid barrier: while a stage's last workgroups finish, the next stages' rows are already landing in the registers of the workgroups
-// behind them; HBM never sees the launch boundary.  Forward progress: a workgroup only ever waits for stages whose tickets are all SMALLER
-// than its own, i.e. were handed to workgroups that are already resident -- the lowest unfinished ticket never waits, by induction nobody
-// waits forever (the scheme of a decoupled look-back scan).  A waiting wave sleeps between polls; only wave 0 of a workgroup polls, the
-// others stand at a bare s_barrier (which does not drain the row loads in flight).  A poll that has not succeeded after ~0.3 s sets the
-// sticky error word and falls through (wrong logits, surfaced by aria_decode_stream_status -- never a hung GPU).
+// behind them.  Forward progress: a workgroup only waits for stages of LOWER index; workgroups are dispatched in index order (per XCD,
+// round-robin), so whatever a resident workgroup waits for is resident or finished -- the lowest unfinished index never waits.  That order
+// is what the hardware does, not what HIP promises: every wait is bounded (~0.3 s), a timeout sets the sticky error word and falls
+// through (wrong logits, reported by aria_decode_stream_sync_offset's word [1]; never a hung GPU), and -DARIA_STREAM_TICKET=1 replaces
+// the index by an atomic ticket (one word: 11 ns per workgroup, serialised).
+// Visibility between XCDs inside the launch: outputs leave as 4- / 8-byte atomic exchanges and are read with agent-scope (sc1) loads; the
+// producer waits for its exchanges before it signals.  (Cache-wide buffer_wbl2 / buffer_inv per wave, the textbook release / acquire,
+// cost 28 ns per workgroup EACH when 78 000 workgroups issue them: the first build ran at 15.9 ms per token.)
 // Attention: the 16 waves the one-workgroup-per-head kernel gives a head are 4 workgroups here (wave index within the head = 4 * part + w,
 // same keys per wave and pass); each wave leaves its state in global scratch, the LAST of the four to arrive (a per-head counter) folds
 // the 16 states with DecodeAttn::fold -- the same tree on the same bits.
+//
+// Where it stands (round 4, MI355X, 25.3 B model, 280-token context; profiles/r04_decode_stream_*.json): bit-exact, 1.985 ms per token
+// against the launch schedule's 1.905 -- NOT faster, hence opt-in.  History of the same kernel: 15.9 ms (wbl2 / inv per wave) -> 4.25
+// (agent-scope words) -> 4.7 (two rows per wave, index order; every resident workgroup polling one counter word) -> 2.76 (flag lines) ->
+// 2.62 / 2.38 (counter tree; 4 / 3 waves per SIMD with / without spills) -> 1.985 (vector once per workgroup in LDS, four rows per wave,
+// 116 registers, 4 waves per SIMD).  The build without any waits or counters (wrong results, -DARIA_STREAM_ABL=3) runs at 1.83: what is
+// left is not synchronisation but the workgroup itself.  The phase timeline (-DARIA_STREAM_ABL=4, r04_decode_stream_phases_*.json) says
+// why: under the bulk weight traffic a dependent memory round trip costs 5-7 us, and a workgroup strings several together -- kernel
+// arguments -> rows (|| vector) -> output exchange -> counter(s) -- ~20 us of life for ~7 us of rows in flight, where a launch-schedule
+// wave lives one round trip.  A version that wins has to END a workgroup without waiting for anything: outputs and the completion
+// count fire-and-forget, the consumer told apart fresh words from stale ones by itself (per-layer buffers pre-filled with a sentinel).
 constexpr int STREAM_MAXL = 28;            // layers whose pointers fit the kernel-argument block (Aria: 28)
-constexpr int STREAM_SYNC_HEADER = 4;      // sync[0] ticket, [1] sticky error, [2], [3] spare; then 8 words per layer, then L * H head counters
+constexpr int STREAM_SYNC_HEADER = 4;      // sync[0] ticket, [1] sticky error, [2], [3] spare; then L * H head counters, the timeline, flag and counter lines
 constexpr int STREAM_SPIN_LIMIT = 1 << 18;
-// ARIA_STREAM_COH 1 (default): what one workgroup hands another travels in agent-scope (sc1) single-word stores / loads; the producer waits for
-// its stores' acknowledgements before it bumps the counter, the consumer issues its loads after it has seen the counter.  0: plain accesses +
-// buffer_wbl2 sc1 / buffer_inv sc1 per wave (the first build: correct, and 8x slower than the launch schedule -- profiles/r04_decode_stream_ab.json).
-// ARIA_STREAM_TICKET 1 (default): order by an atomic ticket; 0: by blockIdx (assumes in-order dispatch; timing experiments only).
-#ifndef ARIA_STREAM_COH
-#define ARIA_STREAM_COH 1
+// Variant switches (A/B builds: tools/probes/build_decode_variant.sh):
+//   ARIA_STREAM_LD 1: sc1 loads of what other workgroups wrote; 0: plain loads behind a buffer_inv sc1 per wave
+//   ARIA_STREAM_ST 1: atomic exchanges + wait for their completion; 0: plain stores + buffer_wbl2 sc1 per wave
+//   ARIA_STREAM_DMA 1: the down-projection's activation images by LDS-DMA (sc1); 0: through registers
+//   ARIA_STREAM_TICKET 0: blockIdx order; 1: atomic ticket
+//   ARIA_STREAM_ABL (timing only, wrong results): 1 = no dependency waits, 2 = no completion atomics
+#ifndef ARIA_STREAM_LD
+#define ARIA_STREAM_LD 1
+#endif
+#ifndef ARIA_STREAM_ST
+#define ARIA_STREAM_ST 1
+#endif
+#ifndef ARIA_STREAM_DMA
+#define ARIA_STREAM_DMA 1
 #endif
 #ifndef ARIA_STREAM_TICKET
-#define ARIA_STREAM_TICKET 1
+#define ARIA_STREAM_TICKET 0
 #endif
-constexpr bool SCOH = ARIA_STREAM_COH != 0;
-// ARIA_STREAM_ABL (timing-only builds, wrong results: tools/probes/decode_stream_ab.py --lib=...): 1 = no dependency waits, 2 = no completion atomics
 #ifndef ARIA_STREAM_ABL
 #define ARIA_STREAM_ABL 0
 #endif
+#ifndef ARIA_STREAM_SLEEP_FAR
+#define ARIA_STREAM_SLEEP_FAR 100  // x 64 cycles between polls while the awaited counter is still 0
+#endif
+#ifndef ARIA_STREAM_SLEEP_NEAR
+#define ARIA_STREAM_SLEEP_NEAR 8
+#endif
+constexpr bool SLD = ARIA_STREAM_LD != 0;
+#ifndef ARIA_STREAM_ST_MASK
+#define ARIA_STREAM_ST_MASK (ARIA_STREAM_ST ? 63 : 0)  // bit s: stage s stores by exchanges; clear: plain stores + buffer_wbl2 sc1
+// per wave.  Bit 6 = the attention stage's wave states, read back by the LAST of a head's four workgroups right after its own arrival: with
+// exchanges a 28-layer token differed from the launch schedule by a few bf16 ulps, the same ones on every run; each of the other stages alone on
+// exchanges was bit-exact (profiles/r04_decode_stream_bisect.json) -- so that one keeps the cache write-back (80 workgroups per layer: cheap)
+#endif
+template <int STAGE>
+constexpr bool sst() { return ((ARIA_STREAM_ST_MASK >> STAGE) & 1) != 0; }
 
 struct StreamArgs {
     const void* hdr[ARIA_DECODE_HEADER_PTRS];
@@ -769,8 +830,11 @@ struct StreamArgs {
     float eps, scale;
     int nb[6];  // workgroups per stage: qkv | attention | wo | router + shared up | routed up | down + combine
     int nbl, nbv, total;
-    int r0, r2, ru, rv;  // rows per wave (2 | 4) of the qkv, wo, routed-up and output GEMVs: what launch_gemv / aria_decode_token choose
-    int nrb, nbx;        // router workgroups of stage 3; workgroups per expert of stage 4
+    int nrb, nbx;  // router workgroups of stage 3; workgroups per expert of stage 4
+    int r4[4];     // four (else two) rows per wave in the qkv, wo, (unused) and output GEMVs
+    unsigned long long* ts;  // timeline words (ARIA_STREAM_ABL & 4)
+    int32_t* flags;          // completion flags: [(layer * 8 + stage)][64 lines][32 words]
+    int32_t* ctr;            // completion counters: [(layer * 8 + stage)][16 lines][32 words]
 };
 static_assert(sizeof(StreamArgs) <= 3840, "kernel arguments: 4 KB limit");
 
@@ -781,45 +845,151 @@ __device__ __forceinline__ int stream_poll(const int32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
-__device__ __forceinline__ void stream_acquire() {  // what other workgroups wrote before the counter value just observed is visible to the loads that follow
+// timeline builds: slot 0 keeps the EARLIEST time (stored inverted under an atomic max), slots 1.. the latest
+__device__ __forceinline__ void stream_stamp(unsigned long long* tsp, int slot) {
 #ifndef ARIA_EMU
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-#if ARIA_STREAM_COH
-    asm volatile("" ::: "memory");  // (the loads that follow are sc1 loads; nothing cached needs to go)
-#else
-    asm volatile("buffer_inv sc1" ::: "memory");
-#endif
-#pragma clang diagnostic pop
+    if ((ARIA_STREAM_ABL & 4) && threadIdx.x == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        atomicMax(tsp + slot, slot < 2 ? ~now : now);
+    }
 #endif
 }
-// Wait until *cnt >= target.  `seen` = a poll wave 0 issued BEFORE its row loads (loads return in order: a poll issued after them would only
-// come back behind them).  cnt == nullptr: nothing to wait for.  Every wave of the workgroup calls this (one bare barrier inside).
-__device__ __forceinline__ void stream_wait(const int32_t* cnt, int target, int seen, int32_t* sync) {
-    if (!cnt) return;
+// What a workgroup needs to synchronise: the counter lines, the flag lines, its own flag slot.
+// A stage's completion travels in three hops, none of which lets many workgroups meet on one word (accesses to one word are served one
+// after the other, ~11 ns each: 500 resident workgroups polling a counter starve the very increments they wait for -- 4.7 ms per token;
+// 1248 increments of one word are 14 us by themselves -- profiles/r04_stream_sync_costs.json, r04_decode_stream_timeline.json):
+//   a finished workgroup bumps ONE of the stage's 8 first-level counters (block-in-stage & 7; returning add), the workgroup that completes
+//   a first-level counter bumps the stage's second-level counter, the one that completes THAT sets the stage's 64 flag words (each on its own
+//   128-byte line); a waiting workgroup polls flag (index & 63) -- eight pollers per line.
+struct StreamSync {
+    int32_t* sync;
+    int32_t* ctr;    // [(layer * 8 + stage)][16 lines][32 words]: lines 0..7 first level, line 8 second level
+    int32_t* flags;  // [(layer * 8 + stage)][64 lines][32 words]
+    int slot;
+};
+constexpr int STREAM_FLAG_SLOTS = 64, STREAM_LINE = 32, STREAM_CTR_LINES = 16;  // (words per 128-byte line)
+__device__ __forceinline__ int32_t* stream_flag(const StreamSync& ss, int idx, int slot) {
+    return ss.flags + ((long long)idx * STREAM_FLAG_SLOTS + slot) * STREAM_LINE;
+}
+// timeline builds: where a workgroup's time goes.  ph[0..] = s_memrealtime at the phase boundaries, taken by thread 0; added into the stage's sums at the end
+struct StreamPhases {
+    unsigned long long t[6];
+    int n;
+};
+__device__ __forceinline__ void phase_mark(StreamPhases& ph) {
+#ifndef ARIA_EMU
+    if ((ARIA_STREAM_ABL & 4) && threadIdx.x == 0 && ph.n < 6) ph.t[ph.n++] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+__device__ __forceinline__ void phase_flush(const StreamPhases& ph, unsigned long long* acc) {  // acc[0] count, acc[1 + i] = sum of (t[i + 1] - t[i])
+#ifndef ARIA_EMU
+    if ((ARIA_STREAM_ABL & 4) && threadIdx.x == 0) {
+        atomicAdd(acc, 1ull);
+        for (int i = 0; i + 1 < ph.n; ++i) atomicAdd(acc + 1 + i, ph.t[i + 1] - ph.t[i]);
+    }
+#endif
+}
+// Wait until stage `idx` (= layer * 8 + stage; < 0: nothing to wait for) is complete.  Every wave of the workgroup calls this: wave 0 polls
+// (sleeping in between), the others stand at a bare s_barrier, which does not drain the row loads they have in flight.
+__device__ __forceinline__ void stream_wait(const StreamSync& ss, int idx) {
+    if (idx < 0) return;
 #ifdef ARIA_EMU
-    if (*cnt < target) sync[1] = 2;  // the emulator runs workgroups in ticket order: an unmet dependency here is a bug in the stage tables
+    if (*stream_flag(ss, idx, ss.slot) == 0) ss.sync[1] = 2;  // the emulator runs workgroups in index order: an unmet dependency is a bug in the stage tables
     emu::syncthreads();
 #else
     if (ARIA_STREAM_ABL & 1) return;
     if ((threadIdx.x >> 6) == 0) {
-        int c = seen, spins = 0;
-        while (c < target) {
-            __builtin_amdgcn_s_sleep(16);
-            c = stream_poll(cnt);
-            if (++spins > STREAM_SPIN_LIMIT || ((spins & 255) == 0 && stream_poll(sync + 1) != 0)) {
-                if (threadIdx.x == 0) __hip_atomic_store(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t* f = stream_flag(ss, idx, ss.slot);
+        int spins = 0;
+        while (stream_poll(f) == 0) {
+            __builtin_amdgcn_s_sleep(ARIA_STREAM_SLEEP_NEAR);
+            if (++spins > STREAM_SPIN_LIMIT || ((spins & 255) == 0 && stream_poll(ss.sync + 1) != 0)) {
+                if (threadIdx.x == 0) __hip_atomic_store(ss.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
     }
     wait_lds();  // (thread 0's LDS notes for the workgroup are written before anybody passes the barrier)
     raw_barrier();
-    stream_acquire();
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#if ARIA_STREAM_LD
+    asm volatile("" ::: "memory");  // (what follows reads with sc1 loads: nothing cached has to go)
+#else
+    asm volatile("buffer_inv sc1" ::: "memory");
+#endif
+#pragma clang diagnostic pop
 #endif
 }
-// This workgroup's writes become visible (agent scope), then its stage counter moves; returns the counter's previous value to every thread
-__device__ __forceinline__ int stream_signal(int32_t* cnt, int* bcast) {
+// is stage `idx` complete already?  (one poll, no waiting)
+__device__ __forceinline__ bool stream_ready(const StreamSync& ss, int idx) { return stream_poll(stream_flag(ss, idx, ss.slot)) != 0; }
+
+// every wave: what it stored for other workgroups has reached the point where the other XCDs read
+#ifndef ARIA_STREAM_WB_MASK
+#define ARIA_STREAM_WB_MASK 0  // (bisection builds: bit s = stage s additionally writes the L2 back before it signals; bit 6 = the per-head arrival)
+#endif
+template <int STAGE>
+__device__ __forceinline__ void stream_release() {
+#ifndef ARIA_EMU
+    if ((ARIA_STREAM_WB_MASK & (1 << STAGE)) || !sst<STAGE>()) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // buffer_wbl2 sc1 + wait
+    wait_vm<0>();  // (its exchanges have been performed)
+#endif
+}
+// wave 0, after the workgroup's barrier: workgroup `r` of the `nb` of stage `idx` is done
+__device__ __forceinline__ void stream_count(const StreamSync& ss, int idx, int r, int nb) {
+    const int shard = r & 7, target1 = (nb - shard + 7) >> 3, target2 = nb < 8 ? nb : 8;
+    int32_t* c1 = ss.ctr + ((long long)idx * STREAM_CTR_LINES + shard) * STREAM_LINE;
+    int32_t* c2 = ss.ctr + ((long long)idx * STREAM_CTR_LINES + 8) * STREAM_LINE;
+#ifdef ARIA_EMU
+    if ((threadIdx.x & 63) == 0) {
+        if (++*c1 == target1 && ++*c2 == target2)
+            for (int i = 0; i < STREAM_FLAG_SLOTS; ++i) *stream_flag(ss, idx, i) = 1;
+    }
+    emu::wave_sync();
+#else
+    if (ARIA_STREAM_ABL & 2) return;
+    int last = 0;
+    if ((threadIdx.x & 63) == 0) {
+        if (__hip_atomic_fetch_add(c1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == target1 - 1)
+            last = __hip_atomic_fetch_add(c2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == target2 - 1;
+    }
+    if (__builtin_amdgcn_readfirstlane(last))
+        (void)__hip_atomic_exchange(stream_flag(ss, idx, threadIdx.x & 63), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// the workgroup (r of nb) is done with its share of stage `idx`
+template <int STAGE>
+__device__ __forceinline__ void stream_done(const StreamSync& ss, int idx, int r, int nb) {
+#ifdef ARIA_EMU
+    emu::syncthreads();
+    if (threadIdx.x < 64) stream_count(ss, idx, r, nb);
+#else
+    stream_release<STAGE>();
+    raw_barrier();
+    if (threadIdx.x < 64) stream_count(ss, idx, r, nb);
+#endif
+}
+// ... whose four waves each hold ONE bf16 result for four consecutive rows: the four leave as one 8-byte word (`dst` 8-byte aligned)
+template <int STAGE>
+__device__ __forceinline__ void stream_done4(const StreamSync& ss, int idx, int r, int nb, bf16_t* dst, uint32_t v, uint32_t* s_o) {
+    const int t = threadIdx.x;
+    if ((t & 63) == 0) s_o[t >> 6] = v;
+#ifdef ARIA_EMU
+    emu::syncthreads();
+    if (t == 0) stx64<false>(dst, s_o[0] | (s_o[1] << 16), s_o[2] | (s_o[3] << 16));
+    if (t < 64) stream_count(ss, idx, r, nb);
+#else
+    wait_lds();
+    raw_barrier();
+    if (t < 64) {
+        if (t == 0) stx64<sst<STAGE>()>(dst, s_o[0] | (s_o[1] << 16), s_o[2] | (s_o[3] << 16));
+        stream_release<STAGE>();
+        stream_count(ss, idx, r, nb);
+    }
+#endif
+}
+// the counter's previous value handed to every thread (the attention stage's per-head counters: four workgroups per word)
+__device__ __forceinline__ int stream_arrive(int32_t* cnt, int* bcast) {
 #ifdef ARIA_EMU
     emu::syncthreads();
     if (threadIdx.x == 0) {
@@ -829,11 +999,7 @@ __device__ __forceinline__ int stream_signal(int32_t* cnt, int* bcast) {
     emu::syncthreads();
     return *bcast;
 #else
-#if ARIA_STREAM_COH
-    wait_vm<0>();  // every wave: its sc1 stores are acknowledged (written through to where the other XCDs read)
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every wave: its own stores (buffer_wbl2 sc1 + wait)
-#endif
+    stream_release<6>();
     raw_barrier();
     if (threadIdx.x == 0) *bcast = (ARIA_STREAM_ABL & 2) ? 0 : __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -841,187 +1007,283 @@ __device__ __forceinline__ int stream_signal(int32_t* cnt, int* bcast) {
 #endif
 }
 
-// y = W . norm(x) (+ residual): gemv_kernel's wave, rows requested before the wait
-template <int R, int NC>
-__device__ __forceinline__ void stream_gemv(int blk, const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w, float eps, int K,
-                                            int N, const bf16_t* residual, bf16_t* y, const int32_t* dep, int target, int32_t* sync) {
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row0 = (blk * 4 + w) * R;
-    const int seen = (dep && w == 0) ? stream_poll(dep) : 0;
-    u32x4 xv[NC], a[R][NC];
-    float acc[R];
-    load_rows<R, NC>(a, W, ldw, min(row0, N - 1), N, K, l);
-    stream_wait(dep, target, seen, sync);
-    load_vector<NC, SCOH>(xv, x, norm_w, eps, K, l);
-    dot_loaded<R, NC>(acc, a, xv);
-    if (l == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (row0 + r < N)
-                stc<SCOH>(y + row0 + r, residual ? f2bf(bf2f(ldc<SCOH>(residual + row0 + r)) + rbf(acc[r])) : f2bf(acc[r]));
-    }
-}
+// The activation vector ONCE per workgroup, in LDS.  (Per wave in registers -- load_vector, what the launch kernels do against their L2 --
+// every wave of the streamed kernel fetched the 5 KB vector from the memory side: with one or two weight rows per wave that was a third
+// of the fabric traffic, and the 40 + 40 registers of vector and norm weights next to the rows in flight kept the kernel at 2-3 waves per
+// SIMD.)  The waves share the chunks (wave w takes chunks w, w + 4, ...), leave the squares' terms in LDS, and EVERY wave sums them in
+// load_vector's order -- the same running sum over the same terms, so the same rstd bit for bit -- then scales its own chunks into sx.
+//   sx[NC * 64] u32x4: chunk c = l + 64 i of the (normalised) vector at sx[c];  sterm[NC * 4 * 64] floats.  Two barriers (one without a norm).
 template <int NC>
-__device__ __forceinline__ void stream_gemv_r(int rows, int blk, const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w,
-                                              float eps, int K, int N, const bf16_t* residual, bf16_t* y, const int32_t* dep, int target,
-                                              int32_t* sync) {
-    if (rows == 4)
-        stream_gemv<4, NC>(blk, W, ldw, x, norm_w, eps, K, N, residual, y, dep, target, sync);
-    else
-        stream_gemv<2, NC>(blk, W, ldw, x, norm_w, eps, K, N, residual, y, dep, target, sync);
-}
-
-// routed up-projection pair + SwiGLU of expert slot j: expert_up_kernel's wave (the vector is normalised while the router stage still runs)
-template <int R, int NC>
-__device__ __forceinline__ void stream_expert_up(int bx, int j, const StreamArgs& a, const bf16_t* W1, const bf16_t* W3, const bf16_t* h,
-                                                 const bf16_t* norm_w, const int32_t* dep_h, int target_h, const int32_t* dep_r, int target_r) {
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int K = a.D, I = a.I, row0 = (bx * 4 + w) * R;
-    const int seen_h = w == 0 ? stream_poll(dep_h) : 0, seen_r = w == 0 ? stream_poll(dep_r) : 0;
-    u32x4 xv[NC];
-    stream_wait(dep_h, target_h, seen_h, a.sync);
-    load_vector<NC, SCOH>(xv, h, norm_w, a.eps, K, l);
-    stream_wait(dep_r, target_r, seen_r, a.sync);
-    float my_score;
-    int my_idx;
-    const int e = route_one_token<SCOH>(a.s.rl, a.E, a.k, l, j, my_score, my_idx);
-    if (bx == 0 && j == 0 && w == 0 && l < a.k) {
-        a.s.scores[l] = f2bf(my_score);
-        a.s.idx[l] = my_idx;
-    }
-    const long long stride = (long long)I * K;
-    float a1[R], a3[R];
-    dot_rows<R, NC>(a1, W1 + (long long)e * stride, K, min(row0, I - 1), I, xv, K, l);
-    dot_rows<R, NC>(a3, W3 + (long long)e * stride, K, min(row0, I - 1), I, xv, K, l);
-    if (l == 0) {
+__device__ __forceinline__ void block_vector(const bf16_t* x, const bf16_t* norm_w, float eps, int K, u32x4* sx, float* sterm) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, nch = K >> 3;
+    constexpr int MINE = (NC + 3) / 4;
+    u32x4 xv[MINE];
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (row0 + r < I) stc<SCOH>(a.s.act + (long long)j * I + row0 + r, f2bf(rbf(silu(rbf(a1[r]))) * rbf(a3[r])));
-    }
-}
-
-template <int NCD, int NCI, int NCS, int HD>
-__global__ __launch_bounds__(256) void decode_stream_kernel(const StreamArgs a) {
-    ARIA_DYN_SMEM(smem);
-    ARIA_SMEM_STATIC int s_b[4];  // [0] ticket, [1] a stage counter's previous value, [2] "the routed activations are complete already"
-    const int t = threadIdx.x, l = t & 63, w = t >> 6;
-    if (t == 0) {
-#ifdef ARIA_EMU
-        s_b[0] = a.sync[0];
-        a.sync[0] += 1;
-#elif ARIA_STREAM_TICKET
-        s_b[0] = __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-        s_b[0] = int(blockIdx.x);
-#endif
+    for (int m = 0; m < MINE; ++m) {
+        const int i = w + 4 * m;
+        if (i < NC) {  // wave-uniform
+            xv[m] = ld16c<SLD>(x + min(l + 64 * i, nch - 1) * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xv[m][q] = (l + 64 * i < nch) ? xv[m][q] : 0u;
+            if (!norm_w) {
+                sx[l + 64 * i] = xv[m];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v0 = bflo(xv[m][q]), v1 = bfhi(xv[m][q]);
+                    sterm[(i * 4 + q) * 64 + l] = v0 * v0 + v1 * v1;
+                }
+            }
+        }
     }
     sync();
+    if (!norm_w) return;  // workgroup-uniform
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ss += sterm[(i * 4 + q) * 64 + l];
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / float(K) + eps);
+#pragma unroll
+    for (int m = 0; m < MINE; ++m) {
+        const int i = w + 4 * m;
+        if (i < NC) {
+            const u32x4 wv = ld16(norm_w + min(l + 64 * i, nch - 1) * 8);
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                o[q] = pack2bf(bflo(wv[q]) * rbf(bflo(xv[m][q]) * r), bfhi(wv[q]) * rbf(bfhi(xv[m][q]) * r));
+            sx[l + 64 * i] = o;
+        }
+    }
+    sync();
+}
+// dot products of the loaded rows with the vector in LDS: dot_loaded's order per row (chunks in order, four pairs each), every lane gets the sums
+template <int R, int NC>
+__device__ __forceinline__ void block_dot(float (&acc)[R], const u32x4 (&a)[R][NC], const u32x4* sx) {
+    const int l = threadIdx.x & 63;
+    float s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const u32x4 xq = sx[l + 64 * i];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[r] = dot2bf(a[r][i][q], xq[q], s[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum_bcast(s[r]);
+}
+
+// y = W . norm(x) (+ residual): gemv_kernel's rows, R per wave, requested before the wait
+template <int R, int NC, int STAGE>
+__device__ __forceinline__ void stream_gemv(int blk, const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w, float eps, int K,
+                                            int N, const bf16_t* residual, bf16_t* y, const StreamSync& ss, int dep, u32x4* sx, float* sterm,
+                                            StreamPhases* ph = nullptr) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row0 = (blk * 4 + w) * R;
+    u32x4 a[R][NC];
+    float acc[R];
+    load_rows<R, NC>(a, W, ldw, min(row0, N - 1), N, K, l);
+    stream_wait(ss, dep);
+    if (ph) phase_mark(*ph);  // [1] rows requested, input complete
+    block_vector<NC>(x, norm_w, eps, K, sx, sterm);
+    if (ph) phase_mark(*ph);  // [2] vector in LDS
+    block_dot<R, NC>(acc, a, sx);
+    if (ph) phase_mark(*ph);  // [3] rows landed, dots done
+    if (l == 0 && row0 < N) {  // (N is a multiple of R -- stream_variant -- so a wave's rows are all inside or all outside)
+        uint32_t yv[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) yv[r] = residual ? f2bf(bf2f(ldc<SLD>(residual + row0 + r)) + rbf(acc[r])) : f2bf(acc[r]);
+        bf16_t* dst = y + row0;
+        if (R == 2)
+            stx32<sst<STAGE>()>(dst, yv[0] | (yv[1] << 16));
+        else
+            stx64<sst<STAGE>()>(dst, yv[0] | (yv[1] << 16), yv[2 % R] | (yv[3 % R] << 16));
+    }
+}
+// (four rows per wave where that leaves enough workgroups, like launch_gemv)
+template <int NC, int STAGE>
+__device__ __forceinline__ void stream_gemv_r(bool four, int blk, const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w, float eps,
+                                              int K, int N, const bf16_t* residual, bf16_t* y, const StreamSync& ss, int dep, u32x4* sx,
+                                              float* sterm, StreamPhases* ph = nullptr) {
+    if (four)
+        stream_gemv<4, NC, STAGE>(blk, W, ldw, x, norm_w, eps, K, N, residual, y, ss, dep, sx, sterm, ph);
+    else
+        stream_gemv<2, NC, STAGE>(blk, W, ldw, x, norm_w, eps, K, N, residual, y, ss, dep, sx, sterm, ph);
+}
+
+#ifndef ARIA_STREAM_WAVES
+#define ARIA_STREAM_WAVES 4  // waves per SIMD the register allocator is told to fit (4: 128 registers, a few spilled words in the norm sections; 0: as it falls, 153 -> 3)
+#endif
+#if !defined(ARIA_EMU) && ARIA_STREAM_WAVES
+#define ARIA_STREAM_OCC __attribute__((amdgpu_waves_per_eu(ARIA_STREAM_WAVES, ARIA_STREAM_WAVES)))
+#else
+#define ARIA_STREAM_OCC
+#endif
+template <int NCD, int NCI, int NCS, int HD>
+__global__ __launch_bounds__(256) ARIA_STREAM_OCC void decode_stream_kernel(const StreamArgs a) {
+    ARIA_DYN_SMEM(smem);
+    ARIA_SMEM_STATIC int s_b[4];       // [1] a head counter's previous value, [2] "the routed activations are complete already"
+    ARIA_SMEM_STATIC uint32_t s_o[4];  // four waves' single results on their way out
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+#if ARIA_STREAM_TICKET && !defined(ARIA_EMU)
+    if (t == 0) s_b[0] = __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sync();
     const int tk = s_b[0];
+#else
+    const int tk = int(blockIdx.x);
+#endif
     if (tk >= a.total) return;
+    StreamPhases ph;
+    ph.n = 0;
+    phase_mark(ph);  // [0] start
+    unsigned long long* const pacc = a.ts + (a.L + 1) * 32;  // per stage 8 words: count, phase sums
+    const StreamSync ss{a.sync, a.ctr, a.flags, tk & (STREAM_FLAG_SLOTS - 1)};
+    u32x4* const sx = reinterpret_cast<u32x4*>(smem);  // the workgroup's activation vector (block_vector)
+    float* const sterm = reinterpret_cast<float*>(smem + NCD * 1024);
     const bf16_t* x_in = static_cast<const bf16_t*>(a.hdr[5]);
     const int layer = tk / a.nbl;
     if (layer >= a.L) {  // output projection on the final norm
-        const int32_t* dep = a.sync + STREAM_SYNC_HEADER + 8 * (a.L - 1) + 5;
-        stream_gemv_r<NCD>(a.rv, tk - a.L * a.nbl, static_cast<const bf16_t*>(a.hdr[2]), a.D, a.L ? a.s.xb : x_in,
-                           static_cast<const bf16_t*>(a.hdr[1]), a.eps, a.D, a.V, nullptr, static_cast<bf16_t*>(const_cast<void*>(a.hdr[6])), dep,
-                           a.nb[5], a.sync);
+        stream_stamp(a.ts + a.L * 32, 0);
+        stream_gemv_r<NCD, 7>(a.r4[3], tk - a.L * a.nbl, static_cast<const bf16_t*>(a.hdr[2]), a.D, a.s.xb, static_cast<const bf16_t*>(a.hdr[1]),
+                              a.eps, a.D, a.V, nullptr, static_cast<bf16_t*>(const_cast<void*>(a.hdr[6])), ss, 8 * (a.L - 1) + 5, sx, sterm);
         return;  // (the kernel boundary publishes the logits)
     }
     int r = tk - layer * a.nbl;
-    int32_t* done = a.sync + STREAM_SYNC_HEADER + 8 * layer;
+    const int st = 8 * layer;  // index of this layer's stage 0 (counter lines, flag lines)
     const void* const* lp = a.lp + ARIA_DECODE_LAYER_PTRS * layer;
-    const bf16_t *attn_norm = static_cast<const bf16_t*>(lp[0]), *wqkv = static_cast<const bf16_t*>(lp[1]),
-                 *wo = static_cast<const bf16_t*>(lp[2]), *ffn_norm = static_cast<const bf16_t*>(lp[3]),
-                 *gate = static_cast<const bf16_t*>(lp[4]), *w1 = static_cast<const bf16_t*>(lp[5]), *w3 = static_cast<const bf16_t*>(lp[6]),
-                 *w2 = static_cast<const bf16_t*>(lp[7]), *sw1 = static_cast<const bf16_t*>(lp[8]), *sw3 = static_cast<const bf16_t*>(lp[9]),
-                 *sw2 = static_cast<const bf16_t*>(lp[10]);
-    const bf16_t* x = layer ? a.s.xb : x_in;
-    bf16_t* h = a.s.xa;
     const int D = a.D;
+    const bf16_t* x = layer ? a.s.xb : x_in;
+    const bf16_t* h = a.s.xa;
+    const bf16_t* rl = a.s.rl;
+    unsigned long long* const tsl = a.ts + layer * 32;  // (timeline builds)
     if (r < a.nb[0]) {  // ---- qkv = wqkv . norm(x)
-        stream_gemv_r<NCD>(a.r0, r, wqkv, D, x, attn_norm, a.eps, D, 3 * D, nullptr, a.s.qkv, layer ? done - 8 + 5 : nullptr, a.nb[5], a.sync);
-        stream_signal(done + 0, &s_b[1]);
+        stream_stamp(tsl + 0, 0);
+        stream_gemv_r<NCD, 0>(a.r4[0], r, static_cast<const bf16_t*>(lp[1]), D, x, static_cast<const bf16_t*>(lp[0]), a.eps, D, 3 * D, nullptr,
+                              a.s.qkv, ss, layer ? st - 8 + 5 : -1, sx, sterm, &ph);
+        stream_stamp(tsl + 0, 2);
+        stream_done<0>(ss, st + 0, r, a.nb[0]);
+        phase_mark(ph);  // [4] outputs out, counted
+        phase_flush(ph, pacc + 0);
         return;
     }
     r -= a.nb[0];
     if (r < a.nb[1]) {  // ---- attention: 4 waves of a head's DECODE_ATTN_WAVES
+        stream_stamp(tsl + 4, 0);
         using A = DecodeAttn<HD, DECODE_ATTN_WAVES>;
         constexpr int PARTS = DECODE_ATTN_WAVES / 4;
         const int head = r / PARTS, part = r % PARTS, sub = l % A::LPK, grp = l / A::LPK;
         bf16_t *kc = static_cast<bf16_t*>(const_cast<void*>(lp[11])), *vc = static_cast<bf16_t*>(const_cast<void*>(lp[12]));
         float(*red)[A::LPK][10] = reinterpret_cast<float(*)[A::LPK][10]>(a.ared) + (long long)head * DECODE_ATTN_WAVES;
-        const int seen = w == 0 ? stream_poll(done + 0) : 0;
-        stream_wait(done + 0, a.nb[0], seen, a.sync);
+        stream_wait(ss, st + 0);
         const int ps = static_cast<const int32_t*>(a.hdr[4])[0];
         float m, lsum, o[8];
-        A::template wave_state<SCOH>(a.s.qkv, static_cast<const bf16_t*>(a.hdr[0]), ps, kc, vc, D, a.scale, head, 0, ps + 1, true, part * 4 + w,
-                                     m, lsum, o);
-        A::template publish<SCOH>(red, part * 4 + w, m, lsum, o);
-        int32_t* hc = a.sync + STREAM_SYNC_HEADER + 8 * a.L + layer * a.H + head;
-        if (stream_signal(hc, &s_b[1]) == PARTS - 1) {  // the last workgroup of the head: fold the wave states, normalise, write the head's output
-            stream_acquire();
+        A::template wave_state<SLD>(a.s.qkv, static_cast<const bf16_t*>(a.hdr[0]), ps, kc, vc, D, a.scale, head, 0, ps + 1, true, part * 4 + w, m,
+                                    lsum, o);
+        A::template publish<sst<6>()>(red, part * 4 + w, m, lsum, o);
+        int32_t* hc = a.sync + STREAM_SYNC_HEADER + layer * a.H + head;
+        if (stream_arrive(hc, &s_b[1]) == PARTS - 1) {  // the last workgroup of the head: fold the wave states, normalise, write the head's output
+#if !ARIA_STREAM_LD && !defined(ARIA_EMU)
+            asm volatile("buffer_inv sc1" ::: "memory");
+#endif
             if (w == 0) {
-                A::template fold<false, SCOH>(red, m, lsum, o);
+                A::template fold<false, SLD>(red, m, lsum, o);
                 if (grp == 0) {
                     const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
                     u32x4 rr;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) rr[q] = pack2bf(o[2 * q] * inv, o[2 * q + 1] * inv);
-                    st16c<SCOH>(a.s.ao + (long long)head * HD + sub * 8, rr);
+                    st16c<sst<1>()>(a.s.ao + (long long)head * HD + sub * 8, rr);
                 }
             }
         }
-        stream_signal(done + 1, &s_b[1]);
+        stream_stamp(tsl + 4, 2);
+        stream_done<1>(ss, st + 1, r, a.nb[1]);
         return;
     }
     r -= a.nb[1];
     if (r < a.nb[2]) {  // ---- h = x + wo . attention
-        stream_gemv_r<NCD>(a.r2, r, wo, D, a.s.ao, nullptr, 0.f, D, D, x, h, done + 1, a.nb[1], a.sync);
-        stream_signal(done + 2, &s_b[1]);
+        stream_stamp(tsl + 8, 0);
+        stream_gemv_r<NCD, 2>(a.r4[1], r, static_cast<const bf16_t*>(lp[2]), D, a.s.ao, nullptr, 0.f, D, D, x, a.s.xa, ss, st + 1, sx, sterm);
+        stream_stamp(tsl + 8, 2);
+        stream_done<2>(ss, st + 2, r, a.nb[2]);
         return;
     }
     r -= a.nb[2];
+    const bf16_t* ffn_norm = static_cast<const bf16_t*>(lp[3]);
     if (r < a.nb[3]) {  // ---- router logits | shared up-projection pair + SwiGLU on norm(h): router_shared_up_kernel's waves
+        stream_stamp(tsl + 12, 0);
         if (r < a.nrb) {
-            stream_gemv<2, NCD>(r, gate, D, h, ffn_norm, a.eps, D, a.E, nullptr, a.s.rl, done + 2, a.nb[2], a.sync);
+            stream_gemv<2, NCD, 3>(r, static_cast<const bf16_t*>(lp[4]), D, h, ffn_norm, a.eps, D, a.E, nullptr, a.s.rl, ss, st + 2, sx, sterm);
+            stream_stamp(tsl + 12, 2);
+            stream_done<3>(ss, st + 3, r, a.nb[3]);
         } else {
-            const int row0 = ((r - a.nrb) * 4 + w) * 2, rows_s = a.Is;
-            const int seen = w == 0 ? stream_poll(done + 2) : 0;
+            const int row0 = ((r - a.nrb) * 4 + w) * 2, rows_s = a.Is;  // (a multiple of 8 -- stream_variant: every row of a workgroup exists)
             float a1[2], a3[2];
-            u32x4 xv[NCD], r1[2][NCD], r3[2][NCD];
-            load_rows<2, NCD>(r1, sw1, D, min(row0, rows_s - 1), rows_s, D, l);
-            load_rows<2, NCD>(r3, sw3, D, min(row0, rows_s - 1), rows_s, D, l);
-            stream_wait(done + 2, a.nb[2], seen, a.sync);
-            load_vector<NCD, SCOH>(xv, h, ffn_norm, a.eps, D, l);
-            dot_loaded<2, NCD>(a1, r1, xv);
-            dot_loaded<2, NCD>(a3, r3, xv);
-            if (l == 0) {
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr)
-                    if (row0 + rr < rows_s) stc<SCOH>(a.s.act + (long long)a.k * a.I + row0 + rr, f2bf(rbf(silu(rbf(a1[rr]))) * rbf(a3[rr])));
-            }
+            u32x4 r1[2][NCD], r3[2][NCD];
+            load_rows<2, NCD>(r1, static_cast<const bf16_t*>(lp[8]), D, row0, rows_s, D, l);
+            load_rows<2, NCD>(r3, static_cast<const bf16_t*>(lp[9]), D, row0, rows_s, D, l);
+            stream_wait(ss, st + 2);
+            block_vector<NCD>(h, ffn_norm, a.eps, D, sx, sterm);
+            block_dot<2, NCD>(a1, r1, sx);
+            block_dot<2, NCD>(a3, r3, sx);
+            if (l == 0)
+                stx32<sst<3>()>(a.s.act + (long long)a.k * a.I + row0,
+                                uint32_t(f2bf(rbf(silu(rbf(a1[0]))) * rbf(a3[0]))) | (uint32_t(f2bf(rbf(silu(rbf(a1[1]))) * rbf(a3[1]))) << 16));
+            stream_stamp(tsl + 12, 2);
+            stream_done<3>(ss, st + 3, r, a.nb[3]);
         }
-        stream_signal(done + 3, &s_b[1]);
         return;
     }
     r -= a.nb[3];
-    if (r < a.nb[4]) {  // ---- routed up-projection pairs + SwiGLU (routing inside)
-        const int j = r / a.nbx, bx = r % a.nbx;
-        if (a.ru == 4)
-            stream_expert_up<4, NCD>(bx, j, a, w1, w3, h, ffn_norm, done + 2, a.nb[2], done + 3, a.nb[3]);
-        else
-            stream_expert_up<2, NCD>(bx, j, a, w1, w3, h, ffn_norm, done + 2, a.nb[2], done + 3, a.nb[3]);
-        stream_signal(done + 4, &s_b[1]);
+    if (r < a.nb[4]) {  // ---- routed up-projection pairs + SwiGLU (routing inside): expert_up_kernel's rows, two pairs per wave, all four rows up front
+        stream_stamp(tsl + 16, 0);
+        const int j = r / a.nbx, bx = r % a.nbx, I = a.I, row0 = (bx * 4 + w) * 2;  // (I a multiple of 8)
+        stream_wait(ss, st + 2);
+        block_vector<NCD>(h, ffn_norm, a.eps, D, sx, sterm);  // (normalised while the router stage may still be running)
+        stream_wait(ss, st + 3);
+        phase_mark(ph);  // [1] vector ready, router complete
+        float my_score;
+        int my_idx;
+        const int e = route_one_token<SLD>(rl, a.E, a.k, l, j, my_score, my_idx);
+        if (bx == 0 && j == 0 && w == 0 && l < a.k) {
+            a.s.scores[l] = f2bf(my_score);
+            a.s.idx[l] = my_idx;
+        }
+        const long long off = (long long)e * I * D;
+        u32x4 r1[2][NCD], r3[2][NCD];
+        load_rows<2, NCD>(r1, static_cast<const bf16_t*>(lp[5]) + off, D, row0, I, D, l);
+        load_rows<2, NCD>(r3, static_cast<const bf16_t*>(lp[6]) + off, D, row0, I, D, l);
+        phase_mark(ph);  // [2] routed, rows requested
+        float a1[2], a3[2];
+        block_dot<2, NCD>(a1, r1, sx);
+        block_dot<2, NCD>(a3, r3, sx);
+        phase_mark(ph);  // [3] rows landed, dots done
+        if (l == 0)
+            stx32<sst<4>()>(a.s.act + (long long)j * I + row0,
+                            uint32_t(f2bf(rbf(silu(rbf(a1[0]))) * rbf(a3[0]))) | (uint32_t(f2bf(rbf(silu(rbf(a1[1]))) * rbf(a3[1]))) << 16));
+        stream_stamp(tsl + 16, 2);
+        stream_done<4>(ss, st + 4, r, a.nb[4]);
+        phase_mark(ph);  // [4] outputs out, counted
+        phase_flush(ph, pacc + 32);
         return;
     }
     r -= a.nb[4];
     {  // ---- every down-projection of one output row per wave + combine + residual: expert_down_combine_kernel's waves.  The routing is
        // derived HERE from the logits (route_one_token: the function the up-projection runs, so the same ids / scores), which lets the
-       // rows be requested while the up-projection is still running; the activation images follow once it has finished.
+       // rows be requested while the up-projection is still running; the activation images follow once it has finished.  The row chunks
+       // come in two waves of requests (shared expert + the first two routed ones, then the rest): 64 registers of rows at a time instead
+       // of 124, which is what lets FOUR waves share a SIMD -- every per-expert dot product and the order they are combined in are unchanged.
+        stream_stamp(tsl + 20, 0);
         u32x4* sa = reinterpret_cast<u32x4*>(smem);
+        const bf16_t *w2 = static_cast<const bf16_t*>(lp[7]), *sw2 = static_cast<const bf16_t*>(lp[10]);
         const int k = a.k, ns = a.ns, I = a.I, N = D;
         const int nchI = I >> 3, nchS = (ns * I) >> 3;
-        const int n = r * 4 + w, nn = min(n, N - 1);
+        const int n = r * 4 + w;  // (N a multiple of 4: the row exists)
         const int ninstr = k * NCI + NCS;
         const bf16_t* act = a.s.act;
         auto images = [&]() {
@@ -1034,20 +1296,31 @@ __global__ __launch_bounds__(256) void decode_stream_kernel(const StreamArgs a) 
                     const int cc = (g - k * NCI) * 64 + l;
                     src = cc < nchS ? act + (long long)k * I + cc * 8 : reinterpret_cast<const bf16_t*>(decode_zero_page) + 8 * (l & 15);
                 }
-                if (SCOH)
+#if ARIA_STREAM_DMA
+                if (SLD)
                     glds16_agent(src, sa + 64 * g);
                 else
                     glds16(src, sa + 64 * g);
+#else
+                sa[64 * g + l] = ld16c<SLD>(src);
+#endif
             }
         };
-        const int seen_r = w == 0 ? stream_poll(done + 3) : 0, seen_u = w == 0 ? stream_poll(done + 4) : 0;
-        if (t == 0) s_b[2] = seen_u >= a.nb[4];
-        stream_wait(done + 3, a.nb[3], seen_r, a.sync);  // (its barrier also publishes s_b[2])
-        const bool up_done = s_b[2] != 0;                // workgroup-uniform
+        constexpr int KA = 2;  // routed experts whose rows travel with the shared expert's
+        u32x4 ws[NCS], wa[KA][NCI];
+        {
+            const bf16_t* row = sw2 + (long long)n * ns * I;
+#pragma unroll
+            for (int i = 0; i < NCS; ++i) ws[i] = ldw16(row + min(l + 64 * i, nchS - 1) * 8);
+        }
+        if (t == 0) s_b[2] = stream_ready(ss, st + 4);
+        stream_wait(ss, st + 3);  // (its barrier also publishes s_b[2])
+        phase_mark(ph);  // [1] router complete
+        const bool up_done = s_b[2] != 0;  // workgroup-uniform
         if (up_done) images();
         float my_score;
         int my_idx;
-        route_one_token<SCOH>(a.s.rl, a.E, k, l, 0, my_score, my_idx);
+        route_one_token<SLD>(rl, a.E, k, l, 0, my_score, my_idx);
         const int my_sc = int(uint32_t(f2bf(my_score)) << 16);
         int e[DOWN_KMAX];
         float sc[DOWN_KMAX];
@@ -1056,39 +1329,36 @@ __global__ __launch_bounds__(256) void decode_stream_kernel(const StreamArgs a) 
             e[j] = read_lane(my_idx, j);
             sc[j] = __builtin_bit_cast(float, read_lane(my_sc, j));
         }
-        u32x4 wr[DOWN_KMAX][NCI], ws[NCS];
-        {
-            const bf16_t* row = sw2 + (long long)nn * ns * I;
+        auto rows_of = [&](u32x4(&dst)[NCI], int j) {
+            const bf16_t* row = w2 + ((long long)(e[j] < 0 ? 0 : e[j]) * N + n) * I;
 #pragma unroll
-            for (int i = 0; i < NCS; ++i) ws[i] = ldw16(row + min(l + 64 * i, nchS - 1) * 8);
-        }
+            for (int i = 0; i < NCI; ++i) dst[i] = ldw16(row + min(l + 64 * i, nchI - 1) * 8);
+        };
+        auto dot_of = [&](const u32x4(&src)[NCI], int j) {
+            float sj = 0.f;
 #pragma unroll
-        for (int j = 0; j < DOWN_KMAX; ++j)
-            if (j < k) {
-                const bf16_t* row = w2 + ((long long)(e[j] < 0 ? 0 : e[j]) * N + nn) * I;
+            for (int i = 0; i < NCI; ++i) {
+                const u32x4 xv = sa[j * NCI * 64 + l + 64 * i];
 #pragma unroll
-                for (int i = 0; i < NCI; ++i) wr[j][i] = ldw16(row + min(l + 64 * i, nchI - 1) * 8);
+                for (int q = 0; q < 4; ++q) sj = dot2bf(src[i][q], xv[q], sj);
             }
+            return rbf(rbf(wave_sum_bcast(sj)) * sc[j]);  // bf16(eo_j * score_j)
+        };
+#pragma unroll
+        for (int j = 0; j < KA; ++j)
+            if (j < k) rows_of(wa[j], j);
         if (!up_done) {
-            stream_wait(done + 4, a.nb[4], 0, a.sync);
+            stream_wait(ss, st + 4);
             images();
         }
+        phase_mark(ph);  // [2] up-projection complete, images requested
         wait_vm<0>();
         sync();
-        float accs = 0.f;
+        phase_mark(ph);  // [3] first rows + images landed
+        float accs = 0.f;  // summed in fp32 in slot order (combine_kernel)
 #pragma unroll
-        for (int j = 0; j < DOWN_KMAX; ++j)
-            if (j < k) {
-                float sj = 0.f;
-#pragma unroll
-                for (int i = 0; i < NCI; ++i) {
-                    const u32x4 xv = sa[j * NCI * 64 + l + 64 * i];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) sj = dot2bf(wr[j][i][q], xv[q], sj);
-                }
-                sj = wave_sum_bcast(sj);
-                accs += rbf(rbf(sj) * sc[j]);
-            }
+        for (int j = 0; j < KA; ++j)
+            if (j < k) accs += dot_of(wa[j], j);
         float sh = 0.f;
 #pragma unroll
         for (int i = 0; i < NCS; ++i) {
@@ -1097,8 +1367,20 @@ __global__ __launch_bounds__(256) void decode_stream_kernel(const StreamArgs a) 
             for (int q = 0; q < 4; ++q) sh = dot2bf(ws[i][q], xv[q], sh);
         }
         sh = wave_sum_bcast(sh);
-        if (l == 0 && n < N) stc<SCOH>(a.s.xb + n, f2bf(bf2f(ldc<SCOH>(h + n)) + rbf(rbf(accs) + rbf(sh))));
-        stream_signal(done + 5, &s_b[1]);
+        {
+            u32x4 wb[DOWN_KMAX - KA][NCI];
+#pragma unroll
+            for (int j = KA; j < DOWN_KMAX; ++j)
+                if (j < k) rows_of(wb[j - KA], j);
+#pragma unroll
+            for (int j = KA; j < DOWN_KMAX; ++j)
+                if (j < k) accs += dot_of(wb[j - KA], j);
+        }
+        stream_stamp(tsl + 20, 2);
+        phase_mark(ph);  // [4] second rows landed, all dots done
+        stream_done4<5>(ss, st + 5, r, a.nb[5], a.s.xb + r * 4, f2bf(bf2f(ldc<SLD>(h + n)) + rbf(rbf(accs) + rbf(sh))), s_o);
+        phase_mark(ph);  // [5] outputs out, counted
+        phase_flush(ph, pacc + 40);
     }
 }
 
@@ -1322,7 +1604,15 @@ int launch_gemv(int N, void* stream, const bf16_t* W, long long ldw, const bf16_
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
-inline size_t stream_sync_words(int64_t L, int64_t H) { return size_t(STREAM_SYNC_HEADER + 8 * L + L * H); }
+// ... then (8-byte aligned) the timeline of -DARIA_STREAM_ABL=4 builds: per layer 8 stages x 4 x 64 bits (first workgroup resident, first past its
+// wait, last done, spare), in s_memrealtime ticks (10 ns)
+inline size_t stream_ts_word(int64_t L, int64_t H) { return size_t((STREAM_SYNC_HEADER + L * H + 1) & ~int64_t(1)); }
+// ... then (128-byte aligned) the completion flags: per (layer, stage) 64 words, each on its own 128-byte line
+inline size_t stream_flags_word(int64_t L, int64_t H) { return (stream_ts_word(L, H) + size_t(64 * (L + 3)) + 31) & ~size_t(31); }
+// ... then the completion counters: per (layer, stage) 16 lines
+inline size_t stream_sync_words(int64_t L, int64_t H) {
+    return stream_flags_word(L, H) + size_t(8 * L) * (STREAM_FLAG_SLOTS + STREAM_CTR_LINES) * STREAM_LINE;
+}
 
 Scratch carve(char* base, int64_t L, int64_t D, int64_t H, int64_t hd, int64_t E, int64_t k, int64_t I, int64_t Is) {
     Scratch s{};
@@ -1358,8 +1648,9 @@ bool decode_stream_enabled() {
 
 // The streamed schedule covers the widths decode_stream_kernel is instantiated for, the 6-launch schedule's fused forms (its waves are what the
 // stages reproduce) and the one-workgroup-per-head attention (no split-KV: caches up to 2048 slots, or up to 16 384 with ARIA_DECODE_SPLIT_KV=0).
-int stream_variant(int64_t L, int64_t D, int64_t hd, int64_t E, int64_t k, int64_t I, int64_t Is, int64_t Smax) {
+int stream_variant(int64_t L, int64_t D, int64_t hd, int64_t E, int64_t k, int64_t I, int64_t Is, int64_t V, int64_t Smax) {
     if (L > STREAM_MAXL || k > DOWN_KMAX || E > 256 || !decode_fuse_enabled()) return 0;
+    if ((D & 3) || (I & 7) || (Is & 7) || (E & 1) || (V & 1)) return 0;  // outputs leave as whole 4- / 8-byte words
     if (Smax > 16384 || decode_splits_for(Smax) > 1) return 0;
     const int ncD = chunks_per_lane(D), ncI = chunks_per_lane(I), ncS = chunks_per_lane(Is);
     if (ncD == 5 && ncI == 4 && ncS == 7 && hd == 128) return 1;  // Aria
@@ -1376,29 +1667,31 @@ int launch_stream(int variant, const void* const* ptrs, const Scratch& s, int64_
     a.s = s;
     a.sync = s.sync;
     a.ared = s.ared;
+    a.ts = reinterpret_cast<unsigned long long*>(s.sync + stream_ts_word(L, H));
+    a.flags = s.sync + stream_flags_word(L, H);
+    a.ctr = a.flags + size_t(8 * L) * STREAM_FLAG_SLOTS * STREAM_LINE;
     a.L = int(L), a.D = int(D), a.H = int(H), a.E = int(E), a.k = int(k), a.I = int(I), a.Is = int(Is), a.ns = int(Is / I), a.V = int(V);
     a.eps = eps;
     a.scale = 1.0f / sqrtf(float(hd));
     auto cdiv = [](int64_t x, int64_t y) { return int((x + y - 1) / y); };
-    a.r0 = 3 * D >= 4096 ? 4 : 2;  // (launch_gemv's choice)
-    a.r2 = D >= 4096 ? 4 : 2;
-    a.rv = V >= 4096 ? 4 : 2;
-    a.ru = I * (k + a.ns) >= 8192 ? 4 : 2;  // (aria_decode_token's choice for expert_up_kernel)
+    // rows per wave: two everywhere (one up-projection pair per wave for the shared expert): 126 registers, four waves per SIMD -- what hides a
+    // wave's wait for its input behind the other waves' rows; the launch schedule's 4-row waves moved rows between waves, not the arithmetic
     a.nrb = cdiv(E, 8);
-    a.nbx = cdiv(I, 4 * a.ru);
-    a.nb[0] = cdiv(3 * D, 4 * a.r0);
+    a.nbx = cdiv(I, 8);
+    a.r4[0] = 3 * D >= 4096 && (3 * D) % 4 == 0, a.r4[1] = D >= 4096 && D % 4 == 0, a.r4[2] = 0, a.r4[3] = V >= 4096 && V % 4 == 0;
+    a.nb[0] = cdiv(3 * D, a.r4[0] ? 16 : 8);
     a.nb[1] = int(H) * (DECODE_ATTN_WAVES / 4);
-    a.nb[2] = cdiv(D, 4 * a.r2);
+    a.nb[2] = cdiv(D, a.r4[1] ? 16 : 8);
     a.nb[3] = a.nrb + cdiv(Is, 8);
     a.nb[4] = a.nbx * int(k);
     a.nb[5] = cdiv(D, 4);
     a.nbl = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4] + a.nb[5];
-    a.nbv = cdiv(V, 4 * a.rv);
+    a.nbv = cdiv(V, a.r4[3] ? 16 : 8);
     a.total = int(L) * a.nbl + a.nbv;
     const int nsync = int(stream_sync_words(L, H));
     ARIA_LAUNCH(decode_stream_reset_kernel, dim3(unsigned((nsync + 255) / 256)), dim3(256), 0, stream, s.sync, nsync);
     const int ncI = chunks_per_lane(I), ncS = chunks_per_lane(Is);
-    const size_t lds = size_t(k * ncI + ncS) * 1024;
+    const size_t lds = std::max(size_t(k * ncI + ncS) * 1024, size_t(chunks_per_lane(D)) * 2048);  // activation images | vector + its squares
     if (variant == 1)
         ARIA_LAUNCH((decode_stream_kernel<5, 4, 7, 128>), dim3(unsigned(a.total)), dim3(256), lds, stream, a);
     else if (variant == 2)
@@ -1414,7 +1707,7 @@ extern "C" {
 
 int aria_decode_stream_supported(const int64_t* dims) {
     if (!dims) return 0;
-    return stream_variant(dims[0], dims[1], dims[3], dims[4], dims[5], dims[6], dims[7], dims[9]) != 0 && dims[7] % dims[6] == 0;
+    return stream_variant(dims[0], dims[1], dims[3], dims[4], dims[5], dims[6], dims[7], dims[8], dims[9]) != 0 && dims[7] % dims[6] == 0;
 }
 
 int64_t aria_decode_stream_sync_offset(const int64_t* dims) {
@@ -1455,7 +1748,7 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
     } while (0)
     const bool fuse = decode_fuse_enabled();
     if (decode_stream_enabled()) {
-        const int variant = stream_variant(L, D, hd, E, k, I, Is, Smax);
+        const int variant = stream_variant(L, D, hd, E, k, I, Is, V, Smax);
         if (variant) return launch_stream(variant, ptrs, s, L, D, H, hd, E, k, I, Is, V, eps, stream);
     }
     for (int64_t li = 0; li < L; ++li) {

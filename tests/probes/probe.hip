@@ -131,8 +131,145 @@ __global__ __launch_bounds__(64) void probe_pingpong_kernel(int* flag, int* out,
     }
     if (A) out[0] = done;
 }
+
+// ---- how fast a GEMV-shaped read streams as a function of the bytes a CU keeps in flight (tools/probes/gemv_stream_rate.py) ----------------
+// A wave owns R + RL consecutive rows of 5120 bytes (Aria's D = 2560 bf16): R rows land in registers (16-byte non-temporal loads, lane l takes
+// chunks l + 64 i -- the decode GEMVs' access shape), RL rows land in LDS by LDS-DMA (no registers).  Everything is requested before the first
+// use; the "use" is an xor fold written only if it has an impossible value.  Workgroups per CU are set from outside by the dynamic LDS size.
+typedef uint32_t pu32x4 __attribute__((ext_vector_type(4)));
+template <int R, int RL>
+__global__ __launch_bounds__(256) void probe_stream_kernel(const uint16_t* W, long long nrows, uint32_t* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NC = 5;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long row0 = ((long long)blockIdx.x * 4 + w) * (R + RL);
+    if (row0 + R + RL > nrows) return;
+    pu32x4 a[R > 0 ? R : 1][NC];
+    char* lds = smem + w * (RL > 0 ? RL : 1) * 5120;
+#pragma unroll
+    for (int r = 0; r < RL; ++r)
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (row0 + R + r) * 2560 + (l + 64 * i) * 8),
+                                             (__attribute__((address_space(3))) void*)(lds + r * 5120 + i * 1024), 16, 0, 2 /* nt */);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+            a[r][i] = __builtin_nontemporal_load(reinterpret_cast<const pu32x4*>(W + (row0 + r) * 2560 + (l + 64 * i) * 8));
+    __builtin_amdgcn_sched_barrier(0);  // every request is out before the first use (the compiler would otherwise fold as it goes, a few loads at a time)
+    uint32_t x = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int i = 0; i < NC; ++i) x ^= a[r][i][0] ^ a[r][i][1] ^ a[r][i][2] ^ a[r][i][3];
+    if (RL > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < RL; ++r)
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const pu32x4 v = *reinterpret_cast<const pu32x4*>(lds + r * 5120 + i * 1024 + l * 16);
+                x ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+            }
+    }
+    if (x == 0x9e3779b9u) out[blockIdx.x & 1023] = x;
+}
+
+// ---- which accesses make one workgroup's data visible to a workgroup on another XCD INSIDE a launch (tools/probes/xcd_visibility.py) ------
+// Workgroups 0 (writer) and `partner` (reader) take turns `iters` times over the SAME 64-word buffer (so the reader's XCD has the previous
+// round's lines in its L2): the writer fills buf[l] = round (one word per lane), makes it visible, bumps `flag`; the reader waits for the
+// flag, reads the buffer, counts the words that are not `round`, answers through `flag2`.
+//   wmode 0: plain stores + s_waitcnt            1: sc1 stores + s_waitcnt           2: plain stores + buffer_wbl2 sc1 + s_waitcnt
+//   rmode 0: plain loads      1: sc1 loads       2: buffer_inv sc1, then plain loads      3: sc0 sc1 loads (system scope)
+// out[0] = rounds completed, out[1] = stale words seen, out[2] = 1 if a wait timed out.
+__global__ __launch_bounds__(64) void probe_visibility_kernel(int* buf, int* flag, int* flag2, int* out, int iters, int partner, int wmode, int rmode) {
+    const int b = blockIdx.x, l = threadIdx.x;
+    if (b != 0 && b != partner) return;
+    int stale = 0;
+    for (int i = 1; i <= iters; ++i) {
+        if (b == 0) {
+            if (wmode == 1)
+                __hip_atomic_store(buf + l, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                *(volatile int*)(buf + l) = i;
+            if (wmode == 2)
+                asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (l == 0) __hip_atomic_store(flag, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(flag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != i && ++spins < (1 << 20)) {}
+            if (spins >= (1 << 20)) {
+                if (l == 0) out[2] = 1;
+                return;
+            }
+        } else {
+            int spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != i && ++spins < (1 << 20)) {}
+            if (spins >= (1 << 20)) {
+                if (l == 0) out[2] = 1;
+                return;
+            }
+            int v;
+            if (rmode == 1)
+                v = __hip_atomic_load(buf + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (rmode == 3)
+                v = __hip_atomic_load(buf + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else {
+                if (rmode == 2) asm volatile("buffer_inv sc1" ::: "memory");
+                v = *(volatile int*)(buf + l);
+            }
+            stale += v != i;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (l == 0) __hip_atomic_store(flag2, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (b == partner) {
+        atomicAdd(out + 1, stale);
+        if (l == 0) out[0] = iters;
+    }
+}
 }  // namespace
 #endif
+
+extern "C" int aria_probe_visibility(int* buf, int* flag, int* flag2, int* out, int iters, int partner, int wmode, int rmode, void* stream) {
+#ifdef ARIA_EMU
+    (void)buf; (void)flag; (void)flag2; (void)out; (void)iters; (void)partner; (void)wmode; (void)rmode; (void)stream;
+    return ARIA_ERR_UNSUPPORTED;
+#else
+    if (!buf || !flag || !flag2 || !out || iters <= 0 || partner <= 0) return ARIA_ERR_INVALID;
+    hipLaunchKernelGGL(probe_visibility_kernel, dim3(unsigned(partner + 1)), dim3(64), 0, static_cast<hipStream_t>(stream), buf, flag, flag2, out,
+                       iters, partner, wmode, rmode);
+    return aria_check_launch();
+#endif
+}
+
+// rows in registers R (0, 2, 4, 8) + rows through LDS RL (0, 2, 4); lds_bytes sets the workgroups a CU can hold (and must cover 4 * RL * 5120)
+extern "C" int aria_probe_stream(const void* W, int64_t nrows, int R, int RL, int64_t lds_bytes, void* out, void* stream) {
+#ifdef ARIA_EMU
+    (void)W; (void)nrows; (void)R; (void)RL; (void)lds_bytes; (void)out; (void)stream;
+    return ARIA_ERR_UNSUPPORTED;
+#else
+    if (!W || !out || nrows <= 0 || lds_bytes < int64_t(4) * RL * 5120 || lds_bytes > 160 * 1024) return ARIA_ERR_INVALID;
+    const int64_t per_block = int64_t(4) * (R + RL);
+    if (per_block <= 0) return ARIA_ERR_INVALID;
+    const dim3 grid(unsigned(nrows / per_block)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint16_t* w = static_cast<const uint16_t*>(W);
+    uint32_t* o = static_cast<uint32_t*>(out);
+#define PS(r, rl)                                                                                               \
+    if (R == r && RL == rl) {                                                                                   \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_stream_kernel<r, rl>),                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));                  \
+        hipLaunchKernelGGL((probe_stream_kernel<r, rl>), grid, block, size_t(lds_bytes), st, w, (long long)nrows, o); \
+        return aria_check_launch();                                                                             \
+    }
+    PS(2, 0) PS(4, 0) PS(8, 0) PS(4, 2) PS(4, 4) PS(2, 2) PS(0, 4) PS(8, 4) PS(6, 0)
+#undef PS
+    return ARIA_ERR_UNSUPPORTED;
+#endif
+}
 
 extern "C" int aria_probe_sync(int* cnt, unsigned short* sink, int64_t nblocks, int mode, void* stream) {
 #ifdef ARIA_EMU
