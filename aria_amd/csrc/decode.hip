@@ -778,8 +778,15 @@ struct Scratch {
 // left is not synchronisation but the workgroup itself.  The phase timeline (-DARIA_STREAM_ABL=4, r04_decode_stream_phases_*.json) says
 // why: under the bulk weight traffic a dependent memory round trip costs 5-7 us, and a workgroup strings several together -- kernel
 // arguments -> rows (|| vector) -> output exchange -> counter(s) -- ~20 us of life for ~7 us of rows in flight, where a launch-schedule
-// wave lives one round trip.  A version that wins has to END a workgroup without waiting for anything: outputs and the completion
-// count fire-and-forget, the consumer told apart fresh words from stale ones by itself (per-layer buffers pre-filled with a sentinel).
+// wave lives one round trip.  The obvious repair was built and measured as well (tools/probes/src/decode_stream_sentinel.patch,
+// profiles/r04_decode_stream_sentinel_*.json): workgroups that END without waiting -- outputs and completion counts fire-and-forget, every
+// layer with its own exchange buffers pre-filled with a value no kernel produces, readers re-reading while they see it -- bit-exact
+// again, a workgroup's tail down from 6 to 1.6 us, and the token SLOWER (2.48 ms): the hint now takes four hops (count -> lead
+// workgroup's sum -> flag -> reader -> data), each a loaded round trip.  What sets that round trip is Little's law: with 1024 resident
+// workgroups x 80 KB of rows requested, 82 MB / 7.2 TB/s = 11 us behind every dependent access -- the deeper the prefetch that is
+// supposed to hide an edge, the longer the edge.  A kernel boundary costs 4.5 us; an in-kernel edge on this chip costs at least one
+// loaded round trip per hop.  The schedule that could win polls the data directly (one hop) with FEW resident workgroups (20 MB in
+// flight: ~3 us per hop); its first trial died of an over-sized LDS request and the round's GPU budget ended there.
 constexpr int STREAM_MAXL = 28;            // layers whose pointers fit the kernel-argument block (Aria: 28)
 constexpr int STREAM_SYNC_HEADER = 4;      // sync[0] ticket, [1] sticky error, [2], [3] spare; then L * H head counters, the timeline, flag and counter lines
 constexpr int STREAM_SPIN_LIMIT = 1 << 18;
