@@ -785,8 +785,10 @@ struct Scratch {
 // workgroup's sum -> flag -> reader -> data), each a loaded round trip.  What sets that round trip is Little's law: with 1024 resident
 // workgroups x 80 KB of rows requested, 82 MB / 7.2 TB/s = 11 us behind every dependent access -- the deeper the prefetch that is
 // supposed to hide an edge, the longer the edge.  A kernel boundary costs 4.5 us; an in-kernel edge on this chip costs at least one
-// loaded round trip per hop.  The schedule that could win polls the data directly (one hop) with FEW resident workgroups (20 MB in
-// flight: ~3 us per hop); its first trial died of an over-sized LDS request and the round's GPU budget ended there.
+// loaded round trip per hop.  Readers polling the data itself (one hop, no counts or flags at all) with 3 / 2 / 1 resident workgroups
+// per CU: 2.53 / 2.47 / 2.96 ms, bit-exact each (r04_decode_stream_sentinel_sweep.json) -- not the hop count either.  What the variants
+// have in common is the workgroup: ~4 us from its start to its first row request (kernel arguments, stage lookup), the vector through LDS
+// behind two barriers, a tail; 75 000 of them per token.  The launch schedule's 1.905 ms stands.
 constexpr int STREAM_MAXL = 28;            // layers whose pointers fit the kernel-argument block (Aria: 28)
 constexpr int STREAM_SYNC_HEADER = 4;      // sync[0] ticket, [1] sticky error, [2], [3] spare; then L * H head counters, the timeline, flag and counter lines
 constexpr int STREAM_SPIN_LIMIT = 1 << 18;
