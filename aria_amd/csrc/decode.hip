@@ -48,7 +48,7 @@ __device__ __forceinline__ u32x4 ld16c(const void* p) {
 // Stores another XCD must see inside the launch travel as ATOMIC EXCHANGES of 4 / 8 bytes (results unused: fire and forget).  Measured on
 // MI355X (profiles/r04_decode_stream_bisect.json): with exchanges every GEMV-type stage of a 28-layer token is bit-exact; plain stores +
 // buffer_wbl2 sc1 per wave are right as well and 8x too slow at 78 000 workgroups; read-modify-write atomics are performed where every
-// XCD looks (the completion counters rely on it).  The one exception is noted at ARIA_STREAM_ST_MASK.
+// XCD looks (the completion counters rely on it).  The one exception (the attention stage's wave states) is noted at the streamed schedule's switches.
 template <bool COH>
 __device__ __forceinline__ void stx32(void* p, uint32_t v) {
 #ifndef ARIA_EMU
@@ -793,41 +793,23 @@ constexpr int STREAM_MAXL = 28;            // layers whose pointers fit the kern
 constexpr int STREAM_SYNC_HEADER = 4;      // sync[0] ticket, [1] sticky error, [2], [3] spare; then L * H head counters, the timeline, flag and counter lines
 constexpr int STREAM_SPIN_LIMIT = 1 << 18;
 // Variant switches (A/B builds: tools/probes/build_decode_variant.sh):
-//   ARIA_STREAM_LD 1: sc1 loads of what other workgroups wrote; 0: plain loads behind a buffer_inv sc1 per wave
-//   ARIA_STREAM_ST 1: atomic exchanges + wait for their completion; 0: plain stores + buffer_wbl2 sc1 per wave
-//   ARIA_STREAM_DMA 1: the down-projection's activation images by LDS-DMA (sc1); 0: through registers
 //   ARIA_STREAM_TICKET 0: blockIdx order; 1: atomic ticket
-//   ARIA_STREAM_ABL (timing only, wrong results): 1 = no dependency waits, 2 = no completion atomics
-#ifndef ARIA_STREAM_LD
-#define ARIA_STREAM_LD 1
-#endif
-#ifndef ARIA_STREAM_ST
-#define ARIA_STREAM_ST 1
-#endif
-#ifndef ARIA_STREAM_DMA
-#define ARIA_STREAM_DMA 1
-#endif
+//   ARIA_STREAM_ABL (timing only, wrong results): 1 = no dependency waits, 2 = no completion atomics, 4 = timeline stamps
+// (The builds that told the visibility protocol apart -- plain stores + write-back / exchanges per stage, loads behind an invalidate,
+// activation images through registers -- are in the history of this file; what they found is in profiles/r04_decode_stream_bisect.json:
+// outputs of the GEMV-type stages travel as atomic exchanges and are read with agent-scope loads; the attention stage's wave states,
+// read back by the LAST of a head's four workgroups right after its own arrival, need plain stores + a cache write-back -- with
+// exchanges a 28-layer token differed from the launch schedule by a few bf16 ulps, the same ones on every run.)
 #ifndef ARIA_STREAM_TICKET
 #define ARIA_STREAM_TICKET 0
 #endif
 #ifndef ARIA_STREAM_ABL
 #define ARIA_STREAM_ABL 0
 #endif
-#ifndef ARIA_STREAM_SLEEP_FAR
-#define ARIA_STREAM_SLEEP_FAR 100  // x 64 cycles between polls while the awaited counter is still 0
-#endif
 #ifndef ARIA_STREAM_SLEEP_NEAR
-#define ARIA_STREAM_SLEEP_NEAR 8
+#define ARIA_STREAM_SLEEP_NEAR 8  // x 64 cycles between polls of a flag
 #endif
-constexpr bool SLD = ARIA_STREAM_LD != 0;
-#ifndef ARIA_STREAM_ST_MASK
-#define ARIA_STREAM_ST_MASK (ARIA_STREAM_ST ? 63 : 0)  // bit s: stage s stores by exchanges; clear: plain stores + buffer_wbl2 sc1
-// per wave.  Bit 6 = the attention stage's wave states, read back by the LAST of a head's four workgroups right after its own arrival: with
-// exchanges a 28-layer token differed from the launch schedule by a few bf16 ulps, the same ones on every run; each of the other stages alone on
-// exchanges was bit-exact (profiles/r04_decode_stream_bisect.json) -- so that one keeps the cache write-back (80 workgroups per layer: cheap)
-#endif
-template <int STAGE>
-constexpr bool sst() { return ((ARIA_STREAM_ST_MASK >> STAGE) & 1) != 0; }
+constexpr bool SLD = true;  // (what another workgroup of the launch wrote is read with agent-scope loads)
 
 struct StreamArgs {
     const void* hdr[ARIA_DECODE_HEADER_PTRS];
@@ -920,28 +902,15 @@ __device__ __forceinline__ void stream_wait(const StreamSync& ss, int idx) {
     }
     wait_lds();  // (thread 0's LDS notes for the workgroup are written before anybody passes the barrier)
     raw_barrier();
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-#if ARIA_STREAM_LD
-    asm volatile("" ::: "memory");  // (what follows reads with sc1 loads: nothing cached has to go)
-#else
-    asm volatile("buffer_inv sc1" ::: "memory");
-#endif
-#pragma clang diagnostic pop
 #endif
 }
 // is stage `idx` complete already?  (one poll, no waiting)
 __device__ __forceinline__ bool stream_ready(const StreamSync& ss, int idx) { return stream_poll(stream_flag(ss, idx, ss.slot)) != 0; }
 
-// every wave: what it stored for other workgroups has reached the point where the other XCDs read
-#ifndef ARIA_STREAM_WB_MASK
-#define ARIA_STREAM_WB_MASK 0  // (bisection builds: bit s = stage s additionally writes the L2 back before it signals; bit 6 = the per-head arrival)
-#endif
-template <int STAGE>
+// every wave: what it stored for other workgroups has been performed where the other XCDs read (the exchanges return their old values)
 __device__ __forceinline__ void stream_release() {
 #ifndef ARIA_EMU
-    if ((ARIA_STREAM_WB_MASK & (1 << STAGE)) || !sst<STAGE>()) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // buffer_wbl2 sc1 + wait
-    wait_vm<0>();  // (its exchanges have been performed)
+    wait_vm<0>();
 #endif
 }
 // wave 0, after the workgroup's barrier: workgroup `r` of the `nb` of stage `idx` is done
@@ -967,19 +936,17 @@ __device__ __forceinline__ void stream_count(const StreamSync& ss, int idx, int 
 #endif
 }
 // the workgroup (r of nb) is done with its share of stage `idx`
-template <int STAGE>
 __device__ __forceinline__ void stream_done(const StreamSync& ss, int idx, int r, int nb) {
 #ifdef ARIA_EMU
     emu::syncthreads();
     if (threadIdx.x < 64) stream_count(ss, idx, r, nb);
 #else
-    stream_release<STAGE>();
+    stream_release();
     raw_barrier();
     if (threadIdx.x < 64) stream_count(ss, idx, r, nb);
 #endif
 }
 // ... whose four waves each hold ONE bf16 result for four consecutive rows: the four leave as one 8-byte word (`dst` 8-byte aligned)
-template <int STAGE>
 __device__ __forceinline__ void stream_done4(const StreamSync& ss, int idx, int r, int nb, bf16_t* dst, uint32_t v, uint32_t* s_o) {
     const int t = threadIdx.x;
     if ((t & 63) == 0) s_o[t >> 6] = v;
@@ -991,8 +958,8 @@ __device__ __forceinline__ void stream_done4(const StreamSync& ss, int idx, int 
     wait_lds();
     raw_barrier();
     if (t < 64) {
-        if (t == 0) stx64<sst<STAGE>()>(dst, s_o[0] | (s_o[1] << 16), s_o[2] | (s_o[3] << 16));
-        stream_release<STAGE>();
+        if (t == 0) stx64<true>(dst, s_o[0] | (s_o[1] << 16), s_o[2] | (s_o[3] << 16));
+        stream_release();
         stream_count(ss, idx, r, nb);
     }
 #endif
@@ -1008,7 +975,7 @@ __device__ __forceinline__ int stream_arrive(int32_t* cnt, int* bcast) {
     emu::syncthreads();
     return *bcast;
 #else
-    stream_release<6>();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the wave states are plain stores: buffer_wbl2 sc1 + wait (see the switches above)
     raw_barrier();
     if (threadIdx.x == 0) *bcast = (ARIA_STREAM_ABL & 2) ? 0 : __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -1088,7 +1055,7 @@ __device__ __forceinline__ void block_dot(float (&acc)[R], const u32x4 (&a)[R][N
 }
 
 // y = W . norm(x) (+ residual): gemv_kernel's rows, R per wave, requested before the wait
-template <int R, int NC, int STAGE>
+template <int R, int NC>
 __device__ __forceinline__ void stream_gemv(int blk, const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w, float eps, int K,
                                             int N, const bf16_t* residual, bf16_t* y, const StreamSync& ss, int dep, u32x4* sx, float* sterm,
                                             StreamPhases* ph = nullptr) {
@@ -1109,20 +1076,20 @@ __device__ __forceinline__ void stream_gemv(int blk, const bf16_t* W, long long 
         for (int r = 0; r < R; ++r) yv[r] = residual ? f2bf(bf2f(ldc<SLD>(residual + row0 + r)) + rbf(acc[r])) : f2bf(acc[r]);
         bf16_t* dst = y + row0;
         if (R == 2)
-            stx32<sst<STAGE>()>(dst, yv[0] | (yv[1] << 16));
+            stx32<true>(dst, yv[0] | (yv[1] << 16));
         else
-            stx64<sst<STAGE>()>(dst, yv[0] | (yv[1] << 16), yv[2 % R] | (yv[3 % R] << 16));
+            stx64<true>(dst, yv[0] | (yv[1] << 16), yv[2 % R] | (yv[3 % R] << 16));
     }
 }
 // (four rows per wave where that leaves enough workgroups, like launch_gemv)
-template <int NC, int STAGE>
+template <int NC>
 __device__ __forceinline__ void stream_gemv_r(bool four, int blk, const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w, float eps,
                                               int K, int N, const bf16_t* residual, bf16_t* y, const StreamSync& ss, int dep, u32x4* sx,
                                               float* sterm, StreamPhases* ph = nullptr) {
     if (four)
-        stream_gemv<4, NC, STAGE>(blk, W, ldw, x, norm_w, eps, K, N, residual, y, ss, dep, sx, sterm, ph);
+        stream_gemv<4, NC>(blk, W, ldw, x, norm_w, eps, K, N, residual, y, ss, dep, sx, sterm, ph);
     else
-        stream_gemv<2, NC, STAGE>(blk, W, ldw, x, norm_w, eps, K, N, residual, y, ss, dep, sx, sterm, ph);
+        stream_gemv<2, NC>(blk, W, ldw, x, norm_w, eps, K, N, residual, y, ss, dep, sx, sterm, ph);
 }
 
 #ifndef ARIA_STREAM_WAVES
@@ -1158,7 +1125,7 @@ __global__ __launch_bounds__(256) ARIA_STREAM_OCC void decode_stream_kernel(cons
     const int layer = tk / a.nbl;
     if (layer >= a.L) {  // output projection on the final norm
         stream_stamp(a.ts + a.L * 32, 0);
-        stream_gemv_r<NCD, 7>(a.r4[3], tk - a.L * a.nbl, static_cast<const bf16_t*>(a.hdr[2]), a.D, a.s.xb, static_cast<const bf16_t*>(a.hdr[1]),
+        stream_gemv_r<NCD>(a.r4[3], tk - a.L * a.nbl, static_cast<const bf16_t*>(a.hdr[2]), a.D, a.s.xb, static_cast<const bf16_t*>(a.hdr[1]),
                               a.eps, a.D, a.V, nullptr, static_cast<bf16_t*>(const_cast<void*>(a.hdr[6])), ss, 8 * (a.L - 1) + 5, sx, sterm);
         return;  // (the kernel boundary publishes the logits)
     }
@@ -1172,10 +1139,10 @@ __global__ __launch_bounds__(256) ARIA_STREAM_OCC void decode_stream_kernel(cons
     unsigned long long* const tsl = a.ts + layer * 32;  // (timeline builds)
     if (r < a.nb[0]) {  // ---- qkv = wqkv . norm(x)
         stream_stamp(tsl + 0, 0);
-        stream_gemv_r<NCD, 0>(a.r4[0], r, static_cast<const bf16_t*>(lp[1]), D, x, static_cast<const bf16_t*>(lp[0]), a.eps, D, 3 * D, nullptr,
+        stream_gemv_r<NCD>(a.r4[0], r, static_cast<const bf16_t*>(lp[1]), D, x, static_cast<const bf16_t*>(lp[0]), a.eps, D, 3 * D, nullptr,
                               a.s.qkv, ss, layer ? st - 8 + 5 : -1, sx, sterm, &ph);
         stream_stamp(tsl + 0, 2);
-        stream_done<0>(ss, st + 0, r, a.nb[0]);
+        stream_done(ss, st + 0, r, a.nb[0]);
         phase_mark(ph);  // [4] outputs out, counted
         phase_flush(ph, pacc + 0);
         return;
@@ -1193,12 +1160,9 @@ __global__ __launch_bounds__(256) ARIA_STREAM_OCC void decode_stream_kernel(cons
         float m, lsum, o[8];
         A::template wave_state<SLD>(a.s.qkv, static_cast<const bf16_t*>(a.hdr[0]), ps, kc, vc, D, a.scale, head, 0, ps + 1, true, part * 4 + w, m,
                                     lsum, o);
-        A::template publish<sst<6>()>(red, part * 4 + w, m, lsum, o);
+        A::template publish<false>(red, part * 4 + w, m, lsum, o);
         int32_t* hc = a.sync + STREAM_SYNC_HEADER + layer * a.H + head;
         if (stream_arrive(hc, &s_b[1]) == PARTS - 1) {  // the last workgroup of the head: fold the wave states, normalise, write the head's output
-#if !ARIA_STREAM_LD && !defined(ARIA_EMU)
-            asm volatile("buffer_inv sc1" ::: "memory");
-#endif
             if (w == 0) {
                 A::template fold<false, SLD>(red, m, lsum, o);
                 if (grp == 0) {
@@ -1206,20 +1170,20 @@ __global__ __launch_bounds__(256) ARIA_STREAM_OCC void decode_stream_kernel(cons
                     u32x4 rr;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) rr[q] = pack2bf(o[2 * q] * inv, o[2 * q + 1] * inv);
-                    st16c<sst<1>()>(a.s.ao + (long long)head * HD + sub * 8, rr);
+                    st16c<true>(a.s.ao + (long long)head * HD + sub * 8, rr);
                 }
             }
         }
         stream_stamp(tsl + 4, 2);
-        stream_done<1>(ss, st + 1, r, a.nb[1]);
+        stream_done(ss, st + 1, r, a.nb[1]);
         return;
     }
     r -= a.nb[1];
     if (r < a.nb[2]) {  // ---- h = x + wo . attention
         stream_stamp(tsl + 8, 0);
-        stream_gemv_r<NCD, 2>(a.r4[1], r, static_cast<const bf16_t*>(lp[2]), D, a.s.ao, nullptr, 0.f, D, D, x, a.s.xa, ss, st + 1, sx, sterm);
+        stream_gemv_r<NCD>(a.r4[1], r, static_cast<const bf16_t*>(lp[2]), D, a.s.ao, nullptr, 0.f, D, D, x, a.s.xa, ss, st + 1, sx, sterm);
         stream_stamp(tsl + 8, 2);
-        stream_done<2>(ss, st + 2, r, a.nb[2]);
+        stream_done(ss, st + 2, r, a.nb[2]);
         return;
     }
     r -= a.nb[2];
@@ -1227,9 +1191,9 @@ __global__ __launch_bounds__(256) ARIA_STREAM_OCC void decode_stream_kernel(cons
     if (r < a.nb[3]) {  // ---- router logits | shared up-projection pair + SwiGLU on norm(h): router_shared_up_kernel's waves
         stream_stamp(tsl + 12, 0);
         if (r < a.nrb) {
-            stream_gemv<2, NCD, 3>(r, static_cast<const bf16_t*>(lp[4]), D, h, ffn_norm, a.eps, D, a.E, nullptr, a.s.rl, ss, st + 2, sx, sterm);
+            stream_gemv<2, NCD>(r, static_cast<const bf16_t*>(lp[4]), D, h, ffn_norm, a.eps, D, a.E, nullptr, a.s.rl, ss, st + 2, sx, sterm);
             stream_stamp(tsl + 12, 2);
-            stream_done<3>(ss, st + 3, r, a.nb[3]);
+            stream_done(ss, st + 3, r, a.nb[3]);
         } else {
             const int row0 = ((r - a.nrb) * 4 + w) * 2, rows_s = a.Is;  // (a multiple of 8 -- stream_variant: every row of a workgroup exists)
             float a1[2], a3[2];
@@ -1241,10 +1205,10 @@ __global__ __launch_bounds__(256) ARIA_STREAM_OCC void decode_stream_kernel(cons
             block_dot<2, NCD>(a1, r1, sx);
             block_dot<2, NCD>(a3, r3, sx);
             if (l == 0)
-                stx32<sst<3>()>(a.s.act + (long long)a.k * a.I + row0,
+                stx32<true>(a.s.act + (long long)a.k * a.I + row0,
                                 uint32_t(f2bf(rbf(silu(rbf(a1[0]))) * rbf(a3[0]))) | (uint32_t(f2bf(rbf(silu(rbf(a1[1]))) * rbf(a3[1]))) << 16));
             stream_stamp(tsl + 12, 2);
-            stream_done<3>(ss, st + 3, r, a.nb[3]);
+            stream_done(ss, st + 3, r, a.nb[3]);
         }
         return;
     }
@@ -1273,10 +1237,10 @@ __global__ __launch_bounds__(256) ARIA_STREAM_OCC void decode_stream_kernel(cons
         block_dot<2, NCD>(a3, r3, sx);
         phase_mark(ph);  // [3] rows landed, dots done
         if (l == 0)
-            stx32<sst<4>()>(a.s.act + (long long)j * I + row0,
+            stx32<true>(a.s.act + (long long)j * I + row0,
                             uint32_t(f2bf(rbf(silu(rbf(a1[0]))) * rbf(a3[0]))) | (uint32_t(f2bf(rbf(silu(rbf(a1[1]))) * rbf(a3[1]))) << 16));
         stream_stamp(tsl + 16, 2);
-        stream_done<4>(ss, st + 4, r, a.nb[4]);
+        stream_done(ss, st + 4, r, a.nb[4]);
         phase_mark(ph);  // [4] outputs out, counted
         phase_flush(ph, pacc + 32);
         return;
@@ -1305,14 +1269,7 @@ __global__ __launch_bounds__(256) ARIA_STREAM_OCC void decode_stream_kernel(cons
                     const int cc = (g - k * NCI) * 64 + l;
                     src = cc < nchS ? act + (long long)k * I + cc * 8 : reinterpret_cast<const bf16_t*>(decode_zero_page) + 8 * (l & 15);
                 }
-#if ARIA_STREAM_DMA
-                if (SLD)
-                    glds16_agent(src, sa + 64 * g);
-                else
-                    glds16(src, sa + 64 * g);
-#else
-                sa[64 * g + l] = ld16c<SLD>(src);
-#endif
+                glds16_agent(src, sa + 64 * g);
             }
         };
         constexpr int KA = 2;  // routed experts whose rows travel with the shared expert's
@@ -1387,7 +1344,7 @@ __global__ __launch_bounds__(256) ARIA_STREAM_OCC void decode_stream_kernel(cons
         }
         stream_stamp(tsl + 20, 2);
         phase_mark(ph);  // [4] second rows landed, all dots done
-        stream_done4<5>(ss, st + 5, r, a.nb[5], a.s.xb + r * 4, f2bf(bf2f(ldc<SLD>(h + n)) + rbf(rbf(accs) + rbf(sh))), s_o);
+        stream_done4(ss, st + 5, r, a.nb[5], a.s.xb + r * 4, f2bf(bf2f(ldc<SLD>(h + n)) + rbf(rbf(accs) + rbf(sh))), s_o);
         phase_mark(ph);  // [5] outputs out, counted
         phase_flush(ph, pacc + 40);
     }
