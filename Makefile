@@ -26,9 +26,6 @@ probes: tests/probes/libaria_probe.so
 tests/probes/libaria_probe.so: tests/probes/probe.hip
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $< -o $@
 
-oracle_c:
-	$(MAKE) -C oracle
-
 clean:
 	rm -rf build aria_amd/libaria_hip.so tests/emu/libaria_emu.so
-.PHONY: all emu probes clean oracle_c
+.PHONY: all emu probes clean

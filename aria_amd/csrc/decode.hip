@@ -29,80 +29,10 @@ using namespace ad;
 
 __device__ __forceinline__ float silu(float a) { return silu_fast(a); }
 
-// Agent-scope ("sc1") accesses for values that one workgroup of the streamed schedule writes and another one, possibly on another XCD, reads
-// within the SAME launch: an sc1 store is written through to where every XCD's L2 sees it, an sc1 load does not return a line another
-// XCD may have changed -- single words, so no cache-wide write-back / invalidate is needed (round 4 measured what those cost when every
-// workgroup of a 78 000-workgroup grid issues them: profiles/r04_stream_sync_costs.json).  COH = false: the plain forms (launch schedule).
-template <bool COH>
-__device__ __forceinline__ u32x4 ld16c(const void* p) {
-#ifndef ARIA_EMU
-    if (COH) {
-        const uint64_t* q = static_cast<const uint64_t*>(p);
-        const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint64_t b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return u32x4{uint32_t(a), uint32_t(a >> 32), uint32_t(b), uint32_t(b >> 32)};
-    }
-#endif
-    return ld16(p);
-}
-// Stores another XCD must see inside the launch travel as ATOMIC EXCHANGES of 4 / 8 bytes (results unused: fire and forget).  Measured on
-// MI355X (profiles/r04_decode_stream_bisect.json): with exchanges every GEMV-type stage of a 28-layer token is bit-exact; plain stores +
-// buffer_wbl2 sc1 per wave are right as well and 8x too slow at 78 000 workgroups; read-modify-write atomics are performed where every
-// XCD looks (the completion counters rely on it).  The one exception (the attention stage's wave states) is noted at the streamed schedule's switches.
-template <bool COH>
-__device__ __forceinline__ void stx32(void* p, uint32_t v) {
-#ifndef ARIA_EMU
-    if (COH) {
-        // the RETURNING form: the old value comes back from where the exchange was performed, so the wait for it (stream_release) is a wait
-        // for the exchange itself
-        const uint32_t old = __hip_atomic_exchange(static_cast<uint32_t*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::"v"(old));
-        return;
-    }
-#endif
-    *static_cast<uint32_t*>(p) = v;
-}
-template <bool COH>
-__device__ __forceinline__ void stx64(void* p, uint32_t lo, uint32_t hi) {
-#ifndef ARIA_EMU
-    if (COH) {
-        const unsigned long long old = __hip_atomic_exchange(static_cast<unsigned long long*>(p), (unsigned long long)lo | ((unsigned long long)hi << 32),
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::"v"(old));
-        return;
-    }
-#endif
-    static_cast<uint32_t*>(p)[0] = lo;
-    static_cast<uint32_t*>(p)[1] = hi;
-}
-template <bool COH>
-__device__ __forceinline__ void st16c(void* p, u32x4 v) {
-    if (COH) {
-        stx64<true>(p, v[0], v[1]);
-        stx64<true>(static_cast<char*>(p) + 8, v[2], v[3]);
-        return;
-    }
-    st16(p, v);
-}
-template <bool COH, class T>
-__device__ __forceinline__ T ldc(const T* p) {
-#ifndef ARIA_EMU
-    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-    return *p;
-}
-template <bool COH>
-__device__ __forceinline__ void stcf(float* p, float v) {  // one fp32 word
-    if (COH)
-        stx32<true>(p, __builtin_bit_cast(uint32_t, v));
-    else
-        *p = v;
-}
-
 // x[K] (bf16) -> this lane's chunks c = l + 64 i (i < NC) as packed bf16 pairs, optionally RMS-normalised exactly like
 // rmsnorm_fwd_kernel (norm.hip: same lane <-> chunk mapping and reduction order, so the same rstd).  Chunks past K read as zeros;
 // no branches, so all loads are in flight together.
-template <int NC, bool COH = false>
+template <int NC>
 __device__ __forceinline__ void load_vector(u32x4 (&xv)[NC], const bf16_t* x, const bf16_t* norm_w, float eps, int K, int l) {
     const int nch = K >> 3;
     u32x4 wv[NC];
@@ -110,8 +40,8 @@ __device__ __forceinline__ void load_vector(u32x4 (&xv)[NC], const bf16_t* x, co
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int cc = min(l + 64 * i, nch - 1);
-        xv[i] = ld16c<COH>(x + cc * 8);
-        wv[i] = ld16(nw + cc * 8);  // (the norm weights are constants: plain loads even when x needs agent-scope ones)
+        xv[i] = ld16(x + cc * 8);
+        wv[i] = ld16(nw + cc * 8);
     }
 #pragma unroll
     for (int i = 0; i < NC; ++i)
@@ -201,7 +131,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* W, long long ld
     }
 }
 
-template <bool COH = false>
 __device__ __forceinline__ int route_one_token(const bf16_t* logits, int E, int k, int l, int want, float& my_score, int& my_idx);
 
 // Up-projection pair + SwiGLU for the k routed experts (e_j = idx[j]) AND the shared expert in one launch: grid.y = k + ns, the shared
@@ -398,11 +327,10 @@ __global__ __launch_bounds__(256) void expert_down_combine_kernel(const bf16_t* 
 // id, softmax over the selected logits in fp32, scores cast to bf16.  One wave; the logits come from a regular (multi-workgroup) GEMV --
 // a single workgroup reading the whole 320 KB gate matrix cost 16 us per layer.
 // returns the expert id of slot `want` (wave-uniform); lanes < k also get (score, id) of their own slot
-template <bool COH>
 __device__ __forceinline__ int route_one_token(const bf16_t* logits, int E, int k, int l, int want, float& my_score, int& my_idx) {
     float val[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) val[i] = (l + 64 * i < E) ? bf2f(ldc<COH>(logits + l + 64 * i)) : -INFINITY;
+    for (int i = 0; i < 4; ++i) val[i] = (l + 64 * i < E) ? bf2f(logits[l + 64 * i]) : -INFINITY;
     float top[8];
     int topi = -1, wanted = 0;
 #pragma unroll
@@ -548,19 +476,17 @@ struct DecodeAttn {
         m = mm;
     }
 
-    // One wave's share of the range: wave `w` of NWV (the streamed schedule spreads the NWV waves of a head over several workgroups and
-    // passes the wave's index within the HEAD).  On return every lane group of the wave holds the wave's unnormalised state.
-    template <bool COH = false>  // COH: q | k | v of the new token were written by other workgroups of this launch (streamed schedule)
+    // One wave's share of the range: wave `w` of NWV.  On return every lane group of the wave holds the wave's unnormalised state.
     static __device__ __forceinline__ void wave_state(const bf16_t* qkv, const bf16_t* fc, int ps, bf16_t* k_cache, bf16_t* v_cache, int D,
                                                       float scale, int head, int kbeg, int kend, bool writes_new, int w, float& m,
                                                       float& lsum, float (&o)[8]) {
         const int l = threadIdx.x & 63, sub = l % LPK, grp = l / LPK;
         const long long col = (long long)head * HD + sub * 8;
         const u32x4 f = ld16(fc + (long long)ps * HD + sub * 8);
-        const u32x4 qr = rope(ld16c<COH>(qkv + col), f);
+        const u32x4 qr = rope(ld16(qkv + col), f);
         // the new token's rotated key / value slice, in EVERY lane group: the pass that covers position ps takes it from these registers, so
         // nobody waits for the cache write below to become visible (it was: store, barrier, read back -- ~2 us in front of the first K / V load)
-        const u32x4 knew = rope(ld16c<COH>(qkv + D + col), f), vnew = ld16c<COH>(qkv + 2 * D + col);
+        const u32x4 knew = rope(ld16(qkv + D + col), f), vnew = ld16(qkv + 2 * D + col);
         if (writes_new && w == 0 && grp == 0) {
             st16(k_cache + (long long)ps * D + col, knew);
             st16(v_cache + (long long)ps * D + col, vnew);
@@ -612,21 +538,20 @@ struct DecodeAttn {
             merge(m, lsum, o, m2, l2, o2);
         }
     }
-    // lane group 0 of a wave leaves the wave's state in red[w] (LDS in the one-workgroup form, global scratch in the streamed one)
-    template <bool COH = false>
+    // lane group 0 of a wave leaves the wave's state in red[w]
     static __device__ __forceinline__ void publish(float (*red)[LPK][10], int w, float m, float lsum, const float (&o)[8]) {
         const int l = threadIdx.x & 63, sub = l % LPK, grp = l / LPK;
         if (grp == 0) {
-            stcf<COH>(&red[w][sub][0], m);
-            stcf<COH>(&red[w][sub][1], lsum);
+            red[w][sub][0] = m;
+            red[w][sub][1] = lsum;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) stcf<COH>(&red[w][sub][2 + e], o[e]);
+            for (int e = 0; e < 8; ++e) red[w][sub][2 + e] = o[e];
         }
     }
     // The NWV wave states as a tree, run by ONE wave: lane group g folds waves g, g + NG, ..., then the groups merge by butterfly.
     // OWN0: the wave IS wave 0 and lane group 0 starts from its registers (which hold exactly what it published in red[0]); otherwise
     // group 0 reads red[0] back -- the same bits, so whichever wave folds, the result is the same.
-    template <bool OWN0, bool COH = false>
+    template <bool OWN0>
     static __device__ __forceinline__ void fold(const float (*red)[LPK][10], float& m, float& lsum, float (&o)[8]) {
         const int l = threadIdx.x & 63, sub = l % LPK, grp = l / LPK;
         constexpr int NG = 64 / LPK;
@@ -635,15 +560,15 @@ struct DecodeAttn {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = 0.f;
         } else if (!OWN0) {
-            m = ldc<COH>(&red[0][sub][0]), lsum = ldc<COH>(&red[0][sub][1]);
+            m = red[0][sub][0], lsum = red[0][sub][1];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = ldc<COH>(&red[0][sub][2 + e]);
+            for (int e = 0; e < 8; ++e) o[e] = red[0][sub][2 + e];
         }
         for (int ww = grp ? grp : NG; ww < NWV; ww += NG) {
             float o2[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o2[e] = ldc<COH>(&red[ww][sub][2 + e]);
-            const float m2 = ldc<COH>(&red[ww][sub][0]), l2 = ldc<COH>(&red[ww][sub][1]);
+            for (int e = 0; e < 8; ++e) o2[e] = red[ww][sub][2 + e];
+            const float m2 = red[ww][sub][0], l2 = red[ww][sub][1];
             merge(m, lsum, o, m2, l2, o2);
         }
 #pragma unroll
@@ -738,622 +663,11 @@ struct Scratch {
     bf16_t *xa, *xb, *qkv, *ao, *rl, *scores, *act, *eo;
     int32_t *idx, *kv_len;
     float* part;  // split-KV attention states: H * DECODE_MAX_SPLITS * (hd + 2) floats
-    int32_t* sync;  // streamed schedule: ticket, error word, per-layer stage counters, per-layer per-head counters
-    float* ared;    // streamed schedule: the attention stage's wave states
+    // rl / scores / idx are kept PER LAYER (strides below, in elements): after a token the scratch holds every layer's router logits and
+    // choice, which is what the full-depth parity case reads back (aria_decode_trace_layout; tests/fullwidth_cases.py::case_decode_full_depth)
+    size_t rl_stride, sc_stride, idx_stride;
     size_t bytes;
 };
-
-// ---- streamed schedule: the whole token as ONE launch (ARIA_DECODE_STREAM=1; opt-in) ----------------------------------------------------
-// The launch schedule above is a chain of 6 x L + 1 short kernels.  Measured (profiles/r04_xcd_visibility.json, "reread"): a kernel that
-// streams X MB takes ~4.5 us + X / 7.2 TB/s on this chip -- launch, ramp and tail are paid per kernel whatever it reads -- so a layer is
-// 6 x 4.5 + 275 MB / 7.2 TB/s = 65 us of which 27 are boundaries (measured 68-71).  What a stage needs from its predecessor is a 5 KB
-// activation vector; the WEIGHTS it is going to stream depend on nothing (except the routed experts', on the router logits).  So the
-// stages become workgroups of one grid:
-//   * a workgroup derives (layer, stage, block-in-stage) from its index, requests its weight rows (non-temporal 16-byte loads into
-//     registers: the rows / lanes / chunks the launch schedule gives a wave of that stage; rows per wave may differ, which moves rows
-//     between waves, not the arithmetic of a row), THEN waits for the producing stage, then gets the activation vector -- once per
-//     workgroup, into LDS (block_vector) -- and finishes as the launch kernel does: same dot-product order, same rounding points, so
-//     hidden state, KV cache and logits equal the 6-launch schedule's bit for bit (tests/model_cases.py::case_decode_engine_streamed,
-//     and the 28-layer model in tools/probes/decode_stream_ab.py);
-//   * a finished workgroup makes its few output words visible and counts itself done (stream_count: 8 + 1 counter lines and 64 flag
-//     lines per stage, so that nobody polls or increments a word everybody else is using).
-// No grid barrier: while a stage's last workgroups finish, the next stages' rows are already landing in the registers of the workgroups
-// behind them.  Forward progress: a workgroup only waits for stages of LOWER index; workgroups are dispatched in index order (per XCD,
-// round-robin), so whatever a resident workgroup waits for is resident or finished -- the lowest unfinished index never waits.  That order
-// is what the hardware does, not what HIP promises: every wait is bounded (~0.3 s), a timeout sets the sticky error word and falls
-// through (wrong logits, reported by aria_decode_stream_sync_offset's word [1]; never a hung GPU), and -DARIA_STREAM_TICKET=1 replaces
-// the index by an atomic ticket (one word: 11 ns per workgroup, serialised).
-// Visibility between XCDs inside the launch: outputs leave as 4- / 8-byte atomic exchanges and are read with agent-scope (sc1) loads; the
-// producer waits for its exchanges before it signals.  (Cache-wide buffer_wbl2 / buffer_inv per wave, the textbook release / acquire,
-// cost 28 ns per workgroup EACH when 78 000 workgroups issue them: the first build ran at 15.9 ms per token.)
-// Attention: the 16 waves the one-workgroup-per-head kernel gives a head are 4 workgroups here (wave index within the head = 4 * part + w,
-// same keys per wave and pass); each wave leaves its state in global scratch, the LAST of the four to arrive (a per-head counter) folds
-// the 16 states with DecodeAttn::fold -- the same tree on the same bits.
-//
-// Where it stands (round 4, MI355X, 25.3 B model, 280-token context; profiles/r04_decode_stream_*.json): bit-exact, 1.985 ms per token
-// against the launch schedule's 1.905 -- NOT faster, hence opt-in.  History of the same kernel: 15.9 ms (wbl2 / inv per wave) -> 4.25
-// (agent-scope words) -> 4.7 (two rows per wave, index order; every resident workgroup polling one counter word) -> 2.76 (flag lines) ->
-// 2.62 / 2.38 (counter tree; 4 / 3 waves per SIMD with / without spills) -> 1.985 (vector once per workgroup in LDS, four rows per wave,
-// 116 registers, 4 waves per SIMD).  The build without any waits or counters (wrong results, -DARIA_STREAM_ABL=3) runs at 1.83: what is
-// left is not synchronisation but the workgroup itself.  The phase timeline (-DARIA_STREAM_ABL=4, r04_decode_stream_phases_*.json) says
-// why: under the bulk weight traffic a dependent memory round trip costs 5-7 us, and a workgroup strings several together -- kernel
-// arguments -> rows (|| vector) -> output exchange -> counter(s) -- ~20 us of life for ~7 us of rows in flight, where a launch-schedule
-// wave lives one round trip.  The obvious repair was built and measured as well (tools/probes/src/decode_stream_sentinel.patch,
-// profiles/r04_decode_stream_sentinel_*.json): workgroups that END without waiting -- outputs and completion counts fire-and-forget, every
-// layer with its own exchange buffers pre-filled with a value no kernel produces, readers re-reading while they see it -- bit-exact
-// again, a workgroup's tail down from 6 to 1.6 us, and the token SLOWER (2.48 ms): the hint now takes four hops (count -> lead
-// workgroup's sum -> flag -> reader -> data), each a loaded round trip.  What sets that round trip is Little's law: with 1024 resident
-// workgroups x 80 KB of rows requested, 82 MB / 7.2 TB/s = 11 us behind every dependent access -- the deeper the prefetch that is
-// supposed to hide an edge, the longer the edge.  A kernel boundary costs 4.5 us; an in-kernel edge on this chip costs at least one
-// loaded round trip per hop.  Readers polling the data itself (one hop, no counts or flags at all) with 3 / 2 / 1 resident workgroups
-// per CU: 2.53 / 2.47 / 2.96 ms, bit-exact each (r04_decode_stream_sentinel_sweep.json) -- not the hop count either.  What the variants
-// have in common is the workgroup: ~4 us from its start to its first row request (kernel arguments, stage lookup), the vector through LDS
-// behind two barriers, a tail; 75 000 of them per token.  The launch schedule's 1.905 ms stands.
-constexpr int STREAM_MAXL = 28;            // layers whose pointers fit the kernel-argument block (Aria: 28)
-constexpr int STREAM_SYNC_HEADER = 4;      // sync[0] ticket, [1] sticky error, [2], [3] spare; then L * H head counters, the timeline, flag and counter lines
-constexpr int STREAM_SPIN_LIMIT = 1 << 18;
-// Variant switches (A/B builds: tools/probes/build_decode_variant.sh):
-//   ARIA_STREAM_TICKET 0: blockIdx order; 1: atomic ticket
-//   ARIA_STREAM_ABL (timing only, wrong results): 1 = no dependency waits, 2 = no completion atomics, 4 = timeline stamps
-// (The builds that told the visibility protocol apart -- plain stores + write-back / exchanges per stage, loads behind an invalidate,
-// activation images through registers -- are in the history of this file; what they found is in profiles/r04_decode_stream_bisect.json:
-// outputs of the GEMV-type stages travel as atomic exchanges and are read with agent-scope loads; the attention stage's wave states,
-// read back by the LAST of a head's four workgroups right after its own arrival, need plain stores + a cache write-back -- with
-// exchanges a 28-layer token differed from the launch schedule by a few bf16 ulps, the same ones on every run.)
-#ifndef ARIA_STREAM_TICKET
-#define ARIA_STREAM_TICKET 0
-#endif
-#ifndef ARIA_STREAM_ABL
-#define ARIA_STREAM_ABL 0
-#endif
-#ifndef ARIA_STREAM_SLEEP_NEAR
-#define ARIA_STREAM_SLEEP_NEAR 8  // x 64 cycles between polls of a flag
-#endif
-constexpr bool SLD = true;  // (what another workgroup of the launch wrote is read with agent-scope loads)
-
-struct StreamArgs {
-    const void* hdr[ARIA_DECODE_HEADER_PTRS];
-    const void* lp[STREAM_MAXL * ARIA_DECODE_LAYER_PTRS];
-    Scratch s;
-    int32_t* sync;  // = s.sync
-    float* ared;    // = s.ared: [H][DECODE_ATTN_WAVES][hd / 8][10] wave states of the attention stage
-    int L, D, H, E, k, I, Is, ns, V;
-    float eps, scale;
-    int nb[6];  // workgroups per stage: qkv | attention | wo | router + shared up | routed up | down + combine
-    int nbl, nbv, total;
-    int nrb, nbx;  // router workgroups of stage 3; workgroups per expert of stage 4
-    int r4[4];     // four (else two) rows per wave in the qkv, wo, (unused) and output GEMVs
-    unsigned long long* ts;  // timeline words (ARIA_STREAM_ABL & 4)
-    int32_t* flags;          // completion flags: [(layer * 8 + stage)][64 lines][32 words]
-    int32_t* ctr;            // completion counters: [(layer * 8 + stage)][16 lines][32 words]
-};
-static_assert(sizeof(StreamArgs) <= 3840, "kernel arguments: 4 KB limit");
-
-__device__ __forceinline__ int stream_poll(const int32_t* p) {
-#ifdef ARIA_EMU
-    return *p;
-#else
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-// timeline builds: slot 0 keeps the EARLIEST time (stored inverted under an atomic max), slots 1.. the latest
-__device__ __forceinline__ void stream_stamp(unsigned long long* tsp, int slot) {
-#ifndef ARIA_EMU
-    if ((ARIA_STREAM_ABL & 4) && threadIdx.x == 0) {
-        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-        atomicMax(tsp + slot, slot < 2 ? ~now : now);
-    }
-#endif
-}
-// What a workgroup needs to synchronise: the counter lines, the flag lines, its own flag slot.
-// A stage's completion travels in three hops, none of which lets many workgroups meet on one word (accesses to one word are served one
-// after the other, ~11 ns each: 500 resident workgroups polling a counter starve the very increments they wait for -- 4.7 ms per token;
-// 1248 increments of one word are 14 us by themselves -- profiles/r04_stream_sync_costs.json, r04_decode_stream_timeline.json):
-//   a finished workgroup bumps ONE of the stage's 8 first-level counters (block-in-stage & 7; returning add), the workgroup that completes
-//   a first-level counter bumps the stage's second-level counter, the one that completes THAT sets the stage's 64 flag words (each on its own
-//   128-byte line); a waiting workgroup polls flag (index & 63) -- eight pollers per line.
-struct StreamSync {
-    int32_t* sync;
-    int32_t* ctr;    // [(layer * 8 + stage)][16 lines][32 words]: lines 0..7 first level, line 8 second level
-    int32_t* flags;  // [(layer * 8 + stage)][64 lines][32 words]
-    int slot;
-};
-constexpr int STREAM_FLAG_SLOTS = 64, STREAM_LINE = 32, STREAM_CTR_LINES = 16;  // (words per 128-byte line)
-__device__ __forceinline__ int32_t* stream_flag(const StreamSync& ss, int idx, int slot) {
-    return ss.flags + ((long long)idx * STREAM_FLAG_SLOTS + slot) * STREAM_LINE;
-}
-// timeline builds: where a workgroup's time goes.  ph[0..] = s_memrealtime at the phase boundaries, taken by thread 0; added into the stage's sums at the end
-struct StreamPhases {
-    unsigned long long t[6];
-    int n;
-};
-__device__ __forceinline__ void phase_mark(StreamPhases& ph) {
-#ifndef ARIA_EMU
-    if ((ARIA_STREAM_ABL & 4) && threadIdx.x == 0 && ph.n < 6) ph.t[ph.n++] = __builtin_amdgcn_s_memrealtime();
-#endif
-}
-__device__ __forceinline__ void phase_flush(const StreamPhases& ph, unsigned long long* acc) {  // acc[0] count, acc[1 + i] = sum of (t[i + 1] - t[i])
-#ifndef ARIA_EMU
-    if ((ARIA_STREAM_ABL & 4) && threadIdx.x == 0) {
-        atomicAdd(acc, 1ull);
-        for (int i = 0; i + 1 < ph.n; ++i) atomicAdd(acc + 1 + i, ph.t[i + 1] - ph.t[i]);
-    }
-#endif
-}
-// Wait until stage `idx` (= layer * 8 + stage; < 0: nothing to wait for) is complete.  Every wave of the workgroup calls this: wave 0 polls
-// (sleeping in between), the others stand at a bare s_barrier, which does not drain the row loads they have in flight.
-__device__ __forceinline__ void stream_wait(const StreamSync& ss, int idx) {
-    if (idx < 0) return;
-#ifdef ARIA_EMU
-    if (*stream_flag(ss, idx, ss.slot) == 0) ss.sync[1] = 2;  // the emulator runs workgroups in index order: an unmet dependency is a bug in the stage tables
-    emu::syncthreads();
-#else
-    if (ARIA_STREAM_ABL & 1) return;
-    if ((threadIdx.x >> 6) == 0) {
-        const int32_t* f = stream_flag(ss, idx, ss.slot);
-        int spins = 0;
-        while (stream_poll(f) == 0) {
-            __builtin_amdgcn_s_sleep(ARIA_STREAM_SLEEP_NEAR);
-            if (++spins > STREAM_SPIN_LIMIT || ((spins & 255) == 0 && stream_poll(ss.sync + 1) != 0)) {
-                if (threadIdx.x == 0) __hip_atomic_store(ss.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    wait_lds();  // (thread 0's LDS notes for the workgroup are written before anybody passes the barrier)
-    raw_barrier();
-#endif
-}
-// is stage `idx` complete already?  (one poll, no waiting)
-__device__ __forceinline__ bool stream_ready(const StreamSync& ss, int idx) { return stream_poll(stream_flag(ss, idx, ss.slot)) != 0; }
-
-// every wave: what it stored for other workgroups has been performed where the other XCDs read (the exchanges return their old values)
-__device__ __forceinline__ void stream_release() {
-#ifndef ARIA_EMU
-    wait_vm<0>();
-#endif
-}
-// wave 0, after the workgroup's barrier: workgroup `r` of the `nb` of stage `idx` is done
-__device__ __forceinline__ void stream_count(const StreamSync& ss, int idx, int r, int nb) {
-    const int shard = r & 7, target1 = (nb - shard + 7) >> 3, target2 = nb < 8 ? nb : 8;
-    int32_t* c1 = ss.ctr + ((long long)idx * STREAM_CTR_LINES + shard) * STREAM_LINE;
-    int32_t* c2 = ss.ctr + ((long long)idx * STREAM_CTR_LINES + 8) * STREAM_LINE;
-#ifdef ARIA_EMU
-    if ((threadIdx.x & 63) == 0) {
-        if (++*c1 == target1 && ++*c2 == target2)
-            for (int i = 0; i < STREAM_FLAG_SLOTS; ++i) *stream_flag(ss, idx, i) = 1;
-    }
-    emu::wave_sync();
-#else
-    if (ARIA_STREAM_ABL & 2) return;
-    int last = 0;
-    if ((threadIdx.x & 63) == 0) {
-        if (__hip_atomic_fetch_add(c1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == target1 - 1)
-            last = __hip_atomic_fetch_add(c2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == target2 - 1;
-    }
-    if (__builtin_amdgcn_readfirstlane(last))
-        (void)__hip_atomic_exchange(stream_flag(ss, idx, threadIdx.x & 63), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-// the workgroup (r of nb) is done with its share of stage `idx`
-__device__ __forceinline__ void stream_done(const StreamSync& ss, int idx, int r, int nb) {
-#ifdef ARIA_EMU
-    emu::syncthreads();
-    if (threadIdx.x < 64) stream_count(ss, idx, r, nb);
-#else
-    stream_release();
-    raw_barrier();
-    if (threadIdx.x < 64) stream_count(ss, idx, r, nb);
-#endif
-}
-// ... whose four waves each hold ONE bf16 result for four consecutive rows: the four leave as one 8-byte word (`dst` 8-byte aligned)
-__device__ __forceinline__ void stream_done4(const StreamSync& ss, int idx, int r, int nb, bf16_t* dst, uint32_t v, uint32_t* s_o) {
-    const int t = threadIdx.x;
-    if ((t & 63) == 0) s_o[t >> 6] = v;
-#ifdef ARIA_EMU
-    emu::syncthreads();
-    if (t == 0) stx64<false>(dst, s_o[0] | (s_o[1] << 16), s_o[2] | (s_o[3] << 16));
-    if (t < 64) stream_count(ss, idx, r, nb);
-#else
-    wait_lds();
-    raw_barrier();
-    if (t < 64) {
-        if (t == 0) stx64<true>(dst, s_o[0] | (s_o[1] << 16), s_o[2] | (s_o[3] << 16));
-        stream_release();
-        stream_count(ss, idx, r, nb);
-    }
-#endif
-}
-// the counter's previous value handed to every thread (the attention stage's per-head counters: four workgroups per word)
-__device__ __forceinline__ int stream_arrive(int32_t* cnt, int* bcast) {
-#ifdef ARIA_EMU
-    emu::syncthreads();
-    if (threadIdx.x == 0) {
-        *bcast = *cnt;
-        *cnt += 1;
-    }
-    emu::syncthreads();
-    return *bcast;
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the wave states are plain stores: buffer_wbl2 sc1 + wait (see the switches above)
-    raw_barrier();
-    if (threadIdx.x == 0) *bcast = (ARIA_STREAM_ABL & 2) ? 0 : __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    return *bcast;
-#endif
-}
-
-// The activation vector ONCE per workgroup, in LDS.  (Per wave in registers -- load_vector, what the launch kernels do against their L2 --
-// every wave of the streamed kernel fetched the 5 KB vector from the memory side: with one or two weight rows per wave that was a third
-// of the fabric traffic, and the 40 + 40 registers of vector and norm weights next to the rows in flight kept the kernel at 2-3 waves per
-// SIMD.)  The waves share the chunks (wave w takes chunks w, w + 4, ...), leave the squares' terms in LDS, and EVERY wave sums them in
-// load_vector's order -- the same running sum over the same terms, so the same rstd bit for bit -- then scales its own chunks into sx.
-//   sx[NC * 64] u32x4: chunk c = l + 64 i of the (normalised) vector at sx[c];  sterm[NC * 4 * 64] floats.  Two barriers (one without a norm).
-template <int NC>
-__device__ __forceinline__ void block_vector(const bf16_t* x, const bf16_t* norm_w, float eps, int K, u32x4* sx, float* sterm) {
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, nch = K >> 3;
-    constexpr int MINE = (NC + 3) / 4;
-    u32x4 xv[MINE];
-#pragma unroll
-    for (int m = 0; m < MINE; ++m) {
-        const int i = w + 4 * m;
-        if (i < NC) {  // wave-uniform
-            xv[m] = ld16c<SLD>(x + min(l + 64 * i, nch - 1) * 8);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xv[m][q] = (l + 64 * i < nch) ? xv[m][q] : 0u;
-            if (!norm_w) {
-                sx[l + 64 * i] = xv[m];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float v0 = bflo(xv[m][q]), v1 = bfhi(xv[m][q]);
-                    sterm[(i * 4 + q) * 64 + l] = v0 * v0 + v1 * v1;
-                }
-            }
-        }
-    }
-    sync();
-    if (!norm_w) return;  // workgroup-uniform
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < NC; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ss += sterm[(i * 4 + q) * 64 + l];
-    ss = wave_sum(ss);
-    const float r = rsqrtf(ss / float(K) + eps);
-#pragma unroll
-    for (int m = 0; m < MINE; ++m) {
-        const int i = w + 4 * m;
-        if (i < NC) {
-            const u32x4 wv = ld16(norm_w + min(l + 64 * i, nch - 1) * 8);
-            u32x4 o;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                o[q] = pack2bf(bflo(wv[q]) * rbf(bflo(xv[m][q]) * r), bfhi(wv[q]) * rbf(bfhi(xv[m][q]) * r));
-            sx[l + 64 * i] = o;
-        }
-    }
-    sync();
-}
-// dot products of the loaded rows with the vector in LDS: dot_loaded's order per row (chunks in order, four pairs each), every lane gets the sums
-template <int R, int NC>
-__device__ __forceinline__ void block_dot(float (&acc)[R], const u32x4 (&a)[R][NC], const u32x4* sx) {
-    const int l = threadIdx.x & 63;
-    float s[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) s[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const u32x4 xq = sx[l + 64 * i];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s[r] = dot2bf(a[r][i][q], xq[q], s[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = wave_sum_bcast(s[r]);
-}
-
-// y = W . norm(x) (+ residual): gemv_kernel's rows, R per wave, requested before the wait
-template <int R, int NC>
-__device__ __forceinline__ void stream_gemv(int blk, const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w, float eps, int K,
-                                            int N, const bf16_t* residual, bf16_t* y, const StreamSync& ss, int dep, u32x4* sx, float* sterm,
-                                            StreamPhases* ph = nullptr) {
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row0 = (blk * 4 + w) * R;
-    u32x4 a[R][NC];
-    float acc[R];
-    load_rows<R, NC>(a, W, ldw, min(row0, N - 1), N, K, l);
-    stream_wait(ss, dep);
-    if (ph) phase_mark(*ph);  // [1] rows requested, input complete
-    block_vector<NC>(x, norm_w, eps, K, sx, sterm);
-    if (ph) phase_mark(*ph);  // [2] vector in LDS
-    block_dot<R, NC>(acc, a, sx);
-    if (ph) phase_mark(*ph);  // [3] rows landed, dots done
-    if (l == 0 && row0 < N) {  // (N is a multiple of R -- stream_variant -- so a wave's rows are all inside or all outside)
-        uint32_t yv[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) yv[r] = residual ? f2bf(bf2f(ldc<SLD>(residual + row0 + r)) + rbf(acc[r])) : f2bf(acc[r]);
-        bf16_t* dst = y + row0;
-        if (R == 2)
-            stx32<true>(dst, yv[0] | (yv[1] << 16));
-        else
-            stx64<true>(dst, yv[0] | (yv[1] << 16), yv[2 % R] | (yv[3 % R] << 16));
-    }
-}
-// (four rows per wave where that leaves enough workgroups, like launch_gemv)
-template <int NC>
-__device__ __forceinline__ void stream_gemv_r(bool four, int blk, const bf16_t* W, long long ldw, const bf16_t* x, const bf16_t* norm_w, float eps,
-                                              int K, int N, const bf16_t* residual, bf16_t* y, const StreamSync& ss, int dep, u32x4* sx,
-                                              float* sterm, StreamPhases* ph = nullptr) {
-    if (four)
-        stream_gemv<4, NC>(blk, W, ldw, x, norm_w, eps, K, N, residual, y, ss, dep, sx, sterm, ph);
-    else
-        stream_gemv<2, NC>(blk, W, ldw, x, norm_w, eps, K, N, residual, y, ss, dep, sx, sterm, ph);
-}
-
-#ifndef ARIA_STREAM_WAVES
-#define ARIA_STREAM_WAVES 4  // waves per SIMD the register allocator is told to fit (4: 128 registers, a few spilled words in the norm sections; 0: as it falls, 153 -> 3)
-#endif
-#if !defined(ARIA_EMU) && ARIA_STREAM_WAVES
-#define ARIA_STREAM_OCC __attribute__((amdgpu_waves_per_eu(ARIA_STREAM_WAVES, ARIA_STREAM_WAVES)))
-#else
-#define ARIA_STREAM_OCC
-#endif
-template <int NCD, int NCI, int NCS, int HD>
-__global__ __launch_bounds__(256) ARIA_STREAM_OCC void decode_stream_kernel(const StreamArgs a) {
-    ARIA_DYN_SMEM(smem);
-    ARIA_SMEM_STATIC int s_b[4];       // [1] a head counter's previous value, [2] "the routed activations are complete already"
-    ARIA_SMEM_STATIC uint32_t s_o[4];  // four waves' single results on their way out
-    const int t = threadIdx.x, l = t & 63, w = t >> 6;
-#if ARIA_STREAM_TICKET && !defined(ARIA_EMU)
-    if (t == 0) s_b[0] = __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sync();
-    const int tk = s_b[0];
-#else
-    const int tk = int(blockIdx.x);
-#endif
-    if (tk >= a.total) return;
-    StreamPhases ph;
-    ph.n = 0;
-    phase_mark(ph);  // [0] start
-    unsigned long long* const pacc = a.ts + (a.L + 1) * 32;  // per stage 8 words: count, phase sums
-    const StreamSync ss{a.sync, a.ctr, a.flags, tk & (STREAM_FLAG_SLOTS - 1)};
-    u32x4* const sx = reinterpret_cast<u32x4*>(smem);  // the workgroup's activation vector (block_vector)
-    float* const sterm = reinterpret_cast<float*>(smem + NCD * 1024);
-    const bf16_t* x_in = static_cast<const bf16_t*>(a.hdr[5]);
-    const int layer = tk / a.nbl;
-    if (layer >= a.L) {  // output projection on the final norm
-        stream_stamp(a.ts + a.L * 32, 0);
-        stream_gemv_r<NCD>(a.r4[3], tk - a.L * a.nbl, static_cast<const bf16_t*>(a.hdr[2]), a.D, a.s.xb, static_cast<const bf16_t*>(a.hdr[1]),
-                              a.eps, a.D, a.V, nullptr, static_cast<bf16_t*>(const_cast<void*>(a.hdr[6])), ss, 8 * (a.L - 1) + 5, sx, sterm);
-        return;  // (the kernel boundary publishes the logits)
-    }
-    int r = tk - layer * a.nbl;
-    const int st = 8 * layer;  // index of this layer's stage 0 (counter lines, flag lines)
-    const void* const* lp = a.lp + ARIA_DECODE_LAYER_PTRS * layer;
-    const int D = a.D;
-    const bf16_t* x = layer ? a.s.xb : x_in;
-    const bf16_t* h = a.s.xa;
-    const bf16_t* rl = a.s.rl;
-    unsigned long long* const tsl = a.ts + layer * 32;  // (timeline builds)
-    if (r < a.nb[0]) {  // ---- qkv = wqkv . norm(x)
-        stream_stamp(tsl + 0, 0);
-        stream_gemv_r<NCD>(a.r4[0], r, static_cast<const bf16_t*>(lp[1]), D, x, static_cast<const bf16_t*>(lp[0]), a.eps, D, 3 * D, nullptr,
-                              a.s.qkv, ss, layer ? st - 8 + 5 : -1, sx, sterm, &ph);
-        stream_stamp(tsl + 0, 2);
-        stream_done(ss, st + 0, r, a.nb[0]);
-        phase_mark(ph);  // [4] outputs out, counted
-        phase_flush(ph, pacc + 0);
-        return;
-    }
-    r -= a.nb[0];
-    if (r < a.nb[1]) {  // ---- attention: 4 waves of a head's DECODE_ATTN_WAVES
-        stream_stamp(tsl + 4, 0);
-        using A = DecodeAttn<HD, DECODE_ATTN_WAVES>;
-        constexpr int PARTS = DECODE_ATTN_WAVES / 4;
-        const int head = r / PARTS, part = r % PARTS, sub = l % A::LPK, grp = l / A::LPK;
-        bf16_t *kc = static_cast<bf16_t*>(const_cast<void*>(lp[11])), *vc = static_cast<bf16_t*>(const_cast<void*>(lp[12]));
-        float(*red)[A::LPK][10] = reinterpret_cast<float(*)[A::LPK][10]>(a.ared) + (long long)head * DECODE_ATTN_WAVES;
-        stream_wait(ss, st + 0);
-        const int ps = static_cast<const int32_t*>(a.hdr[4])[0];
-        float m, lsum, o[8];
-        A::template wave_state<SLD>(a.s.qkv, static_cast<const bf16_t*>(a.hdr[0]), ps, kc, vc, D, a.scale, head, 0, ps + 1, true, part * 4 + w, m,
-                                    lsum, o);
-        A::template publish<false>(red, part * 4 + w, m, lsum, o);
-        int32_t* hc = a.sync + STREAM_SYNC_HEADER + layer * a.H + head;
-        if (stream_arrive(hc, &s_b[1]) == PARTS - 1) {  // the last workgroup of the head: fold the wave states, normalise, write the head's output
-            if (w == 0) {
-                A::template fold<false, SLD>(red, m, lsum, o);
-                if (grp == 0) {
-                    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
-                    u32x4 rr;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) rr[q] = pack2bf(o[2 * q] * inv, o[2 * q + 1] * inv);
-                    st16c<true>(a.s.ao + (long long)head * HD + sub * 8, rr);
-                }
-            }
-        }
-        stream_stamp(tsl + 4, 2);
-        stream_done(ss, st + 1, r, a.nb[1]);
-        return;
-    }
-    r -= a.nb[1];
-    if (r < a.nb[2]) {  // ---- h = x + wo . attention
-        stream_stamp(tsl + 8, 0);
-        stream_gemv_r<NCD>(a.r4[1], r, static_cast<const bf16_t*>(lp[2]), D, a.s.ao, nullptr, 0.f, D, D, x, a.s.xa, ss, st + 1, sx, sterm);
-        stream_stamp(tsl + 8, 2);
-        stream_done(ss, st + 2, r, a.nb[2]);
-        return;
-    }
-    r -= a.nb[2];
-    const bf16_t* ffn_norm = static_cast<const bf16_t*>(lp[3]);
-    if (r < a.nb[3]) {  // ---- router logits | shared up-projection pair + SwiGLU on norm(h): router_shared_up_kernel's waves
-        stream_stamp(tsl + 12, 0);
-        if (r < a.nrb) {
-            stream_gemv<2, NCD>(r, static_cast<const bf16_t*>(lp[4]), D, h, ffn_norm, a.eps, D, a.E, nullptr, a.s.rl, ss, st + 2, sx, sterm);
-            stream_stamp(tsl + 12, 2);
-            stream_done(ss, st + 3, r, a.nb[3]);
-        } else {
-            const int row0 = ((r - a.nrb) * 4 + w) * 2, rows_s = a.Is;  // (a multiple of 8 -- stream_variant: every row of a workgroup exists)
-            float a1[2], a3[2];
-            u32x4 r1[2][NCD], r3[2][NCD];
-            load_rows<2, NCD>(r1, static_cast<const bf16_t*>(lp[8]), D, row0, rows_s, D, l);
-            load_rows<2, NCD>(r3, static_cast<const bf16_t*>(lp[9]), D, row0, rows_s, D, l);
-            stream_wait(ss, st + 2);
-            block_vector<NCD>(h, ffn_norm, a.eps, D, sx, sterm);
-            block_dot<2, NCD>(a1, r1, sx);
-            block_dot<2, NCD>(a3, r3, sx);
-            if (l == 0)
-                stx32<true>(a.s.act + (long long)a.k * a.I + row0,
-                                uint32_t(f2bf(rbf(silu(rbf(a1[0]))) * rbf(a3[0]))) | (uint32_t(f2bf(rbf(silu(rbf(a1[1]))) * rbf(a3[1]))) << 16));
-            stream_stamp(tsl + 12, 2);
-            stream_done(ss, st + 3, r, a.nb[3]);
-        }
-        return;
-    }
-    r -= a.nb[3];
-    if (r < a.nb[4]) {  // ---- routed up-projection pairs + SwiGLU (routing inside): expert_up_kernel's rows, two pairs per wave, all four rows up front
-        stream_stamp(tsl + 16, 0);
-        const int j = r / a.nbx, bx = r % a.nbx, I = a.I, row0 = (bx * 4 + w) * 2;  // (I a multiple of 8)
-        stream_wait(ss, st + 2);
-        block_vector<NCD>(h, ffn_norm, a.eps, D, sx, sterm);  // (normalised while the router stage may still be running)
-        stream_wait(ss, st + 3);
-        phase_mark(ph);  // [1] vector ready, router complete
-        float my_score;
-        int my_idx;
-        const int e = route_one_token<SLD>(rl, a.E, a.k, l, j, my_score, my_idx);
-        if (bx == 0 && j == 0 && w == 0 && l < a.k) {
-            a.s.scores[l] = f2bf(my_score);
-            a.s.idx[l] = my_idx;
-        }
-        const long long off = (long long)e * I * D;
-        u32x4 r1[2][NCD], r3[2][NCD];
-        load_rows<2, NCD>(r1, static_cast<const bf16_t*>(lp[5]) + off, D, row0, I, D, l);
-        load_rows<2, NCD>(r3, static_cast<const bf16_t*>(lp[6]) + off, D, row0, I, D, l);
-        phase_mark(ph);  // [2] routed, rows requested
-        float a1[2], a3[2];
-        block_dot<2, NCD>(a1, r1, sx);
-        block_dot<2, NCD>(a3, r3, sx);
-        phase_mark(ph);  // [3] rows landed, dots done
-        if (l == 0)
-            stx32<true>(a.s.act + (long long)j * I + row0,
-                            uint32_t(f2bf(rbf(silu(rbf(a1[0]))) * rbf(a3[0]))) | (uint32_t(f2bf(rbf(silu(rbf(a1[1]))) * rbf(a3[1]))) << 16));
-        stream_stamp(tsl + 16, 2);
-        stream_done(ss, st + 4, r, a.nb[4]);
-        phase_mark(ph);  // [4] outputs out, counted
-        phase_flush(ph, pacc + 32);
-        return;
-    }
-    r -= a.nb[4];
-    {  // ---- every down-projection of one output row per wave + combine + residual: expert_down_combine_kernel's waves.  The routing is
-       // derived HERE from the logits (route_one_token: the function the up-projection runs, so the same ids / scores), which lets the
-       // rows be requested while the up-projection is still running; the activation images follow once it has finished.  The row chunks
-       // come in two waves of requests (shared expert + the first two routed ones, then the rest): 64 registers of rows at a time instead
-       // of 124, which is what lets FOUR waves share a SIMD -- every per-expert dot product and the order they are combined in are unchanged.
-        stream_stamp(tsl + 20, 0);
-        u32x4* sa = reinterpret_cast<u32x4*>(smem);
-        const bf16_t *w2 = static_cast<const bf16_t*>(lp[7]), *sw2 = static_cast<const bf16_t*>(lp[10]);
-        const int k = a.k, ns = a.ns, I = a.I, N = D;
-        const int nchI = I >> 3, nchS = (ns * I) >> 3;
-        const int n = r * 4 + w;  // (N a multiple of 4: the row exists)
-        const int ninstr = k * NCI + NCS;
-        const bf16_t* act = a.s.act;
-        auto images = [&]() {
-            for (int g = w; g < ninstr; g += 4) {
-                const bf16_t* src;
-                if (g < k * NCI) {
-                    const int j = g / NCI, cc = (g % NCI) * 64 + l;
-                    src = cc < nchI ? act + (long long)j * I + cc * 8 : reinterpret_cast<const bf16_t*>(decode_zero_page) + 8 * (l & 15);
-                } else {
-                    const int cc = (g - k * NCI) * 64 + l;
-                    src = cc < nchS ? act + (long long)k * I + cc * 8 : reinterpret_cast<const bf16_t*>(decode_zero_page) + 8 * (l & 15);
-                }
-                glds16_agent(src, sa + 64 * g);
-            }
-        };
-        constexpr int KA = 2;  // routed experts whose rows travel with the shared expert's
-        u32x4 ws[NCS], wa[KA][NCI];
-        {
-            const bf16_t* row = sw2 + (long long)n * ns * I;
-#pragma unroll
-            for (int i = 0; i < NCS; ++i) ws[i] = ldw16(row + min(l + 64 * i, nchS - 1) * 8);
-        }
-        if (t == 0) s_b[2] = stream_ready(ss, st + 4);
-        stream_wait(ss, st + 3);  // (its barrier also publishes s_b[2])
-        phase_mark(ph);  // [1] router complete
-        const bool up_done = s_b[2] != 0;  // workgroup-uniform
-        if (up_done) images();
-        float my_score;
-        int my_idx;
-        route_one_token<SLD>(rl, a.E, k, l, 0, my_score, my_idx);
-        const int my_sc = int(uint32_t(f2bf(my_score)) << 16);
-        int e[DOWN_KMAX];
-        float sc[DOWN_KMAX];
-#pragma unroll
-        for (int j = 0; j < DOWN_KMAX; ++j) {
-            e[j] = read_lane(my_idx, j);
-            sc[j] = __builtin_bit_cast(float, read_lane(my_sc, j));
-        }
-        auto rows_of = [&](u32x4(&dst)[NCI], int j) {
-            const bf16_t* row = w2 + ((long long)(e[j] < 0 ? 0 : e[j]) * N + n) * I;
-#pragma unroll
-            for (int i = 0; i < NCI; ++i) dst[i] = ldw16(row + min(l + 64 * i, nchI - 1) * 8);
-        };
-        auto dot_of = [&](const u32x4(&src)[NCI], int j) {
-            float sj = 0.f;
-#pragma unroll
-            for (int i = 0; i < NCI; ++i) {
-                const u32x4 xv = sa[j * NCI * 64 + l + 64 * i];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) sj = dot2bf(src[i][q], xv[q], sj);
-            }
-            return rbf(rbf(wave_sum_bcast(sj)) * sc[j]);  // bf16(eo_j * score_j)
-        };
-#pragma unroll
-        for (int j = 0; j < KA; ++j)
-            if (j < k) rows_of(wa[j], j);
-        if (!up_done) {
-            stream_wait(ss, st + 4);
-            images();
-        }
-        phase_mark(ph);  // [2] up-projection complete, images requested
-        wait_vm<0>();
-        sync();
-        phase_mark(ph);  // [3] first rows + images landed
-        float accs = 0.f;  // summed in fp32 in slot order (combine_kernel)
-#pragma unroll
-        for (int j = 0; j < KA; ++j)
-            if (j < k) accs += dot_of(wa[j], j);
-        float sh = 0.f;
-#pragma unroll
-        for (int i = 0; i < NCS; ++i) {
-            const u32x4 xv = sa[k * NCI * 64 + l + 64 * i];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sh = dot2bf(ws[i][q], xv[q], sh);
-        }
-        sh = wave_sum_bcast(sh);
-        {
-            u32x4 wb[DOWN_KMAX - KA][NCI];
-#pragma unroll
-            for (int j = KA; j < DOWN_KMAX; ++j)
-                if (j < k) rows_of(wb[j - KA], j);
-#pragma unroll
-            for (int j = KA; j < DOWN_KMAX; ++j)
-                if (j < k) accs += dot_of(wb[j - KA], j);
-        }
-        stream_stamp(tsl + 20, 2);
-        phase_mark(ph);  // [4] second rows landed, all dots done
-        stream_done4(ss, st + 5, r, a.nb[5], a.s.xb + r * 4, f2bf(bf2f(ldc<SLD>(h + n)) + rbf(rbf(accs) + rbf(sh))), s_o);
-        phase_mark(ph);  // [5] outputs out, counted
-        phase_flush(ph, pacc + 40);
-    }
-}
-
-__global__ void decode_stream_reset_kernel(int32_t* sync, int n) {  // every word but the sticky error
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && i != 1) sync[i] = 0;
-}
 
 // ---- sampling (gptfast/generate.py:35-58: logits_to_probs + multinomial_sample_one_no_sync) -------------------------------------------
 // One token's sampling as ONE launch of one workgroup (1024 threads) instead of ~20 tiny tensor kernels (temperature, top-k, where,
@@ -1570,16 +884,6 @@ int launch_gemv(int N, void* stream, const bf16_t* W, long long ldw, const bf16_
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
-// ... then (8-byte aligned) the timeline of -DARIA_STREAM_ABL=4 builds: per layer 8 stages x 4 x 64 bits (first workgroup resident, first past its
-// wait, last done, spare), in s_memrealtime ticks (10 ns)
-inline size_t stream_ts_word(int64_t L, int64_t H) { return size_t((STREAM_SYNC_HEADER + L * H + 1) & ~int64_t(1)); }
-// ... then (128-byte aligned) the completion flags: per (layer, stage) 64 words, each on its own 128-byte line
-inline size_t stream_flags_word(int64_t L, int64_t H) { return (stream_ts_word(L, H) + size_t(64 * (L + 3)) + 31) & ~size_t(31); }
-// ... then the completion counters: per (layer, stage) 16 lines
-inline size_t stream_sync_words(int64_t L, int64_t H) {
-    return stream_flags_word(L, H) + size_t(8 * L) * (STREAM_FLAG_SLOTS + STREAM_CTR_LINES) * STREAM_LINE;
-}
-
 Scratch carve(char* base, int64_t L, int64_t D, int64_t H, int64_t hd, int64_t E, int64_t k, int64_t I, int64_t Is) {
     Scratch s{};
     size_t off = 0;
@@ -1592,95 +896,30 @@ Scratch carve(char* base, int64_t L, int64_t D, int64_t H, int64_t hd, int64_t E
     s.xb = reinterpret_cast<bf16_t*>(take(D * 2));
     s.qkv = reinterpret_cast<bf16_t*>(take(3 * D * 2));
     s.ao = reinterpret_cast<bf16_t*>(take(D * 2));
-    s.rl = reinterpret_cast<bf16_t*>(take(E * 2));
-    s.scores = reinterpret_cast<bf16_t*>(take(k * 2));
+    s.rl_stride = size_t(E + 63) & ~size_t(63), s.sc_stride = 64, s.idx_stride = 64;  // (k <= 8; 128- / 256-byte aligned rows)
+    s.rl = reinterpret_cast<bf16_t*>(take(L * s.rl_stride * 2));
+    s.scores = reinterpret_cast<bf16_t*>(take(L * s.sc_stride * 2));
     s.act = reinterpret_cast<bf16_t*>(take((k * I + Is) * 2));  // routed rows, then the shared expert's activation vector
     s.eo = reinterpret_cast<bf16_t*>(take((k + 1) * D * 2));     // routed outputs, then the shared expert's output
-    s.idx = reinterpret_cast<int32_t*>(take(k * 4));
+    s.idx = reinterpret_cast<int32_t*>(take(L * s.idx_stride * 4));
     s.kv_len = reinterpret_cast<int32_t*>(take(4));
     s.part = reinterpret_cast<float*>(take(size_t(H) * DECODE_MAX_SPLITS * size_t(hd + 2) * 4));
-    s.sync = reinterpret_cast<int32_t*>(take(stream_sync_words(L, H) * 4));
-    s.ared = reinterpret_cast<float*>(take(size_t(H) * DECODE_ATTN_WAVES * size_t(hd / 8) * 10 * 4));
     s.bytes = off;
     return s;
-}
-
-// ARIA_DECODE_STREAM: "1" = the streamed schedule (one launch per token, decode_stream_kernel) where it has an instantiation; unset / "0" =
-// the launch schedule.  Read per call, like the other decode switches.
-bool decode_stream_enabled() {
-    const char* e = std::getenv("ARIA_DECODE_STREAM");
-    return e && atoi(e) != 0;
-}
-
-// The streamed schedule covers the widths decode_stream_kernel is instantiated for, the 6-launch schedule's fused forms (its waves are what the
-// stages reproduce) and the one-workgroup-per-head attention (no split-KV: caches up to 2048 slots, or up to 16 384 with ARIA_DECODE_SPLIT_KV=0).
-int stream_variant(int64_t L, int64_t D, int64_t hd, int64_t E, int64_t k, int64_t I, int64_t Is, int64_t V, int64_t Smax) {
-    if (L > STREAM_MAXL || k > DOWN_KMAX || E > 256 || !decode_fuse_enabled()) return 0;
-    if ((D & 3) || (I & 7) || (Is & 7) || (E & 1) || (V & 1)) return 0;  // outputs leave as whole 4- / 8-byte words
-    if (Smax > 16384 || decode_splits_for(Smax) > 1) return 0;
-    const int ncD = chunks_per_lane(D), ncI = chunks_per_lane(I), ncS = chunks_per_lane(Is);
-    if (ncD == 5 && ncI == 4 && ncS == 7 && hd == 128) return 1;  // Aria
-    if (ncD == 1 && ncI == 1 && ncS == 1 && hd == 64) return 2;   // the test suite's toy widths
-    if (ncD == 1 && ncI == 1 && ncS == 1 && hd == 128) return 3;
-    return 0;
-}
-
-int launch_stream(int variant, const void* const* ptrs, const Scratch& s, int64_t L, int64_t D, int64_t H, int64_t hd, int64_t E, int64_t k,
-                  int64_t I, int64_t Is, int64_t V, float eps, void* stream) {
-    StreamArgs a{};
-    for (int i = 0; i < ARIA_DECODE_HEADER_PTRS; ++i) a.hdr[i] = ptrs[i];
-    for (int i = 0; i < ARIA_DECODE_LAYER_PTRS * L; ++i) a.lp[i] = ptrs[ARIA_DECODE_HEADER_PTRS + i];
-    a.s = s;
-    a.sync = s.sync;
-    a.ared = s.ared;
-    a.ts = reinterpret_cast<unsigned long long*>(s.sync + stream_ts_word(L, H));
-    a.flags = s.sync + stream_flags_word(L, H);
-    a.ctr = a.flags + size_t(8 * L) * STREAM_FLAG_SLOTS * STREAM_LINE;
-    a.L = int(L), a.D = int(D), a.H = int(H), a.E = int(E), a.k = int(k), a.I = int(I), a.Is = int(Is), a.ns = int(Is / I), a.V = int(V);
-    a.eps = eps;
-    a.scale = 1.0f / sqrtf(float(hd));
-    auto cdiv = [](int64_t x, int64_t y) { return int((x + y - 1) / y); };
-    // rows per wave: two everywhere (one up-projection pair per wave for the shared expert): 126 registers, four waves per SIMD -- what hides a
-    // wave's wait for its input behind the other waves' rows; the launch schedule's 4-row waves moved rows between waves, not the arithmetic
-    a.nrb = cdiv(E, 8);
-    a.nbx = cdiv(I, 8);
-    a.r4[0] = 3 * D >= 4096 && (3 * D) % 4 == 0, a.r4[1] = D >= 4096 && D % 4 == 0, a.r4[2] = 0, a.r4[3] = V >= 4096 && V % 4 == 0;
-    a.nb[0] = cdiv(3 * D, a.r4[0] ? 16 : 8);
-    a.nb[1] = int(H) * (DECODE_ATTN_WAVES / 4);
-    a.nb[2] = cdiv(D, a.r4[1] ? 16 : 8);
-    a.nb[3] = a.nrb + cdiv(Is, 8);
-    a.nb[4] = a.nbx * int(k);
-    a.nb[5] = cdiv(D, 4);
-    a.nbl = a.nb[0] + a.nb[1] + a.nb[2] + a.nb[3] + a.nb[4] + a.nb[5];
-    a.nbv = cdiv(V, a.r4[3] ? 16 : 8);
-    a.total = int(L) * a.nbl + a.nbv;
-    const int nsync = int(stream_sync_words(L, H));
-    ARIA_LAUNCH(decode_stream_reset_kernel, dim3(unsigned((nsync + 255) / 256)), dim3(256), 0, stream, s.sync, nsync);
-    const int ncI = chunks_per_lane(I), ncS = chunks_per_lane(Is);
-    const size_t lds = std::max(size_t(k * ncI + ncS) * 1024, size_t(chunks_per_lane(D)) * 2048);  // activation images | vector + its squares
-    if (variant == 1)
-        ARIA_LAUNCH((decode_stream_kernel<5, 4, 7, 128>), dim3(unsigned(a.total)), dim3(256), lds, stream, a);
-    else if (variant == 2)
-        ARIA_LAUNCH((decode_stream_kernel<1, 1, 1, 64>), dim3(unsigned(a.total)), dim3(256), lds, stream, a);
-    else
-        ARIA_LAUNCH((decode_stream_kernel<1, 1, 1, 128>), dim3(unsigned(a.total)), dim3(256), lds, stream, a);
-    return aria_check_launch();
 }
 
 }  // namespace
 
 extern "C" {
 
-int aria_decode_stream_supported(const int64_t* dims) {
-    if (!dims) return 0;
-    return stream_variant(dims[0], dims[1], dims[3], dims[4], dims[5], dims[6], dims[7], dims[8], dims[9]) != 0 && dims[7] % dims[6] == 0;
-}
-
-int64_t aria_decode_stream_sync_offset(const int64_t* dims) {
-    if (!dims) return -1;
+int aria_decode_trace_layout(const int64_t* dims, int64_t* out) {
+    if (!dims || !out) return ARIA_ERR_INVALID;
     char* const base = reinterpret_cast<char*>(uintptr_t(1) << 20);  // (never dereferenced: carve only does address arithmetic)
     const Scratch s = carve(base, dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], dims[6], dims[7]);
-    return int64_t(reinterpret_cast<char*>(s.sync) - base);
+    out[0] = reinterpret_cast<char*>(s.rl) - base, out[1] = int64_t(s.rl_stride) * 2;      // router logits: bf16 [L][E], row stride in bytes
+    out[2] = reinterpret_cast<char*>(s.idx) - base, out[3] = int64_t(s.idx_stride) * 4;    // expert ids: int32 [L][k]
+    out[4] = reinterpret_cast<char*>(s.scores) - base, out[5] = int64_t(s.sc_stride) * 2;  // scores: bf16 [L][k]
+    return ARIA_OK;
 }
 
 int64_t aria_decode_scratch_bytes(const int64_t* dims) {
@@ -1713,10 +952,6 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
         if (rc != ARIA_OK) return rc; \
     } while (0)
     const bool fuse = decode_fuse_enabled();
-    if (decode_stream_enabled()) {
-        const int variant = stream_variant(L, D, hd, E, k, I, Is, V, Smax);
-        if (variant) return launch_stream(variant, ptrs, s, L, D, H, hd, E, k, I, Is, V, eps, stream);
-    }
     for (int64_t li = 0; li < L; ++li) {
         const void* const* lp = ptrs + ARIA_DECODE_HEADER_PTRS + ARIA_DECODE_LAYER_PTRS * li;
         const bf16_t *attn_norm = static_cast<const bf16_t*>(lp[0]), *wqkv = static_cast<const bf16_t*>(lp[1]),
@@ -1727,6 +962,8 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
                      *sw2 = static_cast<const bf16_t*>(lp[10]);
         bf16_t *kc = static_cast<bf16_t*>(const_cast<void*>(lp[11])), *vc = static_cast<bf16_t*>(const_cast<void*>(lp[12]));
         bf16_t* h = s.xa;  // hidden state after the attention block
+        bf16_t *const rl = s.rl + li * s.rl_stride, *const scores = s.scores + li * s.sc_stride;  // this layer's routing record
+        int32_t* const idx = s.idx + li * s.idx_stride;
         // attention block: h = x + wo( attn( rope(wqkv(norm(x))) ) )
         ARIA_TRY(launch_gemv(int(3 * D), stream, wqkv, (long long)D, x, attn_norm, eps, int(D), nullptr, s.qkv));
         const int splits = decode_splits_for(Smax);
@@ -1747,31 +984,31 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
         if (fuse) {  // three launches: router logits + shared up | routed up (top-k inside) | all down-projections + combine
             const int nrb = int((E + 7) / 8);
 #define CALL(NC)                                                                                                                          \
-    ARIA_LAUNCH((router_shared_up_kernel<2, NC>), dim3(unsigned(nrb + (Is + 7) / 8)), dim3(256), 0, stream, gate, int(E), s.rl, sw1, sw3, \
+    ARIA_LAUNCH((router_shared_up_kernel<2, NC>), dim3(unsigned(nrb + (Is + 7) / 8)), dim3(256), 0, stream, gate, int(E), rl, sw1, sw3, \
                 int(Is), (const bf16_t*)h, ffn_norm, eps, int(D), s.act + k * I, nrb)
             ARIA_NC_SWITCH(ncD, CALL)
 #undef CALL
         } else {  // four launches: router logits | routed + shared up (top-k inside) | down-projections | combine
-            ARIA_TRY(launch_gemv(int(E), stream, gate, (long long)D, h, ffn_norm, eps, int(D), nullptr, s.rl));
+            ARIA_TRY(launch_gemv(int(E), stream, gate, (long long)D, h, ffn_norm, eps, int(D), nullptr, rl));
         }
         // (top-k + softmax of the router run inside expert_up_kernel)
         if (I * (k + ns) >= 8192) {  // enough rows for 4 per wave (8 row reads of 5 KiB in flight per wave) and still > 2000 waves
 #define CALL(NC)                                                                                                                       \
     ARIA_LAUNCH((expert_up_kernel<4, NC>), dim3(unsigned((I + 15) / 16), unsigned(k + ns_up)), dim3(256), 0, stream, w1, w3, sw1, sw3, \
-                (const bf16_t*)s.rl, int(E), s.scores, s.idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act)
+                (const bf16_t*)rl, int(E), scores, idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act)
             ARIA_NC_SWITCH(ncD, CALL)
 #undef CALL
         } else {
 #define CALL(NC)                                                                                                                      \
     ARIA_LAUNCH((expert_up_kernel<2, NC>), dim3(unsigned((I + 7) / 8), unsigned(k + ns_up)), dim3(256), 0, stream, w1, w3, sw1, sw3, \
-                (const bf16_t*)s.rl, int(E), s.scores, s.idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act)
+                (const bf16_t*)rl, int(E), scores, idx, int(k), (const bf16_t*)h, ffn_norm, eps, int(D), int(I), s.act)
             ARIA_NC_SWITCH(ncD, CALL)
 #undef CALL
         }
         if (fused_down) {
 #define DOWNC(NCI, NCS)                                                                                                                 \
     ARIA_LAUNCH((expert_down_combine_kernel<NCI, NCS>), dim3(unsigned((D + 3) / 4)), dim3(256), size_t(k * NCI + NCS) * 1024, stream, w2, \
-                sw2, (const int32_t*)s.idx, (const bf16_t*)s.scores, int(k), ns, (const bf16_t*)s.act, int(I), int(D), (const bf16_t*)h, s.xb)
+                sw2, (const int32_t*)idx, (const bf16_t*)scores, int(k), ns, (const bf16_t*)s.act, int(I), int(D), (const bf16_t*)h, s.xb)
             if (ncI == 4 && ncS == 7) {  // Aria: I = 1664, shared 3328
                 DOWNC(4, 7);
             } else if (ncI == 1 && ncS == 1) {
@@ -1783,7 +1020,7 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
         } else {
 #define DOWN(NCI, NCS)                                                                                                               \
     ARIA_LAUNCH((expert_down_kernel<2, NCI, NCS>), dim3(unsigned((D + 7) / 8), unsigned(k + 1)), dim3(256), 0, stream, w2, sw2, \
-                (const int32_t*)s.idx, int(k), ns, (const bf16_t*)s.act, int(I), int(D), s.eo)
+                (const int32_t*)idx, int(k), ns, (const bf16_t*)s.act, int(I), int(D), s.eo)
             if (ncI == 4 && ncS == 7) {  // Aria: I = 1664, shared 3328
                 DOWN(4, 7);
             } else if (ncI == 1 && ncS == 1) {
@@ -1794,7 +1031,7 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
                 DOWN(8, 8);  // any other width: correct (chunks past the end read as zeros), more load instructions than needed
             }
 #undef DOWN
-            ARIA_LAUNCH(combine_kernel, dim3(unsigned((D / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)s.eo, (const bf16_t*)s.scores,
+            ARIA_LAUNCH(combine_kernel, dim3(unsigned((D / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)s.eo, (const bf16_t*)scores,
                         int(k), (const bf16_t*)(s.eo + k * D), (const bf16_t*)h, s.xb, int(D));
         }
         ARIA_TRY(aria_check_launch());

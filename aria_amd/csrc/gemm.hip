@@ -608,6 +608,7 @@ int aria_gemm_qkv_rope_cache_bf16(const void* X, const void* Wqkv, void* Q, void
                                   int64_t M, int64_t D, int64_t K, int64_t hd, int64_t S, int64_t S_cache, int64_t ldx, int64_t ldw, int64_t ldq,
                                   int64_t ld_cache, void* stream) {
     if (!X || !Wqkv || !Q || !Kc || !Vc || !freqs_cis || M < 0 || D <= 0 || K <= 0 || hd <= 0 || S <= 0 || S_cache <= 0) return ARIA_ERR_INVALID;
+    if (S > S_cache) return ARIA_ERR_INVALID;  // a sequence longer than the cache (rows t % S would land in the next sequence's slots)
     if (!aligned16(X) || !aligned16(Wqkv) || !aligned16(Q) || !aligned16(Kc) || !aligned16(Vc) || !aligned16(freqs_cis) || (ldx & 7) || (ldw & 7) ||
         (ldq & 7) || (ld_cache & 7))
         return ARIA_ERR_ALIGN;

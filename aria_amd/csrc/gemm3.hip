@@ -552,7 +552,8 @@ __device__ __forceinline__ void store_tile3_rows_rope(const P& p, const f32x16 (
                 dst = reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + col0 + cc;
             else
                 dst = static_cast<bf16_t*>(region == 1 ? p.kc : p.vc) + ((long long)seq * p.cache_S + ps) * p.ld_cache + col0 + cc;
-            *reinterpret_cast<u32x4*>(dst) = v;
+            // a caller-supplied position outside the cache never becomes a store (a stray pos corrupted memory silently)
+            if (region == 0 || unsigned(ps) < unsigned(p.cache_S)) *reinterpret_cast<u32x4*>(dst) = v;
         }
     }
 }

@@ -186,7 +186,13 @@ def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w
     send_splits, recv_splits = both[0].sum(1).tolist(), both[1].sum(1).tolist()
     rows = AllToAllRowsFn.apply(perm, send_splits, recv_splits, group)             # ordered (source rank, local expert)
     K = fc1_local.shape[1]
-    if ops.segments_supported(K) and ops.segments_supported(fc2_local.shape[1]) and ops.glu_fusable(K, fc1_local.shape[2]):
+    R_recv = rows.shape[0]   # data-dependent: a routing skew towards this rank's experts grows it (known on the host: sum of recv_splits)
+    # the segment launches are v3-only: per-lane DMA offsets are 32-bit, i.e. 2 * rows * leading dimension < 2^32 for fc1's input and fc2's
+    # (at 64K tokens per rank a ~2.1x skew crossed that line and the step aborted with ARIA_ERR_UNSUPPORTED instead of taking
+    # the reorder path below, whose grouped launches fall back to the v2 kernels)
+    seg_rows_ok = 2 * R_recv * K < (1 << 32) and 2 * R_recv * fc2_local.shape[1] < (1 << 32)
+    if (seg_rows_ok and ops.segments_supported(K) and ops.segments_supported(fc2_local.shape[1])
+            and ops.glu_fusable(K, fc1_local.shape[2])):
         # r04: the grouped launches take the exchange's output AS IT ARRIVED -- W * El segments ordered (source rank, local expert), segment
         # g multiplying with local expert g % El -- so no row passes over [6T, D] in front of fc1 or behind fc2, forward or backward
         seg_off = torch.zeros(W * El + 1, dtype=torch.int32, device=x.device)

@@ -126,16 +126,19 @@ class Attention(nn.Module):
         self.kv_cache: Optional[KVCache] = None
         self.hdp = Fn._pad_hd(config.head_dim, need_bwd=False)  # kernels are native for 64 / 72 / 128
 
-    def forward(self, x2d, B, S, freqs_cis, pos32, kv_len, prefill: bool):
+    def forward(self, x2d, B, S, freqs_cis, pos32, kv_len, prefill: bool, pos_is_arange: bool = False):
         c = self.config
         D, H, hd, hdp = c.dim, c.n_head, c.head_dim, self.hdp
-        if (prefill and self.kv_cache is not None and B == 1 and hdp == hd and x2d.shape[0] == S
-                and ops.qkv_rope_cache_fusable(D, x2d.shape[1], hd)):
+        if (prefill and self.kv_cache is not None and B == 1 and hdp == hd and x2d.shape[0] == S and S <= self.kv_cache.k.shape[1]
+                and pos_is_arange and ops.qkv_rope_cache_fusable(D, x2d.shape[1], hd)):
             # K7: projection + interleaved RoPE + KVCache.update (model.py:423-435, 67-93) as ONE launch -- q to its own buffer, rotated k and v
-            # straight into the static cache (prefill positions are arange(S), generate.py:147-150), which the attention kernel then
-            # reads in place: no [T, 3D] product, no rotation pass, no cache copies
+            # straight into the static cache, which the attention kernel then reads in place: no [T, 3D] product, no rotation pass, no
+            # cache copies.  Taken only when Transformer.forward KNOWS the positions are arange(S) (it built them itself, or the caller's
+            # tensor was checked once per shape): the kernel then derives the position from the row index (pos = None), so neither the
+            # rotation nor the cache row depends on a device tensor nobody validated.  A prompt longer than the cache takes the
+            # path below, whose copy raises.
             cache = self.kv_cache
-            q = ops.gemm_qkv_rope_cache(x2d, self.wqkv.weight, freqs_cis, pos32, cache.k, cache.v, S, hd)
+            q = ops.gemm_qkv_rope_cache(x2d, self.wqkv.weight, freqs_cis, None, cache.k, cache.v, S, hd)
             o, _ = ops.attention_fwd(q, cache.k[0, :S], cache.v[0, :S], 1, S, H, hd, hd ** -0.5, True)
             return ops.gemm(o, self.wo.weight)
         qkv = ops.gemm(x2d, self.wqkv.weight)
@@ -218,7 +221,7 @@ class TransformerBlock(nn.Module):
         self.ffn_norm = RMSNorm(config.dim, config.norm_eps)
         self.attention_norm = RMSNorm(config.dim, config.norm_eps)
 
-    def forward(self, res, delta, B, S, freqs_cis, pos32, kv_len, prefill):
+    def forward(self, res, delta, B, S, freqs_cis, pos32, kv_len, prefill, pos_is_arange=False):
         """gptfast/model.py:236-260 with the two residual adds folded into the norm that follows each (``rmsnorm`` with a residual: the
         sum is rounded to bf16 and written once, then normalised -- the same bits as ``add`` followed by ``rmsnorm``, two launches and two
         passes over [T, D] less per layer).  The block's input is ``res + delta`` (``delta`` None for the first block); it returns
@@ -227,7 +230,7 @@ class TransformerBlock(nn.Module):
             x, xn = res, self.attention_norm(res)
         else:
             xn, x, _ = ops.rmsnorm(delta, self.attention_norm.weight, self.attention_norm.eps, residual=res, want_rstd=False)
-        a = self.attention(xn, B, S, freqs_cis, pos32, kv_len, prefill)
+        a = self.attention(xn, B, S, freqs_cis, pos32, kv_len, prefill, pos_is_arange)
         hn, h, _ = ops.rmsnorm(a, self.ffn_norm.weight, self.ffn_norm.eps, residual=x, want_rstd=False)
         return h, self.feed_forward(hn)
 
@@ -246,6 +249,17 @@ class Transformer(nn.Module):
         self.decode_graph = False         # ... optionally replayed from a natively captured HIP graph (measured SLOWER than the plain
         #                                   enqueue on ROCm 7.2: 6.2 vs 4.8 ms/token -- graph kernel nodes cost more than stream launches)
         self._engine: Optional["DecodeEngine"] = None
+        # bumped by whatever may re-home a weight (module.to / .cuda / casts; load_state_dict, also through a parent module, also assign=True):
+        # the decode engine re-checks its whole pointer table only then
+        self._weights_version = 0
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._bump_weights_version())
+
+    def _bump_weights_version(self):
+        self._weights_version += 1
+
+    def _apply(self, fn, *a, **k):
+        self._weights_version = getattr(self, "_weights_version", 0) + 1
+        return super()._apply(fn, *a, **k)
 
     def _engine_capable(self) -> bool:
         """The one-call-per-token engine serves this model's shape (native head dims of the decode attention kernel)."""
@@ -289,8 +303,14 @@ class Transformer(nn.Module):
         prefill = S > 1 or input_pos is None
         if not prefill and B == 1 and self.use_decode_engine and self._engine_ok():
             return self._engine.step(x, input_pos)
+        pos_is_arange = input_pos is None
         if input_pos is None:
             input_pos = torch.arange(S, device=x.device)
+        elif prefill and input_pos.numel() == S:
+            # the prefill contract is input_pos = arange(S) (gptfast/generate.py:147-150; KVCache.update writes rows 0..S-1): checked here, once
+            # per prefill call (a host read of S integers), so that the fused projection + RoPE + cache-write launch may take the position
+            # from the row index instead of trusting a device tensor
+            pos_is_arange = bool(torch.equal(input_pos.reshape(-1).long().cpu(), torch.arange(S)))
         if prefill:
             pos32 = input_pos.to(torch.int32).reshape(1, S).expand(B, S).reshape(-1).contiguous()
             kv_len = None
@@ -299,7 +319,7 @@ class Transformer(nn.Module):
             kv_len = pos32 + 1
         res, delta = x2d, None
         for layer in self.layers:
-            res, delta = layer(res, delta, B, S, self.freqs_cis, pos32, kv_len, prefill)
+            res, delta = layer(res, delta, B, S, self.freqs_cis, pos32, kv_len, prefill, pos_is_arange)
         h = ops.rmsnorm(delta, self.norm.weight, self.norm.eps, residual=res, want_rstd=False)[0] if delta is not None else self.norm(res)
         if last_only:
             h = h.view(B, S, D)[:, -1].contiguous()
@@ -340,6 +360,8 @@ class DecodeEngine:
             assert t.is_contiguous() and t.device == dev
         self._keep = tensors  # the table holds raw addresses: keep the tensors alive and detect re-allocation
         self._addr = [t.data_ptr() for t in tensors]
+        self._version = model._weights_version
+        self._cheap = self._cheap_key(model)
         self.ptrs = (ctypes.c_void_p * len(tensors))(*self._addr)
         # one graph launch per token instead of ~13 launches per layer (None: capture failed or disabled -> plain enqueue)
         self.graph = lib.cdll.aria_decode_graph_create(self.ptrs, self._dims_p, self.eps) if model.decode_graph else None
@@ -367,18 +389,40 @@ class DecodeEngine:
         (a second cached generate() kept attending over the previous call's cache)."""
         if int(self.dims[9]) != model.max_seq_length or model.layers[0].attention.kv_cache is None:
             return False
-        return [t.data_ptr() for t in self._table(model)] == self._addr
+        if model._weights_version == self._version:
+            # per token (ADVICE r4: the full table was 8 + 13 L module lookups and data_ptr() calls per decoded token): what can be re-homed
+            # WITHOUT bumping the model's weight version -- the caches and freqs_cis, replaced by setup_caches
+            return self._cheap_key(model) == self._cheap
+        ok = [t.data_ptr() for t in self._table(model)] == self._addr   # weights touched (_apply / load_state_dict): the full comparison, once
+        if ok:
+            self._version = model._weights_version
+        return ok
 
-    def streamed(self) -> bool:
-        """Whether aria_decode_token runs this model as ONE launch per token (ARIA_DECODE_STREAM=1 and widths the streamed kernel covers)."""
-        import os
+    @staticmethod
+    def _cheap_key(model: "Transformer"):
+        key = [model.freqs_cis.data_ptr()]
+        for blk in model.layers:
+            c = blk.attention.kv_cache
+            key += [c.k.data_ptr(), c.v.data_ptr()]
+        return key
 
-        return os.environ.get("ARIA_DECODE_STREAM", "0") not in ("", "0") and bool(self._lib.cdll.aria_decode_stream_supported(self._dims_p))
+    def routing_trace(self):
+        """Every layer's routing record of the LAST step (a host sync): (router logits [L, E] bf16, expert ids [L, k] int32, scores [L, k] bf16) --
+        what TopKRouter (gptfast/model.py:355-366) saw and chose inside the engine; read by the full-depth parity case."""
+        import ctypes
 
-    def stream_status(self) -> int:
-        """The streamed schedule's sticky error word (0 = every dependency wait of every token so far was met; a host sync)."""
-        off = int(self._lib.cdll.aria_decode_stream_sync_offset(self._dims_p))
-        return int(self.scratch[off + 4:off + 8].view(torch.int32).item())
+        import numpy as np
+
+        lay = np.zeros(6, dtype=np.int64)
+        self._lib.call("aria_decode_trace_layout", self._dims_p, lay.ctypes.data_as(ctypes.c_void_p))
+        L, E, k = int(self.dims[0]), int(self.dims[4]), int(self.dims[5])
+
+        def rows(off, stride, dtype, width):
+            n = torch.empty(0, dtype=dtype).element_size()
+            raw = self.scratch[off:off + L * stride].view(L, stride)[:, :width * n].contiguous()
+            return raw.view(dtype).view(L, width).clone()
+
+        return rows(int(lay[0]), int(lay[1]), bf16, E), rows(int(lay[2]), int(lay[3]), torch.int32, k), rows(int(lay[4]), int(lay[5]), bf16, k)
 
     def step(self, x_embed: torch.Tensor, input_pos: torch.Tensor) -> torch.Tensor:
         """x_embed [1,1,D] (embedding of the new token), input_pos: device tensor with the cursor -> logits [1,1,V] (a view of the

@@ -22,7 +22,7 @@ ERRORS = {
 }
 
 P, I64, I32, F32 = c_void_p, c_int64, c_int, c_float
-RESTYPES = {"aria_gemm_workspace_bytes": c_int64, "aria_decode_scratch_bytes": c_int64, "aria_decode_stream_sync_offset": c_int64, "aria_decode_graph_create": c_void_p,
+RESTYPES = {"aria_gemm_workspace_bytes": c_int64, "aria_decode_scratch_bytes": c_int64, "aria_decode_graph_create": c_void_p,
             "aria_decode_graph_destroy": None, "aria_decode_attn_workspace_bytes": c_int64}  # everything else returns an int status
 
 # name -> argtypes (all return int).  Kept in one table so tests can check that the shared
@@ -33,8 +33,7 @@ SIGNATURES = {
     "aria_last_attn_bwd_variant": [],
     "aria_last_attn_fwd_variant": [],
     "aria_decode_scratch_bytes": [P],
-    "aria_decode_stream_supported": [P],
-    "aria_decode_stream_sync_offset": [P],
+    "aria_decode_trace_layout": [P, P],
     "aria_decode_token": [P, P, F32, P],
     "aria_decode_route": [P, I64, I64, P, P, P],
     "aria_sample_topk": [P, P, I64, I64, F32, P, P],

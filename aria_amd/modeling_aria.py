@@ -262,10 +262,26 @@ class AriaForConditionalGeneration(nn.Module):
             inputs_embeds = self.language_model.model.embed(input_ids)                       # :250
         image_features = None
         if pixel_values is not None:
-            image_features = self.image_features(pixel_values, pixel_mask)                   # :254-262
             is_img = input_ids == self.config.image_token_index
-            if validate_image_tokens:                                                        # :265-271 (one host sync)
-                n_tok = int(is_img.sum().item())
+            pending = None
+            if validate_image_tokens and is_img.is_cuda:
+                # :265-271 is `.sum().item()`: a host sync in the middle of forward.  Same check, same ValueError, no stall of the GPU: the count
+                # is enqueued FIRST and copied to pinned memory, the ViT + projector (hundreds of launches) are enqueued behind it, and the
+                # host reads the count after that -- by then it has long arrived, and the device has the whole tower queued while we look.
+                host = getattr(self, "_img_count_host", None)
+                if host is None:
+                    host = torch.empty(1, dtype=torch.int64).pin_memory()
+                    object.__setattr__(self, "_img_count_host", host)
+                host.copy_(is_img.sum().view(1), non_blocking=True)
+                pending = torch.cuda.Event()
+                pending.record()
+            image_features = self.image_features(pixel_values, pixel_mask)                   # :254-262
+            if validate_image_tokens:
+                if pending is not None:
+                    pending.synchronize()
+                    n_tok = int(host[0])
+                else:
+                    n_tok = int(is_img.sum().item())
                 n_feat = image_features.shape[0] * image_features.shape[1]
                 if n_tok != n_feat:
                     raise ValueError(f"Image features and image tokens do not match: tokens: {n_tok}, features {n_feat}")

@@ -264,6 +264,8 @@ def gemm_qkv_rope_cache(x: torch.Tensor, wqkv: torch.Tensor, freqs_cis: torch.Te
         raise ValueError("gemm_qkv_rope_cache: caches and freqs_cis must be contiguous")
     if M % S or M // S > k_cache.shape[0]:
         raise ValueError("gemm_qkv_rope_cache: rows must be whole sequences that fit the cache's batch")
+    if S > k_cache.shape[1]:
+        raise ValueError(f"gemm_qkv_rope_cache: {S} positions do not fit a cache of {k_cache.shape[1]} slots (setup_caches first)")
     if pos32 is not None:
         _chk(pos32, torch.int32, "pos32")
         assert pos32.is_contiguous() and pos32.numel() == M

@@ -331,14 +331,11 @@ int aria_cross_entropy(const void* logits, const int32_t* labels, float* loss_su
 #define ARIA_DECODE_LAYER_PTRS 13
 int64_t aria_decode_scratch_bytes(const int64_t* dims);
 int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, void* stream);
-/* ARIA_DECODE_STREAM=1: aria_decode_token enqueues the token as ONE launch (decode_stream_kernel, csrc/decode.hip: the same stages as
- * workgroups of one grid, ordered by tickets and per-stage completion counters, each requesting its weight rows before it waits for its
- * input) where the widths have an instantiation -- _supported tells (1 / 0; it also depends on ARIA_DECODE_FUSE / ARIA_DECODE_SPLIT_KV, which
- * select launch-schedule forms the streamed one does not reproduce).  Results equal the launch schedule's bit for bit.  _sync_offset: byte
- * offset, inside the scratch buffer, of the schedule's int32 words -- [0] tickets handed out by the last token, [1] STICKY error (0 = none,
- * 1 = a dependency wait timed out: the logits of that token are wrong and the caller must not use them). */
-int aria_decode_stream_supported(const int64_t* dims);
-int64_t aria_decode_stream_sync_offset(const int64_t* dims);
+/* Where, inside the scratch buffer, the last aria_decode_token call left every layer's routing record (TopKRouter of
+ * gptfast/model.py:355-366 as the engine evaluated it): out[0], out[1] = byte offset and per-layer byte stride of the router logits (bf16 [L][E]),
+ * out[2], out[3] = the chosen expert ids (int32 [L][top_k]), out[4], out[5] = their scores (bf16 [L][top_k]).  Read by the full-depth parity
+ * case, which forces the oracle onto the engine's routing (tests/fullwidth_cases.py::case_decode_full_depth). */
+int aria_decode_trace_layout(const int64_t* dims, int64_t* out);
 /* sample() of gptfast/generate.py:35-58 for one token as ONE launch: keep the logits >= the top_k-th largest (ties kept; top_k <= 0 or >= V:
  * all), p_i ~ exp((l_i - max) / max(temperature, 1e-5)), out[0] = argmax_i p_i / q_i with q [V] fp32 the caller's Exp(1) draws
  * (multinomial_sample_one_no_sync's trick: the caller's generator stays the source of randomness).  logits bf16 [V]. */

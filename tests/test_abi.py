@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         g.build()
     lib = hip.HipLibrary(hip.LIB_PATH)
     assert lib.missing == []
-    assert lib.cdll.aria_abi_version() == 1
+    assert lib.cdll.aria_abi_version() == 2
 
 
 def test_missing_library_fails_loudly(tmp_path):

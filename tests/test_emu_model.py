@@ -250,19 +250,6 @@ def test_decode_engine_fused_schedule_aria_width():
     M.case_decode_engine_fused_schedule(DEV, aria_width=True, n_tokens=2)
 
 
-@pytest.mark.parametrize("head_dim", [64, 128])
-def test_decode_engine_streamed_schedule_is_bit_identical(head_dim):
-    """ONE launch per token (tickets + stage counters) == the 6-launch schedule; the emulator hands tickets out in order, so an unmet
-    dependency would be a bug in the stage tables (the kernel records it in the error word the case checks)."""
-    M.case_decode_engine_streamed(DEV, n_tokens=4, head_dim=head_dim)
-
-
-@pytest.mark.skipif(__import__("os").environ.get("ARIA_SLOW_TESTS") != "1", reason="~5 min through the emulator; runs on hardware in "
-                    "tests/test_gpu_model.py, and here with ARIA_SLOW_TESTS=1")
-def test_decode_engine_streamed_schedule_aria_width():
-    M.case_decode_engine_streamed(DEV, aria_width=True, n_tokens=2)
-
-
 def test_frozen_lm_head_skips_its_weight_gradient(golden):
     """freeze_llm-style runs: with lm_head frozen the fused lm_head + CE node still returns the hidden-state gradient but no [V, D] GEMM."""
     from aria_amd import autograd as AG

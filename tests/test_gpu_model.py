@@ -60,10 +60,5 @@ def test_decode_engine_fused_schedule(aria_width):  # 6-launch decode schedule =
     M.case_decode_engine_fused_schedule(DEV, aria_width=aria_width, n_tokens=6 if aria_width else 4)
 
 
-@pytest.mark.parametrize("aria_width,head_dim", [(False, 64), (False, 128), (True, 128)])
-def test_decode_engine_streamed_schedule(aria_width, head_dim):  # one launch per token == the 6-launch schedule, bit for bit, no missed wait
-    M.case_decode_engine_streamed(DEV, aria_width=aria_width, n_tokens=12 if aria_width else 8, head_dim=head_dim)
-
-
 def test_lora_linear_lm():  # last on purpose: newest composition of already-covered kernels
     M.case_lora_linear_lm(DEV)

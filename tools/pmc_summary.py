@@ -1,8 +1,8 @@
-"""gpurun_out/r04_pmc_<target>_*.csv (tools/gpu_r4_pmc.sh) -> profiles/r04_pmc_<target>.json: per-launch averages per kernel, HBM-side bytes with
+"""gpurun_out/<tag>_pmc_<target>_*.csv (tools/gpu_pmc.sh <tag> ...) -> profiles/<round>_pmc_<target>.json: per-launch averages per kernel, HBM-side bytes with
 the guide's gfx950 correction (/opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section: FETCH_SIZE is reported in KB and undercounts
 16-byte-per-lane streams by 2x on gfx950; WRITE_SIZE in KB as reported), L2 hit rate, MFMA busy.
 
-    python tools/pmc_summary.py fc1 [attn_bwd vit_fwd]"""
+    python tools/pmc_summary.py <tag> <round, e.g. r05> fc1 [attn_bwd vit_fwd]"""
 import collections
 import csv
 import glob
@@ -25,10 +25,11 @@ def short(name):
     return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()[:80]
 
 
-for target in sys.argv[1:]:
+TAG, ROUND = sys.argv[1], sys.argv[2]
+for target in sys.argv[3:]:
     pat, alg, alg_note = ALG[target]
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(root, "gpurun_out", f"r04_pmc_{target}_*.csv")):
+    for f in glob.glob(os.path.join(root, "gpurun_out", f"{TAG}_pmc_{target}_*.csv")):
         for r in csv.DictReader(open(f)):
             if pat in r["Kernel_Name"]:
                 vals[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -42,7 +43,7 @@ for target in sys.argv[1:]:
             k["l2_hit_rate"] = round(a["TCC_HIT_sum"] / max(1.0, a["TCC_HIT_sum"] + a["TCC_MISS_sum"]), 4)
         kernels[kname] = k
     total = sum(k.get("hbm_bytes_per_launch", 0) for k in kernels.values())
-    out = {"target": target, "what": f"rocprofv3 --pmc, separate passes, --kernel-trace only (tools/gpu_r4_pmc.sh -> tools/pmc_targets.py {target})",
+    out = {"target": target, "what": f"rocprofv3 --pmc, separate passes, --kernel-trace only (tools/gpu_pmc.sh -> tools/pmc_targets.py {target})",
            "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_note": alg_note, "hbm_bytes_per_launch_all_kernels": total,
            "traffic_over_algorithmic": round(total / alg, 3) if total else None, "kernels": kernels,
            "notes": ["FETCH_SIZE (KB) doubled per the guide's gfx950 correction; it counts the L2s' fabric-side requests (infinity-cache hits included): an "
@@ -52,5 +53,5 @@ for target in sys.argv[1:]:
 
         out["kernel_tag"] = bench.PMC_KERNEL_TAG
         out["hbm_bytes_per_launch"] = total
-    json.dump(out, open(os.path.join(root, "profiles", f"r04_pmc_{target}.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(root, "profiles", f"{ROUND}_pmc_{target}.json"), "w"), indent=1)
     print(json.dumps(out, indent=1)[:3000])

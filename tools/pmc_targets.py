@@ -1,4 +1,4 @@
-"""Targets of the round-4 PMC passes (tools/gpu_r4_pmc.sh: rocprofv3 --pmc in separate runs, --kernel-trace only): each launches ONE kernel class
+"""Targets of the round-4 PMC passes (tools/gpu_pmc.sh: rocprofv3 --pmc in separate runs, --kernel-trace only): each launches ONE kernel class
 of the step a few times at the step's shape.
 
     python tools/pmc_targets.py fc1        # experts.fc1 + SwiGLU epilogue, config #3 shape (the bench's roofline kernel)
