@@ -157,6 +157,26 @@ class AriaStaticKVCache:
         self.ensure_rows(batch)
         for r in self.rows:
             r.pads = 0
+        # Rows beyond the first are B - 1 full per-layer caches (19 GB each at 64K positions) + an engine each.  They stay pooled on the twin
+        # for the next call of equal geometry only while they are small; a pool beyond ARIA_HF_CACHE_POOL_GB (default 8) is released when
+        # this cache object is dropped.
+        import os
+        import weakref
+
+        token = object()
+        twin._hf_cache_owner = token
+        limit = float(os.environ.get("ARIA_HF_CACHE_POOL_GB", "8")) * 1e9
+        weakref.finalize(self, AriaStaticKVCache._trim_pool, weakref.ref(twin), token, limit)
+
+    @staticmethod
+    def _trim_pool(twin_ref, token, limit_bytes):
+        twin = twin_ref()
+        pool = getattr(twin, "_hf_cache_rows", None) if twin is not None else None
+        if not pool or getattr(twin, "_hf_cache_owner", None) is not token:   # a newer cache object uses the pool now
+            return
+        extra = sum(kv.k.numel() * kv.k.element_size() * 2 for row in pool[1:] for kv in row.kv)
+        if extra > limit_bytes:
+            del pool[1:]
 
     def ensure_rows(self, batch: int):
         from . import gptfast as G
@@ -444,6 +464,15 @@ class AriaForConditionalGeneration(AriaPretrainedModel, GenerationMixin):
         beams = kwargs.get("num_beams", getattr(gc, "num_beams", 1)) or 1
         servable = (use_cache is not False and kwargs.get("past_key_values") is None and torch.is_tensor(input_ids) and input_ids.dim() == 2
                     and input_ids.shape[0] >= 1 and not self.training and kwargs.get("assistant_model") is None)
+        if servable and am is None:
+            # no mask given: HF will INFER one from the pad tokens (GenerationMixin._prepare_attention_mask_for_generation: inputs != pad when a
+            # pad token is set, occurs in the prompt and is not also an eos token) -- decide on that mask, not on "no mask" (a
+            # right-padded prompt without a mask raised NotImplementedError in the middle of generation instead of running cache-free)
+            pad = kwargs.get("pad_token_id", getattr(gc, "pad_token_id", None))
+            eos = kwargs.get("eos_token_id", getattr(gc, "eos_token_id", None))
+            eos = [] if eos is None else ([int(e) for e in eos] if isinstance(eos, (list, tuple)) else [int(eos)])
+            if pad is not None and int(pad) not in eos and bool((input_ids == int(pad)).any()):
+                am = input_ids.ne(int(pad)).long()
         if servable:
             pads = self.left_pads(am, *input_ids.shape)
             servable = pads is not None and max(pads) < input_ids.shape[1]

@@ -554,8 +554,8 @@ def vit_embeddings(pixel_values: Tensor, patch_mask: Tensor, w: Dict[str, Tensor
     x = F.conv2d(pixel_values, w[prefix + "patch_embedding.weight"], w[prefix + "patch_embedding.bias"],
                  stride=cfg.patch_size)
     x = x.flatten(2).transpose(1, 2)
-    ids = vit_position_ids(patch_mask, cfg.image_size // cfg.patch_size)
-    return x + w[prefix + "position_embedding.weight"][ids]
+    ids = vit_position_ids(patch_mask.cpu(), cfg.image_size // cfg.patch_size).to(x.device)   # (integer bookkeeping on the host; the
+    return x + w[prefix + "position_embedding.weight"][ids]                                    # arithmetic follows the device of its inputs)
 
 
 def vit_encoder_layer(x: Tensor, key_padding: Optional[Tensor], w: Dict[str, Tensor], prefix: str,
@@ -587,7 +587,7 @@ def vit_forward(pixel_values: Tensor, pixel_mask: Optional[Tensor], w: Dict[str,
     B = pixel_values.shape[0]
     n = pixel_values.shape[2] // cfg.patch_size
     if pixel_mask is None:
-        patch_mask = torch.ones(B, n, pixel_values.shape[3] // cfg.patch_size, dtype=torch.bool)
+        patch_mask = torch.ones(B, n, pixel_values.shape[3] // cfg.patch_size, dtype=torch.bool, device=pixel_values.device)
         key_padding = None
     else:
         patch_mask = vit_patch_mask(pixel_mask, cfg.patch_size)

@@ -97,3 +97,24 @@ def test_prefill_gptfast_case_small_with_the_fused_qkv_epilogue(monkeypatch):
     calls.clear()
     F.case_prefill_gptfast("cpu", "emu_prefill_k7_off", **kw)
     assert calls == [] and F.REPORT["emu_prefill_k7_off"]["last-position logits"] == fused
+
+
+# ---------------------------------------------------------------- the full-depth cases' own logic at toy width (hardware: 28 / 27 layers)
+def test_lm_full_depth_case_small():
+    F.case_lm_full_depth("cpu", "emu_lm_depth", hidden=128, heads=2, experts=8, topk=2, inter=128, vocab=160, layers=4, S=24, grad_layers=(0, 2, 3),
+                         block_tol=3e-2, grad_tol=(1.5e-1, 4e-1), expect_big_gemm=False)
+    rep = F.REPORT["emu_lm_depth"]
+    assert len(rep["hidden_state_growth"]) == 4 and rep["gradients_compared"] == 39 and "bf16_reference_logits" in rep
+
+
+def test_vit_full_depth_case_small():
+    F.case_vit_full_depth("cpu", "emu_vit_depth", hidden=144, heads=2, inter=96, image=70, layers=3, queries=4, out_dim=64, n_images=2, valid_rows=40,
+                          tol=(6e-2, 2e-1), oracle_device="cpu")
+    assert F.REPORT["emu_vit_depth_oracle_pin"]["projector (device fp32 vs host fp32)"]["rel_l2"] == 0.0
+
+
+def test_decode_full_depth_case_small():
+    F.case_decode_full_depth("cpu", "emu_decode_depth", hidden=128, heads=2, experts=8, topk=2, inter=128, vocab=160, layers=3, prompt=20,
+                             new_tokens=4, block_tol=4e-2)
+    rep = F.REPORT["emu_decode_depth"]
+    assert len(rep["tokens"]) == 4 and "step04 logits" in rep and "router.layer2" in F.REPORT["emu_decode_depth (decode steps)"]

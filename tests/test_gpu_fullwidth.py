@@ -100,3 +100,22 @@ def test_config4_prefill_53248_two_layers():
 def test_grouped_gemm_operands_beyond_2g():
     """``gemm3_kernel<.., .., 3 / 5 / 6>`` on 430 080 expert rows: every operand crosses 2^31 bytes."""
     F.case_grouped_gemm_beyond_2g(DEV, "grouped_gemm_beyond_2g")
+
+
+# ---------------------------------------------------------------- FULL DEPTH (VERDICT r4 next #1): what every published number is measured on
+def test_lm_28_layers_aria_width_S2048():
+    """28-layer AriaMoELMForCausalLM at Aria's widths and vocabulary, B = 1, S = 2048: eval logits, the hidden state after every layer (the
+    growth curve goes into the report), training loss, gradients of layers 0 / 13 / 27 + embedding + final norm + lm_head; fp32 oracle on
+    the device (pinned on the host oracle in this process), a bf16 run of the oracle code as the third arm."""
+    F.case_lm_full_depth(DEV, "lm_28layers_S2048", oracle_device=DEV)
+
+
+def test_vit_27_layers_980px_and_projector():
+    """27-layer ViT + the 256-query projector on two 980-px images, one padded in rows and columns."""
+    F.case_vit_full_depth(DEV, "vit_27layers_980px", oracle_device=DEV)
+
+
+def test_config2_28_layers_prefill_and_16_decode_engine_steps():
+    """Config #2 at full depth: a 280-position prefill, then 16 greedy decode-engine steps; every step's logits vs the oracle over the
+    growing sequence, the token stream checked wherever the oracle's margin is resolvable, the engine's per-layer routing forced."""
+    F.case_decode_full_depth(DEV, "config2_28layers_prefill280_decode16", oracle_device=DEV)
