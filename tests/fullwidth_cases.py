@@ -696,13 +696,15 @@ class _LayerOutputs:
 
 
 def _depth_tol(base, layer, layers):
-    """rel-L2 bound of the hidden state after ``layer`` + 1 of ``layers`` blocks: independent per-block rounding adds in quadrature, so the
-    bound grows like sqrt(depth) from the shallow cases' measured one-block level (base ~ 1e-2)."""
-    return base * (1.0 + layer) ** 0.5
+    """rel-L2 bound of the hidden state after ``layer`` + 1 of ``layers`` blocks.  Measured on MI355X (profiles/r05_fullwidth_parity.json,
+    28 layers, S = 2048): 1.10e-2 after block 0, 1.77e-2 after 3, 2.51e-2 after 12, 2.97e-2 after 27 -- slower than the sqrt(depth) of
+    independent per-block roundings (every RMSNorm renormalises the stream, and the residual stream's norm grows with depth while a
+    block's rounding error does not): (depth) ** 0.3 fits the curve to 5 %; ``base`` = 1.5 x the one-block level."""
+    return base * (1.0 + layer) ** 0.3
 
 
 def case_lm_full_depth(dev, case, *, hidden=2560, heads=20, experts=64, topk=6, inter=1664, vocab=100352, layers=28, S=2048,
-                       grad_layers=(0, 13, 27), seed=61, oracle_device=None, block_tol=1.2e-2, grad_tol=(8e-2, 2.5e-1), expect_big_gemm=True,
+                       grad_layers=(0, 13, 27), seed=61, oracle_device=None, block_tol=1.7e-2, grad_tol=(7e-2, 1.2e-1), expect_big_gemm=True,
                        bf16_arm=True):
     """``layers``-layer AriaMoELMForCausalLM at Aria's widths, B = 1: eval logits, per-layer hidden states, training loss, and the gradients of
     the chosen layers + embedding + final norm + lm_head, vs O.lm_forward in fp32 (moe_lm.py:548-661) on the same bf16-rounded weights.
@@ -794,9 +796,9 @@ def case_lm_full_depth(dev, case, *, hidden=2560, heads=20, experts=64, topk=6, 
                       require_safe=False)
     for i in range(layers):
         assert curve[i]["device_rel_l2"] <= _depth_tol(block_tol, i, layers), (case, "hidden state", curve[i], _depth_tol(block_tol, i, layers))
-    check(case, "logits", got_logits, want_logits, _depth_tol(block_tol, layers - 1, layers), 4 * _depth_tol(block_tol, layers - 1, layers))
-    if ref_h is not None:   # the device is no further from fp32 than twice what the reference's own bf16 arithmetic is
-        assert rep["logits"]["rel_l2"] <= 2.0 * rep["bf16_reference_logits"]["rel_l2"] + 5e-3, (rep["logits"], rep["bf16_reference_logits"])
+    check(case, "logits", got_logits, want_logits, _depth_tol(block_tol, layers - 1, layers), 2 * _depth_tol(block_tol, layers - 1, layers))
+    if ref_h is not None:   # the device is no further from fp32 than 1.25 x what the reference's own bf16 arithmetic is (measured: 0.90 x)
+        assert rep["logits"]["rel_l2"] <= 1.25 * rep["bf16_reference_logits"]["rel_l2"] + 2e-3, (rep["logits"], rep["bf16_reference_logits"])
     del dev_h, ref_h, lo
 
     # ---- oracle, training: loss + the chosen gradients (aux losses on), on the training pass's routing
@@ -817,7 +819,7 @@ def case_lm_full_depth(dev, case, *, hidden=2560, heads=20, experts=64, topk=6, 
 
 
 def case_vit_full_depth(dev, case, *, hidden=1152, heads=16, inter=4304, image=980, layers=27, queries=256, out_dim=2560, n_images=2,
-                        valid_rows=735, seed=63, oracle_device=None, tol=(4e-2, 1.5e-1), pin_tol=2e-4):
+                        valid_rows=735, seed=63, oracle_device=None, tol=(2e-2, 5e-2), pin_tol=2e-4):
     """The 27-layer Idefics2 tower + the 256-query projector on 980-px images (image 0 padded in rows and columns): valid-patch features of
     the frozen fast path and of the module path, and the projector output, vs O.vit_forward / O.projector_forward in fp32
     (vision_encoder.py:94-152, projector.py:160-189).  With ``oracle_device`` the oracle runs on that device AFTER a one-layer, one-image
@@ -870,7 +872,7 @@ def case_vit_full_depth(dev, case, *, hidden=1152, heads=16, inter=4304, image=9
 
 
 def case_decode_full_depth(dev, case, *, hidden=2560, heads=20, experts=64, topk=6, inter=1664, vocab=100352, layers=28, prompt=280,
-                           new_tokens=16, seed=65, oracle_device=None, block_tol=1.2e-2, expect_engine=True):
+                           new_tokens=16, seed=65, oracle_device=None, block_tol=1.7e-2, expect_engine=True):
     """BASELINE config #2's path at full depth: the gptfast surface prefills ``prompt`` positions into its static bf16 KV cache, then the
     decode engine (aria_decode_token) produces ``new_tokens`` tokens greedily, one call each (gptfast/generate.py:71-110, model.py:178-234,
     318-325, 413-447).  After every step the engine's logits are compared with the fp32 oracle run over the WHOLE sequence so far
@@ -978,4 +980,4 @@ def case_decode_full_depth(dev, case, *, hidden=2560, heads=20, experts=64, topk
     rep["tokens_checked_on_resolvable_margin"] = margins_ok
     tol = _depth_tol(block_tol, layers - 1, layers)
     for t, m in enumerate(errs):
-        assert m["rel_l2"] <= tol and m["max_rel"] <= 4 * tol and m["cos"] >= 1 - 2 * tol * tol, (case, t, m, tol)
+        assert m["rel_l2"] <= tol and m["max_rel"] <= 2 * tol and m["cos"] >= 1 - 2 * tol * tol, (case, t, m, tol)
