@@ -681,6 +681,105 @@ int aria_gemm_dswiglu_bf16(const void* dY, const void* B, const void* H, void* D
     return g_last_variant = 3, aria_launch_gemm3(p, 0, b_oc ? 1 : 0, int((M + 255) / 256), stream);
 }
 
+// ---- LoRA as a K-extension of the base GEMM (GemmParams::ext_k; aria/lora/layers.py:129-139, peft's Linear adapter): v3 only -- shapes the
+// 256 x 256 kernels do not take return ARIA_ERR_UNSUPPORTED and the caller runs the adapter as launches of its own
+static int lora_ext(GemmParams& p, const void* EA, const void* EB, int64_t ext_k, int64_t ld_ea, int64_t ld_eb, int64_t stride_eb) {
+    if (!EA || !EB || ext_k <= 0) return ARIA_ERR_INVALID;
+    if (ext_k > 64 || (ext_k & 7) || (p.K % 64) || p.K < 64) return ARIA_ERR_UNSUPPORTED;
+    if (!aligned16(EA) || !aligned16(EB) || (ld_ea & 7) || (ld_eb & 7) || (stride_eb & 7)) return ARIA_ERR_ALIGN;
+    p.extA = static_cast<const bf16_t*>(EA);
+    p.extB = static_cast<const bf16_t*>(EB);
+    p.ext_k = int(ext_k);
+    p.ld_extA = ld_ea, p.ld_extB = ld_eb, p.stride_extB = stride_eb;
+    return ARIA_OK;
+}
+
+int aria_gemm_lora_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int b_oc, int64_t lda, int64_t ldb, int64_t ldc,
+                        const void* EA, const void* EB, int64_t ext_k, int64_t ld_ea, int64_t ld_eb, void* stream) {
+    if (!A || !B || !C || M < 0 || N <= 0 || K <= 0) return ARIA_ERR_INVALID;
+    if (!aligned16(A) || !aligned16(B) || (lda & 7) || (ldb & 7) || (K & 7) || (N & 1) || (ldc & 1) || (b_oc && (N & 7))) return ARIA_ERR_ALIGN;
+    if (M == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A), p.B = static_cast<const bf16_t*>(B), p.C = C;
+    p.lda = lda, p.ldb = ldb, p.ldc = ldc;
+    p.M = int(M), p.N = int(N), p.K = int(K);
+    p.mode = 0;
+    p.ntn = int((N + BN - 1) / BN);
+    const int rc = lora_ext(p, EA, EB, ext_k, ld_ea, ld_eb, 0);
+    if (rc != ARIA_OK) return rc;
+    const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
+    if (!use_v3(t256, K, 2 * M * lda, 2 * (b_oc ? K * ldb : N * ldb), M, N) || 2 * lda >= (1ll << 24) || 2 * ldb >= (1ll << 24))
+        return ARIA_ERR_UNSUPPORTED;
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, b_oc ? 1 : 0, int((M + 255) / 256), stream);
+}
+
+int aria_gemm_swiglu_lora_bf16(const void* A, const void* B, void* H, void* ACT, int64_t M, int64_t N2, int64_t K, int64_t lda, int64_t ldb,
+                               int64_t ldh, int64_t ldact, const void* EA, const void* EB, int64_t ext_k, int64_t ld_ea, int64_t ld_eb,
+                               void* stream) {
+    int rc = glu_check(A, B, H, ACT, M, N2, K, lda, ldb, ldh, ldact);
+    if (rc != ARIA_OK) return rc;
+    if (2 * M * lda >= (1ll << 32) || 2 * N2 * ldb >= (1ll << 32)) return ARIA_ERR_UNSUPPORTED;
+    if (M == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A), p.B = static_cast<const bf16_t*>(B);
+    p.C = H, p.C2 = ACT;
+    p.lda = lda, p.ldb = ldb, p.ldc = ldh, p.ldc2 = ldact;
+    p.M = int(M), p.N = int(N2), p.K = int(K);
+    p.mode = 0;
+    p.glu = 1;
+    rc = lora_ext(p, EA, EB, ext_k, ld_ea, ld_eb, 0);
+    if (rc != ARIA_OK) return rc;
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int((M + 255) / 256), stream);
+}
+
+int aria_grouped_gemm_lora_bf16(const void* A, const void* B, void* C, const int32_t* offsets, int64_t E, int64_t M_total, int64_t N, int64_t K,
+                                int b_oc, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldc, const void* EA, const void* EB, int64_t ext_k,
+                                int64_t ld_ea, int64_t ld_eb, int64_t stride_eb, void* stream) {
+    if (!A || !B || !C || !offsets || E <= 0 || M_total < 0 || N <= 0) return ARIA_ERR_INVALID;
+    if (!aligned16(A) || !aligned16(B) || (lda & 7) || (ldb & 7) || (K & 7) || (N & 7) || (strideB & 7) || (ldc & 1)) return ARIA_ERR_ALIGN;
+    if (M_total == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A), p.B = static_cast<const bf16_t*>(B), p.C = C;
+    p.lda = lda, p.ldb = ldb, p.ldc = ldc;
+    p.M = int(M_total), p.N = int(N), p.K = int(K);
+    p.mode = 1;
+    p.offsets = offsets;
+    p.E = int(E);
+    p.strideB = strideB;
+    p.ntn = int((N + BN - 1) / BN);
+    const int rc = lora_ext(p, EA, EB, ext_k, ld_ea, ld_eb, stride_eb);
+    if (rc != ARIA_OK) return rc;
+    if (!use_v3((M_total / 256 + 1) * ((N + 255) / 256), K, 2 * M_total * lda, 2 * (b_oc ? K * ldb : N * ldb), M_total, N) ||
+        2 * lda >= (1ll << 24) || 2 * ldb >= (1ll << 24))
+        return ARIA_ERR_UNSUPPORTED;
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, b_oc ? 1 : 0, int(M_total / 256 + E), stream);
+}
+
+int aria_grouped_gemm_swiglu_lora_bf16(const void* A, const void* B, void* H, void* ACT, const int32_t* offsets, int64_t E, int64_t M_total,
+                                       int64_t N2, int64_t K, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldh, int64_t ldact,
+                                       const void* EA, const void* EB, int64_t ext_k, int64_t ld_ea, int64_t ld_eb, int64_t stride_eb,
+                                       void* stream) {
+    if (!offsets || E <= 0) return ARIA_ERR_INVALID;
+    int rc = glu_check(A, B, H, ACT, M_total, N2, K, lda, ldb, ldh, ldact);
+    if (rc != ARIA_OK) return rc;
+    if (strideB & 7) return ARIA_ERR_ALIGN;
+    if (2 * M_total * lda >= (1ll << 32) || 2 * K * ldb >= (1ll << 32)) return ARIA_ERR_UNSUPPORTED;
+    if (M_total == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A), p.B = static_cast<const bf16_t*>(B);
+    p.C = H, p.C2 = ACT;
+    p.lda = lda, p.ldb = ldb, p.ldc = ldh, p.ldc2 = ldact;
+    p.M = int(M_total), p.N = int(N2), p.K = int(K);
+    p.mode = 1;
+    p.offsets = offsets;
+    p.E = int(E);
+    p.strideB = strideB;
+    p.glu = 1;
+    rc = lora_ext(p, EA, EB, ext_k, ld_ea, ld_eb, stride_eb);
+    if (rc != ARIA_OK) return rc;
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, 1, int(M_total / 256 + E), stream);
+}
+
 int aria_grouped_gemm_wgrad_bf16(const void* A, const void* dY, void* dW, const int32_t* offsets, int64_t E, int64_t K,
                                  int64_t N, int64_t lda, int64_t ldy, int c_f32, int accumulate, void* stream) {
     if (!A || !dY || !dW || !offsets || E <= 0) return ARIA_ERR_INVALID;

@@ -201,6 +201,11 @@ struct Stage {  // everything a wave needs to issue its two DMA pieces of any ha
     // offsets of this lane's four A rows of the tile (half x piece) from the operand base at k = 0, chunk term included -- looked up ONCE per
     // tile (the rows of a tile do not change along k); dead fields in every other instantiation
     uint32_t ga[2][2];
+    // K-extension (GemmParams::ext_k): the LAST K-tile's sources.  ext = 0: off
+    int ext;
+    const char* eA;
+    const char* eB;
+    uint32_t ldeA2, ldeB2;
 };
 
 template <bool A_OC, bool B_OC, int OPERAND, int HALF, int BUF, bool TAIL = true, bool GATHER = false>
@@ -218,6 +223,12 @@ __device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
     const char* s0 = (GATHER && OPERAND == 0) ? g + st.ga[HALF][0] : g + ls.offset(0, first, limit, ld2);
     const char* s1 = (GATHER && OPERAND == 0) ? g + st.ga[HALF][1] : g + ls.offset(1, first, limit, ld2);
     if (TAIL && st.tail_k < BK && tile == st.nk - 1) {  // wave-uniform: the ragged end of the reduction -> granules past it read zeros
+        if (st.ext && !(GATHER && OPERAND == 0)) {  // K-extension tile: the adapter's operands, same lane <-> (row, reduction index) map
+            const char* e = OPERAND == 0 ? st.eA : st.eB;
+            const uint32_t le2 = OPERAND == 0 ? st.ldeA2 : st.ldeB2;
+            s0 = e + ls.offset(0, first, limit, le2);
+            s1 = e + ls.offset(1, first, limit, le2);
+        }
         // first reduction index (inside the tile) of this lane's 16 bytes, pieces 0 and 1
         const int k0 = OC ? ls.a : ls.b >> 1, k1 = OC ? ls.a + 4 : (ls.b ^ 64) >> 1;
         const int l = lane_id();
@@ -730,7 +741,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     } else if (!aria_tile_coords(p, blockIdx.x, p.split > 1 ? p.split_first : int(gridDim.x), tmi, tn)) {
         return;
     }
-    long long b_off = 0, c_off = 0;
+    long long b_off = 0, c_off = 0, e_off = 0;
     int m0 = 0, m_end = 0, k_begin = 0, k_len = p.K;
     const int bn_step = p.glu ? 128 : BN;  // fused SwiGLU: a tile covers 128 gate + the matching 128 up columns
     int n0 = tn * bn_step;
@@ -750,10 +761,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         int expert = 0;
         if (!aria_grouped_tile(p, blockIdx.x, l, expert, m0, m_end, tn)) return;
         n0 = tn * bn_step;
-        b_off = (long long)(p.expert_mod > 0 ? expert % p.expert_mod : expert) * p.strideB;
+        const int ew = p.expert_mod > 0 ? expert % p.expert_mod : expert;
+        b_off = (long long)ew * p.strideB;
+        e_off = (long long)ew * p.stride_extB;
     }
     char* C = static_cast<char*>(p.C) + c_off * (p.c_f32 ? 4 : 2);
     int nk = (k_len + BK - 1) / BK, kt_first = 0;
+    const int ext_k = (A_OC || p.mode == 2) ? 0 : p.ext_k;  // (launcher: never with split-K, gathered rows, or the split gate / up form)
+    if (ext_k > 0) nk += 1;                                 // K % 64 == 0 there: the extension is one more K-tile with ext_k valid indices
     const int nk_all = nk;
     if (slab >= 0) {  // K-steps [nk * ks / split, nk * (ks + 1) / split)
         kt_first = int((long long)nk * ks / p.split);
@@ -781,6 +796,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     st.g0 = 0;
     st.nk = nk;
     st.tail_k = (kt_first + nk == nk_all && nk_all > 0) ? k_len - (nk_all - 1) * BK : BK;  // only the overall last K-tile is ragged
+    st.ext = ext_k;
+    if (ext_k > 0) {
+        st.tail_k = ext_k;
+        st.eA = reinterpret_cast<const char*>(p.extA);
+        st.eB = reinterpret_cast<const char*>(p.extB + e_off);
+        st.ldeA2 = uint32_t(2 * p.ld_extA);
+        st.ldeB2 = uint32_t(2 * p.ld_extB);
+    }
     st.m0 = (ARIA_ABL & 2048) ? 0 : m0;  // (timing experiment: every workgroup loads tile (0, 0)'s operands -- all L2 hits)
     st.n0 = (ARIA_ABL & 2048) ? 0 : n0;
     FragAddr<A_OC> aa;
@@ -941,7 +964,7 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     q.split_first = 0;
     q.ws = nullptr;
     long long R = 0;
-    if (p.mode == 0 && workspace && !p.glu) {
+    if (p.mode == 0 && workspace && !p.glu && !p.ext_k) {
         const int S = plan_split((long long)ntn * ntm, (p.K + BK - 1) / BK, &R);
         if (S > 1 && workspace_bytes >= R * S * (long long)(BM * BN) * 4) {
             q.split = S;
@@ -963,6 +986,14 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     if (q.wide_store && !(wsd && wsd[0] == '1')) q.wide_store = 2;  // row form (whole tile parked, complete 512-byte rows per store): +0.6..2.9 % over the per-wave form (=1)
     if (ntn * ntm <= 0) return ARIA_OK;
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
+    if (p.ext_k) {  // K-extension: whole K-tiles in front of it, 16-byte granules, neither split-K nor the forms whose loaders it does not cover
+        if (!p.extA || !p.extB || p.ext_k < 0 || p.ext_k > BK || (p.ext_k & 7) || (p.K % BK) || a_oc || p.mode == 2 || p.gather_rows || p.rope_fc ||
+            (p.glu && p.glu_up_rows > 0) || (p.ld_extA & 7) || (p.ld_extB & 7) || (p.stride_extB & 7) ||
+            (reinterpret_cast<uintptr_t>(p.extA) & 15) || (reinterpret_cast<uintptr_t>(p.extB) & 15) ||
+            2 * (long long)p.M * p.ld_extA >= (1ll << 32) || 2 * p.ld_extA >= (1ll << 24) || 2 * p.ld_extB >= (1ll << 24) ||
+            2 * (b_oc ? (long long)p.ext_k : (long long)p.N) * p.ld_extB >= (1ll << 32))
+            return ARIA_ERR_INVALID;
+    }
     dim3 grid(unsigned(aria_tile_grid(q)), grid_y), block(512);
     if (p.rope_fc) {  // fused wqkv projection (K7): dense, both operands k-contiguous, whole column tiles
         if (a_oc || b_oc || p.mode != 0 || p.glu || p.dglu || p.c_f32 || p.accumulate || p.bias || p.act || (p.N % BN) || (p.rope_D % BN)) return ARIA_ERR_INVALID;

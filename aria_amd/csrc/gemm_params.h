@@ -57,6 +57,16 @@ struct GemmParams {
     // grouped rows whose groups are SEGMENTS of an expert-parallel exchange (rows arrive ordered (source rank, local expert)): group g uses
     // the weight of expert g % expert_mod (0: group g uses weight g).  The all-to-all's output is consumed in arrival order, no re-order pass.
     int expert_mod;
+    // v3, K-EXTENSION (LoRA inside the base GEMM; GroupedGemmLoraLayer.forward aria/lora/layers.py:129-139, peft's Linear adapter):
+    //   C = A B + extA extB, the second product carried by ONE extra K-tile behind the reduction: its DMA granules take their 16 bytes from
+    //   extA [M, ext_k] (k-contiguous rows, like A) and from extB (the B operand's own form: [N, ext_k] rows for k-contiguous weights,
+    //   [ext_k, N] for [K, N] weights; per expert at stride_extB) wherever the reduction index is < ext_k and from the zero page beyond --
+    //   the mechanism of the ragged last K-tile.  ext_k % 8 == 0, <= 64; K % 64 == 0; every epilogue (SwiGLU, SwiGLU backward, wide
+    //   stores) sees base + adapter in its accumulators, rounded ONCE.  0 = off: the kernels' steady-state code does not read these fields.
+    const ad::bf16_t* extA;
+    const ad::bf16_t* extB;
+    long long ld_extA, ld_extB, stride_extB;
+    int ext_k;
 };
 // (the device helpers below are templates on the block's type so that a kernel may also hand them the block where it lies in the
 // kernarg segment -- a reference into the constant address space: scalar loads at the point of use instead of registers held live)

@@ -53,6 +53,10 @@ SIGNATURES = {
     "aria_grouped_gemm_swiglu_split_bf16": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, P],
     "aria_grouped_gemm_seg_bf16": [P, P, P, P, I64, I64, I64, I64, I64, I32, I64, I64, I64, I64, P],
     "aria_grouped_gemm_swiglu_seg_bf16": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, P],
+    "aria_gemm_lora_bf16": [P, P, P, I64, I64, I64, I32, I64, I64, I64, P, P, I64, I64, I64, P],
+    "aria_gemm_swiglu_lora_bf16": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, P, P, I64, I64, I64, P],
+    "aria_grouped_gemm_lora_bf16": [P, P, P, P, I64, I64, I64, I64, I32, I64, I64, I64, I64, P, P, I64, I64, I64, I64, P],
+    "aria_grouped_gemm_swiglu_lora_bf16": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, P, P, I64, I64, I64, I64, P],
     "aria_gemm_qkv_rope_cache_bf16": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, P],
     "aria_grouped_gemm_swiglu_gather_bf16": [P, P, I64, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, P],
     "aria_grouped_gemm_swiglu_split_gather_bf16": [P, P, I64, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, P],

@@ -158,6 +158,100 @@ def gemm_swiglu(x: torch.Tensor, w: torch.Tensor, want_h: bool = True):
     return h, act
 
 
+# ------------------------------------------------------------------------------------------------ LoRA as a K-extension
+def _lora_ext_ok(K: int, ext_k: int) -> bool:
+    import os
+
+    return K % 64 == 0 and K >= 64 and 0 < ext_k <= 64 and ext_k % 8 == 0 and os.environ.get("ARIA_FUSE_LORA", "1") != "0"
+
+
+def _try_lora(name: str, *args) -> bool:
+    """Run a fused base + adapter entry; False when the library says the shape is not one the 256 x 256 kernels take (the caller then runs
+    base and adapter as two launches, the second accumulating) -- every other status raises."""
+    rc = getattr(hip.get_lib().cdll, name)(*args)
+    if rc == 3:   # ARIA_ERR_UNSUPPORTED
+        return False
+    if rc != 0:
+        raise hip.AriaHipError(f"{name} failed: {hip.ERRORS.get(rc, rc)}")
+    return True
+
+
+def gemm_lora(a: torch.Tensor, b: torch.Tensor, ea: torch.Tensor, eb: torch.Tensor, *, b_oc: bool = False) -> torch.Tensor:
+    """C = a b + ea eb in ONE launch (aria/lora/layers.py:129-139 for nn.Linear targets: base(x) + lora_B(scaling * lora_A(x))): a [M, K]; b
+    [N, K] (b_oc False: the Linear's weight; eb [N, r] = lora_B.weight) or [K, N] (b_oc True: the dgrad form; eb [r, N] = lora_A.weight); ea
+    [M, r] (scaling folded in by the caller).  Falls back to two launches (the second accumulating) on shapes the fused kernel does not take."""
+    _chk(a, name="a"), _chk(b, name="b"), _chk(ea, name="ea"), _chk(eb, name="eb")
+    lda, ldb = _rowmajor_2d(a, "a"), _rowmajor_2d(b, "b")
+    M, K = a.shape
+    N = b.shape[1] if b_oc else b.shape[0]
+    r = ea.shape[1]
+    if ea.shape[0] != M or eb.shape != ((r, N) if b_oc else (N, r)):
+        raise ValueError(f"gemm_lora: ea {tuple(ea.shape)} / eb {tuple(eb.shape)} do not extend a [{M}, {K}] x [{N}] product")
+    out = torch.empty((M, N), dtype=bf16, device=a.device)
+    if _lora_ext_ok(K, r) and _try_lora("aria_gemm_lora_bf16", _p(a), _p(b), _p(out), M, N, K, int(b_oc), lda, ldb, N, _p(ea), _p(eb), r,
+                                        _rowmajor_2d(ea, "ea"), _rowmajor_2d(eb, "eb"), _stream(a)):
+        return out
+    gemm(a, b, b_oc=b_oc, out=out)
+    return gemm(ea, eb, b_oc=b_oc, out=out, accumulate=True)
+
+
+def gemm_swiglu_lora(x: torch.Tensor, w: torch.Tensor, ea: torch.Tensor, eb: torch.Tensor, want_h: bool = True):
+    """``gemm_swiglu`` on base + adapter: h = x w^T + ea eb^T ([2I, r] eb), act = glu(h); one launch where the fused kernel takes the shape."""
+    _chk(x, name="x"), _chk(w, name="w"), _chk(ea, name="ea"), _chk(eb, name="eb")
+    M, K = x.shape
+    N2, r = w.shape[0], ea.shape[1]
+    if glu_fusable(K, N2) and _lora_ext_ok(K, r):
+        h = torch.empty((M, N2), dtype=bf16, device=x.device) if want_h else None
+        act = torch.empty((M, N2 // 2), dtype=bf16, device=x.device)
+        if _try_lora("aria_gemm_swiglu_lora_bf16", _p(x), _p(w), _p(h) if want_h else None, _p(act), M, N2, K, _rowmajor_2d(x, "x"),
+                     _rowmajor_2d(w, "w"), N2, N2 // 2, _p(ea), _p(eb), r, _rowmajor_2d(ea, "ea"), _rowmajor_2d(eb, "eb"), _stream(x)):
+            return h, act
+    h = gemm(x, w)
+    gemm(ea, eb, out=h, accumulate=True)
+    return (h if want_h else None), swiglu(h)
+
+
+def grouped_gemm_lora(a: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, ea: torch.Tensor, eb: torch.Tensor, *,
+                      w_is_kn: bool = True) -> torch.Tensor:
+    """experts_gemm on base + adapter (GroupedGemmLoraLayer.forward, aria/lora/layers.py:129-139): rows of expert e times (w[e] + the rank-r
+    product): w [E, K, N] with eb [E, r, N] (w_is_kn: forward, eb = lora_B.weight) or w [E, N, K] used transposed with eb [E, N, r]
+    (dgrad form, eb = lora_A.weight [E, K_in, r] read as [E, N, r]); ea [M, r]."""
+    _chk(a, name="a"), _chk(w, name="w"), _chk(offsets, torch.int32, "offsets"), _chk(ea, name="ea"), _chk(eb, name="eb")
+    if w.dim() != 3 or not w.is_contiguous() or eb.dim() != 3 or not eb.is_contiguous() or eb.shape[0] != w.shape[0]:
+        raise ValueError("grouped_gemm_lora: w and eb must be contiguous [E, ., .] tensors")
+    M, K = a.shape
+    E = w.shape[0]
+    N = w.shape[2] if w_is_kn else w.shape[1]
+    r = ea.shape[1]
+    if eb.shape[1:] != ((r, N) if w_is_kn else (N, r)) or ea.shape[0] != M:
+        raise ValueError(f"grouped_gemm_lora: eb {tuple(eb.shape)} does not extend [{E}, {K}, {N}] by rank {r}")
+    out = torch.empty((M, N), dtype=bf16, device=a.device)
+    if _lora_ext_ok(K, r) and _try_lora("aria_grouped_gemm_lora_bf16", _p(a), _p(w), _p(out), _p(offsets), E, M, N, K, int(w_is_kn),
+                                        _rowmajor_2d(a, "a"), w.shape[2], w.shape[1] * w.shape[2], N, _p(ea), _p(eb), r,
+                                        _rowmajor_2d(ea, "ea"), eb.shape[2], eb.shape[1] * eb.shape[2], _stream(a)):
+        return out
+    grouped_gemm(a, w, offsets, w_is_kn=w_is_kn, out=out)
+    return out.add_(grouped_gemm(ea, eb, offsets, w_is_kn=w_is_kn))
+
+
+def grouped_gemm_swiglu_lora(a: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, ea: torch.Tensor, eb: torch.Tensor, want_h: bool = True):
+    """``grouped_gemm_swiglu`` on base + adapter: fc1 + lora + glu in one launch (w [E, K, 2I], eb [E, r, 2I])."""
+    _chk(a, name="a"), _chk(w, name="w"), _chk(offsets, torch.int32, "offsets"), _chk(ea, name="ea"), _chk(eb, name="eb")
+    M, K = a.shape
+    E, _, N2 = w.shape
+    r = ea.shape[1]
+    if eb.shape != (E, r, N2) or not eb.is_contiguous():
+        raise ValueError("grouped_gemm_swiglu_lora: eb must be a contiguous [E, r, 2I] tensor")
+    if glu_fusable(K, N2) and _lora_ext_ok(K, r):
+        h = torch.empty((M, N2), dtype=bf16, device=a.device) if want_h else None
+        act = torch.empty((M, N2 // 2), dtype=bf16, device=a.device)
+        if _try_lora("aria_grouped_gemm_swiglu_lora_bf16", _p(a), _p(w), _p(h) if want_h else None, _p(act), _p(offsets), E, M, N2, K,
+                     _rowmajor_2d(a, "a"), N2, K * N2, N2, N2 // 2, _p(ea), _p(eb), r, _rowmajor_2d(ea, "ea"), N2, r * N2, _stream(a)):
+            return h, act
+    h = grouped_gemm_lora(a, w, offsets, ea, eb)
+    return (h if want_h else None), swiglu(h)
+
+
 def glu_split_fusable(w_gate: torch.Tensor, w_up: torch.Tensor) -> bool:
     """gate / up weights as two [.., I, K] tensors ([N, K] form, the gptfast wire format): the fused launch reaches the up rows as a ROW
     offset from the gate rows, so both must be contiguous views of one allocation with the up tensor a whole number of rows behind the gate

@@ -107,6 +107,29 @@ int aria_grouped_gemm_swiglu_split_gather_bf16(const void* X, const int32_t* row
                                                const int32_t* offsets, int64_t E, int64_t M_total, int64_t I, int64_t K, int64_t ldx, int64_t ldb,
                                                int64_t strideB, int64_t ldh, int64_t ldact, void* stream);
 
+/* SURVEY 8(f)3 -- LoRA fused into the base GEMM (GroupedGemmLoraLayer.forward aria/lora/layers.py:129-139: result = base(x) + lora_B(lora_A(
+ * dropout(x))) * scaling; peft's Linear adapter, same line for nn.Linear targets, recipes/config_lora.yaml:44-59).  The adapter's second
+ * projection rides in the base launch as a K-EXTENSION: C = A B + EA EB, with EA [M, ext_k] = scaling * lora_A(dropout(x)) (k-contiguous rows,
+ * leading dimension ld_ea) and EB the adapter's B factor in the base weight's own form -- b_oc = 0 ([N, K] weights, nn.Linear): EB [N, ext_k];
+ * b_oc = 1 ([K, N] weights, the experts): EB [ext_k, N], per expert at stride_eb.  One extra K-tile whose DMA granules come from EA / EB (zero
+ * page beyond ext_k): no output-sized add pass, no y + delta round trip, and the fused epilogues (SwiGLU) see base + adapter in ONE fp32
+ * accumulator, rounded once (the reference rounds base, adapter and sum separately: the fused result is the closer one to exact).  Several
+ * adapters that share an input (q / k / v; gate / up) go in as ONE extension: EA = their columns side by side, EB block-diagonal.
+ * ext_k % 8 == 0, <= 64; K % 64 == 0; shapes the 256 x 256 kernels do not take: ARIA_ERR_UNSUPPORTED (run base and adapter as separate
+ * launches, the second one accumulating).  The dgrad uses the same entries with (EA, EB) = (d_u, lora_A) when there is no dropout. */
+int aria_gemm_lora_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int b_oc, int64_t lda, int64_t ldb, int64_t ldc,
+                        const void* EA, const void* EB, int64_t ext_k, int64_t ld_ea, int64_t ld_eb, void* stream);
+int aria_gemm_swiglu_lora_bf16(const void* A, const void* B, void* H, void* ACT, int64_t M, int64_t N2, int64_t K, int64_t lda, int64_t ldb,
+                               int64_t ldh, int64_t ldact, const void* EA, const void* EB, int64_t ext_k, int64_t ld_ea, int64_t ld_eb,
+                               void* stream);
+int aria_grouped_gemm_lora_bf16(const void* A, const void* B, void* C, const int32_t* offsets, int64_t E, int64_t M_total, int64_t N, int64_t K,
+                                int b_oc, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldc, const void* EA, const void* EB, int64_t ext_k,
+                                int64_t ld_ea, int64_t ld_eb, int64_t stride_eb, void* stream);
+int aria_grouped_gemm_swiglu_lora_bf16(const void* A, const void* B, void* H, void* ACT, const int32_t* offsets, int64_t E, int64_t M_total,
+                                       int64_t N2, int64_t K, int64_t lda, int64_t ldb, int64_t strideB, int64_t ldh, int64_t ldact,
+                                       const void* EA, const void* EB, int64_t ext_k, int64_t ld_ea, int64_t ld_eb, int64_t stride_eb,
+                                       void* stream);
+
 /* K7: gptfast's Attention.forward up to the attention call (gptfast/model.py:413-435) as ONE launch: the fused wqkv projection
  * X [M, K] x Wqkv^T ([3 D, K]: q rows, k rows, v rows), the interleaved-pair RoPE of q and k (apply_rotary_emb :519-531: fp32 arithmetic on
  * the bf16-rounded product with the bf16 freqs_cis table [positions, hd / 2, 2], one rounding) and KVCache.update (:67-93) as the GEMM's

@@ -187,6 +187,110 @@ def case_gemm_swiglu_split(dev, counts, K, I, T_dense):
     assert torch.equal(ops.gemm_swiglu_split(x, s1, s3)[1].cpu(), ref.cpu())
 
 
+def case_gemm_lora_ext(dev, counts, K, I, T_dense, r=8, expect_fused=True):
+    """LoRA as a K-extension of the base GEMM (aria_*_lora_bf16; GroupedGemmLoraLayer.forward aria/lora/layers.py:129-139, peft's Linear
+    adapter): result = base(x) + lora_B(scaling * lora_A(x)) from ONE launch, for every base form the decoder layer uses -- dense [N, K]
+    weights (q/k/v/o, down), the dgrad form ([K, N]), dense gate|up + SwiGLU, grouped [E, K, N] experts forward and dgrad form, grouped
+    fc1 + SwiGLU -- on ragged / empty experts.  Checks per form: (1) vs the fp32 oracle (O.lora_linear / O.lora_grouped_gemm: the reference's
+    own line); (2) with a ZERO adapter input the launch gives the plain base launch's bits (the extension tile adds exact zeros); (3) with a
+    ZERO base input it gives the bits of the adapter product run as a GEMM of its own (same accumulation); (4) the two-launch fallback
+    (ARIA_FUSE_LORA=0) agrees to rounding."""
+    import os
+
+    from aria_amd import hip, ops
+
+    lib = hip.get_lib().cdll
+    E, M = len(counts), sum(counts)
+    tpe = torch.tensor(counts)
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(tpe, 0)
+    offd = off.to(dev)
+
+    def fused(fn, *a, **k):
+        out = fn(*a, **k)
+        if expect_fused:
+            assert lib.aria_last_gemm_variant() == 3
+        return out
+
+    def unfused(fn, *a, **k):
+        before = os.environ.get("ARIA_FUSE_LORA")
+        os.environ["ARIA_FUSE_LORA"] = "0"
+        try:
+            return fn(*a, **k)
+        finally:
+            if before is None:
+                os.environ.pop("ARIA_FUSE_LORA", None)
+            else:
+                os.environ["ARIA_FUSE_LORA"] = before
+
+    # ---- dense, Linear weight [N, K] (N = 2 I so that the same tensors serve the SwiGLU form), adapter B [N, r]
+    N = 2 * I
+    x = rnd(T_dense, K, seed=201).to(dev)
+    w = rnd(N, K, seed=202, scale=0.2).to(dev)
+    u = rnd(T_dense, r, seed=203).to(dev)
+    lb = rnd(N, r, seed=204, scale=0.3).to(dev)
+    want = x.float().cpu() @ w.float().cpu().t() + u.float().cpu() @ lb.float().cpu().t()
+    got = fused(ops.gemm_lora, x, w, u, lb)
+    close(got, want.to(bf16), 1e-2, 1e-2 * K ** 0.5)
+    ops.GEMM_SPLIT_K = False   # (the plain launches below must use one K order: the fused one never splits)
+    try:
+        assert torch.equal(fused(ops.gemm_lora, x, w, torch.zeros_like(u), lb).cpu(), ops.gemm(x, w).cpu())
+        close(unfused(ops.gemm_lora, x, w, u, lb), got, 2e-2, 2e-2 * K ** 0.5)
+        # ---- dgrad form: b [K', N'] = the same storage read as [N, K] -> C = dy [T, N] x w [N, K]; adapter A as [r, K]
+        dy = rnd(T_dense, N, seed=205).to(dev)
+        la = rnd(r, K, seed=206, scale=0.3).to(dev)
+        if N % 64 == 0:
+            want = dy.float().cpu() @ w.float().cpu() + u.float().cpu() @ la.float().cpu()
+            got = fused(ops.gemm_lora, dy, w, u, la, b_oc=True)
+            close(got, want.to(bf16), 1e-2, 1e-2 * N ** 0.5)
+            assert torch.equal(fused(ops.gemm_lora, dy, w, torch.zeros_like(u), la, b_oc=True).cpu(), ops.gemm(dy, w, b_oc=True).cpu())
+        # ---- dense gate | up + SwiGLU
+        h_want = x.float().cpu() @ w.float().cpu().t() + u.float().cpu() @ lb.float().cpu().t()
+        h, act = fused(ops.gemm_swiglu_lora, x, w, u, lb, want_h=True)
+        close(h, h_want.to(bf16), 1e-2, 1e-2 * K ** 0.5)
+        assert torch.equal(act.cpu(), ops.swiglu(h).cpu())          # the epilogue rounds h, then applies glu: the two-step chain's bits
+        h0, act0 = ops.gemm_swiglu(x, w, want_h=True)
+        hz, actz = fused(ops.gemm_swiglu_lora, x, w, torch.zeros_like(u), lb, want_h=True)
+        assert torch.equal(hz.cpu(), h0.cpu()) and torch.equal(actz.cpu(), act0.cpu())
+        assert torch.equal(fused(ops.gemm_swiglu_lora, x, w, u, lb, want_h=False)[1].cpu(), act.cpu())
+    finally:
+        ops.GEMM_SPLIT_K = True
+    if M == 0:
+        return
+    # ---- grouped experts [E, K, N] forward: adapter A [E, K, r] applied by the caller, B [E, r, N]
+    a = rnd(M, K, seed=207).to(dev)
+    we = rnd(E, K, N, seed=208, scale=0.2).to(dev)
+    ue = rnd(M, r, seed=209).to(dev)
+    lbe = rnd(E, r, N, seed=210, scale=0.3).to(dev)
+    want = O.sequential_gemm(a.float().cpu(), we.float().cpu(), tpe) + O.sequential_gemm(ue.float().cpu(), lbe.float().cpu(), tpe)
+    got = fused(ops.grouped_gemm_lora, a, we, offd, ue, lbe)
+    close(got, want.to(bf16), 1e-2, 1e-2 * K ** 0.5)
+    assert torch.equal(fused(ops.grouped_gemm_lora, a, we, offd, torch.zeros_like(ue), lbe).cpu(), ops.grouped_gemm(a, we, offd).cpu())
+    close(unfused(ops.grouped_gemm_lora, a, we, offd, ue, lbe), got, 2e-2, 2e-2 * K ** 0.5)
+    # ... the reference's whole line, lora_A included (O.lora_grouped_gemm), scaling folded into u
+    lae = rnd(E, K, r, seed=211, scale=0.2).to(dev)
+    u_dev = ops.grouped_gemm(a, lae, offd)
+    sc = 4.0
+    want = O.lora_grouped_gemm(a.float().cpu(), we.float().cpu(), lae.float().cpu(), lbe.float().cpu(), tpe, sc)
+    got = fused(ops.grouped_gemm_lora, a, we, offd, (u_dev.float() * sc).to(bf16), lbe)
+    close(got, want.to(bf16), 2e-2, 2e-2 * K ** 0.5)
+    # ---- grouped dgrad form: dy [M, N] x we[e]^T -> [M, K]; adapter factor read as [E, K, r]
+    if N % 64 == 0:
+        dye = rnd(M, N, seed=212).to(dev)
+        want = O.sequential_gemm(dye.float().cpu(), we.float().cpu().transpose(1, 2), tpe) + \
+            O.sequential_gemm(ue.float().cpu(), lae.float().cpu().transpose(1, 2), tpe)
+        got = fused(ops.grouped_gemm_lora, dye, we, offd, ue, lae, w_is_kn=False)
+        close(got, want.to(bf16), 1e-2, 1e-2 * N ** 0.5)
+    # ---- grouped fc1 + SwiGLU
+    h, act = fused(ops.grouped_gemm_swiglu_lora, a, we, offd, ue, lbe, want_h=True)
+    want = O.sequential_gemm(a.float().cpu(), we.float().cpu(), tpe) + O.sequential_gemm(ue.float().cpu(), lbe.float().cpu(), tpe)
+    close(h, want.to(bf16), 1e-2, 1e-2 * K ** 0.5)
+    assert torch.equal(act.cpu(), ops.swiglu(h).cpu())
+    h0, act0 = ops.grouped_gemm_swiglu(a, we, offd, want_h=True)
+    hz, actz = fused(ops.grouped_gemm_swiglu_lora, a, we, offd, torch.zeros_like(ue), lbe, want_h=True)
+    assert torch.equal(hz.cpu(), h0.cpu()) and torch.equal(actz.cpu(), act0.cpu())
+
+
 def case_gemm_qkv_rope_cache(dev, B, S, D, hd, K, S_cache, shuffled_pos=False):
     """K7: wqkv projection + interleaved RoPE + KV-cache write in one launch (``gemm3_kernel<false, false, 7>``; gptfast/model.py:413-435,
     67-93, 519-531) == the chain gemm (v3, no split-K) -> rope_interleaved_ -> row copies, bit for bit: q, and the cache rows at the tokens'

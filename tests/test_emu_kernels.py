@@ -191,6 +191,11 @@ def test_gemm_swiglu_split(force_gemm_v3, counts, K, I, T):
     C.case_gemm_swiglu_split(DEV, counts, K, I, T)
 
 
+@pytest.mark.parametrize("counts,K,I,T,r", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300, 8), ([130, 520], 192, 128, 72, 24), ([0, 0, 257], 64, 256, 9, 16)])
+def test_gemm_lora_k_extension(force_gemm_v3, counts, K, I, T, r):
+    C.case_gemm_lora_ext(DEV, counts, K, I, T, r)
+
+
 @pytest.mark.parametrize("counts,K,I,T", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300), ([130, 520], 192, 384, 72), ([0, 0, 257], 64, 256, 1)])
 def test_gemm_dswiglu_fused(force_gemm_v3, counts, K, I, T):
     C.case_gemm_dswiglu_fused(DEV, counts, K, I, T)

@@ -202,6 +202,12 @@ def test_gemm_swiglu_fused(counts, K, I, T):
     C.case_gemm_swiglu_fused(DEV, counts, K, I, T)
 
 
+@pytest.mark.parametrize("counts,K,I,T,r", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300, 8), ([1536] * 8 + [1500, 1580], 2560, 1664, 4096, 8),
+                                              ([1536] * 8 + [1500, 1580], 2560, 1664, 4096, 24)])
+def test_gemm_lora_k_extension(counts, K, I, T, r):  # LoRA's second projection inside the base launch, every base form
+    C.case_gemm_lora_ext(DEV, counts, K, I, T, r, expect_fused=K >= 2560)
+
+
 @pytest.mark.parametrize("counts,K,I,T", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300), ([1536] * 8 + [1500, 1580], 2560, 1664, 4096)])
 def test_gemm_swiglu_split(counts, K, I, T):  # gptfast wire format: w1 / w3 as two tensors of one allocation
     C.case_gemm_swiglu_split(DEV, counts, K, I, T)
