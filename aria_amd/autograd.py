@@ -297,6 +297,41 @@ class DecoderLayerFn(torch.autograd.Function):
         return (dx, None, None, None, None, None, None, None, None, None) + tuple(g[k] if k in wanted else None for k in _LAYER_KEYS)
 
 
+class LoraDecoderLayerFn(torch.autograd.Function):
+    """One MoEDecoderLayer whose GEMMs carry LoRA adapters (recipes/config_lora.yaml:44-59) as a single node: the adapters' second projections
+    ride inside the base launches (K-extension), everything else is the un-adapted layer's kernel sequence (aria_amd.lora_functional).
+    ``keys``: the adapted parameter keys (subset of lora_functional.SITES), ``hyper``: (scaling, dropout p) per key; tensors: the 12 layer
+    parameters, then (lora_A.weight, lora_B.weight) per key.  The dropout masks are a function of ``seed``: re-running the forward (the
+    recipe's gradient checkpointing) reproduces them."""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin, B, S, acfg, mcfg, eps, kv_len, training, seed, keys, hyper, *tensors):
+        from . import lora_functional as LF
+
+        params, ab = tensors[:len(_LAYER_KEYS)], tensors[len(_LAYER_KEYS):]
+        p = dict(zip(_LAYER_KEYS, params))
+        L = {k: LF.LoraSite(ab[2 * i], ab[2 * i + 1], hyper[i][0], hyper[i][1]) for i, k in enumerate(keys)}
+        out, c = LF.decoder_layer_lora_fwd(x, p, L, cos, sin, B, S, acfg, mcfg, eps, kv_len, training, seed)
+        ctx.c, ctx.keys = c, keys
+        ctx.save_for_backward(cos, sin, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import lora_functional as LF
+
+        cos, sin, *params = ctx.saved_tensors
+        p = dict(zip(_LAYER_KEYS, params))
+        n0 = 13
+        need = {k for k, w in zip(_LAYER_KEYS, ctx.needs_input_grad[n0:n0 + len(_LAYER_KEYS)]) if w}
+        dx, gb, g = LF.decoder_layer_lora_bwd(_c(dout), ctx.c, p, cos, sin, need)
+        ctx.c = None
+        ab = []
+        for k in ctx.keys:
+            ab += list(g.get(k, (None, None)))
+        return (dx,) + (None,) * 12 + tuple(gb[k] if k in need else None for k in _LAYER_KEYS) + tuple(ab)
+
+
 class LMHeadLossFn(torch.autograd.Function):
     """final-norm output -> lm_head -> shifted masked CE (modeling_aria.py:301-323); gradients are produced during
     the forward (the logits buffer is overwritten with dlogits), backward just scales them."""

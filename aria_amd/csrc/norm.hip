@@ -195,6 +195,53 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* a, const bf16_t*
     }
 }
 
+// LoRA's input dropout (nn.Dropout(lora_dropout) in front of lora_A: aria/lora/layers.py:83-85, 131; recipes/config_lora.yaml:46): inverted
+// dropout on 8-element chunks -- out = keep ? bf16(x / (1 - p)) : 0 and ONE mask byte per chunk (bit e = element e kept), so the backward
+// re-applies the same mask from 1/16 of the bytes instead of keeping a second activation-sized tensor.  Counter-based randomness: the 8
+// draws of chunk c are the 16-bit fields of two splitmix64 outputs of (seed, c) -- reproducible from (seed, index), no generator state.
+__device__ __forceinline__ unsigned long long drop_mix(unsigned long long z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const bf16_t* x, bf16_t* out, unsigned char* mask, long long nchunks, unsigned thresh,
+                                                          float scale, unsigned long long seed) {
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long r0 = drop_mix(seed ^ (unsigned long long)(2 * c)), r1 = drop_mix(seed ^ (unsigned long long)(2 * c + 1));
+        const u32x4 v = ld16(x + c * 8);
+        u32x4 o;
+        unsigned m = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long r = q < 2 ? r0 : r1;
+            const bool k0 = unsigned((r >> (32 * (q & 1))) & 0xffffu) >= thresh, k1 = unsigned((r >> (32 * (q & 1) + 16)) & 0xffffu) >= thresh;
+            m |= (unsigned(k0) << (2 * q)) | (unsigned(k1) << (2 * q + 1));
+            o[q] = pack2bf(k0 ? bflo(v[q]) * scale : 0.f, k1 ? bfhi(v[q]) * scale : 0.f);
+        }
+        st16(out + c * 8, o);
+        mask[c] = (unsigned char)m;
+    }
+}
+
+// dx (+)= keep ? term / (1 - p) : 0 -- the backward of the dropout above applied to the adapter's input gradient
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const bf16_t* term, const unsigned char* mask, bf16_t* dx, long long nchunks, float scale,
+                                                          int accumulate) {
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (long long)gridDim.x * blockDim.x) {
+        const u32x4 t = ld16(term + c * 8);
+        const unsigned m = mask[c];
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (accumulate) o = ld16(dx + c * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = ((m >> (2 * q)) & 1u) ? bflo(t[q]) * scale : 0.f, b = ((m >> (2 * q + 1)) & 1u) ? bfhi(t[q]) * scale : 0.f;
+            o[q] = accumulate ? pack2bf(bflo(o[q]) + rbf(a), bfhi(o[q]) + rbf(b)) : pack2bf(a, b);
+        }
+        st16(dx + c * 8, o);
+    }
+}
+
 // gptfast RoPE (gptfast/model.py:519-531): interleaved pairs (x[2i], x[2i+1]), bf16 freqs_cis cache [S, hd/2, 2] = (cos, sin),
 // arithmetic in fp32 with ONE rounding; position of row t = pos[t] (device int32, e.g. the decode cursor) or t % S.
 __global__ __launch_bounds__(256) void rope_interleaved_kernel(bf16_t* x, const bf16_t* fc, const int32_t* pos, long long nitems,
@@ -346,6 +393,25 @@ int aria_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stre
     if (n == 0) return ARIA_OK;
     ARIA_LAUNCH(add_kernel, dim3(grid1d(n / 8, 256)), dim3(256), 0, stream, static_cast<const bf16_t*>(a),
                 static_cast<const bf16_t*>(b), static_cast<bf16_t*>(out), (long long)(n / 8));
+    return aria_check_launch();
+}
+
+int aria_dropout_fwd_bf16(const void* x, void* out, void* mask, int64_t n, float p, uint64_t seed, void* stream) {
+    if (!x || !out || !mask || n < 0 || !(p >= 0.f && p < 1.f)) return ARIA_ERR_INVALID;
+    if ((n & 7) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return ARIA_ERR_ALIGN;
+    if (n == 0) return ARIA_OK;
+    const unsigned thresh = unsigned(p * 65536.f + 0.5f);
+    ARIA_LAUNCH(dropout_fwd_kernel, dim3(grid1d(n / 8, 256)), dim3(256), 0, stream, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(out),
+                static_cast<unsigned char*>(mask), (long long)(n / 8), thresh, 1.f / (1.f - p), (unsigned long long)seed);
+    return aria_check_launch();
+}
+
+int aria_dropout_bwd_bf16(const void* term, const void* mask, void* dx, int64_t n, float p, int accumulate, void* stream) {
+    if (!term || !mask || !dx || n < 0 || !(p >= 0.f && p < 1.f)) return ARIA_ERR_INVALID;
+    if ((n & 7) || (reinterpret_cast<uintptr_t>(term) & 15) || (reinterpret_cast<uintptr_t>(dx) & 15)) return ARIA_ERR_ALIGN;
+    if (n == 0) return ARIA_OK;
+    ARIA_LAUNCH(dropout_bwd_kernel, dim3(grid1d(n / 8, 256)), dim3(256), 0, stream, static_cast<const bf16_t*>(term),
+                static_cast<const unsigned char*>(mask), static_cast<bf16_t*>(dx), (long long)(n / 8), 1.f / (1.f - p), accumulate);
     return aria_check_launch();
 }
 

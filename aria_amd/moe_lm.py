@@ -325,6 +325,34 @@ class MoEDecoderLayer(nn.Module):
         self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
+    def _lora_sites(self):
+        """{functional key: adapter module} when this layer's GEMMs carry LoRA adapters the fused node serves (aria_amd.lora layers, not merged,
+        not disabled, not under expert parallelism; ARIA_LORA_FUSED=0 keeps the module-by-module arrangement) -- else None."""
+        import os
+
+        from .lora import GroupedGemmLoraLayer, LinearLoraLayer
+
+        a, m = self.self_attn, self.mlp
+        mods = dict(wq=a.q_proj, wk=a.k_proj, wv=a.v_proj, wo=a.o_proj, fc1=m.experts.fc1, fc2=m.experts.fc2, gate=m.shared_experts.gate_proj,
+                    up=m.shared_experts.up_proj, down=m.shared_experts.down_proj)
+        found = {}
+        for key, mod in mods.items():
+            if isinstance(mod, (GroupedGemmLoraLayer, LinearLoraLayer)):
+                if mod.disable_adapters or mod.merged:   # the base weight alone is the module's function (merged: delta already inside it)
+                    if mod.disable_adapters and mod.merged:
+                        return None                      # (the module un-merges itself on its next call: let it)
+                    continue
+                if getattr(mod, "bias", None) is not None and isinstance(mod, LinearLoraLayer):
+                    return None
+                found[key] = mod
+            elif type(mod) not in (Linear, GroupedGEMM):
+                return None
+        if not found or m.ep_enabled or os.environ.get("ARIA_LORA_FUSED", "1") == "0":
+            return None
+        if a.config.num_key_value_heads != a.config.num_attention_heads or a.config.head_dim not in (64, 128):
+            return None
+        return found
+
     def layer_params(self):
         a, m = self.self_attn, self.mlp
         return (self.input_layernorm.weight, a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.o_proj.weight,
@@ -335,6 +363,25 @@ class MoEDecoderLayer(nn.Module):
                 kv_len: Optional[torch.Tensor] = None, recompute_level: Optional[str] = None) -> torch.Tensor:
         B, S, D = hidden_states.shape
         a = self.self_attn
+        sites = self._lora_sites()
+        if sites is not None:   # LoRA adapters on this layer's GEMMs: ONE node, the adapters inside the base launches (aria_amd.lora_functional)
+            keys = tuple(sites)
+            hyper = tuple((float(s.scaling), float(getattr(s.lora_dropout, "p", 0.0))) for s in sites.values())
+            ab = [t for s in sites.values() for t in (s.lora_A.weight, s.lora_B.weight)]
+            x = hidden_states.reshape(B * S, D)
+            x = x if x.is_contiguous() else x.contiguous()
+            seed = int(torch.empty((), dtype=torch.int64).random_()) if self.training else 0   # (host generator: torch.manual_seed governs it)
+            mcfg, acfg, eps = self.mlp.moe_config(), self.self_attn.attn_config(), self.config.rms_norm_eps
+
+            def node(xx):
+                return AG.LoraDecoderLayerFn.apply(xx, cos, sin, B, S, acfg, mcfg, eps, kv_len, self.training, seed, keys, hyper,
+                                                   *self.layer_params(), *ab)
+
+            if self.config.gradient_checkpointing and self.training and torch.is_grad_enabled():
+                from torch.utils.checkpoint import checkpoint   # (the masks are a function of `seed`: the re-run forward repeats them)
+
+                return checkpoint(node, x, use_reentrant=False).view(B, S, D)
+            return node(x).view(B, S, D)
         if self.mlp.ep_enabled or self.mlp.has_adapter() or not _plain_linears(a.q_proj, a.k_proj, a.v_proj, a.o_proj):
             # an adapter (aria_amd/lora.py) wraps a GEMM of this layer, or the experts are sharded over ranks (an all-to-all sits inside
             # the MoE block): LlamaDecoderLayer.forward module by module (modeling_llama.py:295-325)

@@ -158,6 +158,27 @@ def gemm_swiglu(x: torch.Tensor, w: torch.Tensor, want_h: bool = True):
     return h, act
 
 
+def dropout(x: torch.Tensor, p: float, seed: int):
+    """nn.Dropout(p) of the LoRA layers (aria/lora/layers.py:83-85) in training mode: -> (x_dropped, mask uint8 [numel / 8]); the mask is a
+    counter-based function of (seed, element index)."""
+    _chk(x, name="x")
+    if not x.is_contiguous() or x.numel() % 8:
+        raise ValueError("dropout: contiguous tensor with numel % 8 == 0")
+    out = torch.empty_like(x)
+    mask = torch.empty((x.numel() // 8,), dtype=torch.uint8, device=x.device)
+    hip.get_lib().call("aria_dropout_fwd_bf16", _p(x), _p(out), _p(mask), x.numel(), float(p), int(seed) & ((1 << 64) - 1), _stream(x))
+    return out, mask
+
+
+def dropout_bwd_(dx: torch.Tensor, term: torch.Tensor, mask: torch.Tensor, p: float, accumulate: bool = True) -> torch.Tensor:
+    """dx (+)= mask * term / (1 - p), in place."""
+    _chk(dx, name="dx"), _chk(term, name="term"), _chk(mask, torch.uint8, "mask")
+    if not (dx.is_contiguous() and term.is_contiguous()) or dx.shape != term.shape or mask.numel() * 8 != dx.numel():
+        raise ValueError("dropout_bwd_: contiguous dx / term of one shape, one mask byte per 8 elements")
+    hip.get_lib().call("aria_dropout_bwd_bf16", _p(term), _p(mask), _p(dx), dx.numel(), float(p), int(accumulate), _stream(dx))
+    return dx
+
+
 # ------------------------------------------------------------------------------------------------ LoRA as a K-extension (SURVEY 8(f)3)
 def _lora_ext_ok(K: int, ext_k: int) -> bool:
     import os

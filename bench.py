@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--gen-image", type=int, default=1, help="debug only (config #2: one 980px image)")
     ap.add_argument("--prefill-seq", type=int, default=53248, help="debug only (config #4: 32 x 128 frame tokens + 49 152 text tokens)")
     ap.add_argument("--prefill-frames", type=int, default=32, help="debug only (config #4: 32 frames at 490px)")
+    ap.add_argument("--no-lora-record", action="store_true", help="skip the `lora_config` sub-record (N = 1 only: recipes/config_lora.yaml's adapter set "
+                    "on the same model and micro-batch, three timed steps + the frozen-base forward + input-gradient reference)")
     ap.add_argument("--ep", action="store_true", help="BASELINE config #5 instead of #3: routed experts sharded over the N ranks (all-to-all "
                                                       "dispatch over xGMI), everything else data-parallel; not what the driver runs")
     args = ap.parse_args()
@@ -327,6 +329,88 @@ def prefill_config4_record(twin, tcfg, S=53248, frames=32, runs=2, img_px=490, q
                          "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / t / 2.5e15, 4), "algorithmic_flops": flops, "traffic": None}}
 
 
+def lora_config_record(model, cfg, step, ops, B, S, steps=3):
+    """recipes/config_lora.yaml on the SAME model and micro-batch (the reference's cheapest recipe: 1 GPU): LoRA r = 8, alpha = 32, dropout
+    0.05 on fc1 / fc2 / q,k,v,o_proj / gate,up,down_proj / lm_head of the language model (aria/train.py:100-112, aria/lora/layers.py:129-139),
+    ViT and projector frozen, every base weight frozen.  Timed: 1 warm-up + `steps` steps of forward + backward (a) with the adapters through
+    the fused node (their second projection inside the base launches), (b) the frozen-base reference -- the un-adapted model with only the
+    embedding trainable, i.e. forward + every input gradient and NO weight gradient: the floor a LoRA step cannot go below -- and (c) the
+    adapters with the recipe's gradient checkpointing.  The adapters are unwrapped afterwards (B factors are drawn N(0, 0.02) for the timing --
+    peft's zero init would put exact zeros through the extension tile -- so nothing is merged)."""
+    from aria_amd.lora import GroupedGemmLoraLayer, LinearLoraLayer, apply_lora_from_config
+
+    lm = model.language_model
+    req = {n: p.requires_grad for n, p in model.named_parameters()}
+
+    def timed(n=steps):
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    # (b) frozen base: forward + input gradients only
+    for n, p in model.named_parameters():
+        p.requires_grad_(n.endswith("embed_tokens.weight"))
+    t_floor = timed()
+    # (a) the recipe's adapters
+    recipe = dict(use_peft=True, lora_r=8, lora_alpha=32, lora_dropout=0.05, freeze_vit=True, freeze_projector=True,
+                  lora_target_modules=["fc1", "fc2", "q_proj", "k_proj", "v_proj", "linear", "o_proj", "up_proj", "down_proj", "out_proj", "gate_proj",
+                                       "lm_head"])
+    apply_lora_from_config(model, recipe)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    adapters = [(n, m) for n, m in model.named_modules() if isinstance(m, (GroupedGemmLoraLayer, LinearLoraLayer))]
+    with torch.no_grad():
+        for _, m in adapters:
+            m.lora_B.weight.normal_(0.0, 0.02, generator=g)
+    ev = []
+    orig = ops.grouped_gemm_swiglu_lora
+
+    def timed_fc1(*a, **k):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = orig(*a, **k)
+        e.record()
+        ev.append((s, e))
+        return r
+
+    ops.grouped_gemm_swiglu_lora = timed_fc1
+    try:
+        t_lora = timed()
+        durs = [s.elapsed_time(e) * 1e-3 for s, e in ev[len(ev) // (steps + 1):]]   # (the warm-up step's launches dropped)
+        ops.grouped_gemm_swiglu_lora = orig
+        cfg.gradient_checkpointing = True
+        t_ckpt = timed()
+    finally:
+        ops.grouped_gemm_swiglu_lora = orig
+        cfg.gradient_checkpointing = False
+        for name, layer in adapters:   # unwrap (nothing merged: the base weights were never touched)
+            parent = model.get_submodule(name.rsplit(".", 1)[0]) if "." in name else model
+            setattr(parent, name.rsplit(".", 1)[-1], layer.base_layer)
+        for n, p in model.named_parameters():
+            p.requires_grad_(req.get(n, True))
+        model.zero_grad(set_to_none=True)
+    M = B * S * cfg.moe_topk
+    flops = 2.0 * M * (cfg.hidden_size + 8) * (2 * cfg.moe_intermediate_size)
+    avg = sum(durs) / max(1, len(durs))
+    n_ad = len(adapters)
+    del adapters
+    return {"workload": f"recipes/config_lora.yaml on the config #3 micro-batch ({B} x {S}, 2 x 980px images per sample), 1 GPU: LoRA r=8 alpha=32 dropout=0.05 on "
+                        f"{n_ad} modules of the {cfg.num_hidden_layers}-layer language model (fc1, fc2, q/k/v/o_proj, gate/up/down_proj, lm_head), ViT + projector + every base "
+                        "weight frozen; forward + backward; gradient checkpointing OFF in `ms_per_step` (`recipe_grad_checkpointing_ms` = the recipe as written)",
+            "ms_per_step": round(t_lora * 1e3, 1), "value": round(B * S / t_lora, 1), "unit": "tokens/s", "steps": steps, "warmup": 1,
+            "frozen_base_fwd_dgrad_ms": round(t_floor * 1e3, 1), "over_frozen_base": round(t_lora / t_floor, 4),
+            "adapter_path": "module-by-module (ARIA_LORA_FUSED=0)" if os.environ.get("ARIA_LORA_FUSED", "1") == "0" else
+                            "fused node: adapters' second projection inside the base launches (K-extension)",
+            "recipe_grad_checkpointing_ms": round(t_ckpt * 1e3, 1),
+            "roofline": {"kernel": "gemm3_kernel<rc,oc,3>+swiglu+K-extension grouped-M (experts.fc1 + LoRA second projection + SwiGLU, one launch)",
+                         "bound": "mfma", "achieved": round(flops / avg / 1e12, 1) if durs else None, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(flops / avg / 2.5e15, 4) if durs else None, "launches_timed": len(durs), "avg_launch_ms": round(avg * 1e3, 4),
+                         "algorithmic_flops_per_launch": flops, "traffic": None}}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (no torchrun around it): re-exec this script under torch.distributed.run with N ranks on
     127.0.0.1, one per GPU, so that the plain form measures N GPUs instead of silently measuring one."""
@@ -587,6 +671,13 @@ def main():
         except Exception as ex:  # noqa: BLE001
             res["sub_records_error"] = f"{type(ex).__name__}: {ex}"[:400]
             cfg.gradient_checkpointing = bool(args.recompute)
+        try:
+            if world == 1 and not args.long and not args.ep and not args.recompute and not args.no_lora_record:
+                res["lora_config"] = lora_config_record(model, cfg, step, ops, B, S)
+                if not full_depth:
+                    res["lora_config"]["INVALID"] = "debug run (reduced depth)"
+        except Exception as ex:  # noqa: BLE001
+            res["lora_record_error"] = f"{type(ex).__name__}: {ex}"[:400]
         try:
             if world == 1 and not args.long and not args.ep and not args.no_inference_records:
                 # BASELINE configs #2 (generate) and #4 (long prefill) on the gptfast surface of the SAME weights (the reference's own

@@ -130,6 +130,12 @@ int aria_grouped_gemm_swiglu_lora_bf16(const void* A, const void* B, void* H, vo
                                        const void* EA, const void* EB, int64_t ext_k, int64_t ld_ea, int64_t ld_eb, int64_t stride_eb,
                                        void* stream);
 
+/* nn.Dropout(lora_dropout) in front of lora_A (aria/lora/layers.py:83-85, 131; recipes/config_lora.yaml:46) and its backward.  Inverted
+ * dropout on n bf16 elements (n % 8 == 0): out = keep ? bf16(x / (1 - p)) : 0, mask[n / 8] = one byte per 8 elements (bit e = kept).  The
+ * draws are a counter-based function of (seed, element index): p is resolved to 1 / 65536.  _bwd: dx (+)= keep ? term / (1 - p) : 0. */
+int aria_dropout_fwd_bf16(const void* x, void* out, void* mask, int64_t n, float p, uint64_t seed, void* stream);
+int aria_dropout_bwd_bf16(const void* term, const void* mask, void* dx, int64_t n, float p, int accumulate, void* stream);
+
 /* K7: gptfast's Attention.forward up to the attention call (gptfast/model.py:413-435) as ONE launch: the fused wqkv projection
  * X [M, K] x Wqkv^T ([3 D, K]: q rows, k rows, v rows), the interleaved-pair RoPE of q and k (apply_rotary_emb :519-531: fp32 arithmetic on
  * the bf16-rounded product with the bf16 freqs_cis table [positions, hd / 2, 2], one rounding) and KVCache.update (:67-93) as the GEMM's

@@ -981,3 +981,84 @@ def case_decode_full_depth(dev, case, *, hidden=2560, heads=20, experts=64, topk
     tol = _depth_tol(block_tol, layers - 1, layers)
     for t, m in enumerate(errs):
         assert m["rel_l2"] <= tol and m["max_rel"] <= 2 * tol and m["cos"] >= 1 - 2 * tol * tol, (case, t, m, tol)
+
+
+# ------------------------------------------------------------------------------------------------------------ LoRA at width
+def case_lm_lora(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, B, S, r=8, alpha=32, seed=71, oracle_device=None,
+                 grad_tol=(4e-2, 1e-1), expect_fused=True):
+    """recipes/config_lora.yaml's adapter set (fc1, fc2, q/k/v/o_proj, gate/up/down_proj, lm_head; r = 8, alpha = 32) on an L-layer LM at the
+    given width, dropout off (the dropout path is pinned mask-for-mask at site level: model_cases.case_lora_fused_sites): training loss and
+    the gradient of EVERY LoRA factor of the fused node (adapters inside the base launches, aria_amd.lora_functional) against the fp32
+    oracle on merged weights W + scaling * delta(A, B) with autograd through A and B (aria/lora/layers.py:129-139, 196-224), routing forced
+    to the device's ids.  Base weights must stay without gradient."""
+    from aria_amd import autograd as AG
+    from aria_amd.lora import apply_lora_from_config
+    from aria_amd.moe_lm import AriaMoELMConfig, AriaMoELMForCausalLM, load_reference_state_dict
+
+    od = oracle_device or "cpu"
+    if oracle_device:
+        oracle_device_pin(oracle_device, hidden=hidden, heads=heads, experts=experts, topk=topk, inter=inter)
+    ocfg = O.LMConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, num_key_value_heads=heads, vocab_size=vocab,
+                      moe_intermediate_size=inter, moe_num_experts=experts, moe_topk=topk)
+    w = lm_weights(ocfg, seed)
+    cfg = AriaMoELMConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, vocab_size=vocab,
+                          moe_intermediate_size=inter, moe_num_experts=experts, moe_topk=topk, moe_num_shared_experts=2,
+                          rms_norm_eps=ocfg.rms_norm_eps, rope_theta=ocfg.rope_theta, moe_z_loss_coeff=ocfg.moe_z_loss_coeff,
+                          moe_aux_loss_coeff=ocfg.moe_aux_loss_coeff)
+    lm = AriaMoELMForCausalLM(cfg)
+    load_reference_state_dict(lm, w)
+    skipped = apply_lora_from_config(lm, dict(use_peft=True, lora_r=r, lora_alpha=alpha, lora_dropout=0.0,
+                                              lora_target_modules=["fc1", "fc2", "q_proj", "k_proj", "v_proj", "linear", "o_proj", "up_proj", "down_proj",
+                                                                   "out_proj", "gate_proj", "lm_head"]))
+    assert skipped == []
+    g = torch.Generator().manual_seed(seed + 3)
+    with torch.no_grad():
+        for n, p in lm.named_parameters():
+            if "lora_B" in n:   # (peft initialises B = 0: give the adapters something to do)
+                p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(bf16))
+    lm = lm.to(dev).train()
+    ids = torch.randint(0, vocab, (B, S), generator=torch.Generator().manual_seed(seed + 1))
+    calls = []
+    orig = AG.LoraDecoderLayerFn.apply
+    AG.LoraDecoderLayerFn.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        with _Recorder() as rec:
+            out = lm(input_ids=ids.to(dev), labels=ids.to(dev))
+            out.loss.backward()
+    finally:
+        AG.LoraDecoderLayerFn.apply = orig
+    assert len(calls) == layers and len(rec.idx) == layers, (len(calls), len(rec.idx))
+    if expect_fused:
+        assert rec.hip.get_lib().cdll.aria_last_gemm_variant() >= 1
+    sd = {k: v.detach().float().to(od) for k, v in lm.state_dict().items()}
+    leaves, wm = {}, {}
+    scaling = alpha / r
+    for key, val in sd.items():
+        if ".lora_A." in key or ".lora_B." in key:
+            leaves[key] = val.clone().requires_grad_(True)
+    for key, val in sd.items():
+        if key.endswith(".base_layer.weight"):
+            stem = key[: -len(".base_layer.weight")]
+            la, lb = leaves[stem + ".lora_A.weight"], leaves[stem + ".lora_B.weight"]
+            wm[stem + ".weight"] = val + (O.lora_delta_weight(la, lb, scaling) if val.dim() == 3 else O.lora_linear_delta_weight(la, lb, scaling))
+        elif ".lora_" not in key:
+            wm[key] = val
+    ids_o = ids.to(od)
+    with _OracleLogits() as ol, O.forced_routing(rec.idx):
+        lg = O.lm_forward(wm["model.embed_tokens.weight"][ids_o], wm, ocfg, training=True)
+    for i in range(layers):
+        router_parity(case, i, rec.idx[i], rec.logits[i], ol.logits[i].detach().cpu(), topk)
+    loss_o = torch.nn.functional.cross_entropy(lg[:, :-1].reshape(-1, vocab), ids_o[:, 1:].reshape(-1))
+    loss_o.backward()
+    rel = abs(float(out.loss.detach()) - float(loss_o.detach())) / abs(float(loss_o.detach()))
+    REPORT.setdefault(case, {})["loss"] = {"got": float(out.loss.detach()), "want": float(loss_o.detach()), "rel": round(rel, 6)}
+    assert rel <= 5e-3, REPORT[case]["loss"]
+    n = 0
+    for name, p in lm.named_parameters():
+        if ".lora_" not in name:
+            assert p.grad is None, name
+            continue
+        check(case, "grad " + name, p.grad, leaves[name].grad, *grad_tol)
+        n += 1
+    assert n == 2 * (9 * layers + 1)
+    REPORT[case]["adapters"] = n // 2

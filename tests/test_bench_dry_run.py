@@ -41,5 +41,10 @@ def test_bench_line_carries_the_contract(world):
         assert pre["value"] > 0 and pre["finite_logits"] is True and pre["roofline"]["bound"] == "mfma" and "INVALID" in pre
         assert res["long64k"]["recompute_level"] == "moe" and res["recipe_grad_checkpointing"]["recompute_level"] == "moe"
         assert "recipe gradient checkpointing: OFF" in res["config"]["workload"]
+        # recipes/config_lora.yaml on the same model: the adapters' step, the frozen-base floor, the recipe's checkpointing
+        assert "lora_record_error" not in res, res.get("lora_record_error")
+        lora = res["lora_config"]
+        assert lora["ms_per_step"] > 0 and lora["frozen_base_fwd_dgrad_ms"] > 0 and lora["recipe_grad_checkpointing_ms"] > 0 and "INVALID" in lora
+        assert lora["roofline"]["bound"] == "mfma" and "lora_dropout" not in lora and "dropout=0.05" in lora["workload"]
     else:
         assert "long64k" not in res and "generate_config2" not in res

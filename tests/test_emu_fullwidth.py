@@ -118,3 +118,10 @@ def test_decode_full_depth_case_small():
                              new_tokens=4, block_tol=4e-2)
     rep = F.REPORT["emu_decode_depth"]
     assert len(rep["tokens"]) == 4 and "step04 logits" in rep and "router.layer2" in F.REPORT["emu_decode_depth (decode steps)"]
+
+
+def test_lm_lora_case_small(monkeypatch):
+    monkeypatch.setenv("ARIA_GEMM_FORCE", "3")   # the K-extension launches (toy shapes otherwise take the two-launch fallback)
+    F.case_lm_lora("cpu", "emu_lm_lora", hidden=128, heads=2, experts=8, topk=2, inter=128, vocab=160, layers=2, B=2, S=24,
+                   grad_tol=(1.2e-1, 3e-1), expect_fused=False)
+    assert F.REPORT["emu_lm_lora"]["adapters"] == 19

@@ -204,6 +204,20 @@ def test_seam_attention_interface_native_hd72_without_grad():
     M.rel_close(out, want, 2e-2, "hd 72 attention through the seam")
 
 
+@pytest.mark.parametrize("force_v3", [False, True])
+def test_lora_fused_sites_with_dropout(force_v3, monkeypatch):
+    if force_v3:   # the K-extension launches themselves (otherwise toy shapes take the two-launch fallback inside ops.*_lora)
+        monkeypatch.setenv("ARIA_GEMM_FORCE", "3")
+    M.case_lora_fused_sites(DEV)
+
+
+@pytest.mark.parametrize("force_v3", [False, True])
+def test_lora_fused_node_matches_modular(force_v3, monkeypatch):
+    if force_v3:
+        monkeypatch.setenv("ARIA_GEMM_FORCE", "3")
+    M.case_lora_fused_vs_modular(DEV)
+
+
 def test_adapted_decoder_layer_with_gradient_checkpointing():
     """recipes/config_lora.yaml runs with gradient_checkpointing: the module-by-module decoder layer recomputed in backward gives the same
     loss and the same LoRA gradients as the stored-activation run (dropout off: bit-identical)."""

@@ -119,3 +119,9 @@ def test_config2_28_layers_prefill_and_16_decode_engine_steps():
     """Config #2 at full depth: a 280-position prefill, then 16 greedy decode-engine steps; every step's logits vs the oracle over the
     growing sequence, the token stream checked wherever the oracle's margin is resolvable, the engine's per-layer routing forced."""
     F.case_decode_full_depth(DEV, "config2_28layers_prefill280_decode16", oracle_device=DEV)
+
+
+def test_lora_recipe_adapters_aria_width_T4096():
+    """recipes/config_lora.yaml's adapter set on ONE full-width decoder layer + lm_head, T = 2 x 2048: the fused node (LoRA's second projection
+    inside the base launches) vs the fp32 oracle on merged weights: loss and the gradients of all 20 LoRA factors pairs."""
+    F.case_lm_lora(DEV, "lora_layer_T4096", hidden=2560, heads=20, experts=64, topk=6, inter=1664, vocab=4096, layers=1, B=2, S=2048)

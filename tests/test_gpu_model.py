@@ -60,5 +60,13 @@ def test_decode_engine_fused_schedule(aria_width):  # 6-launch decode schedule =
     M.case_decode_engine_fused_schedule(DEV, aria_width=aria_width, n_tokens=6 if aria_width else 4)
 
 
+def test_lora_fused_sites_with_dropout():   # adapters inside the base launches, dropout masks applied in forward and backward (site level)
+    M.case_lora_fused_sites(DEV)
+
+
+def test_lora_fused_node_matches_modular():
+    M.case_lora_fused_vs_modular(DEV)
+
+
 def test_lora_linear_lm():  # last on purpose: newest composition of already-covered kernels
     M.case_lora_linear_lm(DEV)
