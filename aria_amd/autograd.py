@@ -355,6 +355,29 @@ class LMHeadLossFn(torch.autograd.Function):
         return d_hn, g_w, None
 
 
+class LoraLMHeadLossFn(torch.autograd.Function):
+    """LMHeadLossFn with a LoRA adapter on lm_head (lora_functional.lm_head_lora_loss_fwd_bwd): labelled rows only, the adapter's second
+    projection inside the lm_head launch; gradients produced during the forward like the un-adapted node."""
+
+    @staticmethod
+    def forward(ctx, hn, lm_w, labels_shifted, lora_a, lora_b, scaling, p, training, seed):
+        from . import lora_functional as LF
+
+        loss, d_hn, dA, dB = LF.lm_head_lora_loss_fwd_bwd(hn, lm_w, labels_shifted, LF.LoraSite(lora_a, lora_b, scaling, p), training, seed,
+                                                         need_hn=hn.requires_grad)
+        ctx.g = (d_hn, dA, dB)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        d_hn, dA, dB = ctx.g
+        ctx.g = None
+        for t in (d_hn, dA, dB):
+            if t is not None:
+                t.mul_(dloss)
+        return d_hn, None, None, dA, dB, None, None, None, None
+
+
 class EmbeddingFn(torch.autograd.Function):
     """embed_tokens lookup (modeling_aria.py:250) as a row gather; backward = row scatter-add."""
 

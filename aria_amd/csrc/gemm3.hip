@@ -944,9 +944,10 @@ int plan_split(long long tiles, long long nk, long long* remainder) {
 }  // namespace
 
 long long aria_gemm3_workspace_bytes(long long M, long long N, long long K) {
-    // at least one full tile each way -- or a skinny output with a long reduction (router weight gradient [64 x 2560], K = tokens),
-    // but never the decode GEMVs (M = batch)
-    if (K < 64 || M < 32 || N < 32 || ((M < 256 || N < 256) && K < 2048)) return 0;
+    // at least one full tile each way -- or a skinny output with a long reduction (router weight gradient [64 x 2560], K = tokens; the LoRA
+    // factors' gradients [r x in] / [out x r], r = 8..24, which took 320 us each on 20 workgroups of the 128 x 128 kernel: profiles/
+    // r05_lora_kernel_stats.txt) -- but never the decode GEMVs (M = batch < 8)
+    if (K < 64 || M < 8 || N < 8 || ((M < 256 || N < 256) && K < 2048)) return 0;
     long long R = 0;
     const int S = plan_split(((M + 255) / 256) * ((N + 255) / 256), (K + 63) / 64, &R);
     return S > 1 ? R * S * (long long)(BM * BN) * 4 : 0;

@@ -249,3 +249,42 @@ def decoder_layer_lora_bwd(dout, c, p: dict, cos, sin, need_base=None) -> Tuple[
         gb["wq"], gb["wk"], gb["wv"] = g_qkv[:Dq], g_qkv[Dq:2 * Dq], g_qkv[2 * Dq:]
     dx, gb["ln1"] = ops.rmsnorm_bwd(dxn, c["x"], p["ln1"], c["rstd1"], dres=dh)
     return dx, gb, g
+
+
+# ------------------------------------------------------------------------------------------------------------------ lm_head + loss
+def lm_head_lora_loss_fwd_bwd(hn, lm_w, labels_shifted, site: LoraSite, training: bool, seed: int, need_hn: bool = True):
+    """functional.lm_head_loss_fwd_bwd with an adapter on lm_head (recipes/config_lora.yaml:59): logits = hn W^T + scaling * (dropout(hn) A^T) B^T
+    over the LABELLED rows only (the module-by-module form computes and adapts all B x S rows of the [., V] logits: 3.3 GB per elementwise
+    pass at the recipe's micro-batch), shifted masked CE with the gradient written over the logits, then d_hn, d lora_A, d lora_B.
+    -> (loss, d_hn | None, dA, dB)"""
+    rows = torch.nonzero(labels_shifted >= 0).flatten().to(torch.int32)          # (host sync: the GEMMs' M)
+    n = int(rows.numel())
+    if n == 0:
+        zero = torch.zeros((), dtype=torch.float32, device=hn.device)
+        return zero, (torch.zeros_like(hn) if need_hn else None), torch.zeros_like(site.a), torch.zeros_like(site.b)
+    pad = (-n) % 8
+    if pad:
+        rows = torch.cat([rows, rows[-1:].expand(pad)])
+    labels_v = labels_shifted[rows.long()].contiguous()
+    if pad:
+        labels_v[n:] = -100
+    hv = ops.moe_permute(hn, rows, 1)
+    d = _Drop(hv, site.p, training, _seed([int(seed)]))
+    U = _scaled(ops.gemm(d.xd, site.a), site.scaling)
+    logits = ops.gemm_lora(hv, lm_w, U, site.b)
+    count_in = torch.full((1,), n, dtype=torch.int32, device=hn.device)
+    loss_sum, _, _ = ops.cross_entropy(logits, labels_v, grad_scale=1.0, dlogits=logits, count_in=count_in)
+    loss = (loss_sum / float(n)).reshape(())
+    du = _scaled(ops.gemm(logits, site.b, b_oc=True), site.scaling)              # [rows, r] = dlogits lora_B
+    dB = ops.gemm(logits, U, a_oc=True, b_oc=True)                               # [V, r]
+    dA = ops.gemm(du, d.xd, a_oc=True, b_oc=True)                                # [r, D]
+    d_hn = None
+    if need_hn:
+        d_hv = ops.gemm(logits, lm_w, b_oc=True)
+        if d.mask is None:
+            ops.gemm(du, site.a, b_oc=True, out=d_hv, accumulate=True)
+        else:
+            ops.dropout_bwd_(d_hv, ops.gemm(du, site.a, b_oc=True), d.mask, d.p)
+        d_hn = torch.zeros_like(hn)
+        d_hn.index_copy_(0, rows[:n].long(), d_hv[:n])
+    return loss, d_hn, dA, dB

@@ -482,6 +482,15 @@ class AriaMoELMForCausalLM(nn.Module):
         self.vocab_size = config.vocab_size
         self.lm_head = Linear(config.hidden_size, config.vocab_size)
 
+    def _lm_head_lora_fusable(self) -> bool:
+        import os
+
+        from .lora import LinearLoraLayer
+
+        h = self.lm_head
+        return (isinstance(h, LinearLoraLayer) and not h.merged and not h.disable_adapters and h.bias is None and not h.base_layer.weight.requires_grad
+                and os.environ.get("ARIA_LORA_FUSED", "1") != "0")
+
     def set_z_loss_coeff(self, v: float):
         self.config.moe_z_loss_coeff = v
 
@@ -498,8 +507,13 @@ class AriaMoELMForCausalLM(nn.Module):
         loss = logits = None
         if labels is not None:
             ls = labels.reshape(-1).to(torch.int32) if labels_are_shifted else Fn.shift_labels(labels, attention_mask)
-            if _plain_linears(self.lm_head):
-                loss = AG.LMHeadLossFn.apply(hn.reshape(B * S, D), self.lm_head.weight, ls.contiguous())
+            head = self.lm_head
+            if _plain_linears(head):
+                loss = AG.LMHeadLossFn.apply(hn.reshape(B * S, D), head.weight, ls.contiguous())
+            elif self._lm_head_lora_fusable():   # recipes/config_lora.yaml:59: the adapter inside the lm_head launch, labelled rows only
+                seed = int(torch.empty((), dtype=torch.int64).random_()) if self.training else 0
+                loss = AG.LoraLMHeadLossFn.apply(hn.reshape(B * S, D), head.weight, ls.contiguous(), head.lora_A.weight, head.lora_B.weight,
+                                                 float(head.scaling), float(getattr(head.lora_dropout, "p", 0.0)), self.training, seed)
             else:  # an adapted lm_head: its own forward produces the logits, then the CE kernel
                 loss = AG.CrossEntropyFn.apply(self.lm_head(hn.reshape(B * S, D)), ls.contiguous())
         if return_logits or (labels is None and return_logits is None):

@@ -241,9 +241,12 @@ def case_gemm_lora_ext(dev, counts, K, I, T_dense, r=8, expect_fused=True):
         la = rnd(r, K, seed=206, scale=0.3).to(dev)
         if N % 64 == 0:
             want = dy.float().cpu() @ w.float().cpu() + u.float().cpu() @ la.float().cpu()
+            few = expect_fused and ((T_dense + 255) // 256) * ((K + 255) // 256) < 192   # (too few output tiles for the 256 x 256 kernels: two launches)
+            expect_fused = expect_fused and not few
             got = fused(ops.gemm_lora, dy, w, u, la, b_oc=True)
             close(got, want.to(bf16), 1e-2, 1e-2 * N ** 0.5)
             assert torch.equal(fused(ops.gemm_lora, dy, w, torch.zeros_like(u), la, b_oc=True).cpu(), ops.gemm(dy, w, b_oc=True).cpu())
+            expect_fused = expect_fused or few
         # ---- dense gate | up + SwiGLU
         h_want = x.float().cpu() @ w.float().cpu().t() + u.float().cpu() @ lb.float().cpu().t()
         h, act = fused(ops.gemm_swiglu_lora, x, w, u, lb, want_h=True)

@@ -169,6 +169,18 @@ def test_gemm_v3_split_k(a_oc, b_oc):
     assert lib.aria_last_gemm_variant() == 3
 
 
+@pytest.mark.parametrize("M,N,a_oc,b_oc", [(8, 264, True, True), (520, 24, True, True), (264, 24, False, True), (264, 8, False, False)])
+def test_gemm_v3_split_k_skinny_outputs(M, N, a_oc, b_oc):
+    """The LoRA factors' gradients and projections: outputs 8 .. 24 wide (or tall) with a reduction over the tokens -- split along K into fp32
+    slabs like the router's weight gradient, instead of a handful of 128 x 128 workgroups walking the whole reduction."""
+    from aria_amd import hip
+
+    lib = hip.get_lib().cdll
+    assert lib.aria_gemm_workspace_bytes(M, N, 2048, int(a_oc), int(b_oc)) > 0
+    C.case_gemm_layouts(DEV, M, N, 2048, a_oc, b_oc)
+    assert lib.aria_last_gemm_variant() == 3
+
+
 @pytest.mark.parametrize("counts", [[3, 0, 130, 5, 0, 0, 300, 1], [1, 1, 1]])
 def test_grouped_gemm_v3(force_gemm_v3, counts):
     from aria_amd import hip
