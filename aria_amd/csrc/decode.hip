@@ -131,8 +131,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* W, long long ld
     }
 }
 
-__device__ __forceinline__ int route_one_token(const bf16_t* logits, int E, int k, int l, int want, float& my_score, int& my_idx);
-
 // Up-projection pair + SwiGLU for the k routed experts (e_j = idx[j]) AND the shared expert in one launch: grid.y = k + ns, the shared
 // expert's [ns*I, D] matrices are ns further "experts" of I rows each, so act rows k .. k+ns-1 are its activation vector of length ns*I.
 //   act[j][n] = bf16( bf16(silu(bf16(W1[n,:] . xn))) * bf16(W3[n,:] . xn) )
@@ -321,53 +319,6 @@ __global__ __launch_bounds__(256) void expert_down_combine_kernel(const bf16_t* 
     }
     sh = wave_sum_bcast(sh);
     if (l == 0 && n < N) out[n] = f2bf(bf2f(h[n]) + rbf(rbf(accs) + rbf(sh)));
-}
-
-// TopKRouter.routing on the E logits of one token, exactly as route_kernel (moe.hip): k rounds of arg-max with ties to the lowest expert
-// id, softmax over the selected logits in fp32, scores cast to bf16.  One wave; the logits come from a regular (multi-workgroup) GEMV --
-// a single workgroup reading the whole 320 KB gate matrix cost 16 us per layer.
-// returns the expert id of slot `want` (wave-uniform); lanes < k also get (score, id) of their own slot
-__device__ __forceinline__ int route_one_token(const bf16_t* logits, int E, int k, int l, int want, float& my_score, int& my_idx) {
-    float val[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) val[i] = (l + 64 * i < E) ? bf2f(logits[l + 64 * i]) : -INFINITY;
-    float top[8];
-    int topi = -1, wanted = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        top[j] = -INFINITY;
-        if (j < k) {
-            // round j: the largest remaining logit, ties to the LOWEST expert id.  The maximum comes from a DPP ladder (vector ALU) and the
-            // id from ballots over the four id-ordered slots -- every workgroup of the up-projection runs this in front of its first weight
-            // load, and the butterfly form (two ds_bpermute round trips per step, 6 steps, k rounds) was ~2 us of pure latency there
-            const float m = wave_max_bcast(fmaxf(fmaxf(val[0], val[1]), fmaxf(val[2], val[3])));
-            int bi = -1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned long long hit = ballot(val[i] == m);
-                if (bi < 0 && hit) bi = __builtin_ctzll(hit) + 64 * i;
-            }
-            if (bi < 0) bi = 0;  // (NaN logits: no lane compares equal -- stay in range)
-            top[j] = m;
-            if (l == j) topi = bi;
-            if (j == want) wanted = bi;
-            if ((bi & 63) == l) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i == (bi >> 6)) val[i] = -INFINITY;
-            }
-        }
-    }
-    const float mx = top[0];
-    float den = 0.f, mine = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (j < k) den += expf(top[j] - mx);
-        if (j == l) mine = top[j];
-    }
-    my_score = expf(mine - mx) / den;
-    my_idx = topi;
-    return wanted;
 }
 
 // stand-alone form of the routing the up-projection runs in front of its rows (aria_decode_route: parity tests against aria_moe_route)

@@ -10,6 +10,84 @@ using namespace ad;
 
 constexpr int kMaxPerLane = 4;  // E <= 256
 
+// ------------------------------------------------------------------------------------------- K1: router GEMM + routing, one launch
+// TopKRouter.forward (moe_lm.py:190-201, 243-293): logits = x W^T ([T, D] x [E, D]^T, E = 32 NB), then per token top-k with ties to the
+// lowest expert id, softmax over the selected logits in fp32, scores cast to bf16, and the tokens-per-expert histogram -- the logits GEMM
+// (a 75 %-empty 256-wide tile of the general kernel), a memset and route_kernel as ONE launch.  One wave = 32 tokens:
+//   * logits on the matrix pipe straight from global memory: per 16 reduction indices ONE 16-byte load per lane is the A fragment (32 token
+//     rows x 32 bytes) and one per 32 experts the B fragment (the 320 KB of W stay in the L2s); four 64-index chunks of x in flight per wave
+//     (the launch is a single pass over x: HBM-bound), W one chunk ahead.  Accumulation order = the general kernels' (k ascending in blocks
+//     of 16 on v_mfma_f32_32x32x16_bf16): the bf16 logits are bit-identical to aria_gemm_bf16's, so is everything derived from them.
+//   * the rounded logits go to the wave's LDS tile [32 tokens][E] and from there to HBM (the backward wants them) in 16-byte pieces;
+//   * routing per token by route_one_token (aria_device.h: the decode engine's; lane = expert) on the LDS row; histogram per wave in LDS,
+//     one global atomic per (wave, expert with a count).
+template <int NB>
+__global__ __launch_bounds__(64) void router_fused_kernel(const bf16_t* x, const bf16_t* w, bf16_t* logits, bf16_t* scores, int32_t* indices,
+                                                          int32_t* counts, int T, int D, int k, long long ldx) {
+    constexpr int E = 32 * NB, CH = 4, DEPTH = 4;
+    ARIA_SMEM_STATIC bf16_t tile[32 * E];
+    ARIA_SMEM_STATIC int hist[64];
+    const int l = threadIdx.x & 63, lr = l & 31, kh = l >> 5;
+    const int t0 = blockIdx.x * 32;
+    hist[l] = 0;
+    const bf16_t* xp = x + (long long)min(t0 + lr, T - 1) * ldx + 8 * kh;   // (rows past T: clamped, computed, never stored)
+    const bf16_t* wp = w + (long long)lr * D + 8 * kh;
+    f32x16 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[b][j] = 0.f;
+    s16x8 xa[DEPTH][CH], wb[2][NB][CH];
+    const int nch = D / 64;   // (a multiple of DEPTH: the launcher checks D % 256 == 0)
+#define RF_LOADX(slot, c)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < CH; ++i) xa[slot][i] = *reinterpret_cast<const s16x8*>(xp + (c) * 64 + 16 * i)
+#define RF_LOADW(slot, c)                                                                       \
+    _Pragma("unroll") for (int b = 0; b < NB; ++b) _Pragma("unroll") for (int i = 0; i < CH; ++i)  \
+        wb[slot][b][i] = *reinterpret_cast<const s16x8*>(wp + (long long)(32 * b) * D + (c) * 64 + 16 * i)
+    RF_LOADX(0, 0);
+    RF_LOADX(1, 1);
+    RF_LOADX(2, 2);
+    RF_LOADW(0, 0);
+    for (int c0 = 0; c0 < nch; c0 += DEPTH) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            const int c = c0 + s;
+            if (c + DEPTH - 1 < nch) RF_LOADX((s + DEPTH - 1) % DEPTH, c + DEPTH - 1);
+            if (c + 1 < nch) RF_LOADW((s + 1) & 1, c + 1);
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] = mfma32(xa[s][i], wb[s & 1][b][i], acc[b]);
+        }
+    }
+#undef RF_LOADX
+#undef RF_LOADW
+    // C layout of the 32 x 32 tile: register j of lane l = (token (j & 3) + 8 (j >> 2) + 4 (l >> 5), expert l & 31)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tile[((j & 3) + 8 * (j >> 2) + 4 * kh) * E + 32 * b + lr] = f2bf(acc[b][j]);
+    sync();
+#pragma unroll
+    for (int it = 0; it < (32 * E) / (64 * 8); ++it) {   // the tile = rows t0 .. t0 + 31 of logits [T, E]: contiguous, 16 bytes per lane
+        const int ci = it * 64 + l, tr = ci / (E / 8);
+        if (t0 + tr < T) st16(logits + (long long)t0 * E + ci * 8, ld16(tile + ci * 8));
+    }
+    const int nt = min(32, T - t0);
+    for (int t = 0; t < nt; ++t) {
+        float sc;
+        int id;
+        route_one_token(tile + t * E, E, k, l, 0, sc, id);
+        if (l < k) {
+            scores[(long long)(t0 + t) * k + l] = f2bf(sc);
+            indices[(long long)(t0 + t) * k + l] = id;
+            atomic_add(&hist[id], 1);
+        }
+    }
+    sync();
+    if (l < E && hist[l]) atomic_add(&counts[l], hist[l]);
+}
+
 // ------------------------------------------------------------------------------------------- route
 // one wave per token; lane i owns experts i, i+64, ...
 template <bool F32>
@@ -545,6 +623,28 @@ int aria_moe_route(const void* logits, int logits_f32, void* scores, int32_t* in
         ARIA_LAUNCH((route_kernel<true>), grid, block, 0, stream, logits, scores, indices, counts, int(T), int(E), int(k));
     else
         ARIA_LAUNCH((route_kernel<false>), grid, block, 0, stream, logits, scores, indices, counts, int(T), int(E), int(k));
+    return aria_check_launch();
+}
+
+int aria_moe_router_fused(const void* x, const void* w, void* logits, void* scores, int32_t* indices, int32_t* counts, int64_t T, int64_t D,
+                          int64_t E, int64_t k, int64_t ldx, void* stream) {
+    if (!x || !w || !logits || !scores || !indices || !counts || T < 0 || D <= 0 || E <= 0 || k <= 0) return ARIA_ERR_INVALID;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) || (reinterpret_cast<uintptr_t>(logits) & 15) || (ldx & 7))
+        return ARIA_ERR_ALIGN;
+    if ((E != 32 && E != 64) || (D % 256) || k > 8 || k > E || T >= (1ll << 26)) return ARIA_ERR_UNSUPPORTED;   // (else: aria_gemm_bf16 + aria_moe_route)
+#ifdef ARIA_EMU
+    for (int64_t e = 0; e < E; ++e) counts[e] = 0;
+#else
+    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * E, static_cast<hipStream_t>(stream)) != hipSuccess) return ARIA_ERR_LAUNCH;
+#endif
+    if (T == 0) return ARIA_OK;
+    const dim3 grid(unsigned((T + 31) / 32)), block(64);
+    if (E == 64)
+        ARIA_LAUNCH((router_fused_kernel<2>), grid, block, 0, stream, static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w),
+                    static_cast<bf16_t*>(logits), static_cast<bf16_t*>(scores), indices, counts, int(T), int(D), int(k), (long long)ldx);
+    else
+        ARIA_LAUNCH((router_fused_kernel<1>), grid, block, 0, stream, static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w),
+                    static_cast<bf16_t*>(logits), static_cast<bf16_t*>(scores), indices, counts, int(T), int(D), int(k), (long long)ldx);
     return aria_check_launch();
 }
 

@@ -62,8 +62,11 @@ def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save=Tr
     the backward from what is kept (selective recompute: the routed experts only, 60 % of the layer's forward GEMM flops)."""
     k = cfg.topk
     lean = save == "lean"
-    logits = ops.gemm(x, router_w)                                   # TopKRouter.gating  moe_lm.py:190-201
-    scores, idx, counts = ops.moe_route(logits, k)                   # routing :261-269 (device-side histogram)
+    if ops.router_fusable(x.shape[1], router_w.shape[0], k):         # K1: gating GEMM + routing as ONE launch (bit-identical to the two below)
+        logits, scores, idx, counts = ops.moe_router_fused(x, router_w, k)
+    else:
+        logits = ops.gemm(x, router_w)                               # TopKRouter.gating  moe_lm.py:190-201
+        scores, idx, counts = ops.moe_route(logits, k)               # routing :261-269 (device-side histogram)
     offsets, sorted_src, inv = ops.moe_sort(idx, counts)             # token_permutation :326-334 (stable)
     fused = ops.glu_fusable(fc1.shape[1], fc1.shape[2])
     if fused and (lean or not save) and ops.gather_fusable(fc1.shape[1]):

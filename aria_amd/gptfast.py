@@ -188,8 +188,11 @@ class MOEFeedForward(nn.Module):
 
     def forward(self, x2d):
         k = self.config.router_topk
-        logits = ops.gemm(x2d, self.gate.weight)
-        scores, idx, counts = ops.moe_route(logits, k)                 # topk + softmax (model.py:359-363)
+        if ops.router_fusable(x2d.shape[1], self.gate.weight.shape[0], k):   # K1: gate GEMM + topk + softmax (model.py:355-363) as one launch
+            logits, scores, idx, counts = ops.moe_router_fused(x2d, self.gate.weight, k)
+        else:
+            logits = ops.gemm(x2d, self.gate.weight)
+            scores, idx, counts = ops.moe_route(logits, k)             # topk + softmax (model.py:359-363)
         offsets, sorted_src, inv = ops.moe_sort(idx, counts)           # token_permutation (:243-254)
         cf = self.cond_ffn
         if _glu_pair_ready(cf.w1, cf.w3) and ops.gather_fusable(x2d.shape[1]):

@@ -66,6 +66,7 @@ SIGNATURES = {
     "aria_grouped_gemm_dswiglu_bf16": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, P],
     "aria_gemm_dswiglu_bf16": [P, P, P, P, I64, I64, I64, I32, I64, I64, I64, I64, P],
     "aria_moe_route": [P, I32, P, P, P, I64, I64, I64, P],
+    "aria_moe_router_fused": [P, P, P, P, P, P, I64, I64, I64, I64, I64, P],
     "aria_moe_sort": [P, P, P, P, P, P, I64, I64, I64, P],
     "aria_moe_permute": [P, P, P, I64, I64, I64, I64, P],
     "aria_moe_unpermute": [P, P, P, P, P, I64, I64, I64, P],

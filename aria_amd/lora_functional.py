@@ -159,8 +159,11 @@ def decoder_layer_lora_fwd(x, p: dict, L: Dict[str, LoraSite], cos, sin, B: int,
     a, c_o = dense_lora_fwd(o, p["wo"], [L.get("wo")], [p["wo"].shape[0]], training, seeds)
     hn, h, rstd2 = ops.rmsnorm(a, p["ln2"], eps, residual=x, want_rstd=True)
     # ---- MoE block (moe_lm.py:548-577)
-    logits = ops.gemm(hn, p["router"])
-    scores, idx, counts = ops.moe_route(logits, k)
+    if ops.router_fusable(hn.shape[1], p["router"].shape[0], k):
+        logits, scores, idx, counts = ops.moe_router_fused(hn, p["router"], k)
+    else:
+        logits = ops.gemm(hn, p["router"])
+        scores, idx, counts = ops.moe_route(logits, k)
     offsets, sorted_src, inv = ops.moe_sort(idx, counts)
     perm = ops.moe_permute(hn, sorted_src, k)
     fc1, fc2 = p["fc1"], p["fc2"]

@@ -540,6 +540,30 @@ def moe_route(logits: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor,
     return scores, idx, counts
 
 
+def router_fusable(D: int, E: int, k: int) -> bool:
+    """Shapes the one-launch router takes (K1: logits GEMM + top-k + softmax + histogram); ARIA_FUSE_ROUTER=0 keeps the two-step form."""
+    import os
+
+    return E in (32, 64) and D % 256 == 0 and k <= 8 and os.environ.get("ARIA_FUSE_ROUTER", "1") != "0"
+
+
+def moe_router_fused(x: torch.Tensor, w: torch.Tensor, k: int):
+    """TopKRouter.forward in one launch: x [T, D], w [E, D] -> (logits [T, E] bf16, scores [T, k] bf16, indices int32 [T, k], counts int32 [E]);
+    bit-identical to ``gemm(x, w)`` + ``moe_route``."""
+    _chk(x, name="x"), _chk(w, name="w")
+    T, D = x.shape
+    E = w.shape[0]
+    if w.shape[1] != D or not w.is_contiguous():
+        raise ValueError("moe_router_fused: w must be a contiguous [E, D] tensor")
+    logits = torch.empty((T, E), dtype=bf16, device=x.device)
+    scores = torch.empty((T, k), dtype=bf16, device=x.device)
+    idx = torch.empty((T, k), dtype=torch.int32, device=x.device)
+    counts = torch.empty((E,), dtype=torch.int32, device=x.device)
+    hip.get_lib().call("aria_moe_router_fused", _p(x), _p(w), _p(logits), _p(scores), _p(idx), _p(counts), T, D, E, k, _rowmajor_2d(x, "x"),
+                       _stream(x))
+    return logits, scores, idx, counts
+
+
 def moe_sort(indices: torch.Tensor, counts: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """-> offsets int32 [E+1], sorted_src int32 [T*k] (== reference sorted_indices), inv int32 [T*k]."""
     _chk(indices, torch.int32, "indices"), _chk(counts, torch.int32, "counts")

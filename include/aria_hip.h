@@ -189,6 +189,12 @@ int aria_grouped_gemm_wgrad_bf16(const void* A, const void* dY, void* dW, const 
  * in fp32 then cast to the logits dtype (:262), histogram of selected ids (:264-269).
  *   logits [T,E] bf16 (logits_f32=0) or fp32;  scores [T,k] same dtype as logits;  indices int32 [T,k]
  *   (descending logit order, like torch.topk);  counts int32[E] (zeroed here, then accumulated). */
+/* K1: TopKRouter.forward (moe_lm.py:190-201 gating + :243-293 routing) as ONE launch: logits [T, E] = x [T, D] W^T (W [E, D], the
+ * router's weight) on the matrix pipe with the routing above as its epilogue.  Writes logits (bf16: the backward's input), scores [T, k]
+ * bf16, indices int32 [T, k], counts int32 [E] (zeroed here).  Bit-identical to aria_gemm_bf16 followed by aria_moe_route (same accumulation
+ * order, same tie rule, same softmax).  E = 32 or 64, D % 256 == 0, k <= 8: anything else returns ARIA_ERR_UNSUPPORTED (run the two calls). */
+int aria_moe_router_fused(const void* x, const void* w, void* logits, void* scores, int32_t* indices, int32_t* counts, int64_t T, int64_t D,
+                          int64_t E, int64_t k, int64_t ldx, void* stream);
 int aria_moe_route(const void* logits, int logits_f32, void* scores, int32_t* indices, int32_t* counts, int64_t T,
                    int64_t E, int64_t k, void* stream);
 

@@ -94,7 +94,13 @@ class _Recorder:
 
     def __enter__(self):
         ops = self.ops
-        self._route, self._gg, self._ggs = ops.moe_route, ops.grouped_gemm, ops.grouped_gemm_swiglu
+        self._route, self._gg, self._ggs, self._rf = ops.moe_route, ops.grouped_gemm, ops.grouped_gemm_swiglu, ops.moe_router_fused
+
+        def router_fused(x, w, k):     # (K1: the gating GEMM and the routing as one launch -- the same record)
+            r = self._rf(x, w, k)
+            self.idx.append(r[2].detach().cpu().long())
+            self.logits.append(r[0].detach().float().cpu())
+            return r
 
         def route(logits, k):
             r = self._route(logits, k)
@@ -114,11 +120,11 @@ class _Recorder:
             return r
 
         self.fused = 0
-        ops.moe_route, ops.grouped_gemm, ops.grouped_gemm_swiglu = route, gg, ggs
+        ops.moe_route, ops.grouped_gemm, ops.grouped_gemm_swiglu, ops.moe_router_fused = route, gg, ggs, router_fused
         return self
 
     def __exit__(self, *exc):
-        self.ops.moe_route, self.ops.grouped_gemm, self.ops.grouped_gemm_swiglu = self._route, self._gg, self._ggs
+        self.ops.moe_route, self.ops.grouped_gemm, self.ops.grouped_gemm_swiglu, self.ops.moe_router_fused = self._route, self._gg, self._ggs, self._rf
         return False
 
 

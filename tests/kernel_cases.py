@@ -892,3 +892,31 @@ def case_decode_attention(dev, H, hd, pos, splits, S_max=None):
         outs[ns] = out.float().cpu()
     if splits > 1:  # same per-key arithmetic; only the merge order of partial states differs
         close(outs[splits], outs[1], 1e-2, 4e-3)
+
+
+def case_router_fused(dev, T, D, E, k):
+    """K1: TopKRouter.forward (moe_lm.py:190-201, 243-293) as ONE launch == the gating GEMM followed by aria_moe_route, bit for bit: logits,
+    scores, indices, histogram -- on token counts that are not multiples of the wave's 32 rows, with forced ties in the weights (duplicated
+    expert rows: the tie rule "lowest expert id" decides) -- and the routing against the oracle's own top-k on the SAME bf16 logits."""
+    from aria_amd import ops
+
+    x = rnd(T, D, seed=301).to(dev)
+    w = rnd(E, D, seed=302, scale=0.05)
+    w[5] = w[3]                      # exact ties between experts 3 and 5 (and 17 / 40 when they exist) on every token
+    if E > 40:
+        w[40] = w[17]
+    w = w.to(dev)
+    assert ops.router_fusable(D, E, k)
+    logits, scores, idx, counts = ops.moe_router_fused(x, w, k)
+    ops.GEMM_SPLIT_K = False
+    try:
+        l_ref = ops.gemm(x, w)
+    finally:
+        ops.GEMM_SPLIT_K = True
+    s_ref, i_ref, c_ref = ops.moe_route(l_ref, k)
+    assert torch.equal(logits.cpu(), l_ref.cpu()), "fused router logits != gemm(x, w)"
+    assert torch.equal(idx.cpu(), i_ref.cpu()) and torch.equal(scores.cpu(), s_ref.cpu()) and torch.equal(counts.cpu(), c_ref.cpu())
+    want_scores, want_idx, want_tpe = O.router_routing(logits.float().cpu(), k, E)
+    assert torch.equal(idx.cpu().long(), want_idx) and torch.equal(counts.cpu().long(), want_tpe)
+    close(scores, want_scores.to(bf16), 1e-2, 1e-3)
+    assert int(counts.sum()) == T * k

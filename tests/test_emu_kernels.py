@@ -213,6 +213,11 @@ def test_gemm_dswiglu_fused(force_gemm_v3, counts, K, I, T):
     C.case_gemm_dswiglu_fused(DEV, counts, K, I, T)
 
 
+@pytest.mark.parametrize("T,D,E,k", [(70, 256, 64, 6), (33, 512, 32, 2), (1, 256, 64, 1), (64, 256, 64, 8)])
+def test_router_fused_is_gemm_plus_route(T, D, E, k):
+    C.case_router_fused(DEV, T, D, E, k)
+
+
 @pytest.mark.parametrize("V,top_k,temperature", [(5000, 200, 0.8), (1000, 1, 1.0), (300, 500, 0.7), (4099, None, 1.3), (40, 7, 1e-6)])
 def test_sample_topk_matches_the_tensor_path(V, top_k, temperature):
     C.case_sample_topk(DEV, V, top_k, temperature)

@@ -202,6 +202,11 @@ def test_gemm_swiglu_fused(counts, K, I, T):
     C.case_gemm_swiglu_fused(DEV, counts, K, I, T)
 
 
+@pytest.mark.parametrize("T,D,E,k", [(70, 256, 64, 6), (16384, 2560, 64, 6), (4099, 2560, 64, 6), (33, 512, 32, 2)])
+def test_router_fused_is_gemm_plus_route(T, D, E, k):   # K1: gating GEMM + top-k + softmax + histogram in one launch, bit for bit
+    C.case_router_fused(DEV, T, D, E, k)
+
+
 @pytest.mark.parametrize("counts,K,I,T,r", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300, 8), ([1536] * 8 + [1500, 1580], 2560, 1664, 4096, 8),
                                               ([1536] * 8 + [1500, 1580], 2560, 1664, 4096, 24)])
 def test_gemm_lora_k_extension(counts, K, I, T, r):  # LoRA's second projection inside the base launch, every base form
