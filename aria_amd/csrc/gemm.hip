@@ -631,6 +631,28 @@ int aria_gemm_qkv_rope_cache_bf16(const void* X, const void* Wqkv, void* Q, void
     return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int((M + 255) / 256), stream);
 }
 
+// The HF layer's q | k | v projection + half-split RoPE in one launch (LlamaAttention.forward, modeling_llama.py:243-281, 130-160)
+int aria_gemm_qkv_rope_hf_bf16(const void* X, const void* Wqkv, void* QKV, const void* cos, const void* sin, int64_t M, int64_t D, int64_t K,
+                               int64_t hd, int64_t S, int64_t ldx, int64_t ldw, int64_t ldc, void* stream) {
+    if (!X || !Wqkv || !QKV || !cos || !sin || M < 0 || D <= 0 || K <= 0 || hd <= 0 || S <= 0) return ARIA_ERR_INVALID;
+    if (!aligned16(X) || !aligned16(Wqkv) || !aligned16(QKV) || !aligned16(cos) || !aligned16(sin) || (ldx & 7) || (ldw & 7) || (ldc & 7)) return ARIA_ERR_ALIGN;
+    if ((D % 256) || (256 % hd) || (hd & 15) || (K % 64) || K < 64 || 2 * M * ldx >= (1ll << 32) || 2 * 3 * D * ldw >= (1ll << 32) || 2 * ldx >= (1ll << 24) ||
+        2 * ldw >= (1ll << 24) || !use_v3(((M + 255) / 256) * (3 * D / 256), K, 2 * M * ldx, 2 * 3 * D * ldw, M, 3 * D))
+        return ARIA_ERR_UNSUPPORTED;
+    if (M == 0) return ARIA_OK;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(X);
+    p.B = static_cast<const bf16_t*>(Wqkv);
+    p.C = QKV;
+    p.lda = ldx, p.ldb = ldw, p.ldc = ldc;
+    p.M = int(M), p.N = int(3 * D), p.K = int(K);
+    p.mode = 0;
+    p.rope_fc = static_cast<const bf16_t*>(cos);
+    p.rope_sn = static_cast<const bf16_t*>(sin);
+    p.rope_hd = int(hd), p.rope_D = int(D), p.rope_S = int(S);
+    return g_last_variant = 3, aria_launch_gemm3(p, 0, 0, int((M + 255) / 256), stream);
+}
+
 // shared validation of the fused input-gradient + SwiGLU-backward entries (gemm3_kernel<.., .., 5>)
 static int dglu_check(const void* A, const void* B, const void* H, const void* DH, int64_t M, int64_t I, int64_t K, int64_t lda, int64_t ldb,
                       int64_t ldh, int64_t lddh) {

@@ -569,6 +569,58 @@ __device__ __forceinline__ void store_tile3_rows_rope(const P& p, const f32x16 (
     }
 }
 
+// The same for the HF layer (LlamaAttention.forward, modeling_llama.py:243-281 through moe_lm.py:594): q | k | v as ONE wide projection whose q
+// and k column tiles leave ROTATED -- apply_rotary_pos_emb's half-split form q cos + rotate_half(q) sin (modeling_llama.py:130-160) with the
+// cos / sin tables [S, hd] (emb = cat(freqs, freqs)) of the token's position t % S.  A 256-column tile is two whole heads (hd = 128): the
+// partner x[i +- hd / 2] of a lane's 8 columns lies in the SAME parked row, 128 bytes away -- one more 16-byte LDS read instead of a second
+// pass over [T, 2 D] (rope_kernel: 55 us per layer).  Arithmetic = rope_kernel's, rounding for rounding: bf16(bf16(x cos) + bf16(+-x' sin)).
+template <class P>
+__device__ __forceinline__ void store_tile3_rows_rope_hf(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
+                                                         int wm, int wn, char* smem) {
+    const int c = l & 31, h = l >> 5, odd = l & 1;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    const float v0 = acc[a][i][b][2 * rp], v1 = acc[a][i][b][2 * rp + 1];
+                    const int r = 2 * rp;
+                    const int row = a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;  // inside the tile
+                    const float got = xor1(odd ? v0 : v1);
+                    const float lo = odd ? got : v0, hi = odd ? v1 : got;
+                    *reinterpret_cast<uint32_t*>(smem + row * ROWP3 + (b * 128 + wn * 32 + (c & ~1)) * 2) = pack2bf(lo, hi);
+                }
+    sync();
+    const bool rotate = n0 < 2 * p.rope_D;            // q and k column tiles (tile-uniform); v leaves as it is
+    const int rr = l >> 5, cc = (l & 31) * 8;
+    const int half = p.rope_hd >> 1;
+    const int fcol = (n0 + cc) % p.rope_hd;           // position of the lane's 8 columns inside their head
+    const bool second = fcol >= half;
+    const int pc = second ? cc - half : cc + half;    // the partner's columns: the other half of the same head, same parked row
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+        const int row = w * 32 + s2 * 2 + rr;
+        u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * ROWP3 + cc * 2);
+        const int m = m0 + row;
+        if (m < m_end) {
+            if (rotate) {
+                const u32x4 pv = *reinterpret_cast<const u32x4*>(smem + row * ROWP3 + pc * 2);
+                const int ps = m % p.rope_S;
+                const u32x4 fc = ld16(p.rope_fc + (long long)ps * p.rope_hd + fcol), fs = ld16(p.rope_sn + (long long)ps * p.rope_hd + fcol);
+                const float sg = second ? 1.f : -1.f;   // rotate_half = cat(-x2, x1)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    v[q] = pack2bf(rbf(bflo(v[q]) * bflo(fc[q])) + rbf(sg * bflo(pv[q]) * bflo(fs[q])),
+                                   rbf(bfhi(v[q]) * bfhi(fc[q])) + rbf(sg * bfhi(pv[q]) * bfhi(fs[q])));
+            }
+            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + n0 + cc) = v;
+        }
+    }
+}
+
 template <int ACT, class P>
 __device__ __forceinline__ void store_any3(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w, int wm,
                                            int wn, char* smem) {
@@ -877,6 +929,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         store_tile3_rows_rope(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
         return;
     }
+    if (VER == 10) {  // the HF layer's q | k | v projection with the half-split RoPE as its epilogue
+        store_tile3_rows_rope_hf(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
+        return;
+    }
     if (p.glu)
         store_tile3_glu(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
     else if (p.act == 1)  // (one wave-uniform branch here instead of one per value inside the unrolled epilogues)
@@ -996,6 +1052,13 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
             return ARIA_ERR_INVALID;
     }
     dim3 grid(unsigned(aria_tile_grid(q)), grid_y), block(512);
+    if (p.rope_fc && p.rope_sn) {  // HF form: q | k | v projection + half-split RoPE (two whole heads per column tile)
+        if (a_oc || b_oc || p.mode != 0 || p.glu || p.dglu || p.c_f32 || p.accumulate || p.bias || p.act || (p.N % BN) || (p.rope_D % BN) ||
+            (BN % p.rope_hd) || (p.rope_hd & 15) || !q.wide_store)
+            return ARIA_ERR_INVALID;
+        ARIA_LAUNCH((gemm3_kernel<false, false, 10>), grid, block, shmem, stream, q);
+        return aria_check_launch();
+    }
     if (p.rope_fc) {  // fused wqkv projection (K7): dense, both operands k-contiguous, whole column tiles
         if (a_oc || b_oc || p.mode != 0 || p.glu || p.dglu || p.c_f32 || p.accumulate || p.bias || p.act || (p.N % BN) || (p.rope_D % BN)) return ARIA_ERR_INVALID;
         ARIA_LAUNCH((gemm3_kernel<false, false, 7>), grid, block, shmem, stream, q);

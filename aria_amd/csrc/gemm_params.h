@@ -63,6 +63,9 @@ struct GemmParams {
     //   [ext_k, N] for [K, N] weights; per expert at stride_extB) wherever the reduction index is < ext_k and from the zero page beyond --
     //   the mechanism of the ragged last K-tile.  ext_k % 8 == 0, <= 64; K % 64 == 0; every epilogue (SwiGLU, SwiGLU backward, wide
     //   stores) sees base + adapter in its accumulators, rounded ONCE.  0 = off: the kernels' steady-state code does not read these fields.
+    // the HF layer's q | k | v projection with the half-split RoPE in its epilogue (gemm3_kernel<false, false, 10>): rope_fc = cos, rope_sn = sin,
+    // both [rope_S, rope_hd] bf16; columns [0, 2 rope_D) rotate, position of row m = m % rope_S
+    const ad::bf16_t* rope_sn;
     const ad::bf16_t* extA;
     const ad::bf16_t* extB;
     long long ld_extA, ld_extB, stride_extB;

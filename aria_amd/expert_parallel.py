@@ -140,6 +140,130 @@ def shard_expert_weights(fc1: torch.Tensor, fc2: torch.Tensor, rank: int, world:
     return fc1[rank * per:(rank + 1) * per], fc2[rank * per:(rank + 1) * per]
 
 
+def ep_chunks(T: int) -> int:
+    """Token chunks the exchange is cut into (ARIA_EP_CHUNKS, default 2; 1 = the whole micro-batch as one exchange): chunk i + 1's dispatch
+    all-to-all runs under chunk i's grouped GEMMs, chunk i's combine under chunk i + 1's.  Never chunks of fewer than 1024 tokens."""
+    import os
+
+    c = max(1, int(os.environ.get("ARIA_EP_CHUNKS", "2")))
+    least = max(8, int(os.environ.get("ARIA_EP_CHUNK_MIN", "1024")))   # (the tests lower it to chunk their 21-token batches)
+    return max(1, min(c, T // least))
+
+
+class _Streams:
+    """Main / communication stream pair of one forward (CPU tensors: every method is a no-op, the code path is the same)."""
+
+    def __init__(self, ref: torch.Tensor):
+        self.on = ref.is_cuda
+        if self.on:
+            self.main = torch.cuda.current_stream(ref.device)
+            self.comm = _side_stream(ref.device, 1)
+
+    def on_comm(self):
+        import contextlib
+
+        return torch.cuda.stream(self.comm) if self.on else contextlib.nullcontext()
+
+    def comm_after_main(self, *tensors):   # what follows on the comm stream sees everything enqueued on main so far
+        if self.on:
+            self.comm.wait_stream(self.main)
+            for t in tensors:
+                t.record_stream(self.comm)
+
+    def main_after_comm(self, *tensors):
+        if self.on:
+            self.main.wait_stream(self.comm)
+            for t in tensors:
+                t.record_stream(self.main)
+
+
+def _ep_moe_forward_chunked(x, router_w, fc1_local, fc2_local, gate_w, up_w, down_w, cfg: Fn.MoEConfig, group, C: int) -> torch.Tensor:
+    """The segment form of ``ep_moe_forward`` with the exchange cut into C token chunks (the Megatron dispatcher the
+    reference's is derived from, moe_lm.py:296-365, exchanges the whole micro-batch at once and waits for it):
+
+      main stream:  route / sort / permute of every chunk | GEMMs(0) | GEMMs(1) | ... | un-permute(0..C-1)
+      comm stream:                                         a2a_d(0) a2a_d(1) ...  a2a_c(0)  a2a_c(1) ...
+      side stream:  shared expert (whole micro-batch)
+
+    a2a_d(i + 1) runs under GEMMs(i) and a2a_c(i) under GEMMs(i + 1); the host reads the split sizes of ALL chunks with one copy (one host
+    wait per layer, hidden behind the shared expert's enqueue as before).  Autograd runs every node's backward on the stream its forward ran
+    on, so the backward overlaps the same way in reverse.  Results per row are those of the unchunked form (a row's products do not depend on
+    what else is in the launch); weight gradients are summed over the chunks."""
+    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    E, k = cfg.num_experts, cfg.topk
+    El = E // W
+    T = x.shape[0]
+    bounds = [(T * c // C) // 8 * 8 for c in range(C)] + [T]
+    st = _Streams(x)
+    parts = []
+    for c in range(C):
+        xc = x[bounds[c]:bounds[c + 1]]
+        logits = AG.linear(xc, router_w)
+        scores, idx, counts = RouteFn.apply(logits, cfg)
+        offsets, sorted_src, inv = ops.moe_sort(idx, counts)
+        parts.append(dict(scores=scores, inv=inv, counts=counts, perm=PermuteFn.apply(xc, sorted_src, inv, k)))
+    send_counts = torch.stack([p["counts"].view(W, El) for p in parts], dim=1).contiguous()          # [dest rank, chunk, local expert]
+    recv_counts = torch.empty_like(send_counts)                                                       # [source rank, chunk, local expert]
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all_single(recv_counts, send_counts, group=group)
+    else:
+        gathered = [torch.empty_like(send_counts) for _ in range(W)]
+        dist.all_gather(gathered, send_counts, group=group)
+        recv_counts = torch.stack([g[rank] for g in gathered])
+    both_dev = torch.stack([send_counts, recv_counts])
+    sh, side = None, None
+    if x.is_cuda:
+        both = torch.empty(both_dev.shape, dtype=both_dev.dtype, pin_memory=True)
+        both.copy_(both_dev, non_blocking=True)
+        copied = torch.cuda.Event()
+        copied.record()
+        side = _side_stream(x.device)
+        side.wait_stream(st.main)
+        with torch.cuda.stream(side):
+            sh = _shared_expert(x, gate_w, up_w, down_w)
+        copied.synchronize()
+    else:
+        both = both_dev.cpu()
+    send_sp = [both[0][:, c].sum(1).tolist() for c in range(C)]
+    recv_sp = [both[1][:, c].sum(1).tolist() for c in range(C)]
+    # dispatch all-to-alls, in chunk order, on the comm stream (they wait for the permutes only)
+    st.comm_after_main(*[p["perm"] for p in parts])
+    ev_d = []
+    for c, p in enumerate(parts):
+        with st.on_comm():
+            p["rows"] = AllToAllRowsFn.apply(p["perm"], send_sp[c], recv_sp[c], group)
+            if st.on:
+                e = torch.cuda.Event()
+                e.record(st.comm)
+                ev_d.append(e)
+    ev_g = []
+    for c, p in enumerate(parts):
+        if st.on:
+            st.main.wait_event(ev_d[c])
+            p["rows"].record_stream(st.main)
+        seg_off = torch.zeros(W * El + 1, dtype=torch.int32, device=x.device)
+        seg_off[1:] = torch.cumsum(recv_counts[:, c].reshape(-1), 0).to(torch.int32)
+        act = AG.ExpertsGluSegFn.apply(p["rows"], fc1_local, seg_off)
+        p["eo_local"] = AG.ExpertsGemmSegFn.apply(act, fc2_local, seg_off)
+        if st.on:
+            e = torch.cuda.Event()
+            e.record(st.main)
+            ev_g.append(e)
+            st.comm.wait_event(e)
+            p["eo_local"].record_stream(st.comm)
+        with st.on_comm():
+            p["eo"] = AllToAllRowsFn.apply(p["eo_local"], recv_sp[c], send_sp[c], group)
+    st.main_after_comm(*[p["eo"] for p in parts])
+    if sh is None:
+        sh = _shared_expert(x, gate_w, up_w, down_w)
+    else:
+        st.main.wait_stream(side)
+        sh.record_stream(st.main)
+        x.record_stream(side)
+    outs = [UnpermuteFn.apply(p["eo"], p["inv"], p["scores"], sh[bounds[c]:bounds[c + 1]], k) for c, p in enumerate(parts)]
+    return torch.cat(outs, dim=0)
+
+
 def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w, down_w, cfg: Fn.MoEConfig,
                    group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """MoELayer.forward with the routed experts sharded over `group`.  x [T, D] (this rank's tokens) -> [T, D].
@@ -150,6 +274,12 @@ def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w
     E, k = cfg.num_experts, cfg.topk
     El = E // W
     assert fc1_local.shape[0] == El
+    C = ep_chunks(x.shape[0])
+    if (C > 1 and ops.segments_supported(fc1_local.shape[1]) and ops.segments_supported(fc2_local.shape[1])
+            and ops.glu_fusable(fc1_local.shape[1], fc1_local.shape[2]) and 2 * 4 * x.shape[0] * k * fc1_local.shape[1] < (1 << 32)):
+        # (a chunk may receive up to 4 x its share of rows before the segment launches' 32-bit row offsets overflow: beyond that the
+        # unchunked form below decides per call, on the row count it knows)
+        return _ep_moe_forward_chunked(x, router_w, fc1_local, fc2_local, gate_w, up_w, down_w, cfg, group, C)
     logits = AG.linear(x, router_w)
     scores, idx, counts = RouteFn.apply(logits, cfg)
     offsets, sorted_src, inv = ops.moe_sort(idx, counts)
@@ -239,9 +369,9 @@ def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w
 _SIDE_STREAMS = {}
 
 
-def _side_stream(device):
-    """One extra stream per device for the shared expert (created once: stream creation is not free)."""
-    key = torch.device(device).index
+def _side_stream(device, which: int = 0):
+    """Extra streams per device -- 0: the shared expert, 1: the all-to-alls of the chunked exchange (created once: stream creation is not free)."""
+    key = (torch.device(device).index, which)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]

@@ -225,8 +225,7 @@ def attn_block_fwd(x, wq, wk, wv, wo, cos, sin, B: int, S: int, cfg: AttnConfig,
     Dq = H * hd
     qkv = torch.empty((T, 3 * Dq), dtype=bf16, device=x.device)
     wqkv = fused_weight(wq, wk, wv)
-    ops.gemm(x, wqkv, out=qkv)
-    ops.rope_(qkv[:, :2 * Dq], cos, sin, S, 2 * H, hd)
+    ops.gemm_qkv_rope(x, wqkv, cos, sin, S, hd, out=qkv)           # q | k | v projection with the rotation as its epilogue (one launch)
     if attn_cache is not None and _pad_hd(hd) == hd:
         o, lse = attn_cache
         actx = dict(q=qkv[:, :Dq], k=qkv[:, Dq:2 * Dq], v=qkv[:, 2 * Dq:], o=o, lse=lse, hdp=hd)

@@ -699,6 +699,33 @@ def rope_(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, S: int, n_heads
     return x
 
 
+def gemm_qkv_rope(x: torch.Tensor, wqkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, S: int, hd: int,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LlamaAttention's q | k | v projections + apply_rotary_pos_emb (modeling_llama.py:243-281, 130-160) in one launch: x [T, K], wqkv [3D, K]
+    (q rows, k rows, v rows) -> qkv [T, 3D] with the q and k columns rotated (half-split form, position t % S).  Bit-identical to ``gemm`` +
+    ``rope_``; shapes the fused launch does not take (or ARIA_FUSE_QKV_ROPE=0) run exactly those two."""
+    import os
+
+    _chk(x, name="x"), _chk(wqkv, name="wqkv"), _chk(cos, name="cos"), _chk(sin, name="sin")
+    T, K = x.shape
+    D = wqkv.shape[0] // 3
+    if wqkv.shape != (3 * D, K) or D % hd:
+        raise ValueError("gemm_qkv_rope: wqkv [3D, K] with D a multiple of the head dim")
+    if out is None:
+        out = torch.empty((T, 3 * D), dtype=bf16, device=x.device)
+    assert cos.is_contiguous() and sin.is_contiguous() and cos.shape[1] == hd and cos.shape[0] >= S and sin.shape == cos.shape
+    if os.environ.get("ARIA_FUSE_QKV_ROPE", "1") != "0" and D % 256 == 0 and 256 % hd == 0 and hd % 16 == 0 and K % 64 == 0 and K >= 64:
+        rc = hip.get_lib().cdll.aria_gemm_qkv_rope_hf_bf16(_p(x), _p(wqkv), _p(out), _p(cos), _p(sin), T, D, K, hd, S, _rowmajor_2d(x, "x"),
+                                                           _rowmajor_2d(wqkv, "wqkv"), _rowmajor_2d(out, "out"), _stream(x))
+        if rc == 0:
+            return out
+        if rc != 3:
+            raise hip.AriaHipError(f"aria_gemm_qkv_rope_hf_bf16 failed: {hip.ERRORS.get(rc, rc)}")
+    gemm(x, wqkv, out=out)
+    rope_(out[:, :2 * D], cos, sin, S, 2 * D // hd, hd)
+    return out
+
+
 def rope_interleaved_(x: torch.Tensor, freqs_cis: torch.Tensor, n_heads: int, hd: int, pos: Optional[torch.Tensor] = None):
     """gptfast RoPE in place on the first n_heads*hd columns of x [T, >=n_heads*hd]; freqs_cis bf16 [S, hd/2, 2]."""
     _chk(x, name="x"), _chk(freqs_cis, name="freqs_cis")

@@ -164,8 +164,10 @@ def cpu_baseline(cfg_kwargs, seconds_budget=40.0):
     return {"value": round(value, 3), "unit": "tokens/s", "cores": nthreads, "kind": "port",
             "sample": f"oracle fp32, 1 of 28 full-width decoder layers fwd+bwd (1 warm-up + 3 timed at B=1,S={S}: "
                       f"{', '.join(f'{t:.2f}' for t in t_layers)} s, median {t_layer:.2f}) + lm_head/CE fwd+bwd (median of 3: {t_head:.2f} s); "
-                      f"value = S/(28*t_layer+t_head); os.cpu_count()={os.cpu_count()}; the LIVE reference at config #1 and at this shape, "
-                      f"timed in the build container: profiles/r05_cpu_reference_config1.json"}
+                      f"value = S/(28*t_layer+t_head); os.cpu_count()={os.cpu_count()}; the LIVE reference (cannot travel to this box) timed in the build "
+                      f"container, 8 cores (profiles/r05_cpu_reference_config1.json): config #1 forward 39.2 tok/s vs this port 36.7; at THIS shape "
+                      f"31.0 s per layer vs the port's 3.1 (its sequential_gemm backward builds full-size zero gradients) -- the port overstates the "
+                      f"reference's CPU rate ~10x here"}
 
 
 def long64k_record(model, cfg, make_inputs, ops, steps=3, warmup=1, S=65536, n_img=8):

@@ -146,6 +146,14 @@ int aria_gemm_qkv_rope_cache_bf16(const void* X, const void* Wqkv, void* Q, void
                                   int64_t M, int64_t D, int64_t K, int64_t hd, int64_t S, int64_t S_cache, int64_t ldx, int64_t ldw, int64_t ldq,
                                   int64_t ld_cache, void* stream);
 
+/* The HF layer's counterpart (LlamaAttention.forward, transformers modeling_llama.py:243-281 reached through moe_lm.py:594): the q | k | v
+ * projections as one wide GEMM X [M, K] x Wqkv^T ([3 D, K]) with apply_rotary_pos_emb's half-split rotation (:130-160) of the q and k columns as
+ * its epilogue -- cos / sin [S, hd] bf16 (emb = cat(freqs, freqs), as LlamaRotaryEmbedding builds them), position of row m = m % S.  QKV [M, 3 D]
+ * holds rotated q, rotated k, v.  Bit-identical to aria_gemm_bf16 followed by aria_rope_inplace.  D % 256 == 0, 256 % hd == 0, K % 64 == 0,
+ * enough tiles for the 256 x 256 kernels: ARIA_ERR_UNSUPPORTED otherwise (run the two calls). */
+int aria_gemm_qkv_rope_hf_bf16(const void* X, const void* Wqkv, void* QKV, const void* cos, const void* sin, int64_t M, int64_t D, int64_t K,
+                               int64_t hd, int64_t S, int64_t ldx, int64_t ldw, int64_t ldc, void* stream);
+
 /* Expert parallelism (BASELINE config #5; the reference's dispatcher is local, moe_lm.py:313-365): the grouped GEMM and the fused fc1 + glu
  * launch over the SEGMENTS of an all-to-all's output.  Rows arrive ordered (source rank s, local expert e); offsets int32 [n_seg + 1] bound the
  * n_seg = ranks x n_local segments in that order, and segment g multiplies with the weight of local expert g % n_local (B + (g % n_local) *

@@ -207,7 +207,8 @@ def _ep_worker(rank, world, port, outdir, backend, width):
         out.backward(gy)
     if dev.type == "cuda":
         torch.cuda.synchronize()
-    assert width is None or len(seg_calls) == 2, seg_calls
+    chunks = int(os.environ.get("ARIA_EP_CHUNKS", "1")) if int(os.environ.get("ARIA_EP_CHUNK_MIN", "1024")) <= 8 else 1
+    assert width is None or len(seg_calls) == 2 * chunks, (seg_calls, chunks)
     torch.save(dict(out=out.detach().float().cpu(), dx=x.grad.float().cpu(), grads=[p.grad.float().cpu() for p in ps]),
                os.path.join(outdir, f"ep{rank}.pt"))
     dist.barrier()

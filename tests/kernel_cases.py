@@ -920,3 +920,37 @@ def case_router_fused(dev, T, D, E, k):
     assert torch.equal(idx.cpu().long(), want_idx) and torch.equal(counts.cpu().long(), want_tpe)
     close(scores, want_scores.to(bf16), 1e-2, 1e-3)
     assert int(counts.sum()) == T * k
+
+
+def case_gemm_qkv_rope_hf(dev, B, S, D, hd, K):
+    """LlamaAttention's q | k | v projection + half-split RoPE in one launch (gemm3_kernel<false, false, 10>) == gemm + rope_ (the stand-alone
+    kernel), bit for bit; v columns untouched; the rotation itself against the oracle's apply_rope_half on the bf16-rounded product."""
+    import os
+
+    from aria_amd import functional as Fn
+    from aria_amd import hip, ops
+
+    T = B * S
+    x = rnd(T, K, seed=311, scale=0.5).to(dev)
+    w = rnd(3 * D, K, seed=312, scale=0.1).to(dev)
+    cos, sin = Fn.rope_tables(S + 3, hd, 5e6, dev)
+    got = ops.gemm_qkv_rope(x, w, cos, sin, S, hd)
+    fused = hip.get_lib().cdll.aria_last_gemm_variant() == 3
+    os.environ["ARIA_FUSE_QKV_ROPE"] = "0"
+    ops.GEMM_SPLIT_K = False
+    try:
+        ref = ops.gemm_qkv_rope(x, w, cos, sin, S, hd)
+        plain = ops.gemm(x, w)
+    finally:
+        os.environ.pop("ARIA_FUSE_QKV_ROPE", None)
+        ops.GEMM_SPLIT_K = True
+    assert torch.equal(got.cpu(), ref.cpu()), float((got.float() - ref.float()).abs().max())
+    assert torch.equal(got[:, 2 * D:].cpu(), plain[:, 2 * D:].cpu())
+    H = D // hd
+    q = plain[:, :D].float().cpu().view(B, S, H, hd).transpose(1, 2)
+    kk = plain[:, D:2 * D].float().cpu().view(B, S, H, hd).transpose(1, 2)
+    co, si = cos[:S].float().cpu()[None], sin[:S].float().cpu()[None]
+    qo, ko = O.apply_rope_half(q, kk, co, si)
+    close(got[:, :D], qo.transpose(1, 2).reshape(T, D).to(bf16), 2e-2, 2e-2)
+    close(got[:, D:2 * D], ko.transpose(1, 2).reshape(T, D).to(bf16), 2e-2, 2e-2)
+    return fused

@@ -22,6 +22,14 @@ def test_ep_layer_two_ranks():
     D.run_ep_layer("gloo", 2)
 
 
+def test_ep_layer_chunked_exchange(monkeypatch):
+    """The exchange cut into two token chunks (chunk i + 1's dispatch under chunk i's GEMMs on hardware; here: the same code, one stream):
+    outputs, input gradients and every weight gradient equal the local layer's -- the segment launches run once per chunk."""
+    monkeypatch.setenv("ARIA_EP_CHUNKS", "2")
+    monkeypatch.setenv("ARIA_EP_CHUNK_MIN", "8")
+    D.run_ep_layer("gloo", 2, width=(128, 128, 8, 2))
+
+
 def test_ep_layer_consumes_the_exchange_in_arrival_order():
     """Width the segment launches take (D 128, I 128, 8 experts top-2): fc1 + glu and fc2 run over (source rank, local expert) segments with
     weight index = segment mod local experts -- no row re-order around the grouped GEMMs; weight gradients summed over the source ranks."""

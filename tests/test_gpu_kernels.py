@@ -202,6 +202,11 @@ def test_gemm_swiglu_fused(counts, K, I, T):
     C.case_gemm_swiglu_fused(DEV, counts, K, I, T)
 
 
+@pytest.mark.parametrize("B,S,D,hd,K", [(2, 37, 256, 128, 128), (8, 2048, 2560, 128, 2560), (3, 1000, 2560, 128, 2560)])
+def test_gemm_qkv_rope_hf_is_gemm_plus_rope(B, S, D, hd, K):   # q | k | v projection with the HF-form rotation as its epilogue, bit for bit
+    assert C.case_gemm_qkv_rope_hf(DEV, B, S, D, hd, K) == (D >= 2560)
+
+
 @pytest.mark.parametrize("T,D,E,k", [(70, 256, 64, 6), (16384, 2560, 64, 6), (4099, 2560, 64, 6), (33, 512, 32, 2)])
 def test_router_fused_is_gemm_plus_route(T, D, E, k):   # K1: gating GEMM + top-k + softmax + histogram in one launch, bit for bit
     C.case_router_fused(DEV, T, D, E, k)

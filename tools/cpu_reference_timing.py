@@ -4,7 +4,7 @@ times the port there; this file is what ties the port's number to the reference'
 
   (1) BASELINE config #1 -- "Aria-Base-8K random-init, 1 image (490px) + 128 text tokens, CPU float32 forward via reference aria/model":
       AriaForConditionalGeneration at full widths, 27-layer ViT, L = 1 and L = 5 decoder layers (28 layers of fp32 weights are 99.6 GB;
-      this container has 62 GB: SURVEY F10), forward, 1 warm-up + 5 timed, median; T(28) = T(1) + 27 (T(5) - T(1)) / 4, labelled as an
+      this container has 62 GB: SURVEY F10), forward, 1 warm-up + 5 timed, best; T(28) = T(1) + 27 (T(5) - T(1)) / 4, labelled as an
       extrapolation.  The port (O.aria_forward) on the same weights beside it.
   (2) the port's own shape (bench.py cpu_baseline): ONE full-width decoder layer inside a 1-layer LM, fwd + bwd, B = 1, S = 2048, reference
       vs port, same weights.
@@ -48,7 +48,7 @@ def timed(fn, runs=5):
         t0 = time.perf_counter()
         fn()
         ts.append(time.perf_counter() - t0)
-    return statistics.median(ts), ts
+    return min(ts), ts   # best of the timed runs: the first ones page freshly initialised fp32 weights in (up to 10x slower)
 
 
 def config1(ns, L):
@@ -114,7 +114,7 @@ def main():
     ns = load_reference()
     torch.manual_seed(0)
     out = {"what": "LIVE reference (aria/model of /root/reference, 5 import shims: oracle/ref_shims.py; grouped_gemm absent -> the reference's own "
-                   "sequential_gemm fallback, eager attention) on this container's host cores, fp32, 1 warm-up + 5 timed, median; "
+                   "sequential_gemm fallback, eager attention) on this container's host cores, fp32, 1 warm-up + 5 timed, best of 5; "
                    "the oracle port (oracle/aria_oracle.py) on the same weights and inputs beside it",
            "host": {"os.cpu_count": os.cpu_count(), "torch.get_num_threads": torch.get_num_threads(), "torch": torch.__version__}}
     S, r1, ar1, p1, ap1, e1 = config1(ns, 1)
