@@ -141,11 +141,15 @@ def shard_expert_weights(fc1: torch.Tensor, fc2: torch.Tensor, rank: int, world:
 
 
 def ep_chunks(T: int) -> int:
-    """Token chunks the exchange is cut into (ARIA_EP_CHUNKS, default 2; 1 = the whole micro-batch as one exchange): chunk i + 1's dispatch
-    all-to-all runs under chunk i's grouped GEMMs, chunk i's combine under chunk i + 1's.  Never chunks of fewer than 1024 tokens."""
+    """Token chunks the exchange is cut into (ARIA_EP_CHUNKS; default 1 = the whole micro-batch as one exchange): chunk i + 1's dispatch
+    all-to-all runs under chunk i's grouped GEMMs, chunk i's combine under chunk i + 1's.  Never chunks of fewer than 1024 tokens.
+    OPT-IN: measured on ONE MI355X (bench.py --ep at world 1, where the "exchange" is a device copy and there is no link time to hide;
+    profiles/r05_bench_ep_world1.json) 2 chunks cost +5.8 % and 4 chunks +22.6 % of the step (more launches, smaller grouped GEMMs, the copies
+    competing with the GEMMs for HBM) -- whether 2 chunks pay at 8 GPUs, where 7 / 8 of the rows cross xGMI, is for the first multi-GPU lease
+    to measure."""
     import os
 
-    c = max(1, int(os.environ.get("ARIA_EP_CHUNKS", "2")))
+    c = max(1, int(os.environ.get("ARIA_EP_CHUNKS", "1")))
     least = max(8, int(os.environ.get("ARIA_EP_CHUNK_MIN", "1024")))   # (the tests lower it to chunk their 21-token batches)
     return max(1, min(c, T // least))
 

@@ -951,6 +951,7 @@ def case_gemm_qkv_rope_hf(dev, B, S, D, hd, K):
     kk = plain[:, D:2 * D].float().cpu().view(B, S, H, hd).transpose(1, 2)
     co, si = cos[:S].float().cpu()[None], sin[:S].float().cpu()[None]
     qo, ko = O.apply_rope_half(q, kk, co, si)
-    close(got[:, :D], qo.transpose(1, 2).reshape(T, D).to(bf16), 2e-2, 2e-2)
-    close(got[:, D:2 * D], ko.transpose(1, 2).reshape(T, D).to(bf16), 2e-2, 2e-2)
+    # (three bf16 roundings -- product, x cos, x' sin -- against the oracle's fp32 rotation of the rounded product: 2^-8 of |x| ~ 10 per term)
+    close(got[:, :D], qo.transpose(1, 2).reshape(T, D).to(bf16), 2e-2, 1e-1)
+    close(got[:, D:2 * D], ko.transpose(1, 2).reshape(T, D).to(bf16), 2e-2, 1e-1)
     return fused
