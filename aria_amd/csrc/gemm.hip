@@ -703,6 +703,33 @@ int aria_gemm_dswiglu_bf16(const void* dY, const void* B, const void* H, void* D
     return g_last_variant = 3, aria_launch_gemm3(p, 0, b_oc ? 1 : 0, int((M + 255) / 256), stream);
 }
 
+// The weight gradient of experts.fc1 WITHOUT the permuted copy of the tokens (moe_lm.py:326-334: permuted = x.index_select(0, sorted // topk)):
+// dW[e] = sum over the expert's permuted rows r of x[rows[r]]^T dY[r].  X [T, K] un-permuted tokens, rows int32 [M_total + 64] (token row per
+// permuted row; the 64 entries of padding are read, never used).  v3 only.
+int aria_grouped_gemm_wgrad_gather_bf16(const void* X, const int32_t* rows, const void* dY, void* dW, const int32_t* offsets, int64_t E, int64_t T,
+                                        int64_t K, int64_t N, int64_t ldx, int64_t ldy, int c_f32, int accumulate, void* stream) {
+    if (!X || !rows || !dY || !dW || !offsets || E <= 0 || T <= 0) return ARIA_ERR_INVALID;
+    if (K == 0 || N == 0) return ARIA_OK;
+    if (!aligned16(X) || !aligned16(dY) || (ldx & 7) || (ldy & 7) || (K & 7) || (N & 7) || (reinterpret_cast<uintptr_t>(rows) & 3)) return ARIA_ERR_ALIGN;
+    if (T >= (1ll << 24) || 2 * ldx >= (1ll << 24) || 2 * T * ldx >= (1ll << 32) || !use_v3(((K + 255) / 256) * ((N + 255) / 256) * E, 64, 0, 0, K, N))
+        return ARIA_ERR_UNSUPPORTED;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(X);
+    p.B = static_cast<const bf16_t*>(dY);
+    p.C = dW;
+    p.lda = ldx, p.ldb = ldy, p.ldc = N;
+    p.M = int(K), p.N = int(N), p.K = 0;
+    p.mode = 2;
+    p.offsets = offsets;
+    p.E = int(E);
+    p.strideC = K * N;
+    p.c_f32 = c_f32;
+    p.accumulate = accumulate;
+    p.gather_rows = rows;
+    p.ntn = int((N + BN - 1) / BN);
+    return g_last_variant = 3, aria_launch_gemm3(p, 1, 1, int((K + 255) / 256), stream);
+}
+
 // ---- LoRA as a K-extension of the base GEMM (GemmParams::ext_k; aria/lora/layers.py:129-139, peft's Linear adapter): v3 only -- shapes the
 // 256 x 256 kernels do not take return ARIA_ERR_UNSUPPORTED and the caller runs the adapter as launches of its own
 static int lora_ext(GemmParams& p, const void* EA, const void* EB, int64_t ext_k, int64_t ld_ea, int64_t ld_eb, int64_t stride_eb) {

@@ -201,6 +201,14 @@ struct Stage {  // everything a wave needs to issue its two DMA pieces of any ha
     // offsets of this lane's four A rows of the tile (half x piece) from the operand base at k = 0, chunk term included -- looked up ONCE per
     // tile (the rows of a tile do not change along k); dead fields in every other instantiation
     uint32_t ga[2][2];
+    // GATHER with an output-contiguous A (the per-expert weight gradient dW1[e] = x[tok(r)]^T d_h1[r], moe_lm.py:326-334 read backwards: the
+    // reduction runs over the expert's permuted rows r, whose A rows are TOKEN rows reached through the dispatcher's index -- the [6T, D]
+    // permuted copy is never built).  A piece of an A half-tile = 4 reduction rows x 256 bytes of features: the lane's two rows of the tile
+    // being staged, as byte offsets from the operand base (gk[CUR]: the tile phase 1 stages, gk[NXT]: the one phase 3 stages).  The indices
+    // arrive by SCALAR loads (lgkmcnt: the counted vmcnt pipeline of the DMA pieces never sees them), eight per wave and tile.
+    uint32_t gk[2][2];
+    const int* grows;   // gather_rows at the expert's first reduction row (+ this workgroup's first K-tile)
+    const char* gA0;    // the operand base (token row 0)
     // K-extension (GemmParams::ext_k): the LAST K-tile's sources.  ext = 0: off
     int ext;
     const char* eA;
@@ -208,9 +216,32 @@ struct Stage {  // everything a wave needs to issue its two DMA pieces of any ha
     uint32_t ldeA2, ldeB2;
 };
 
-template <bool A_OC, bool B_OC, int OPERAND, int HALF, int BUF, bool TAIL = true, bool GATHER = false>
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+// eight consecutive int32 at a WAVE-UNIFORM address as a scalar load: issue now, wait (lgkmcnt) at the point of use
+__device__ __forceinline__ void sload8_issue(i32x8& r, const int* p) {
+#ifdef ARIA_EMU
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = p[j];
+#else
+    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(r) : "s"(p));
+#endif
+}
+__device__ __forceinline__ void sload8_wait(i32x8& r) {
+#ifndef ARIA_EMU
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r));   // (the registers pass THROUGH the wait: no use can be scheduled in front of it)
+#endif
+}
+// this lane's two reduction rows of a tile (piece s holds rows 8 w + (l >> 4) + 4 s) -> byte offsets of their token rows
+__device__ __forceinline__ void gather_k_rows(Stage& st, int which, const i32x8& r, int l) {
+    const int q = l >> 4;
+    const int a = q == 0 ? r[0] : q == 1 ? r[1] : q == 2 ? r[2] : r[3];
+    const int b = q == 0 ? r[4] : q == 1 ? r[5] : q == 2 ? r[6] : r[7];
+    st.gk[which][0] = mul24(uint32_t(a), st.ldA2);
+    st.gk[which][1] = mul24(uint32_t(b), st.ldA2);
+}
+
+template <bool A_OC, bool B_OC, int OPERAND, int HALF, int BUF, bool TAIL = true, bool GATHER = false, int GKW = -1>
 __device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
-    static_assert(!GATHER || !A_OC, "gathered A rows are k-contiguous token rows");
     constexpr bool OC = OPERAND == 0 ? A_OC : B_OC;
     const int tile = gtile - st.g0;
     const char* g = (OPERAND == 0 ? st.gA + tile * st.kstepA : st.gB + tile * st.kstepB);
@@ -222,6 +253,12 @@ __device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
     const uint32_t ld2 = OPERAND == 0 ? st.ldA2 : st.ldB2;
     const char* s0 = (GATHER && OPERAND == 0) ? g + st.ga[HALF][0] : g + ls.offset(0, first, limit, ld2);
     const char* s1 = (GATHER && OPERAND == 0) ? g + st.ga[HALF][1] : g + ls.offset(1, first, limit, ld2);
+    if (GATHER && A_OC && OPERAND == 0) {   // gathered reduction rows: which row-offset pair (GKW; default: phase 1 stages half 1 = CUR, phase 3 half 0 = NXT)
+        constexpr int WH = GKW >= 0 ? GKW : (HALF == 1 ? 0 : 1);
+        const uint32_t col2 = 2u * uint32_t(min(first + ls.b, limit - 8));
+        s0 = st.gA0 + st.gk[WH][0] + col2;
+        s1 = st.gA0 + st.gk[WH][1] + col2;
+    }
     if (TAIL && st.tail_k < BK && tile == st.nk - 1) {  // wave-uniform: the ragged end of the reduction -> granules past it read zeros
         if (st.ext && !(GATHER && OPERAND == 0)) {  // K-extension tile: the adapter's operands, same lane <-> (row, reduction index) map
             const char* e = OPERAND == 0 ? st.eA : st.eB;
@@ -351,17 +388,25 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
 
 template <bool A_OC, bool B_OC, int BUF, bool EDGE, bool STEADY = false, bool GATHER = false>
 __device__ __forceinline__ void k_tile(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
-                                       const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int t, int nk, int rl, int cl) {
+                                       const FragAddr<B_OC>& ab, const char* smem, Stage& st, int t, int nk, int rl, int cl) {
     const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+    constexpr bool GK = GATHER && A_OC;   // gathered reduction rows: tile t + 2's indices requested behind phase 1, consumed in front of phase 3
+    i32x8 gr;
     phase<A_OC, B_OC, 0, 0, true, true, BUF, 0, 1, BUF ^ 1, 1, EDGE, STEADY, GATHER>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, n1, rl, cl);
+    if (GK && n2) sload8_issue(gr, st.grows + (t + 2) * BK + 8 * st.w);
     phase<A_OC, B_OC, 0, 1, false, true, BUF, 1, 1, BUF ^ 1, 0, EDGE, STEADY, GATHER>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
+    if (GK && n2) {
+        sload8_wait(gr);
+        gather_k_rows(st, 1, gr, lane_id());
+    }
     phase<A_OC, B_OC, 1, 1, true, false, BUF, 0, 0, BUF, 0, EDGE, STEADY, GATHER>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, false, rl, cl);
     phase<A_OC, B_OC, 1, 0, false, false, BUF, 1, 0, BUF, 4, EDGE, STEADY, GATHER>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, n2, rl, cl);
+    if (GK) st.gk[0][0] = st.gk[1][0], st.gk[0][1] = st.gk[1][1];
 }
 
 template <bool A_OC, bool B_OC, bool EDGE, bool GATHER = false>
 __device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
-                                        const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int nk, int rl, int cl) {
+                                        const FragAddr<B_OC>& ab, const char* smem, Stage& st, int nk, int rl, int cl) {
     int kt = 0;
     if (!EDGE) {
         // steady part: K-tile t stages tiles t + 1 and t + 2, both of which must exist and be full -- t + 2 <= last full tile
@@ -831,10 +876,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     // one barrier apart -- both waves of a SIMD in their MFMA sections together, fragment reads exposed
     const bool stagger_groups = !((p.order >> 10) & 1);
     // VER 8 / 9: the fused SwiGLU launches ([gate | up] weights / the gptfast two-tensor form) with GATHERED A rows
-    constexpr bool GATHER = VER == 8 || VER == 9;
+    constexpr bool GATHER = VER == 8 || VER == 9 || VER == 11;   // (11: the weight gradient with gathered reduction rows, A_OC)
     Stage st;
     stage_init<A_OC, B_OC, VER == 6 || VER == 9>(st, p, w, l, smem);
-    if (GATHER) {  // this lane's four A rows of the tile -> token rows (one index load each, ONCE per tile; rows past the end clamped)
+    if (GATHER && !A_OC) {  // this lane's four A rows of the tile -> token rows (one index load each, ONCE per tile; rows past the end clamped)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
@@ -882,11 +927,27 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     } else {
         // ---- prologue: tile 0 completely, A0 and B0 of tile 1 (phases 1 and 2 of tile 0 issue its A1 and B1) -- the steady-state
         // queue shape
+        if (GATHER && A_OC) {   // reduction rows of tiles 0 and 1 (rows past the expert's end are read -- the index array is padded -- and zero-paged)
+            st.gA0 = reinterpret_cast<const char*>(p.A);
+            st.grows = p.gather_rows + k_begin + kt_first * BK;
+            i32x8 gr;
+            sload8_issue(gr, st.grows + 8 * w);
+            sload8_wait(gr);
+            gather_k_rows(st, 0, gr, l);
+            st.gk[1][0] = st.gk[0][0], st.gk[1][1] = st.gk[0][1];
+        }
         if (nk > 0) {
             stage_half<A_OC, B_OC, 0, 0, 0, true, GATHER>(st, 0);
             stage_half<A_OC, B_OC, 1, 0, 0>(st, 0);
             stage_half<A_OC, B_OC, 1, 1, 0>(st, 0);
             stage_half<A_OC, B_OC, 0, 1, 0, true, GATHER>(st, 0);
+        }
+        if (GATHER && A_OC && nk > 1) {
+            i32x8 gr;
+            sload8_issue(gr, st.grows + BK + 8 * w);
+            sload8_wait(gr);
+            gather_k_rows(st, 1, gr, l);                        // A0 of tile 1 below takes NXT ...
+            st.gk[0][0] = st.gk[1][0], st.gk[0][1] = st.gk[1][1];   // ... and phase 1 of K-tile 0 (A1 of tile 1) CUR
         }
         if (nk > 1) {
             stage_half<A_OC, B_OC, 0, 0, 1, true, GATHER>(st, 1);
@@ -1062,6 +1123,11 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     if (p.rope_fc) {  // fused wqkv projection (K7): dense, both operands k-contiguous, whole column tiles
         if (a_oc || b_oc || p.mode != 0 || p.glu || p.dglu || p.c_f32 || p.accumulate || p.bias || p.act || (p.N % BN) || (p.rope_D % BN)) return ARIA_ERR_INVALID;
         ARIA_LAUNCH((gemm3_kernel<false, false, 7>), grid, block, shmem, stream, q);
+        return aria_check_launch();
+    }
+    if (p.gather_rows && p.mode == 2) {  // the per-expert weight gradient with gathered reduction rows
+        if (!a_oc || !b_oc || p.glu || p.dglu || p.ext_k) return ARIA_ERR_INVALID;
+        ARIA_LAUNCH((gemm3_kernel<true, true, 11>), grid, block, shmem, stream, q);
         return aria_check_launch();
     }
     if (p.gather_rows) {  // gathered A rows (K2): the two fused SwiGLU launches over grouped rows only

@@ -69,11 +69,14 @@ def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save=Tr
         scores, idx, counts = ops.moe_route(logits, k)               # routing :261-269 (device-side histogram)
     offsets, sorted_src, inv = ops.moe_sort(idx, counts)             # token_permutation :326-334 (stable)
     fused = ops.glu_fusable(fc1.shape[1], fc1.shape[2])
-    if fused and (lean or not save) and ops.gather_fusable(fc1.shape[1]):
-        # K2: no backward will read `perm` out of THIS forward (inference, or the forward pass of a checkpointed step -- the backward
-        # rebuilds the expert-row tensors): the row gather rides in fc1's A loader, the [6T, D] copy is neither written nor read
-        perm = h1 = None
-        act = ops.grouped_gemm_swiglu_gather(x, ops.permuted_token_rows(sorted_src, k), fc1, offsets, want_h=False)[1]
+    rows = None
+    if fused and ops.gather_fusable(fc1.shape[1]) and ((lean or not save) or ops.wgrad_gather_fusable(fc1.shape[1])):
+        # K2: the row gather rides in fc1's A loader, the [6T, D] permuted copy is neither written nor read -- inference, the forward pass of a
+        # checkpointed step, and (r05) the plain training step too: fc1's weight gradient reaches the token rows through the same index
+        # (ops.grouped_gemm_wgrad_gather), so nothing in the backward wants `perm` as a tensor
+        perm = None
+        rows = ops.permuted_token_rows(sorted_src, k)
+        h1, act = ops.grouped_gemm_swiglu_gather(x, rows, fc1, offsets, want_h=bool(save) and not lean)
     else:
         perm = ops.moe_permute(x, sorted_src, k)
         if fused:                                                    # experts.fc1 :522 + glu :505-507 in ONE launch (no D2H sync)
@@ -95,7 +98,7 @@ def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save=Tr
     out = ops.moe_unpermute(eo, inv, scores, k, add=sh)              # token_unpermutation :336-365 + `output += shared` :576
     ctx = None
     if save:
-        ctx = dict(x=x, logits=logits, scores=scores, idx=idx, counts=counts, offsets=offsets, inv=inv, sorted_src=sorted_src,
+        ctx = dict(x=x, logits=logits, scores=scores, idx=idx, counts=counts, offsets=offsets, inv=inv, sorted_src=sorted_src, rows=rows,
                    perm=None if lean else perm, h1=None if lean else h1, act=None if lean else act, eo=None if lean else eo,
                    gu=gu, sact=sact, cfg=cfg, wgu=wgu)
     return out, ctx
@@ -103,15 +106,19 @@ def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save=Tr
 
 def moe_rematerialize(ctx, fc1, fc2) -> None:
     """Rebuild the expert-row tensors a lean ``moe_fwd`` did not keep (same kernels on the same inputs: bit-identical to the kept ones)."""
-    if ctx["perm"] is not None:
+    if ctx["act"] is not None:
         return
     k = ctx["cfg"].topk
-    perm = ops.moe_permute(ctx["x"], ctx["sorted_src"], k)
-    if ops.glu_fusable(fc1.shape[1], fc1.shape[2]):
-        h1, act = ops.grouped_gemm_swiglu(perm, fc1, ctx["offsets"], want_h=True)
+    perm = None
+    if ctx.get("rows") is not None and ops.wgrad_gather_fusable(fc1.shape[1]):   # (the weight gradient will gather too: no permuted copy at all)
+        h1, act = ops.grouped_gemm_swiglu_gather(ctx["x"], ctx["rows"], fc1, ctx["offsets"], want_h=True)
     else:
-        h1 = ops.grouped_gemm(perm, fc1, ctx["offsets"])
-        act = ops.swiglu(h1)
+        perm = ops.moe_permute(ctx["x"], ctx["sorted_src"], k)
+        if ops.glu_fusable(fc1.shape[1], fc1.shape[2]):
+            h1, act = ops.grouped_gemm_swiglu(perm, fc1, ctx["offsets"], want_h=True)
+        else:
+            h1 = ops.grouped_gemm(perm, fc1, ctx["offsets"])
+            act = ops.swiglu(h1)
     ctx.update(perm=perm, h1=h1, act=act, eo=ops.grouped_gemm(act, fc2, ctx["offsets"]))
 
 
@@ -134,7 +141,14 @@ def moe_bwd(dout, ctx, router_w, fc1, fc2, gate_w, up_w, down_w, need=None):
         d_h1 = ops.swiglu_bwd(ctx["h1"], ops.grouped_gemm(d_eo, fc2, offsets, w_is_kn=False))
     g_fc2 = ops.grouped_gemm_wgrad(ctx["act"], d_eo, offsets, E) if _want(need, "fc2") else None
     d_perm = ops.grouped_gemm(d_h1, fc1, offsets, w_is_kn=False)
-    g_fc1 = ops.grouped_gemm_wgrad(ctx["perm"], d_h1, offsets, E) if _want(need, "fc1") else None
+    g_fc1 = None
+    if _want(need, "fc1"):
+        if ctx["perm"] is None:   # the forward gathered: so does the weight gradient (or, shapes the gathered launch does not take, permute now)
+            g_fc1 = ops.grouped_gemm_wgrad_gather(x, ctx["rows"], d_h1, offsets, E)
+            if g_fc1 is None:
+                g_fc1 = ops.grouped_gemm_wgrad(ops.moe_permute(x, ctx["sorted_src"], k), d_h1, offsets, E)
+        else:
+            g_fc1 = ops.grouped_gemm_wgrad(ctx["perm"], d_h1, offsets, E)
     dx = ops.moe_unpermute(d_perm, inv, None, k)                     # backward of the row gather
     # shared expert
     if ops.dglu_fusable(down_w.shape[1], down_w.shape[0]):

@@ -59,6 +59,7 @@ SIGNATURES = {
     "aria_grouped_gemm_swiglu_lora_bf16": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, P, P, I64, I64, I64, I64, P],
     "aria_dropout_fwd_bf16": [P, P, P, I64, F32, ctypes.c_uint64, P],
     "aria_dropout_bwd_bf16": [P, P, P, I64, F32, I32, P],
+    "aria_grouped_gemm_wgrad_gather_bf16": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, P],
     "aria_gemm_qkv_rope_hf_bf16": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, P],
     "aria_gemm_qkv_rope_cache_bf16": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, P],
     "aria_grouped_gemm_swiglu_gather_bf16": [P, P, I64, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, P],

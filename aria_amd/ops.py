@@ -398,9 +398,39 @@ def gather_fusable(K: int) -> bool:
     return K % 64 == 0 and K >= 64 and os.environ.get("ARIA_FUSE_GATHER", "1") != "0"
 
 
-def permuted_token_rows(sorted_src: torch.Tensor, k: int) -> torch.Tensor:
-    """Token row of every permuted row (``sorted_indices // topk``, moe_lm.py:330): int32 [T * k]."""
-    return torch.div(sorted_src, k, rounding_mode="floor").to(torch.int32)
+def permuted_token_rows(sorted_src: torch.Tensor, k: int, pad: int = 64) -> torch.Tensor:
+    """Token row of every permuted row (``sorted_indices // topk``, moe_lm.py:330): int32 [T * k] -- a view of a buffer with ``pad`` more entries
+    (the weight gradient's gathered loader reads a whole K-tile of indices at the end of the last expert)."""
+    n = sorted_src.numel()
+    buf = torch.zeros((n + pad,), dtype=torch.int32, device=sorted_src.device)
+    torch.div(sorted_src, k, rounding_mode="floor", out=buf[:n])
+    return buf[:n]
+
+
+def wgrad_gather_fusable(K: int) -> bool:
+    """The fc1 weight gradient can take the UN-permuted tokens + the dispatcher's index (no permuted copy in the training step)."""
+    import os
+
+    return gather_fusable(K) and os.environ.get("ARIA_FUSE_WGRAD_GATHER", "1") != "0"
+
+
+def grouped_gemm_wgrad_gather(x: torch.Tensor, rows: torch.Tensor, dy: torch.Tensor, offsets: torch.Tensor, E: int, out_dtype=bf16):
+    """``grouped_gemm_wgrad(moe_permute(x, ..), dy, offsets, E)`` without the permuted copy: x [T, K], rows = ``permuted_token_rows`` (its
+    padded buffer), dy [M, N] -> dW [E, K, N]; None when the library does not take the shape (the caller permutes and uses the plain entry)."""
+    _chk(x, name="x"), _chk(dy, name="dy"), _chk(offsets, torch.int32, "offsets"), _chk(rows, torch.int32, "rows")
+    if rows.untyped_storage().nbytes() - rows.storage_offset() * 4 < (rows.numel() + 64) * 4 or not rows.is_contiguous():
+        raise ValueError("grouped_gemm_wgrad_gather: rows must come from permuted_token_rows (64 entries of padding behind it)")
+    K, N = x.shape[1], dy.shape[1]
+    out = torch.empty((E, K, N), dtype=out_dtype, device=x.device)
+    if dy.shape[0] == 0:
+        return out.zero_()
+    rc = hip.get_lib().cdll.aria_grouped_gemm_wgrad_gather_bf16(_p(x), _p(rows), _p(dy), _p(out), _p(offsets), E, x.shape[0], K, N, _rowmajor_2d(x, "x"),
+                                                                _rowmajor_2d(dy, "dy"), int(out_dtype == torch.float32), 0, _stream(x))
+    if rc == 3:
+        return None
+    if rc != 0:
+        raise hip.AriaHipError(f"aria_grouped_gemm_wgrad_gather_bf16 failed: {hip.ERRORS.get(rc, rc)}")
+    return out
 
 
 def grouped_gemm_swiglu_gather(x: torch.Tensor, rows: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, want_h: bool = False):

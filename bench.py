@@ -84,31 +84,34 @@ def init_params(model, seed):
                     flat[o:o + chunk].normal_(0.0, 0.02, generator=g)
 
 
-PMC_FILE = "r04_pmc_fc1.json"
-KERNEL_REV = "r04b"   # bumped with every change of the v3 K loop / epilogues: a PMC pass of an older build does not describe this one
-PMC_KERNEL_TAG = "gemm3_kernel<rc,oc,3>+wide_store+ragged_last+swiglu@r04b"   # the fc1 launch the committed PMC pass profiled
+PMC_FILE = "r05_pmc_fc1.json"
+KERNEL_REV = "r05"    # bumped with every change of the v3 K loop / epilogues: a PMC pass of an older build does not describe this one
+PMC_KERNEL_TAG = "gemm3_kernel<rc,oc,8>+gather+wide_store+ragged_last+swiglu@r05"   # the fc1 launch the committed PMC pass profiled
 
 
-def fc1_kernel_tag(variant):
-    """What the default path launched for experts.fc1 in THIS run, spelled like profiles/r04_pmc_fc1.json's kernel_tag."""
+def fc1_kernel_tag(variant, gather=None):
+    """What the default path launched for experts.fc1 in THIS run, spelled like profiles/r05_pmc_fc1.json's kernel_tag."""
     if variant != 3:
         return f"gemm{variant}_kernel<rc,oc>"
+    if gather is None:
+        gather = os.environ.get("ARIA_FUSE_GATHER", "1") != "0" and os.environ.get("ARIA_FUSE_WGRAD_GATHER", "1") != "0" and \
+            os.environ.get("ARIA_FUSE_SWIGLU", "1") != "0"
     wide = os.environ.get("ARIA_GEMM_WIDE_STORE", "1") != "0"
     fused = os.environ.get("ARIA_FUSE_SWIGLU", "1") != "0"
     order = os.environ.get("ARIA_GEMM_ORDER")
     ragged_last = fused if order is None else bool(int(order) & 512)   # the fused launch's default tile order since r04b
-    return ("gemm3_kernel<rc,oc,3>" + ("+wide_store" if wide else "") + ("+ragged_last" if ragged_last else "+expert_major") +
-            ("+swiglu" if fused else "") + "@" + KERNEL_REV)
+    return ("gemm3_kernel<rc,oc," + ("8>+gather" if gather and fused else "3>") + ("+wide_store" if wide else "") +
+            ("+ragged_last" if ragged_last else "+expert_major") + ("+swiglu" if fused else "") + "@" + KERNEL_REV)
 
 
-def pmc_traffic(variant=3):
+def pmc_traffic(variant=3, gather=None):
     """Bytes beyond the L2s per fc1 launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
     tools/gemm_pmc_target.py = the same shape and the same fused launch; gfx950 FETCH_SIZE x2 correction applied) -- counters cannot be read inside the timed run.
     None unless the pass profiled exactly the kernel / epilogue / tile order this run launched."""
     try:
         with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             d = json.load(f)
-        return round(d["hbm_bytes_per_launch"]) if d["kernel_tag"] == fc1_kernel_tag(variant) else None
+        return round(d["hbm_bytes_per_launch"]) if d["kernel_tag"] == fc1_kernel_tag(variant, gather) else None
     except Exception:
         return None
 
@@ -551,7 +554,25 @@ def main():
         return r
 
     timed_grouped_gemm.fused = False
+    timed_grouped_gemm.gather = False
     ops.grouped_gemm_swiglu = timed_grouped_gemm_swiglu
+
+    # ... since r05 on the UN-permuted tokens through the dispatcher's index (K2 in the training step too): the same launch, gathered A rows
+    orig_ggsg = ops.grouped_gemm_swiglu_gather
+
+    def timed_grouped_gemm_swiglu_gather(x, rows, w, offsets, want_h=False):
+        if not timed_grouped_gemm.on or fc1_events is None:
+            return orig_ggsg(x, rows, w, offsets, want_h=want_h)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = orig_ggsg(x, rows, w, offsets, want_h=want_h)
+        e.record()
+        fc1_events.append((s, e))
+        timed_grouped_gemm.variant = hip.get_lib().cdll.aria_last_gemm_variant()
+        timed_grouped_gemm.fused = timed_grouped_gemm.gather = True
+        return r
+
+    ops.grouped_gemm_swiglu_gather = timed_grouped_gemm_swiglu_gather
 
     dense_events = {}  # --time-grouped also classifies the dense GEMMs by operand form and size class (diagnostics)
     orig_gemm = ops.gemm
@@ -636,11 +657,11 @@ def main():
                        "grad_exchange": None if world == 1 else ("all_reduce" if args.allreduce else "reduce_scatter (ZeRO-2)"), "grad_checkpointing": bool(args.recompute),
                        "optimizer_in_step": False,  # metric = fwd+bwd; AdamW state (299 GB fp32) only exists sharded over >= 2 GPUs
                        "loss": round(float(loss), 4)},
-            "roofline": {"kernel": fc1_kernel_tag(timed_grouped_gemm.variant) + " grouped-M (experts.fc1 forward" +
+            "roofline": {"kernel": fc1_kernel_tag(timed_grouped_gemm.variant, timed_grouped_gemm.gather) + " grouped-M (experts.fc1 forward" +
                                    (" + SwiGLU epilogue)" if timed_grouped_gemm.fused else ")"), "bound": "mfma",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / peak, 4),
-                         "traffic": pmc_traffic(timed_grouped_gemm.variant),
+                         "traffic": pmc_traffic(timed_grouped_gemm.variant, timed_grouped_gemm.gather),
                          "launches_timed": len(durs), "avg_launch_ms": round(avg * 1e3, 4),
                          "algorithmic_flops_per_launch": flops_launch},
         }

@@ -136,6 +136,15 @@ int aria_grouped_gemm_swiglu_lora_bf16(const void* A, const void* B, void* H, vo
 int aria_dropout_fwd_bf16(const void* x, void* out, void* mask, int64_t n, float p, uint64_t seed, void* stream);
 int aria_dropout_bwd_bf16(const void* term, const void* mask, void* dx, int64_t n, float p, int accumulate, void* stream);
 
+/* K2 for the TRAINING step (round 5): the weight gradient of experts.fc1 through the dispatcher's index -- dW[e] = sum over the expert's permuted rows r
+ * of X[rows[r]]^T dY[r] (autograd of experts_gemm(index_select(x, sorted // topk), fc1), moe_lm.py:326-334, 467-484) -- so that the [6T, D] permuted copy
+ * of the tokens is never written: forward = aria_grouped_gemm_swiglu_gather_bf16, weight gradient = this.  The indices of a K-tile reach the loader by
+ * scalar loads (eight per wave), outside the counted-vmcnt pipeline of its DMA pieces.  rows: int32 [M_total + 64] (64 entries of padding are read,
+ * never used); T < 2^24, 2 T ldx < 2^32.  Bit-identical to aria_moe_permute + aria_grouped_gemm_wgrad_bf16.  Shapes the 256 x 256 kernels do not take:
+ * ARIA_ERR_UNSUPPORTED. */
+int aria_grouped_gemm_wgrad_gather_bf16(const void* X, const int32_t* rows, const void* dY, void* dW, const int32_t* offsets, int64_t E, int64_t T,
+                                        int64_t K, int64_t N, int64_t ldx, int64_t ldy, int c_f32, int accumulate, void* stream);
+
 /* K7: gptfast's Attention.forward up to the attention call (gptfast/model.py:413-435) as ONE launch: the fused wqkv projection
  * X [M, K] x Wqkv^T ([3 D, K]: q rows, k rows, v rows), the interleaved-pair RoPE of q and k (apply_rotary_emb :519-531: fp32 arithmetic on
  * the bf16-rounded product with the bf16 freqs_cis table [positions, hd / 2, 2], one rounding) and KVCache.update (:67-93) as the GEMM's

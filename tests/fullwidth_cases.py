@@ -95,6 +95,13 @@ class _Recorder:
     def __enter__(self):
         ops = self.ops
         self._route, self._gg, self._ggs, self._rf = ops.moe_route, ops.grouped_gemm, ops.grouped_gemm_swiglu, ops.moe_router_fused
+        self._ggsg = ops.grouped_gemm_swiglu_gather
+
+        def ggsg(*a, **kw):            # (K2: the fused fc1 + SwiGLU launch on gathered rows -- the training step's form since r05)
+            r = self._ggsg(*a, **kw)
+            self.variants.append(int(self.hip.get_lib().cdll.aria_last_gemm_variant()))
+            self.fused += 1
+            return r
 
         def router_fused(x, w, k):     # (K1: the gating GEMM and the routing as one launch -- the same record)
             r = self._rf(x, w, k)
@@ -121,10 +128,12 @@ class _Recorder:
 
         self.fused = 0
         ops.moe_route, ops.grouped_gemm, ops.grouped_gemm_swiglu, ops.moe_router_fused = route, gg, ggs, router_fused
+        ops.grouped_gemm_swiglu_gather = ggsg
         return self
 
     def __exit__(self, *exc):
         self.ops.moe_route, self.ops.grouped_gemm, self.ops.grouped_gemm_swiglu, self.ops.moe_router_fused = self._route, self._gg, self._ggs, self._rf
+        self.ops.grouped_gemm_swiglu_gather = self._ggsg
         return False
 
 

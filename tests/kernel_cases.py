@@ -955,3 +955,34 @@ def case_gemm_qkv_rope_hf(dev, B, S, D, hd, K):
     close(got[:, :D], qo.transpose(1, 2).reshape(T, D).to(bf16), 2e-2, 1e-1)
     close(got[:, D:2 * D], ko.transpose(1, 2).reshape(T, D).to(bf16), 2e-2, 1e-1)
     return fused
+
+
+def case_grouped_gemm_wgrad_gather(dev, T, E, k, K, N, seed=321):
+    """The weight gradient of experts.fc1 through the dispatcher's index (aria_grouped_gemm_wgrad_gather_bf16: the reduction rows of a K-tile
+    are token rows reached by scalar index loads) == aria_moe_permute + aria_grouped_gemm_wgrad_bf16, bit for bit (same tiles, same reduction
+    order), bf16 and fp32 outputs, on a real routing (ragged and empty experts: expert 1 gets no token, the last one ends mid-tile)."""
+    from aria_amd import hip, ops
+
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(T, K, generator=g) * 0.5).to(bf16).to(dev)
+    logits = torch.randn(T, E, generator=g)
+    logits[:, 1] = -1e9                                        # nobody routes to expert 1
+    idx = torch.topk(logits, k, dim=1).indices.to(torch.int32).to(dev)
+    counts = torch.bincount(idx.flatten().long(), minlength=E).to(torch.int32)
+    offsets, sorted_src, inv = ops.moe_sort(idx, counts)
+    M = T * k
+    dy = (torch.randn(M, N, generator=g) * 0.5).to(bf16).to(dev)
+    perm = ops.moe_permute(x, sorted_src, k)
+    rows = ops.permuted_token_rows(sorted_src, k)
+    assert torch.equal(perm.cpu(), x.cpu()[rows.long().cpu()])
+    for dt in (bf16, torch.float32):
+        ref = ops.grouped_gemm_wgrad(perm, dy, offsets, E, out_dtype=dt)
+        assert hip.get_lib().cdll.aria_last_gemm_variant() == 3, "the case must run the v3 weight gradient (ARIA_GEMM_FORCE=3 at toy sizes)"
+        got = ops.grouped_gemm_wgrad_gather(x, rows, dy, offsets, E, out_dtype=dt)
+        assert got is not None and torch.equal(got.cpu(), ref.cpu()), float((got.float() - ref.float()).abs().max())
+    assert float(got[1].abs().max()) == 0.0
+    want = torch.zeros(E, K, N)
+    off = offsets.cpu().tolist()
+    for e in range(E):
+        want[e] = perm[off[e]:off[e + 1]].float().cpu().t() @ dy[off[e]:off[e + 1]].float().cpu()
+    close(got, want, 1e-4, 1e-3 * max(1, max(counts.tolist())) ** 0.5)

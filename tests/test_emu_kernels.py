@@ -213,6 +213,11 @@ def test_gemm_dswiglu_fused(force_gemm_v3, counts, K, I, T):
     C.case_gemm_dswiglu_fused(DEV, counts, K, I, T)
 
 
+@pytest.mark.parametrize("T,E,k,K,N", [(150, 8, 2, 264, 136), (40, 4, 3, 64, 72), (700, 8, 1, 128, 256)])
+def test_grouped_gemm_wgrad_with_gathered_rows(force_gemm_v3, T, E, k, K, N):
+    C.case_grouped_gemm_wgrad_gather(DEV, T, E, k, K, N)
+
+
 @pytest.mark.parametrize("B,S,D,hd,K", [(2, 37, 256, 128, 128), (1, 300, 256, 64, 64)])
 def test_gemm_qkv_rope_hf_is_gemm_plus_rope(force_gemm_v3, B, S, D, hd, K):
     assert C.case_gemm_qkv_rope_hf(DEV, B, S, D, hd, K)

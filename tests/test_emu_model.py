@@ -218,6 +218,11 @@ def test_lora_fused_node_matches_modular(force_v3, monkeypatch):
     M.case_lora_fused_vs_modular(DEV)
 
 
+def test_training_step_without_permuted_copy(monkeypatch):
+    monkeypatch.setenv("ARIA_GEMM_FORCE", "3")   # (toy shapes: the 256 x 256 kernels -- the gathered weight gradient is one of them)
+    M.case_training_step_without_permuted_copy(DEV)
+
+
 def test_adapted_decoder_layer_with_gradient_checkpointing():
     """recipes/config_lora.yaml runs with gradient_checkpointing: the module-by-module decoder layer recomputed in backward gives the same
     loss and the same LoRA gradients as the stored-activation run (dropout off: bit-identical)."""

@@ -202,6 +202,13 @@ def test_gemm_swiglu_fused(counts, K, I, T):
     C.case_gemm_swiglu_fused(DEV, counts, K, I, T)
 
 
+@pytest.mark.parametrize("T,E,k,K,N", [(4096, 64, 6, 2560, 3328), (16384, 64, 6, 2560, 3328), (1000, 8, 2, 264, 136)])
+def test_grouped_gemm_wgrad_with_gathered_rows(T, E, k, K, N, monkeypatch):   # fc1's weight gradient through the dispatcher's index, bit for bit
+    if K < 2560:
+        monkeypatch.setenv("ARIA_GEMM_FORCE", "3")
+    C.case_grouped_gemm_wgrad_gather(DEV, T, E, k, K, N)
+
+
 @pytest.mark.parametrize("B,S,D,hd,K", [(2, 37, 256, 128, 128), (8, 2048, 2560, 128, 2560), (3, 1000, 2560, 128, 2560)])
 def test_gemm_qkv_rope_hf_is_gemm_plus_rope(B, S, D, hd, K):   # q | k | v projection with the HF-form rotation as its epilogue, bit for bit
     assert C.case_gemm_qkv_rope_hf(DEV, B, S, D, hd, K) == (D >= 2560)

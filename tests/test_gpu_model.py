@@ -60,6 +60,11 @@ def test_decode_engine_fused_schedule(aria_width):  # 6-launch decode schedule =
     M.case_decode_engine_fused_schedule(DEV, aria_width=aria_width, n_tokens=6 if aria_width else 4)
 
 
+def test_training_step_without_permuted_copy(monkeypatch):   # K2 in the training step: gathered fc1 forward + gathered weight gradient, bit for bit
+    monkeypatch.setenv("ARIA_GEMM_FORCE", "3")
+    M.case_training_step_without_permuted_copy(DEV)
+
+
 def test_lora_fused_sites_with_dropout():   # adapters inside the base launches, dropout masks applied in forward and backward (site level)
     M.case_lora_fused_sites(DEV)
 

@@ -29,9 +29,9 @@ if what == "fc1":
     scores, idx, counts = ops.moe_route(logits, k)
     off, sorted_src, inv = ops.moe_sort(idx, counts)
     fc1 = rn(E, D, 2 * I, scale=0.02)
-    perm = ops.moe_permute(x, sorted_src, k)
+    rows = ops.permuted_token_rows(sorted_src, k)   # (r05: the training step's fc1 launch takes the un-permuted tokens + the dispatcher's index)
     for _ in range(3):
-        h, act = ops.grouped_gemm_swiglu(perm, fc1, off, True)
+        h, act = ops.grouped_gemm_swiglu_gather(x, rows, fc1, off, True)
 elif what == "attn_bwd":
     B, S, H, hd = 1, 65536, 20, 128
     D = H * hd
