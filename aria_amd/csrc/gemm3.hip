@@ -240,8 +240,10 @@ __device__ __forceinline__ void gather_k_rows(Stage& st, int which, const i32x8&
     st.gk[which][1] = mul24(uint32_t(b), st.ldA2);
 }
 
-template <bool A_OC, bool B_OC, int OPERAND, int HALF, int BUF, bool TAIL = true, bool GATHER = false, int GKW = -1>
+template <bool A_OC, bool B_OC, int OPERAND, int HALF, int BUF, bool TAIL = true, int XM = 0, int GKW = -1>
 __device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
+    // XM (compile time, so that the default kernels carry none of it): bit 0 = gathered A rows, bit 1 = K-extension tile behind the reduction
+    constexpr bool GATHER = XM & 1, EXT = (XM & 2) != 0;
     constexpr bool OC = OPERAND == 0 ? A_OC : B_OC;
     const int tile = gtile - st.g0;
     const char* g = (OPERAND == 0 ? st.gA + tile * st.kstepA : st.gB + tile * st.kstepB);
@@ -260,7 +262,7 @@ __device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
         s1 = st.gA0 + st.gk[WH][1] + col2;
     }
     if (TAIL && st.tail_k < BK && tile == st.nk - 1) {  // wave-uniform: the ragged end of the reduction -> granules past it read zeros
-        if (st.ext && !(GATHER && OPERAND == 0)) {  // K-extension tile: the adapter's operands, same lane <-> (row, reduction index) map
+        if (EXT && !(GATHER && OPERAND == 0)) {  // K-extension tile: the adapter's operands, same lane <-> (row, reduction index) map
             const char* e = OPERAND == 0 ? st.eA : st.eB;
             const uint32_t le2 = OPERAND == 0 ? st.ldeA2 : st.ldeB2;
             s0 = e + ls.offset(0, first, limit, le2);
@@ -306,7 +308,7 @@ __device__ __forceinline__ void stage_init(Stage& st, const P& p, int w, int l, 
 // are in flight behind every wait -- the phase is straight-line code (the general form spends two scalar branches, a handful of selects
 // and a chain of compares per phase on conditions that only change in a tile's last three K-tiles).
 template <bool A_OC, bool B_OC, int QA, int QB, bool LOAD_A, bool LOAD_B, int BUF, int SO, int SH, int SB, int WAIT, bool EDGE,
-          bool STEADY = false, bool GATHER = false>
+          bool STEADY = false, int XM = 0>
 __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                       const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int stage_tile, bool do_stage,
                                       bool more_in_flight, int rows_left, int cols_left) {
@@ -334,9 +336,9 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
     constexpr bool LATE = true;
     if (!LATE) {
         if (STEADY)
-            stage_half<A_OC, B_OC, SO, SH, SB, false, GATHER>(st, stage_tile);
+            stage_half<A_OC, B_OC, SO, SH, SB, false, XM>(st, stage_tile);
         else if (do_stage)
-            stage_half<A_OC, B_OC, SO, SH, SB, true, GATHER>(st, stage_tile);
+            stage_half<A_OC, B_OC, SO, SH, SB, true, XM>(st, stage_tile);
     }
     if (!(ARIA_ABL & 32) && WAIT == 1) {  // phase 1: B1 and A1 of THIS tile must have landed; newer = A0, B0 (and, early placement, A1) of the next tile
         if (STEADY || more_in_flight)
@@ -365,14 +367,14 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
                 if (ARIA_ABL & 4) {
                     // (timing experiment: no DMA)
                 } else if (STEADY)
-                    stage_half<A_OC, B_OC, SO, SH, SB, false, GATHER>(st, stage_tile);
+                    stage_half<A_OC, B_OC, SO, SH, SB, false, XM>(st, stage_tile);
                 else if (do_stage)
-                    stage_half<A_OC, B_OC, SO, SH, SB, true, GATHER>(st, stage_tile);
+                    stage_half<A_OC, B_OC, SO, SH, SB, true, XM>(st, stage_tile);
                 sched_fence();
             }
         }
     } else {
-        if (LATE && do_stage) stage_half<A_OC, B_OC, SO, SH, SB, true, GATHER>(st, stage_tile);
+        if (LATE && do_stage) stage_half<A_OC, B_OC, SO, SH, SB, true, XM>(st, stage_tile);
         if (col_ok) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -386,25 +388,25 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
     if (!(ARIA_ABL & 8)) raw_barrier();
 }
 
-template <bool A_OC, bool B_OC, int BUF, bool EDGE, bool STEADY = false, bool GATHER = false>
+template <bool A_OC, bool B_OC, int BUF, bool EDGE, bool STEADY = false, int XM = 0>
 __device__ __forceinline__ void k_tile(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                        const FragAddr<B_OC>& ab, const char* smem, Stage& st, int t, int nk, int rl, int cl) {
     const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-    constexpr bool GK = GATHER && A_OC;   // gathered reduction rows: tile t + 2's indices requested behind phase 1, consumed in front of phase 3
+    constexpr bool GK = (XM & 1) && A_OC;   // gathered reduction rows: tile t + 2's indices requested behind phase 1, consumed in front of phase 3
     i32x8 gr;
-    phase<A_OC, B_OC, 0, 0, true, true, BUF, 0, 1, BUF ^ 1, 1, EDGE, STEADY, GATHER>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, n1, rl, cl);
+    phase<A_OC, B_OC, 0, 0, true, true, BUF, 0, 1, BUF ^ 1, 1, EDGE, STEADY, XM>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, n1, rl, cl);
     if (GK && n2) sload8_issue(gr, st.grows + (t + 2) * BK + 8 * st.w);
-    phase<A_OC, B_OC, 0, 1, false, true, BUF, 1, 1, BUF ^ 1, 0, EDGE, STEADY, GATHER>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
+    phase<A_OC, B_OC, 0, 1, false, true, BUF, 1, 1, BUF ^ 1, 0, EDGE, STEADY, XM>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
     if (GK && n2) {
         sload8_wait(gr);
         gather_k_rows(st, 1, gr, lane_id());
     }
-    phase<A_OC, B_OC, 1, 1, true, false, BUF, 0, 0, BUF, 0, EDGE, STEADY, GATHER>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, false, rl, cl);
-    phase<A_OC, B_OC, 1, 0, false, false, BUF, 1, 0, BUF, 4, EDGE, STEADY, GATHER>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, n2, rl, cl);
+    phase<A_OC, B_OC, 1, 1, true, false, BUF, 0, 0, BUF, 0, EDGE, STEADY, XM>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, false, rl, cl);
+    phase<A_OC, B_OC, 1, 0, false, false, BUF, 1, 0, BUF, 4, EDGE, STEADY, XM>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, n2, rl, cl);
     if (GK) st.gk[0][0] = st.gk[1][0], st.gk[0][1] = st.gk[1][1];
 }
 
-template <bool A_OC, bool B_OC, bool EDGE, bool GATHER = false>
+template <bool A_OC, bool B_OC, bool EDGE, int XM = 0>
 __device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                         const FragAddr<B_OC>& ab, const char* smem, Stage& st, int nk, int rl, int cl) {
     int kt = 0;
@@ -412,15 +414,15 @@ __device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4
         // steady part: K-tile t stages tiles t + 1 and t + 2, both of which must exist and be full -- t + 2 <= last full tile
         const int last_full = st.tail_k < BK ? nk - 2 : nk - 1;
         for (; kt + 1 <= last_full - 2; kt += 2) {
-            k_tile<A_OC, B_OC, 0, false, true, GATHER>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
-            k_tile<A_OC, B_OC, 1, false, true, GATHER>(acc, fa, fb, aa, ab, smem, st, kt + 1, nk, rl, cl);
+            k_tile<A_OC, B_OC, 0, false, true, XM>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
+            k_tile<A_OC, B_OC, 1, false, true, XM>(acc, fa, fb, aa, ab, smem, st, kt + 1, nk, rl, cl);
         }
     }
     for (; kt + 1 < nk; kt += 2) {
-        k_tile<A_OC, B_OC, 0, EDGE, false, GATHER>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
-        k_tile<A_OC, B_OC, 1, EDGE, false, GATHER>(acc, fa, fb, aa, ab, smem, st, kt + 1, nk, rl, cl);
+        k_tile<A_OC, B_OC, 0, EDGE, false, XM>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
+        k_tile<A_OC, B_OC, 1, EDGE, false, XM>(acc, fa, fb, aa, ab, smem, st, kt + 1, nk, rl, cl);
     }
-    if (kt < nk) k_tile<A_OC, B_OC, 0, EDGE, false, GATHER>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
+    if (kt < nk) k_tile<A_OC, B_OC, 0, EDGE, false, XM>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
 }
 
 template <int ACT, class P>
@@ -755,6 +757,27 @@ __device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)
     const int c = l & 31, h = l >> 5, odd = l & 1;
     char* mine = smem + 16384 * w;  // [a][b][64 rows][64 bytes]
     const int I = p.N;
+    const int rr = l >> 2, cc = (l & 3) * 8;  // this lane's row inside a 16-row slab / first of its 8 columns
+    const bf16_t* H = p.H;
+    bf16_t* DH = reinterpret_cast<bf16_t*>(C);
+    // r05: the forward's [gate | up] values do not depend on the accumulators -- ALL 32 16-byte loads per lane (both 128-row halves) are requested right
+    // behind the parking, when the 128 accumulator registers are dead: one HBM round trip for the whole tile, half 1's rows land under half 0's
+    // arithmetic and stores.  (Requesting a part BEFORE the parking, beside the live accumulators, spilled 24 registers to scratch.)  (Was: park, load half 0, wait, compute, store,
+    // load half 1, wait, compute, store -- two exposed round trips of ~2 us on a CU with nothing else to do: 270 us of the launch's 1094.)
+    u32x4 vg[2][2][4], vu[2][2][4];
+    auto load_h = [&](int a, int b0, int b1) {
+#pragma unroll
+        for (int b = b0; b < b1; ++b)
+            if (n0 + b * 128 < I) {  // block-uniform
+#pragma unroll
+                for (int s16 = 0; s16 < 4; ++s16) {
+                    const int m = min(m0 + a * 128 + wm * 64 + s16 * 16 + rr, m_end - 1);  // clamped: loaded, never stored
+                    const bf16_t* src = H + (long long)m * p.ldh + n0 + b * 128 + wn * 32 + cc;
+                    vg[a][b][s16] = ld16(src);
+                    vu[a][b][s16] = ld16(src + I);
+                }
+            }
+    };
     wave_barrier();
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -772,24 +795,16 @@ __device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)
                     *reinterpret_cast<uint32_t*>(mine + (a * 2 + b) * 4096 + row * 64 + (c & ~1) * 2) = pack2bf(lo, hi);
                 }
     wave_barrier();
-    sched_fence();  // (the H loads below must not be hoisted above the parking: the accumulators are still live there)
-    const int rr = l >> 2, cc = (l & 3) * 8;  // this lane's row inside a 16-row slab / first of its 8 columns
-    const bf16_t* H = p.H;
-    bf16_t* DH = reinterpret_cast<bf16_t*>(C);
+    sched_fence();  // (half 1's loads must not be hoisted above the parking: the accumulators are still live there)
+    load_h(0, 0, 2);
+    load_h(1, 0, 1);
+    sched_fence();
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        u32x4 vg[2][4], vu[2][4];
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-            if (n0 + b * 128 < I) {  // block-uniform
-#pragma unroll
-                for (int s16 = 0; s16 < 4; ++s16) {
-                    const int m = min(m0 + a * 128 + wm * 64 + s16 * 16 + rr, m_end - 1);  // clamped: loaded, never stored
-                    const bf16_t* src = H + (long long)m * p.ldh + n0 + b * 128 + wn * 32 + cc;
-                    vg[b][s16] = ld16(src);
-                    vu[b][s16] = ld16(src + I);
-                }
-            }
+        if (a == 1) {   // (the last quarter's loads: requested once half 0's registers are free)
+            load_h(1, 1, 2);
+            sched_fence();
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b)
             if (n0 + b * 128 < I) {
@@ -801,8 +816,8 @@ __device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float da[2], db[2];
-                        swiglu_bwd_elem(bflo(vg[b][s16][q]), bflo(vu[b][s16][q]), bflo(d[q]), da[0], db[0]);
-                        swiglu_bwd_elem(bfhi(vg[b][s16][q]), bfhi(vu[b][s16][q]), bfhi(d[q]), da[1], db[1]);
+                        swiglu_bwd_elem(bflo(vg[a][b][s16][q]), bflo(vu[a][b][s16][q]), bflo(d[q]), da[0], db[0]);
+                        swiglu_bwd_elem(bfhi(vg[a][b][s16][q]), bfhi(vu[a][b][s16][q]), bfhi(d[q]), da[1], db[1]);
                         og[q] = pack2bf(da[0], da[1]);
                         ou[q] = pack2bf(db[0], db[1]);
                     }
@@ -864,7 +879,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     }
     char* C = static_cast<char*>(p.C) + c_off * (p.c_f32 ? 4 : 2);
     int nk = (k_len + BK - 1) / BK, kt_first = 0;
-    const int ext_k = (A_OC || p.mode == 2) ? 0 : p.ext_k;  // (launcher: never with split-K, gathered rows, or the split gate / up form)
+    const int ext_k = VER == 12 ? p.ext_k : 0;  // (its own instantiations: the default kernels keep none of the extension's registers live)
     if (ext_k > 0) nk += 1;                                 // K % 64 == 0 there: the extension is one more K-tile with ext_k valid indices
     const int nk_all = nk;
     if (slab >= 0) {  // K-steps [nk * ks / split, nk * (ks + 1) / split)
@@ -877,6 +892,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     const bool stagger_groups = !((p.order >> 10) & 1);
     // VER 8 / 9: the fused SwiGLU launches ([gate | up] weights / the gptfast two-tensor form) with GATHERED A rows
     constexpr bool GATHER = VER == 8 || VER == 9 || VER == 11;   // (11: the weight gradient with gathered reduction rows, A_OC)
+    constexpr bool EXT = VER == 12;                                 // (12: the default epilogues behind a K-extension tile -- LoRA inside the base launch)
+    constexpr int XM = (GATHER ? 1 : 0) | (EXT ? 2 : 0);
     Stage st;
     stage_init<A_OC, B_OC, VER == 6 || VER == 9>(st, p, w, l, smem);
     if (GATHER && !A_OC) {  // this lane's four A rows of the tile -> token rows (one index load each, ONCE per tile; rows past the end clamped)
@@ -937,10 +954,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
             st.gk[1][0] = st.gk[0][0], st.gk[1][1] = st.gk[0][1];
         }
         if (nk > 0) {
-            stage_half<A_OC, B_OC, 0, 0, 0, true, GATHER>(st, 0);
-            stage_half<A_OC, B_OC, 1, 0, 0>(st, 0);
-            stage_half<A_OC, B_OC, 1, 1, 0>(st, 0);
-            stage_half<A_OC, B_OC, 0, 1, 0, true, GATHER>(st, 0);
+            stage_half<A_OC, B_OC, 0, 0, 0, true, XM>(st, 0);
+            stage_half<A_OC, B_OC, 1, 0, 0, true, XM & 2>(st, 0);
+            stage_half<A_OC, B_OC, 1, 1, 0, true, XM & 2>(st, 0);
+            stage_half<A_OC, B_OC, 0, 1, 0, true, XM>(st, 0);
         }
         if (GATHER && A_OC && nk > 1) {
             i32x8 gr;
@@ -950,8 +967,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
             st.gk[0][0] = st.gk[1][0], st.gk[0][1] = st.gk[1][1];   // ... and phase 1 of K-tile 0 (A1 of tile 1) CUR
         }
         if (nk > 1) {
-            stage_half<A_OC, B_OC, 0, 0, 1, true, GATHER>(st, 1);
-            stage_half<A_OC, B_OC, 1, 0, 1>(st, 1);
+            stage_half<A_OC, B_OC, 0, 0, 1, true, XM>(st, 1);
+            stage_half<A_OC, B_OC, 1, 0, 1, true, XM & 2>(st, 1);
             wait_vm<4>();
         } else {
             wait_vm<0>();
@@ -960,9 +977,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         ts_mark(1);
         if (wm == 1 && stagger_groups) raw_barrier();  // waves 4-7 run one barrier behind waves 0-3
         if (interior)
-            k_loop3<A_OC, B_OC, false, GATHER>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
+            k_loop3<A_OC, B_OC, false, XM>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
         else
-            k_loop3<A_OC, B_OC, true, GATHER>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
+            k_loop3<A_OC, B_OC, true, XM>(acc, fa, fb, aa, ab, smem, st, nk, rows_left, cols_left);
     }
     if (wm == 0 && stagger_groups) raw_barrier();  // balance the barrier count of the two groups
     ts_mark(2);
@@ -1106,7 +1123,7 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
     if (p.ext_k) {  // K-extension: whole K-tiles in front of it, 16-byte granules, neither split-K nor the forms whose loaders it does not cover
         if (!p.extA || !p.extB || p.ext_k < 0 || p.ext_k > BK || (p.ext_k & 7) || (p.K % BK) || a_oc || p.mode == 2 || p.gather_rows || p.rope_fc ||
-            (p.glu && p.glu_up_rows > 0) || (p.ld_extA & 7) || (p.ld_extB & 7) || (p.stride_extB & 7) ||
+            (p.glu && p.glu_up_rows > 0) || p.dglu || (p.ld_extA & 7) || (p.ld_extB & 7) || (p.stride_extB & 7) ||
             (reinterpret_cast<uintptr_t>(p.extA) & 15) || (reinterpret_cast<uintptr_t>(p.extB) & 15) ||
             2 * (long long)p.M * p.ld_extA >= (1ll << 32) || 2 * p.ld_extA >= (1ll << 24) || 2 * p.ld_extB >= (1ll << 24) ||
             2 * (b_oc ? (long long)p.ext_k : (long long)p.N) * p.ld_extB >= (1ll << 32))
@@ -1149,6 +1166,13 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
             ARIA_LAUNCH((gemm3_kernel<false, false, 5>), grid, block, shmem, stream, q);
         else
             ARIA_LAUNCH((gemm3_kernel<false, true, 5>), grid, block, shmem, stream, q);
+        return aria_check_launch();
+    }
+    if (p.ext_k) {  // K-extension (LoRA inside the base launch): its own instantiations of the default epilogues
+        if (!b_oc)
+            ARIA_LAUNCH((gemm3_kernel<false, false, 12>), grid, block, shmem, stream, q);
+        else
+            ARIA_LAUNCH((gemm3_kernel<false, true, 12>), grid, block, shmem, stream, q);
         return aria_check_launch();
     }
     if (!a_oc && !b_oc)
