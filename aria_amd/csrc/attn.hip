@@ -1190,7 +1190,6 @@ __global__ __launch_bounds__(512) void attn_bwd5_dq_kernel(const bf16_t* Q, cons
 //     pipe, as in v2), key j stored at row rho(j) = 8 (j >> 3) + 2 (j & 3) + ((j >> 2) & 1) so that the four keys of a transposing read lie
 //     16 banks apart.
 // Same arithmetic in the same order as v2: results are bit-identical (tests compare the two).
-__device__ const uint32_t aria_ones_chunk[4] = {0x00003F80u, 0u, 0u, 0u};  // bf16 {1, 0, 0, 0, 0, 0, 0, 0}
 
 template <int HD>
 struct FwdFmt;
@@ -1209,55 +1208,6 @@ struct FwdFmt<128> {
     static __device__ __forceinline__ s16x8 kfrag(const char* s, int row, int kk, int l) { return frag_rc3<128>(s, row, kk, l); }
     static __device__ __forceinline__ s16x8 vfrag(const char* s, int rb, int d0, int l) { return frag_tr3<128>(s, rb, d0, l); }
 };
-template <>
-struct FwdFmt<72> {
-    static constexpr int KS = 5, DT = 3, KROW = 144, VROW = 160;
-    static constexpr int KTILE = 64 * KROW + 16, VTILE = 64 * VROW + 32;  // (+ what the last row's pad-column reads touch)
-    static constexpr bool ROWSUM_IN_MFMA = true;
-    // per-lane constants of the DMA pieces: K piece p holds image chunks 64 p + l = (row, chunk) = (q / 9, q % 9); V piece p the chunks
-    // (LDS row R, chunk) = (q / 10, q % 10), LDS row R holding key 8 (R >> 3) + 4 (R & 1) + ((R >> 1) & 3)
-    // (wave w issues pieces w and w + nw: with 8 waves K's ninth piece falls to wave 0 and V's ninth / tenth to waves 0 / 1; with 12 waves
-    // every wave has at most one piece of each)
-    int krow[2], kcol[2], vkey[2], vcol[2], nw;
-    __device__ __forceinline__ void init(int w, int l, int nwaves) {
-        nw = nwaves;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int p = w + nwaves * i;
-            const int qk = 64 * p + l, qv = 64 * p + l;
-            krow[i] = qk / 9, kcol[i] = (qk % 9) * 8;
-            const int R = qv / 10;
-            vkey[i] = 8 * (R >> 3) + 4 * (R & 1) + ((R >> 1) & 3), vcol[i] = (qv % 10) * 8;
-        }
-    }
-    __device__ __forceinline__ void dma_k(const bf16_t* base, long long ld, int row0, int row_last, char* s, int w, int l) const {
-        if (w < 9) glds16_raw(base + (long long)min(row0 + krow[0], row_last) * ld + kcol[0], s + w * 1024);
-        if (w + nw < 9) glds16_raw(base + (long long)min(row0 + krow[1], row_last) * ld + kcol[1], s + (w + nw) * 1024);
-    }
-    __device__ __forceinline__ void dma_v(const bf16_t* base, long long ld, int row0, int row_last, char* s, int w, int l) const {
-        const bf16_t* ones = reinterpret_cast<const bf16_t*>(aria_ones_chunk);
-        if (w < 10) glds16_raw(vcol[0] < 72 ? base + (long long)min(row0 + vkey[0], row_last) * ld + vcol[0] : ones, s + w * 1024);
-        if (w + nw < 10) glds16_raw(vcol[1] < 72 ? base + (long long)min(row0 + vkey[1], row_last) * ld + vcol[1] : ones, s + (w + nw) * 1024);
-    }
-    static __device__ __forceinline__ s16x8 kfrag(const char* s, int row, int kk, int l) {
-        return *reinterpret_cast<const s16x8*>(s + row * KROW + kk * 32 + (l >> 5) * 16);
-    }
-    // fragment of feature columns d0 .. d0 + 31 whose 8 k-slots are keys rb + 4 h + (e & 3) + 8 (e >> 2); rb % 16 == 0
-    static __device__ __forceinline__ s16x8 vfrag(const char* s, int rb, int d0, int l) {
-        const int R0 = rb + 2 * ((l & 15) >> 2) + (l >> 5);  // rho(rb + 4 h + c) = rb + 2 c + h;  rho(.. + 8) = R0 + 8
-        const int col = d0 + 16 * ((l >> 4) & 1) + 4 * (l & 3);
-        const s16x4 a0 = ds_read_tr16(reinterpret_cast<const bf16_t*>(s + R0 * VROW + col * 2));
-        const s16x4 a1 = ds_read_tr16(reinterpret_cast<const bf16_t*>(s + (R0 + 8) * VROW + col * 2));
-        s16x8 f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            f[e] = a0[e];
-            f[4 + e] = a1[e];
-        }
-        return f;
-    }
-};
-
 template <int HD>
 struct Fwd3Smem {
     using F = FwdFmt<HD>;
@@ -1520,21 +1470,12 @@ int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     const char* fwdv = std::getenv("ARIA_ATTN_FWD");          // "2": the round-1..3 kernels (A/B measurements, bit-identity tests)
     // default: hd 128 -> v3 pipelined (+4..8 % over v2 from 2K to 64K tokens); hd 72 -> v2 with 12 waves (measured, same box: v2 2.23-2.46 ms,
     // v3 with 12 waves + LDS-DMA 2.38-2.45, v3 pipelined with 8 waves 2.78-2.81 per ViT launch: profiles/r04_attn_fwd3_ab.json).
-    // ARIA_ATTN_FWD = "2": v2 everywhere; "3": v3 for hd 72 too (12 waves, scores in step); "3p": hd 72 pipelined with 8 waves.
-    const bool want3 = fwdv && fwdv[0] == '3';
-    const bool v3 = !(fwdv && fwdv[0] == '2') && (hd == 128 || (hd == 72 && want3)) && Skv > 0;
-    const bool pipe72 = want3 && fwdv[1] == 'p';
+    // ARIA_ATTN_FWD = "2": v2 everywhere.
+    // (r05: the two hd-72 forms of v3 -- measured slower than v2's 12 waves -- left the library: tools/probes/src/attn_fwd3_hd72.patch)
+    const bool v3 = !(fwdv && fwdv[0] == '2') && hd == 128 && Skv > 0;
     g_last_fwd_variant = v3 ? 3 : 2;
-    if (v3 && hd == 128)
+    if (v3)
         ARIA_LAUNCH((attn_fwd3_kernel<128, 8, true>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Fwd3Smem<128>::BYTES), stream, Q, K, V,
-                    static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
-                    (long long)ldv, (long long)ldo, scale, causal, int(B));
-    else if (v3 && pipe72)
-        ARIA_LAUNCH((attn_fwd3_kernel<72, 8, true>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Fwd3Smem<72>::BYTES), stream, Q, K, V,
-                    static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
-                    (long long)ldv, (long long)ldo, scale, causal, int(B));
-    else if (v3)
-        ARIA_LAUNCH((attn_fwd3_kernel<72, 12, false>), dim3(attn_grid((Sq + 383) / 384, H, B)), dim3(768), size_t(Fwd3Smem<72>::BYTES), stream, Q, K, V,
                     static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
                     (long long)ldv, (long long)ldo, scale, causal, int(B));
     else if (hd == 128)

@@ -821,8 +821,8 @@ def case_attention_forward_variants(dev, B, Sq, Skv, H, hd, causal, masked, use_
             km[0, Skv - Skv // 4:] = 0
     if use_len:
         kl = torch.randint(1, Skv + 1, (B,), generator=g).to(torch.int32)
-    want_variant = {"2": 2, "3": 3, "3p": 3}
-    vers = ("2", "3", "3p") if hd == 72 else ("2", "3")
+    want_variant = {"2": 2, "3": 3 if hd == 128 else 2}   # (r05: hd 72 has only v2 in the library; "3" there selects nothing)
+    vers = ("2", "3")
     prev = os.environ.get("ARIA_ATTN_FWD")
     got = {}
     try:
