@@ -106,7 +106,23 @@ __device__ __forceinline__ f32x16 zero_acc() {
 __device__ __forceinline__ bool attn_block_coords(int nblk, int H, int B, int causal, bool reverse, int& blk, int& head, int& b) {
     const int n = blockIdx.x, nbh = H * B;
     int bh;
-    if (causal) {
+    if (causal == 2) {
+        // r05, causal == 2 (the host asks for it: the FORWARD from 32 K tokens up): like the non-causal order -- the blocks of one (b, head) run
+        // TOGETHER on one XCD, longest first, so the ~32 workgroups an XCD has resident share a few K / V panels.  Measured on one box
+        // (profiles/r05_attn_causal_order_ab.json), this order against the one below: forward 64K 22.76 -> 21.45 ms (-5.7 %), but 16K 1.48 -> 1.60
+        // and 8 x 2048 0.312 -> 0.356 ms, backward 0.866 -> 0.95 / 4.86 -> 5.12 / 76.6 -> 76.2 ms: below ~32 K tokens the chip-wide
+        // longest-first order's load balance is worth more than the panels' L2 residency, and the backward kernels do not notice the L2 at all
+        // (the config #3 step: 585.9 vs 594.0 ms with this order everywhere).  Equal work per XCD needs the number of units to be a multiple of
+        // 8: a (b, head) is cut into P = 8 / gcd(H B, 8) interleaved parts (blocks p, p + P, ...), units are dealt round-robin to the XCDs.
+        const int g = (nbh & 7) == 0 ? 8 : (nbh & 3) == 0 ? 4 : (nbh & 1) == 0 ? 2 : 1, P = 8 / g;
+        const int nbu = (nblk + P - 1) / P;
+        const int xcd = n & 7, j = n >> 3;
+        const int u = (j / nbu) * 8 + xcd, t = j % nbu;
+        bh = u / P;
+        const int pos = t * P + (u % P);   // 0 = the longest block
+        if (pos >= nblk) return false;
+        blk = reverse ? nblk - 1 - pos : pos;
+    } else if (causal) {
         const int z = n / nbh;
         if (z >= nblk) return false;
         bh = n % nbh;
@@ -121,7 +137,12 @@ __device__ __forceinline__ bool attn_block_coords(int nblk, int H, int B, int ca
     b = bh / H;
     return true;
 }
-inline unsigned attn_grid(long long nblk, long long H, long long B) { return unsigned(((H * B + 7) & ~7ll) * nblk); }
+inline unsigned attn_grid(long long nblk, long long H, long long B) {
+    // covers both orders: (b, head) pairs rounded up to 8 times the blocks, and P parts of ceil(nblk / P) blocks per (b, head) for the causal one
+    const long long nbh = H * B, g = (nbh & 7) == 0 ? 8 : (nbh & 3) == 0 ? 4 : (nbh & 1) == 0 ? 2 : 1, P = 8 / g;
+    const long long causal_ids = ((nbh * P + 7) / 8) * 8 * ((nblk + P - 1) / P);
+    return unsigned(std::max(((nbh + 7) & ~7ll) * nblk, causal_ids));
+}
 
 // =========================================================================================== forward v2
 // NW waves / 32 NW queries per block (8 for hd 64/128; 12 for hd 72, whose ~165 VGPRs allow three waves per SIMD -- the extra
@@ -1468,6 +1489,8 @@ int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     const bf16_t *Q = static_cast<const bf16_t*>(q), *K = static_cast<const bf16_t*>(k), *V = static_cast<const bf16_t*>(v);
     const char* nw72 = std::getenv("ARIA_ATTN_HD72_WAVES");  // "8": the two-waves-per-SIMD variant (A/B measurements)
     const char* fwdv = std::getenv("ARIA_ATTN_FWD");          // "2": the round-1..3 kernels (A/B measurements, bit-identity tests)
+    const char* grp = std::getenv("ARIA_ATTN_CAUSAL_GROUPED");   // "1" / "0": force the XCD-grouped causal block order on / off (tests, A/B)
+    const int causal_arg = causal ? ((grp ? grp[0] == '1' : Sq >= 32768) ? 2 : 1) : 0;   // (2: attn_block_coords' grouped order; default: the forward from 32 K tokens up)
     // default: hd 128 -> v3 pipelined (+4..8 % over v2 from 2K to 64K tokens); hd 72 -> v2 with 12 waves (measured, same box: v2 2.23-2.46 ms,
     // v3 with 12 waves + LDS-DMA 2.38-2.45, v3 pipelined with 8 waves 2.78-2.81 per ViT launch: profiles/r04_attn_fwd3_ab.json).
     // ARIA_ATTN_FWD = "2": v2 everywhere.
@@ -1477,7 +1500,7 @@ int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     if (v3)
         ARIA_LAUNCH((attn_fwd3_kernel<128, 8, true>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Fwd3Smem<128>::BYTES), stream, Q, K, V,
                     static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
-                    (long long)ldv, (long long)ldo, scale, causal, int(B));
+                    (long long)ldv, (long long)ldo, scale, causal_arg, int(B));
     else if (hd == 128)
         ARIA_LAUNCH((attn_fwd2_kernel<128, 8>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Cfg2<128>::SMEM), stream, Q, K, V,
                     static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,

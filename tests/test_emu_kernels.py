@@ -213,6 +213,23 @@ def test_gemm_dswiglu_fused(force_gemm_v3, counts, K, I, T):
     C.case_gemm_dswiglu_fused(DEV, counts, K, I, T)
 
 
+@pytest.mark.parametrize("B,S,H", [(1, 600, 1), (2, 300, 2), (1, 1100, 5)])
+def test_causal_forward_grouped_block_order_gives_the_same_bits(B, S, H, monkeypatch):
+    """The XCD-grouped causal block order (the forward's from 32 K tokens up; here forced) only re-assigns blocks to workgroup ids."""
+    import torch
+
+    from aria_amd import ops
+
+    D = H * 128
+    qkv = torch.randn(B * S, 3 * D, generator=torch.Generator().manual_seed(S)).to(torch.bfloat16)
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ARIA_ATTN_CAUSAL_GROUPED", mode)
+        o, lse = ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, S, H, 128, 128 ** -0.5, True)
+        outs.append((o.clone(), lse.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("T,E,k,K,N", [(150, 8, 2, 264, 136), (40, 4, 3, 64, 72), (700, 8, 1, 128, 256)])
 def test_grouped_gemm_wgrad_with_gathered_rows(force_gemm_v3, T, E, k, K, N):
     C.case_grouped_gemm_wgrad_gather(DEV, T, E, k, K, N)
