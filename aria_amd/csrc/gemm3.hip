@@ -760,23 +760,23 @@ __device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)
     const int rr = l >> 2, cc = (l & 3) * 8;  // this lane's row inside a 16-row slab / first of its 8 columns
     const bf16_t* H = p.H;
     bf16_t* DH = reinterpret_cast<bf16_t*>(C);
-    // r05: the forward's [gate | up] values do not depend on the accumulators -- ALL 32 16-byte loads per lane (both 128-row halves) are requested right
-    // behind the parking, when the 128 accumulator registers are dead: one HBM round trip for the whole tile, half 1's rows land under half 0's
-    // arithmetic and stores.  (Requesting a part BEFORE the parking, beside the live accumulators, spilled 24 registers to scratch.)  (Was: park, load half 0, wait, compute, store,
-    // load half 1, wait, compute, store -- two exposed round trips of ~2 us on a CU with nothing else to do: 270 us of the launch's 1094.)
+    // r05: the forward's [gate | up] values do not depend on the accumulators -- 20 of the 32 16-byte loads per lane (half 0 + the first quarter's half
+    // of half 1) are requested right behind the parking, when the 128 accumulator registers are dead, and every finished quarter (32 registers
+    // freed) requests the next 8: one exposed HBM round trip for the whole tile, half 1's rows land under half 0's arithmetic and stores.
+    // (Requesting a part BEFORE the parking, beside the live accumulators, spilled 24 registers; 24 loads behind it spilled 16; 20 is spill-free.)
+    // (Was: park, load half 0, wait, compute, store, load half 1, wait, compute, store -- two exposed round trips of ~2 us on a CU with
+    // nothing else to do: 270 us of the launch's 1094.)
     u32x4 vg[2][2][4], vu[2][2][4];
-    auto load_h = [&](int a, int b0, int b1) {
+    auto load_q = [&](int a, int b, int s0, int s1) {  // pieces s0 .. s1-1 of quarter (a, b) = this wave's 64 rows x 32 columns of a 128 x 128 block
+        if (n0 + b * 128 < I) {  // block-uniform
 #pragma unroll
-        for (int b = b0; b < b1; ++b)
-            if (n0 + b * 128 < I) {  // block-uniform
-#pragma unroll
-                for (int s16 = 0; s16 < 4; ++s16) {
-                    const int m = min(m0 + a * 128 + wm * 64 + s16 * 16 + rr, m_end - 1);  // clamped: loaded, never stored
-                    const bf16_t* src = H + (long long)m * p.ldh + n0 + b * 128 + wn * 32 + cc;
-                    vg[a][b][s16] = ld16(src);
-                    vu[a][b][s16] = ld16(src + I);
-                }
+            for (int s16 = s0; s16 < s1; ++s16) {
+                const int m = min(m0 + a * 128 + wm * 64 + s16 * 16 + rr, m_end - 1);  // clamped: loaded, never stored
+                const bf16_t* src = H + (long long)m * p.ldh + n0 + b * 128 + wn * 32 + cc;
+                vg[a][b][s16] = ld16(src);
+                vu[a][b][s16] = ld16(src + I);
             }
+        }
     };
     wave_barrier();
 #pragma unroll
@@ -796,17 +796,14 @@ __device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)
                 }
     wave_barrier();
     sched_fence();  // (half 1's loads must not be hoisted above the parking: the accumulators are still live there)
-    load_h(0, 0, 2);
-    load_h(1, 0, 1);
+    load_q(0, 0, 0, 4);
+    load_q(0, 1, 0, 4);
+    load_q(1, 0, 0, 2);
     sched_fence();
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        if (a == 1) {   // (the last quarter's loads: requested once half 0's registers are free)
-            load_h(1, 1, 2);
-            sched_fence();
-        }
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
             if (n0 + b * 128 < I) {
 #pragma unroll
                 for (int s16 = 0; s16 < 4; ++s16) {
@@ -829,7 +826,18 @@ __device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)
                     }
                 }
             }
-        sched_fence();
+            sched_fence();
+            // rolling requests: a finished quarter frees 32 registers -> the next 8 loads (20 in flight at the peak)
+            if (a == 0 && b == 0) {
+                load_q(1, 0, 2, 4);
+                load_q(1, 1, 0, 2);
+                sched_fence();
+            }
+            if (a == 0 && b == 1) {
+                load_q(1, 1, 2, 4);
+                sched_fence();
+            }
+        }
     }
 }
 
