@@ -19,7 +19,6 @@
 #include "aria_device.h"
 #include "aria_hip.h"
 #include <cstdlib>
-#include <type_traits>
 
 namespace {
 using namespace ad;
@@ -425,282 +424,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd2_kernel(const bf16_t* Q, con
                 }
             }
     }
-}
-
-// =========================================================================================== forward v2, phase-staggered (r05)
-// The same arithmetic as attn_fwd2_kernel<HD, 12> (bit-identical), re-timed.  A key tile is three phases per wave -- QK (10 MFMAs at hd 72 +
-// the K fragment reads), SM (the softmax: ~100 vector instructions, 32 of them quarter-rate exponentials) and PV (12 MFMAs + the V fragment
-// reads) -- and v2's single barrier per tile starts all three waves of a SIMD on the SAME phase: they queue on the matrix pipe, then on the
-// vector ALU, then on the matrix pipe again (profiles/r04_attn_fwd_ablate.json: vector work alone 1.22 ms, matrix work alone 1.60, together
-// 2.20 -- only 0.6 ms of the two overlapped).  Here the block runs on barrier INTERVALS, three per tile, and wave group G = w / 4 (the
-// SIMD's G-th wave) runs G intervals behind group 0:
-//      interval j:   group 0: phase j % 3 of tile j / 3      group 1: phase (j-1) % 3 of tile (j-1) / 3      group 2: (j-2) % 3, (j-2) / 3
-// so in every interval a SIMD has one wave in QK, one in SM and one in PV: the matrix pipe serves QK + PV while the vector ALU serves SM.
-// Staging follows the global interval, not the wave's own phase: tile T+1 is requested from HBM in interval 3T (all threads) and written to
-// the LDS in interval 3T+2 -- buffer (T+1)&1's K was last read in interval 3T-1 (group 2's QK of tile T-1), its V in 3T+1 (group 2's PV),
-// and group 0's QK of tile T+1 runs in 3T+3.  Barriers are bare (wait for the wave's own LDS traffic, s_barrier): the tile requests stay in
-// flight across two of them.  PRIO: the matrix phases run at wave priority 1 (an MFMA issues as soon as the pipe frees; SM fills the rest).
-template <int HD, int NW, bool PRIO>
-__global__ __launch_bounds__(NW * 64) void attn_fwd2s_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE,
-                                                         const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
-                                                         long long ldq, long long ldk, long long ldv, long long ldo, float scale,
-                                                         int causal, int nbatch) {
-    using C = Cfg2<HD, NW>;
-    static_assert(NW == 12, "three wave groups: one wave of each on every SIMD");
-    ARIA_DYN_SMEM(smem);
-    bf16_t* sK = reinterpret_cast<bf16_t*>(smem);          // [2][64][KP]
-    bf16_t* sV = sK + 2 * 64 * C::KP;                      // [2][64][VP]
-    unsigned* sMk = reinterpret_cast<unsigned*>(sV + 2 * 64 * C::VP);  // [2][2]: the tile's valid-key bits (key_mask) as one 64-bit word per buffer
-    const int t = threadIdx.x, l = t & 63, w = t >> 6, h2 = l >> 5;
-    const int grp = first_lane(w >> 2);
-    int qblk, head, b;
-    if (!attn_block_coords((Sq + C::QB - 1) / C::QB, H, nbatch, causal, true, qblk, head, b)) return;
-    const int q0 = qblk * C::QB;
-    const long long tok0 = (long long)b * S, tokq0 = (long long)b * Sq;
-    const bf16_t* Qb = Q + tokq0 * ldq + head * HD;
-    const bf16_t* Kb = K + tok0 * ldk + head * HD;
-    const bf16_t* Vb = V + tok0 * ldv + head * HD;
-    const uint8_t* kmb = key_mask ? key_mask + tok0 : nullptr;
-    const int q_wmin = q0 + 32 * w, q_abs = q_wmin + (l & 31);
-    const int klen = kv_len ? min(S, kv_len[b]) : S;
-    const float scale2 = scale * 1.4426950408889634f;
-
-    s16x8 qf[C::KS];
-#pragma unroll
-    for (int kk = 0; kk < C::KS; ++kk) {
-        u32x4 v = zero16();
-        const int col = kk * 16 + h2 * 8;
-        if (q_abs < Sq && col < HD) v = ld16(Qb + (long long)q_abs * ldq + col);
-        qf[kk] = __builtin_bit_cast(s16x8, v);
-    }
-#pragma unroll
-    for (int kk = 0; kk < C::KS; ++kk) settle(qf[kk]);
-    f32x16 o[C::DT];
-#pragma unroll
-    for (int i = 0; i < C::DT; ++i) o[i] = zero_acc();
-    float m = -INFINITY, lsum = 0.f;
-
-    int kv_end = klen;
-    if (causal) kv_end = min(kv_end, q0 + C::QB);
-    const int ntiles = (kv_end + 63) / 64;
-
-    if (C::HDK != HD || C::VP > HD) {
-        for (int i = t; i < 2 * 64; i += C::NT2) {
-            if (C::HDK != HD) st16(sK + i * C::KP + HD, zero16());
-            for (int c = HD; c < C::VP; c += 8) st16(sV + i * C::VP + c, zero16());
-            if (C::ROWSUM_IN_MFMA) sV[i * C::VP + HD] = 0x3F80;  // bf16 1.0: the "ones" column
-        }
-    }
-    // staging: one 16-byte chunk of K and one of V per thread (64 rows x 9 chunks = 576 of the 768 threads); the tile's base is a scalar, the
-    // thread's part a 32-bit offset (a 64-bit address pair per tensor kept across the phases had the register allocator spilling)
-    static_assert(C::NCH == 1, "one chunk per thread");
-    u32x4 rk, rv;
-    // (the thread's row / column / offsets are re-derived from its index at every use -- hold() hides the index from the optimiser: kept in
-    // registers across the phases, these invariants were what the allocator spilled, and a scratch reload is a memory round trip per tile)
-    auto request = [&](int tile) __attribute__((always_inline)) {  // HBM -> registers
-        if (tile < ntiles) {
-            int tt = t;
-            hold(tt);
-            const int srow = tt / C::CPR, scol = (tt % C::CPR) * 8;
-            const unsigned koff = 2u * (unsigned(srow) * unsigned(ldk) + scol), voff = 2u * (unsigned(srow) * unsigned(ldv) + scol);  // bytes
-            const bf16_t* kb = Kb + (long long)tile * 64 * ldk;
-            const bf16_t* vb = Vb + (long long)tile * 64 * ldv;
-            const bool in = tt < 64 * C::CPR && tile * 64 + srow < S;
-            rk = in ? ld16(reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(kb) + koff)) : zero16();
-            rv = in ? ld16(reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(vb) + voff)) : zero16();
-        }
-    };
-    auto stage = [&](int tile) __attribute__((always_inline)) {    // registers -> LDS buffer tile & 1 (+ the tile's valid-key bits)
-        if (tile < ntiles) {
-            const int nb = tile & 1, kvn = tile * 64;
-            int tt = t;
-            hold(tt);
-            const int srow = tt / C::CPR, scol = (tt % C::CPR) * 8;
-            if (tt < 64 * C::CPR) {
-                st16(sK + nb * 64 * C::KP + srow * C::KP + scol, rk);
-                st16(sV + nb * 64 * C::VP + srow * C::VP + scol, rv);
-            }
-            if (kmb && tt < 64) {
-                const uint8_t mv = (kvn + tt < S) ? (kmb + kvn)[unsigned(tt)] : 0;
-                const unsigned long long all = ballot(mv != 0);
-                if (tt == 0) {
-                    sMk[2 * nb] = unsigned(all);
-                    sMk[2 * nb + 1] = unsigned(all >> 32);
-                }
-            }
-        }
-    };
-    auto bar = [&]() __attribute__((always_inline)) {
-        wait_lds();
-        raw_barrier();
-    };
-    request(0);
-    stage(0);
-    bar();
-
-    f32x16 st[2];
-    s16x8 pf[2][2];
-    bool live = false;
-    float mx = 0.f;
-    auto phase_qk = [&](int it) __attribute__((always_inline)) {
-        const int cur = it & 1, kv0 = it * 64;
-        const bf16_t* cK = sK + cur * 64 * C::KP;
-        // (a tile without a single valid key contributes exactly nothing; wave-uniform)
-        unsigned long long ok = ~0ull;   // wave-uniform: the tile's keys that exist and are not padding
-        if (kmb) ok = (unsigned long long)unsigned(first_lane(int(sMk[2 * cur]))) | ((unsigned long long)unsigned(first_lane(int(sMk[2 * cur + 1]))) << 32);
-        if (kv0 + 64 > klen) ok &= klen > kv0 ? (1ull << (klen - kv0)) - 1 : 0ull;
-        live = !(causal && kv0 > q_wmin + 31) && ok != 0ull;
-        if (!live) return;
-        if (PRIO) wave_prio<1>();
-        st[0] = zero_acc();
-        st[1] = zero_acc();
-        auto kf = [&](int i, int kk) __attribute__((always_inline)) -> s16x8 {
-            return *reinterpret_cast<const s16x8*>(cK + (i * 32 + (l & 31)) * C::KP + kk * 16 + h2 * 8);
-        };
-        s16x8 fr[2][2];
-        fr[0][0] = kf(0, 0);
-        fr[0][1] = kf(1, 0);
-#pragma unroll
-        for (int kk = 0; kk < C::KS; ++kk) {
-            if (kk + 1 < C::KS) {
-                fr[(kk + 1) & 1][0] = kf(0, kk + 1);
-                fr[(kk + 1) & 1][1] = kf(1, kk + 1);
-            }
-            sched_fence();
-#pragma unroll
-            for (int i = 0; i < 2; ++i) st[i] = mfma32(fr[kk & 1][i], qf[kk], st[i]);
-            sched_fence();
-        }
-        if (PRIO) wave_prio<0>();
-        if (ok != ~0ull || (causal && kv0 + 63 > q_wmin)) {
-            // the lane's keys are 32 i + (r & 3) + 8 (r >> 2) + 4 h2: one 64-bit word of allowed keys per lane, shifted by 4 h2, tested at
-            // compile-time bit positions (v2 reads a mask byte from the LDS and compares two indices per element)
-            unsigned long long okl = ok;
-            if (causal) {
-                const int d = q_abs - kv0;   // keys 0 .. d of the tile are visible
-                okl &= d >= 63 ? ~0ull : d < 0 ? 0ull : (2ull << d) - 1;
-            }
-            okl >>= 4 * h2;
-            const unsigned wd[2] = {unsigned(okl), unsigned(okl >> 32)};
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (!((wd[i] >> ((r & 3) + 8 * (r >> 2))) & 1u)) st[i][r] = -INFINITY;
-        }
-    };
-    auto phase_sm = [&](int) __attribute__((always_inline)) {
-        if (!live) return;
-        mx = st[0][0];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[i][r]);
-        mx = fmaxf(mx, shfl_xor(mx, 32));
-        const float m_new = fmaxf(m, mx * scale2);
-        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-        if (ballot(m_new > m) != 0ull) {  // wave-uniform lazy rescale: exact (alpha == 1 whenever it is skipped)
-            const float alpha = exp2_fast(m - m_safe);
-            if (!C::ROWSUM_IN_MFMA) lsum *= alpha;
-#pragma unroll
-            for (int i = 0; i < C::DT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-            m = m_new;
-        }
-        float ps = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 x = fma2(st[i][r], st[i][r + 1], scale2, -m_safe);
-#pragma unroll
-                for (int z = 0; z < 2; ++z) {
-                    const float p = exp2_fast(x[z]);
-                    st[i][r + z] = p;
-                    if (!C::ROWSUM_IN_MFMA) ps += p;
-                }
-            }
-        if (!C::ROWSUM_IN_MFMA) lsum += ps;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) pf[i][u] = pack_frag(st[i], u);
-    };
-    auto phase_pv = [&](int it) __attribute__((always_inline)) {  // O^T += V^T P^T
-        if (!live) return;
-        if (PRIO) wave_prio<1>();
-        const bf16_t* cV = sV + (it & 1) * 64 * C::VP;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const bf16_t* vrow = cV + (i * 32 + 16 * u + 4 * h2 + ((l & 15) >> 2)) * C::VP + 16 * ((l >> 4) & 1) + 4 * (l & 3);
-#pragma unroll
-                for (int dt = 0; dt < C::DT; ++dt) {
-                    s16x8 vf;
-                    const s16x4 a0 = ds_read_tr16(vrow + 32 * dt);
-                    const s16x4 a1 = ds_read_tr16(vrow + 8 * C::VP + 32 * dt);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        vf[e] = a0[e];
-                        vf[4 + e] = a1[e];
-                    }
-                    o[dt] = mfma32(vf, pf[i][u], o[dt]);
-                }
-            }
-        if (PRIO) wave_prio<0>();
-    };
-    auto finish = [&]() __attribute__((always_inline)) {  // (inside every group's copy: no 50-register merge of the three loops' results)
-        const float ltot = C::ROWSUM_IN_MFMA ? shfl(o[C::DT - 1][4], l & 31) : lsum + shfl_xor(lsum, 32);
-        const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
-        if (q_abs < Sq) {
-            if (h2 == 0 && LSE)
-                LSE[((long long)b * H + head) * Sq + q_abs] = (ltot > 0.f) ? (m + log2f(ltot)) * 0.6931471805599453f : -INFINITY;
-            bf16_t* orow = O + (tokq0 + q_abs) * ldo + head * HD;
-    #pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt)
-    #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int d0 = 32 * dt + 8 * rg + 4 * h2;
-                    if (d0 < HD) {
-                        u32x2 v;
-                        v[0] = pack2bf(o[dt][4 * rg] * inv, o[dt][4 * rg + 1] * inv);
-                        v[1] = pack2bf(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
-                        *reinterpret_cast<u32x2*>(orow + d0) = v;
-                    }
-                }
-        }
-    };
-    // group G's phase p of tile `it` runs in interval 3 it + p + G; the interval's staging duty: request tile j/3 + 1 when j % 3 == 0,
-    // stage tile (j-2)/3 + 1 when j % 3 == 2
-    auto run = [&](auto Gc) __attribute__((always_inline)) {
-        constexpr int G = decltype(Gc)::value;
-        if (G >= 1) {  // interval 0
-            request(1);
-            bar();
-        }
-        if (G >= 2) bar();  // interval 1
-        for (int it = 0; it < ntiles; ++it) {
-            if ((0 + G) % 3 == 0) request(it + (0 + G) / 3 + 1);
-            phase_qk(it);
-            if ((0 + G) % 3 == 2) stage(it + (0 + G - 2) / 3 + 1);
-            bar();
-            if ((1 + G) % 3 == 0) request(it + (1 + G) / 3 + 1);
-            phase_sm(it);
-            if ((1 + G) % 3 == 2) stage(it + (1 + G - 2) / 3 + 1);
-            bar();
-            if ((2 + G) % 3 == 0) request(it + (2 + G) / 3 + 1);
-            phase_pv(it);
-            if ((2 + G) % 3 == 2) stage(it + (2 + G - 2) / 3 + 1);
-            bar();
-        }
-        for (int j = G; j < 2; ++j) bar();  // the intervals the later groups still run
-        finish();
-    };
-    if (grp == 0) run(std::integral_constant<int, 0>());
-    else if (grp == 1) run(std::integral_constant<int, 1>());
-    else run(std::integral_constant<int, 2>());
 }
 
 // =========================================================================================== delta = rowsum(O * dO)
@@ -1766,8 +1489,6 @@ int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     const bf16_t *Q = static_cast<const bf16_t*>(q), *K = static_cast<const bf16_t*>(k), *V = static_cast<const bf16_t*>(v);
     const char* nw72 = std::getenv("ARIA_ATTN_HD72_WAVES");  // "8": the two-waves-per-SIMD variant (A/B measurements)
     const char* fwdv = std::getenv("ARIA_ATTN_FWD");          // "2": the round-1..3 kernels (A/B measurements, bit-identity tests)
-    const char* stg = std::getenv("ARIA_ATTN_HD72_STAGGER");  // "0": v2's one barrier per tile; "1": the phase-staggered form; "2": + wave priority in the matrix phases
-    const int stag72 = stg ? stg[0] - '0' : 0;
     const char* grp = std::getenv("ARIA_ATTN_CAUSAL_GROUPED");   // "1" / "0": force the XCD-grouped causal block order on / off (tests, A/B)
     const int causal_arg = causal ? ((grp ? grp[0] == '1' : Sq >= 32768) ? 2 : 1) : 0;   // (2: attn_block_coords' grouped order; default: the forward from 32 K tokens up)
     // default: hd 128 -> v3 pipelined (+4..8 % over v2 from 2K to 64K tokens); hd 72 -> v2 with 12 waves (measured, same box: v2 2.23-2.46 ms,
@@ -1786,14 +1507,6 @@ int aria_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
                     (long long)ldv, (long long)ldo, scale, causal, int(B));
     else if (hd == 72 && nw72 && nw72[0] == '8')
         ARIA_LAUNCH((attn_fwd2_kernel<72, 8>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(Cfg2<72>::SMEM), stream, Q, K, V,
-                    static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
-                    (long long)ldv, (long long)ldo, scale, causal, int(B));
-    else if (hd == 72 && stag72 == 1)
-        ARIA_LAUNCH((attn_fwd2s_kernel<72, 12, false>), dim3(attn_grid((Sq + 383) / 384, H, B)), dim3(768), size_t(Cfg2<72>::SMEM), stream, Q, K, V,
-                    static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
-                    (long long)ldv, (long long)ldo, scale, causal, int(B));
-    else if (hd == 72 && stag72 == 2)
-        ARIA_LAUNCH((attn_fwd2s_kernel<72, 12, true>), dim3(attn_grid((Sq + 383) / 384, H, B)), dim3(768), size_t(Cfg2<72>::SMEM), stream, Q, K, V,
                     static_cast<bf16_t*>(o), lse, kv_len, key_mask, int(Sq), int(Skv), int(H), (long long)ldq, (long long)ldk,
                     (long long)ldv, (long long)ldo, scale, causal, int(B));
     else if (hd == 72)

@@ -855,62 +855,6 @@ def case_attention_forward_variants(dev, B, Sq, Skv, H, hd, causal, masked, use_
     close(got["3"][0], want.transpose(1, 2).reshape(B * Sq, D), 2e-2, 2e-2)
 
 
-def case_attention_hd72_stagger(dev, B, Sq, Skv, H, causal, masked, use_len):
-    """Round 5: ``attn_fwd2s_kernel`` (hd 72: the three wave groups of a block run one barrier interval apart -- one wave of a SIMD in QK,
-    one in the softmax, one in PV -- with the valid-key bits of a tile as one 64-bit word) performs ``attn_fwd2_kernel<72, 12>``'s arithmetic
-    per wave: ARIA_ATTN_HD72_STAGGER = 0 / 1 / 2 (2 = + wave priority in the matrix phases) give the same bits, within the attention
-    tolerance of the fp32 eager oracle (idefics2 eager attention, key padding vision_encoder.py:147-152)."""
-    import os
-
-    from aria_amd import ops
-
-    hd = 72
-    D = H * hd
-    g = torch.Generator().manual_seed(B * 1000 + Sq + Skv + 7 * H)
-    q = torch.randn(B * Sq, D, generator=g).to(bf16)
-    kv = torch.randn(B * Skv, 2 * D, generator=g).to(bf16)
-    km = kl = None
-    if masked:
-        km = (torch.rand(B, Skv, generator=g) > 0.3).to(torch.uint8)
-        km[:, 0] = 1
-        if Skv > 130:
-            km[0, 64:128] = 0          # a whole tile without a valid key
-        if Skv > 200:
-            km[0, Skv - Skv // 4:] = 0  # and a run of them at the end
-        if B > 1 and Skv > 70:
-            km[1, :64] = 0             # the FIRST tile of another sequence
-            km[1, 64] = 1
-    if use_len:
-        kl = torch.randint(1, Skv + 1, (B,), generator=g).to(torch.int32)
-    prev = os.environ.get("ARIA_ATTN_HD72_STAGGER")
-    got = {}
-    try:
-        for mode in ("0", "1", "2"):
-            os.environ["ARIA_ATTN_HD72_STAGGER"] = mode
-            o, lse = ops.attention_fwd(q.to(dev), kv[:, :D].to(dev), kv[:, D:].to(dev), B, Sq, H, hd, hd ** -0.5, causal,
-                                       kv_len=None if kl is None else kl.to(dev), key_mask=None if km is None else km.to(dev), Skv=Skv)
-            got[mode] = (o.cpu(), lse.cpu())
-    finally:
-        if prev is None:
-            os.environ.pop("ARIA_ATTN_HD72_STAGGER", None)
-        else:
-            os.environ["ARIA_ATTN_HD72_STAGGER"] = prev
-    for mode in ("1", "2"):
-        assert torch.equal(got["0"][0], got[mode][0]), (mode, float((got["0"][0].float() - got[mode][0].float()).abs().max()))
-        assert torch.equal(got["0"][1], got[mode][1]), mode
-    pad = None
-    if km is not None or kl is not None:
-        pad = torch.zeros(B, Skv, dtype=torch.bool)
-        if km is not None:
-            pad |= km == 0
-        if kl is not None:
-            pad |= torch.arange(Skv)[None, :] >= kl[:, None].long()
-    qq = q.float().view(B, Sq, H, hd).transpose(1, 2)
-    kk, vv = (kv[:, i * D:(i + 1) * D].float().view(B, Skv, H, hd).transpose(1, 2) for i in range(2))
-    want = O.attention_eager(qq, kk, vv, hd ** -0.5, causal, key_padding=pad)
-    close(got["1"][0], want.transpose(1, 2).reshape(B * Sq, D), 2e-2, 2e-2)
-
-
 # ------------------------------------------------------------------------------------------ single-query decode attention
 def case_decode_attention(dev, H, hd, pos, splits, S_max=None):
     """aria_decode_attn (RoPE of q / k with freqs_cis[pos], cache write at row pos, softmax over rows 0..pos) against fp32 torch on the same

@@ -104,13 +104,6 @@ def test_attention_hd72_forward(B, Sq, Skv, H, masked):
     C.case_attention_hd72_forward(DEV, B, Sq, Skv, H, masked)
 
 
-@pytest.mark.parametrize("B,Sq,Skv,H,causal,masked,use_len", [(2, 70, 70, 2, False, True, False), (1, 400, 333, 1, False, False, False),
-                                                                (2, 100, 330, 1, False, True, True), (1, 450, 450, 1, True, False, False),
-                                                                (1, 33, 20, 2, False, False, True)])
-def test_attention_hd72_staggered_phases_give_the_same_bits(B, Sq, Skv, H, causal, masked, use_len):
-    C.case_attention_hd72_stagger(DEV, B, Sq, Skv, H, causal, masked, use_len)
-
-
 @pytest.mark.parametrize("B,Sq,Skv,H,hd,causal,masked,use_len", [
     (1, 64, 64, 1, 128, True, False, False), (2, 200, 200, 2, 128, True, False, False), (1, 330, 330, 1, 128, False, True, False),
     (2, 150, 150, 1, 128, False, False, True), (1, 513, 513, 1, 128, True, False, True), (1, 16, 200, 2, 128, False, False, False),

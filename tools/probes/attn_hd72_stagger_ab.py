@@ -1,7 +1,9 @@
 """ViT attention forward (hd 72) at the config #3 step's shape (16 images x 4900 patches x 16 heads) and the projector's cross shape, the three
 selectable forms interleaved in ONE process (ARIA_ATTN_HD72_STAGGER is read per launch): 0 = attn_fwd2_kernel<72, 12> (one barrier per key tile),
 1 = attn_fwd2s_kernel (wave groups one barrier interval apart: QK / softmax / PV of three tiles overlap on every SIMD), 2 = 1 + wave priority in the
-matrix phases.  Prints per-form medians and whether the outputs are bit-equal."""
+matrix phases.  Prints per-form medians and whether the outputs are bit-equal.
+Needs tools/probes/src/attn_fwd2s_stagger.patch applied (git apply; make): the staggered form measured 10 % slower (profiles/r05_attn_hd72_stagger_ab.json) and
+is not in the library."""
 import json
 import os
 import statistics
