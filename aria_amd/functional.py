@@ -47,13 +47,52 @@ class MoEConfig:
     aux_scale: float = 1.0  # MoEAuxLossAutoScaler.main_loss_backward_scale (train.py:229)
 
 
+def _adjacent_rows_view(ws) -> Optional[torch.Tensor]:
+    """The [sum rows, D] tensor the weights already ARE when they lie back to back in one allocation (``pack_adjacent_``), else None."""
+    w0 = ws[0]
+    if w0.dim() != 2 or not w0.is_contiguous():
+        return None
+    st, end, rows = w0.untyped_storage().data_ptr(), w0.storage_offset() + w0.numel(), w0.shape[0]
+    for w in ws[1:]:
+        if (w.dim() != 2 or w.shape[1] != w0.shape[1] or w.dtype != w0.dtype or w.device != w0.device or not w.is_contiguous()
+                or w.untyped_storage().data_ptr() != st or w.storage_offset() != end):
+            return None
+        end += w.numel()
+        rows += w.shape[0]
+    return w0.detach().as_strided((rows, w0.shape[1]), (w0.shape[1], 1), w0.storage_offset())
+
+
+def pack_adjacent_(*params: torch.Tensor) -> bool:
+    """Re-home nn.Linear weights that read the same input (q|k|v, shared gate|up) into ONE allocation, in order, so that ``fused_weight`` is a
+    view instead of a copy per forward (r05: the copy was 63 ``CatArrayBatchedCopy`` launches = 1.7 ms of the config #3 step).  The
+    parameters keep their identity, shape and values (``p.data`` becomes a slice of the new buffer): state dicts, optimizers and DDP see
+    nothing; ``nn.Module._apply`` (``.to()``, ``.bfloat16()``) gives every parameter an allocation of its own again, which the decoder layer
+    answers by packing again (moe_lm.py ``_PackedWeights``).  False (nothing done) for meta / mixed-device / mixed-dtype / non-2-D weights."""
+    w0 = params[0]
+    if any(w.dim() != 2 or w.shape[1] != w0.shape[1] or w.dtype != w0.dtype or w.device != w0.device or w.device.type == "meta" for w in params):
+        return False
+    if _adjacent_rows_view(params) is not None:
+        return True
+    with torch.no_grad():
+        buf = torch.empty((sum(w.shape[0] for w in params), w0.shape[1]), dtype=w0.dtype, device=w0.device)
+        r = 0
+        for w in params:
+            n = w.shape[0]
+            buf[r:r + n].copy_(w)
+            w.data = buf[r:r + n]
+            r += n
+    return True
+
+
 def fused_weight(*ws: torch.Tensor) -> torch.Tensor:
     """Row-wise concatenation of nn.Linear weights that read the same input (q/k/v: [3D, D]; shared gate/up: [2I, D]).  One wide GEMM
     instead of three (two) narrow ones: a [16384, 2560] output is 640 tiles = 2.5 rounds on 256 CUs, the fused [16384, 7680] one 7.5 --
-    and the input gradient becomes ONE GEMM with the long reduction instead of accumulate passes over dx.  Built once per forward (a
-    39 / 34 MB copy, ~15 us) and kept in the layer context for the backward; deliberately NOT cached across calls (a cache keyed on
-    addresses / versions can go stale when tensors are freed and re-allocated)."""
-    return torch.cat([w.detach() for w in ws], dim=0)
+    and the input gradient becomes ONE GEMM with the long reduction instead of accumulate passes over dx.  A VIEW when the weights lie back
+    to back in one allocation (``pack_adjacent_``: the decoder layer's parameters do); otherwise built per forward (a 39 / 34 MB copy, ~27 us)
+    and kept in the layer context for the backward -- deliberately NOT cached across calls (a cache keyed on addresses / versions can go
+    stale when tensors are freed and re-allocated; adjacency is checked on the tensors themselves at every call)."""
+    v = _adjacent_rows_view(ws)
+    return v if v is not None else torch.cat([w.detach() for w in ws], dim=0)
 
 
 def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save=True):

@@ -87,6 +87,27 @@ class Linear(nn.Module):
         return AG.linear(x, self.weight, self.bias)
 
 
+class _PackedWeights(nn.Module):
+    """Keeps the weights of the projections that read the same input (``_packed()``: q|k|v, shared gate|up) back to back in one allocation,
+    so the fused blocks' [3D, D] / [2I, D] operand is a view of the parameters, not a per-forward copy (functional.py ``fused_weight`` /
+    ``pack_adjacent_``).  Packed at construction and again after every ``_apply`` (``.to()``, ``.bfloat16()``, ``.cuda()`` re-allocate each
+    parameter on its own); anything that breaks the adjacency later (``load_state_dict(assign=True)``, an adapter wrapping one projection)
+    only brings the copy back -- ``fused_weight`` checks the tensors at every call."""
+
+    def _packed(self):
+        return ()
+
+    def pack_weights_(self) -> None:
+        mods = self._packed()
+        if mods and all(type(m) is Linear and isinstance(m.weight, nn.Parameter) for m in mods):
+            Fn.pack_adjacent_(*(m.weight for m in mods))
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.pack_weights_()
+        return out
+
+
 def _plain_linears(*mods) -> bool:
     """True when every module is the stock ``Linear`` (the fused blocks read ``.weight`` directly); False as soon as an adapter
     (aria_amd/lora.py) wraps one of them -- the block then runs module by module so the adapter's forward is what executes."""
@@ -178,8 +199,11 @@ class GroupedMLP(nn.Module):
         return self.fc2(AG.SwiGLUFn.apply(h), tokens_per_expert)
 
 
-class SharedExpertMLP(nn.Module):
+class SharedExpertMLP(_PackedWeights):
     """moe_lm.py:368-395 (LlamaMLP with I = moe_intermediate_size * moe_num_shared_experts, no bias)."""
+
+    def _packed(self):
+        return (self.gate_proj, self.up_proj)
 
     def __init__(self, config: AriaMoELMConfig):
         super().__init__()
@@ -188,6 +212,7 @@ class SharedExpertMLP(nn.Module):
         self.gate_proj = Linear(self.hidden_size, self.intermediate_size)
         self.up_proj = Linear(self.hidden_size, self.intermediate_size)
         self.down_proj = Linear(self.intermediate_size, self.hidden_size)
+        self.pack_weights_()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         shp = x.shape
@@ -271,8 +296,11 @@ class MoELayer(nn.Module):
         return UnpermuteFn.apply(expert_out, inv, scores, self.shared_experts(x), cfg.topk)
 
 
-class AriaAttention(nn.Module):
+class AriaAttention(_PackedWeights):
     """LlamaAttention's parameter surface (q/k/v/o_proj, no bias; seam B2) with RoPE + flash attention in HIP."""
+
+    def _packed(self):
+        return (self.q_proj, self.k_proj, self.v_proj)
 
     def __init__(self, config: AriaMoELMConfig, layer_idx: int = 0):
         super().__init__()
@@ -282,6 +310,7 @@ class AriaAttention(nn.Module):
         self.k_proj = Linear(D, Hkv * hd)
         self.v_proj = Linear(D, Hkv * hd)
         self.o_proj = Linear(H * hd, D)
+        self.pack_weights_()
 
     def attn_config(self) -> Fn.AttnConfig:
         c = self.config

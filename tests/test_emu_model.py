@@ -339,3 +339,7 @@ def test_frozen_parameters_skip_their_weight_gradient_gemms(golden):
             assert part[n] is None, n
         else:
             assert torch.equal(part[n], full[n]), n
+
+
+def test_projection_weights_are_packed_and_the_fused_operand_is_a_view():
+    M.case_packed_projection_weights(DEV)

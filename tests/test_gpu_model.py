@@ -75,3 +75,7 @@ def test_lora_fused_node_matches_modular():
 
 def test_lora_linear_lm():  # last on purpose: newest composition of already-covered kernels
     M.case_lora_linear_lm(DEV)
+
+
+def test_projection_weights_are_packed_and_the_fused_operand_is_a_view():
+    M.case_packed_projection_weights(DEV)
