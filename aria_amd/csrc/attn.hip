@@ -861,7 +861,8 @@ __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, co
                                                              const float* LSE, const float* DELTA, bf16_t* dK, bf16_t* dV,
                                                              const int32_t* kv_len, const uint8_t* key_mask, int Sq, int S, int H,
                                                              long long ldq, long long ldk, long long ldv, long long lddo,
-                                                             long long lddk, long long lddv, float scale, int causal, int nbatch) {
+                                                             long long lddk, long long lddv, float scale, int causal, int nbatch,
+                                                             const bf16_t* rope_cs, const bf16_t* rope_sn, int rope_S) {
     using C = Cfg3<HD>;
     ARIA_DYN_SMEM(smem);
     char* sQ = smem;                                   // [2] tiles
@@ -1035,6 +1036,29 @@ __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, co
     }
     bf16_t* out = role ? dK : dV;
     const long long ldout = role ? lddk : lddv;
+    if (role == 1 && rope_cs) {
+        // r05: the inverse half-split RoPE of dK (the chain rule through apply_rotary_pos_emb, modeling_llama.py:130-160; was an in-place pass
+        // over [T, 2 D] after this kernel: rope_kernel, 55 us per layer).  Feature f = 32 dt + (l & 31) pairs with f + HD / 2 = tile dt + DT / 2,
+        // same lane, same register; the key's position is its index in the sequence.  Rounding for rounding what the two launches did: the
+        // gradient rounded to bf16 (the store), then bf16(bf16(a cos) + bf16(b sin)) / bf16(bf16(b cos) - bf16(a sin)).
+        static_assert(C::DT % 2 == 0, "half-split pairs are whole feature tiles");
+#pragma unroll
+        for (int dt = 0; dt < C::DT / 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kv_wmin + acc_row(r, l);
+                if (kv >= S) continue;
+                const int f = 32 * dt + (l & 31);
+                const long long tb = (long long)(kv % rope_S) * HD;
+                const float c1 = bf2f(rope_cs[tb + f]), c2 = bf2f(rope_cs[tb + f + HD / 2]);
+                const float s1 = bf2f(rope_sn[tb + f]), s2 = bf2f(rope_sn[tb + f + HD / 2]);
+                const float a = rbf(acc[dt][r]), b = rbf(acc[dt + C::DT / 2][r]);
+                bf16_t* orow = out + (tok0 + kv) * ldout + head * HD + f;
+                orow[0] = f2bf(rbf(a * c1) + rbf(b * s1));
+                orow[HD / 2] = f2bf(rbf(b * c2) + rbf(-a * s2));
+            }
+        return;
+    }
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
@@ -1058,7 +1082,8 @@ template <int HD>
 __global__ __launch_bounds__(512) void attn_bwd5_dq_kernel(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
                                                            const float* LSE, const float* DELTA, bf16_t* dQ, const int32_t* kv_len,
                                                            const uint8_t* key_mask, int Sq, int S, int H, int ldq, int ldk, int ldv,
-                                                           int lddo, int lddq, float scale, int causal, int nbatch) {
+                                                           int lddo, int lddq, float scale, int causal, int nbatch,
+                                                           const bf16_t* rope_cs, const bf16_t* rope_sn, int rope_S) {
     using C = Cfg3<HD>;
     ARIA_DYN_SMEM(smem);
     char* sK = smem;                                   // [2] tiles
@@ -1178,7 +1203,39 @@ __global__ __launch_bounds__(512) void attn_bwd5_dq_kernel(const bf16_t* Q, cons
             if (t == 0) sFlag[nb] = int(all == ~0ull) | (int(all == 0ull) << 1);
         }
     }
-    if (q_abs < Sq) {
+    if (q_abs < Sq && rope_cs) {
+        // r05: the inverse half-split RoPE of dQ in the register epilogue (see attn_bwd3_dkdv_kernel): a lane owns ONE query, features
+        // d0 .. d0 + 3 of tile dt pair with the same registers of tile dt + DT / 2
+        static_assert(C::DT % 2 == 0, "half-split pairs are whole feature tiles");
+        bf16_t* row = dQ + (tokq0 + q_abs) * lddq + head * HD;
+        const bf16_t* cs = rope_cs + (long long)(q_abs % rope_S) * HD;
+        const bf16_t* sn = rope_sn + (long long)(q_abs % rope_S) * HD;
+#pragma unroll
+        for (int dt = 0; dt < C::DT / 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d0 = 32 * dt + 8 * rg + 4 * h2;
+                const u32x2 c1 = *reinterpret_cast<const u32x2*>(cs + d0), c2 = *reinterpret_cast<const u32x2*>(cs + d0 + HD / 2);
+                const u32x2 s1 = *reinterpret_cast<const u32x2*>(sn + d0), s2 = *reinterpret_cast<const u32x2*>(sn + d0 + HD / 2);
+                u32x2 va, vb;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float oa[2], ob[2];
+#pragma unroll
+                    for (int z = 0; z < 2; ++z) {
+                        const float a = rbf(dq[dt][4 * rg + 2 * q + z]), b = rbf(dq[dt + C::DT / 2][4 * rg + 2 * q + z]);
+                        const float ca = z ? bfhi(c1[q]) : bflo(c1[q]), cb = z ? bfhi(c2[q]) : bflo(c2[q]);
+                        const float sa = z ? bfhi(s1[q]) : bflo(s1[q]), sb = z ? bfhi(s2[q]) : bflo(s2[q]);
+                        oa[z] = rbf(a * ca) + rbf(b * sa);
+                        ob[z] = rbf(b * cb) + rbf(-a * sb);
+                    }
+                    va[q] = pack2bf(oa[0], oa[1]);
+                    vb[q] = pack2bf(ob[0], ob[1]);
+                }
+                *reinterpret_cast<u32x2*>(row + d0) = va;
+                *reinterpret_cast<u32x2*>(row + d0 + HD / 2) = vb;
+            }
+    } else if (q_abs < Sq) {
         bf16_t* row = dQ + (tokq0 + q_abs) * lddq + head * HD;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt)
@@ -1527,8 +1584,20 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                   void* dq, void* dk, void* dv, const int32_t* kv_len, const uint8_t* key_mask, int64_t B, int64_t Sq, int64_t Skv,
                   int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
                   float scale, int causal, void* stream) {
+    return aria_attn_bwd_rope(q, k, v, o, d_o, lse, delta, dq, dk, dv, kv_len, key_mask, B, Sq, Skv, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv,
+                              scale, causal, nullptr, nullptr, 0, stream);
+}
+
+int aria_attn_bwd_rope(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
+                       void* dq, void* dk, void* dv, const int32_t* kv_len, const uint8_t* key_mask, int64_t B, int64_t Sq, int64_t Skv,
+                       int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
+                       float scale, int causal, const void* rope_cos, const void* rope_sin, int64_t rope_S, void* stream) {
     if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv || B < 0 || Sq < 0 || Skv < 0 || H <= 0)
         return ARIA_ERR_INVALID;
+    if ((rope_cos != nullptr) != (rope_sin != nullptr) || (rope_cos && rope_S <= 0)) return ARIA_ERR_INVALID;
+    if (rope_cos && hd != 128) return ARIA_ERR_UNSUPPORTED;   // (the decoder's heads; the hd 64 / 72 kernels have no such epilogue)
+    if (rope_cos && ((reinterpret_cast<uintptr_t>(rope_cos) | reinterpret_cast<uintptr_t>(rope_sin)) & 7)) return ARIA_ERR_ALIGN;
+    const bf16_t *rcs = static_cast<const bf16_t*>(rope_cos), *rsn = static_cast<const bf16_t*>(rope_sin);
     if (hd != 64 && hd != 72 && hd != 128) return ARIA_ERR_UNSUPPORTED;
     if (causal && Sq != Skv) return ARIA_ERR_UNSUPPORTED;
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(d_o) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) ||
@@ -1549,10 +1618,10 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
         ARIA_LAUNCH((attn_bwd3_dkdv_kernel<128>), dim3(attn_grid((Skv + 127) / 128, H, B)), dim3(512), size_t(Cfg3<128>::SMEM_DKDV), stream, Q, K, V, dO, lse,
                     (const float*)delta, static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), kv_len, key_mask, int(Sq), int(Skv),
                     int(H), (long long)ldq, (long long)ldk, (long long)ldv, (long long)ldo, (long long)lddk, (long long)lddv, scale,
-                    causal, int(B));
+                    causal, int(B), rcs, rsn, int(rope_S));
         ARIA_LAUNCH((attn_bwd5_dq_kernel<128>), dim3(attn_grid((Sq + 255) / 256, H, B)), dim3(512), size_t(4 * Cfg3<128>::TILE + 128 + 16), stream, Q, K, V,
                     dO, lse, (const float*)delta, static_cast<bf16_t*>(dq), kv_len, key_mask, int(Sq), int(Skv), int(H), int(ldq), int(ldk),
-                    int(ldv), int(ldo), int(lddq), scale, causal, int(B));
+                    int(ldv), int(ldo), int(lddq), scale, causal, int(B), rcs, rsn, int(rope_S));
         g_last_bwd_variant = 5;
     } else if (hd == 72) {  // ViT / projector heads (an unfrozen ViT, the trainable projector's cross-attention): the v2 pair with padded tiles
         using C = Cfg<72>;

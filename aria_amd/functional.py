@@ -252,9 +252,10 @@ def sdpa_fwd(q, k, v, B, S, H, hd, scale, causal, kv_len=None):
     return o, dict(q=q, k=k, v=v, o=o, lse=lse, hdp=hd)
 
 
-def sdpa_bwd(do, ctx, B, S, H, hd, scale, causal, kv_len=None, dq=None, dk=None, dv=None):
+def sdpa_bwd(do, ctx, B, S, H, hd, scale, causal, kv_len=None, dq=None, dk=None, dv=None, rope=None):
     hdp = ctx["hdp"]
     if hdp != hd:
+        assert rope is None
         dop = _pad_heads(do, H, hd, hdp)
         gq, gk, gv = ops.attention_bwd(ctx["q"], ctx["k"], ctx["v"], ctx["o"], dop, ctx["lse"], B, S, H, hdp, scale, causal, kv_len)
         outs = [_unpad_heads(t, H, hd, hdp) for t in (gq, gk, gv)]
@@ -263,7 +264,7 @@ def sdpa_bwd(do, ctx, B, S, H, hd, scale, causal, kv_len=None, dq=None, dk=None,
                 dst.copy_(src)
         return tuple(d if d is not None else s for d, s in zip((dq, dk, dv), outs))
     return ops.attention_bwd(ctx["q"], ctx["k"], ctx["v"], ctx["o"], do, ctx["lse"], B, S, H, hd, scale, causal, kv_len,
-                             dq=dq, dk=dk, dv=dv)
+                             dq=dq, dk=dk, dv=dv, rope=rope)
 
 
 def attn_block_fwd(x, wq, wk, wv, wo, cos, sin, B: int, S: int, cfg: AttnConfig, kv_len=None, save: bool = True, attn_cache=None,
@@ -300,9 +301,12 @@ def attn_block_bwd(dout, ctx, wq, wk, wv, wo, cos, sin, need=None):
     d_o = ops.gemm(dout, wo, b_oc=True)
     g_wo = ops.gemm(dout, o if o.is_contiguous() else o.contiguous(), a_oc=True, b_oc=True) if _want(need, "wo") else None
     dqkv = torch.empty((T, 3 * Dq), dtype=bf16, device=x.device)
+    # r05: the inverse rotation of dq | dk rides in the attention backward's register epilogues (was a pass over [T, 2 D] behind them)
+    fused_rope = ctx["actx"]["hdp"] == hd and ops.attention_bwd_rope_fusable(hd, S, cos)
     sdpa_bwd(d_o, ctx["actx"], B, S, H, hd, hd ** -0.5, cfg.causal, ctx["kv_len"], dq=dqkv[:, :Dq], dk=dqkv[:, Dq:2 * Dq],
-             dv=dqkv[:, 2 * Dq:])
-    ops.rope_(dqkv[:, :2 * Dq], cos, sin, S, 2 * H, hd, inverse=True)
+             dv=dqkv[:, 2 * Dq:], rope=(cos, sin) if fused_rope else None)
+    if not fused_rope:
+        ops.rope_(dqkv[:, :2 * Dq], cos, sin, S, 2 * H, hd, inverse=True)
     dx = ops.gemm(dqkv, ctx["wqkv"], b_oc=True)
     # q, k, v weight gradients as ONE wide GEMM ([3*Dq, D] = dqkv^T x)
     g_wq = g_wk = g_wv = None

@@ -87,6 +87,7 @@ SIGNATURES = {
     "aria_add_bf16": [P, P, P, I64, P],
     "aria_attn_fwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
     "aria_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
+    "aria_attn_bwd_rope": [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P, P, I64, P],
     "aria_layernorm_fwd": [P, P, P, P, P, P, I64, I64, F32, P],
     "aria_layernorm_bwd": [P, P, P, P, P, P, P, P, I64, I64, I64, P],
     "aria_gelu_tanh_fwd": [P, P, I64, P],

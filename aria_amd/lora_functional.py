@@ -243,8 +243,11 @@ def decoder_layer_lora_bwd(dout, c, p: dict, cos, sin, need_base=None) -> Tuple[
     if "wo" in need:
         gb["wo"] = ops.gemm(dh, o, a_oc=True, b_oc=True)
     dqkv = torch.empty((T, 3 * Dq), dtype=bf16, device=dh.device)
-    Fn.sdpa_bwd(d_o, c["actx"], B, S, H, hd, hd ** -0.5, acfg.causal, c["kv_len"], dq=dqkv[:, :Dq], dk=dqkv[:, Dq:2 * Dq], dv=dqkv[:, 2 * Dq:])
-    ops.rope_(dqkv[:, :2 * Dq], cos, sin, S, 2 * H, hd, inverse=True)
+    fused_rope = c["actx"]["hdp"] == hd and ops.attention_bwd_rope_fusable(hd, S, cos)   # (the inverse rotation inside the attention backward's epilogues)
+    Fn.sdpa_bwd(d_o, c["actx"], B, S, H, hd, hd ** -0.5, acfg.causal, c["kv_len"], dq=dqkv[:, :Dq], dk=dqkv[:, Dq:2 * Dq], dv=dqkv[:, 2 * Dq:],
+                rope=(cos, sin) if fused_rope else None)
+    if not fused_rope:
+        ops.rope_(dqkv[:, :2 * Dq], cos, sin, S, 2 * H, hd, inverse=True)
     dxn = ops.gemm(dqkv, c["wqkv"], b_oc=True)
     dense_lora_bwd(dqkv, c["c_qkv"], dxn, g, ["wq", "wk", "wv"])
     if need & {"wq", "wk", "wv"}:

@@ -5,6 +5,7 @@ PyTorch is plumbing here (device memory + the current HIP stream); all arithmeti
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -909,9 +910,11 @@ def attention_fwd(q, k, v, B: int, S: int, H: int, hd: int, scale: float, causal
 
 def attention_bwd(q, k, v, o, do, lse, B: int, S: int, H: int, hd: int, scale: float, causal: bool,
                   kv_len: Optional[torch.Tensor] = None, dq=None, dk=None, dv=None, key_mask: Optional[torch.Tensor] = None,
-                  Skv: Optional[int] = None):
+                  Skv: Optional[int] = None, rope=None):
     """Two kernels (dK/dV per key block, dQ per query block: 7 GEMM units of S x S x hd per head, deterministic).  A single-pass form with
-    fp32 atomic dQ accumulation was built and measured slower at every length (profiles/r03_attention_notes.md)."""
+    fp32 atomic dQ accumulation was built and measured slower at every length (profiles/r03_attention_notes.md).
+    ``rope`` = (cos, sin) bf16 [S_rope, hd] tables: q / k are the ROTATED tensors of LlamaAttention.forward and dq / dk leave with the inverse
+    half-split rotation applied in the kernels' register epilogues (hd 128; bit-identical to ``rope_(.., inverse=True)`` afterwards)."""
     dev = q.device
     Skv = S if Skv is None else Skv
     if dq is None:
@@ -921,11 +924,26 @@ def attention_bwd(q, k, v, o, do, lse, B: int, S: int, H: int, hd: int, scale: f
     if dv is None:
         dv = torch.empty((B * Skv, H * hd), dtype=bf16, device=dev)
     delta = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+    if rope is not None:
+        cos, sin = rope
+        _chk(cos, name="rope cos"), _chk(sin, name="rope sin")
+        assert cos.is_contiguous() and sin.is_contiguous() and cos.shape == sin.shape and cos.dim() == 2 and cos.shape[1] == hd, "rope tables"
+        hip.get_lib().call("aria_attn_bwd_rope", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv),
+                           _p(kv_len), _p(key_mask), B, S, Skv, H, hd, _rowmajor_2d(q, "q"), _rowmajor_2d(k, "k"), _rowmajor_2d(v, "v"),
+                           _rowmajor_2d(o, "o"), _rowmajor_2d(dq, "dq"), _rowmajor_2d(dk, "dk"), _rowmajor_2d(dv, "dv"), float(scale),
+                           int(causal), _p(cos), _p(sin), cos.shape[0], _stream(q))
+        return dq, dk, dv
     hip.get_lib().call("aria_attn_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(kv_len),
                        _p(key_mask), B, S, Skv, H, hd, _rowmajor_2d(q, "q"), _rowmajor_2d(k, "k"), _rowmajor_2d(v, "v"),
                        _rowmajor_2d(o, "o"), _rowmajor_2d(dq, "dq"), _rowmajor_2d(dk, "dk"), _rowmajor_2d(dv, "dv"), float(scale),
                        int(causal), _stream(q))
     return dq, dk, dv
+
+
+def attention_bwd_rope_fusable(hd: int, S: int, cos: torch.Tensor) -> bool:
+    """the attention backward's inverse-RoPE epilogue: the decoder's head dim, positions = index in the sequence (the tables cover S rows),
+    ARIA_FUSE_QKV_ROPE=0 switches it off together with the forward's fused rotation"""
+    return hd == 128 and cos.dim() == 2 and cos.shape[0] >= S and cos.shape[1] == hd and os.environ.get("ARIA_FUSE_QKV_ROPE", "1") != "0"
 
 
 def decode_attention(qkv: torch.Tensor, freqs_cis: torch.Tensor, pos: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,

@@ -315,6 +315,16 @@ int aria_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                   float* delta /* fp32 [B,H,Sq] scratch */, void* dq, void* dk, void* dv, const int32_t* kv_len,
                   const uint8_t* key_mask, int64_t B, int64_t Sq, int64_t Skv, int64_t H, int64_t hd, int64_t ldq, int64_t ldk,
                   int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal, void* stream);
+/* The same with the INVERSE half-split RoPE of dq and dk in the two kernels' register epilogues (the chain rule through
+ * apply_rotary_pos_emb, transformers/models/llama/modeling_llama.py:130-160, which LlamaAttention.forward :243-281 applies to q and k in
+ * front of the attention: q, k here are the ROTATED tensors, dq / dk leave as gradients of the un-rotated projections).  rope_cos /
+ * rope_sin: [rope_S, hd] bf16 tables (emb = cat(freqs, freqs)); the position of token t of a sequence is t % rope_S.  Bit-identical to
+ * aria_attn_bwd followed by aria_rope_inplace(inverse) on dq | dk.  hd == 128 only (ARIA_ERR_UNSUPPORTED otherwise); both tables NULL =
+ * aria_attn_bwd. */
+int aria_attn_bwd_rope(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
+                       void* dq, void* dk, void* dv, const int32_t* kv_len, const uint8_t* key_mask, int64_t B, int64_t Sq, int64_t Skv,
+                       int64_t H, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk,
+                       int64_t lddv, float scale, int causal, const void* rope_cos, const void* rope_sin, int64_t rope_S, void* stream);
 
 /* which backward the calling thread's last aria_attn_bwd ran: 2 = padded-tile pair (hd 64 / 72), 5 = role-split dK/dV + dQ v5 (hd 128) */
 int aria_last_attn_bwd_variant(void);

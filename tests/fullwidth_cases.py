@@ -126,14 +126,26 @@ class _Recorder:
             self.fused += 1
             return r
 
-        self.fused = 0
+        self._rope, self._abwd = ops.rope_, ops.attention_bwd
+
+        def rope_(x, cos, sin, S, n_heads, hd, inverse=False):   # (r05: the inverse rotation of dq | dk belongs to the attention backward)
+            self.inverse_rope += bool(inverse)
+            return self._rope(x, cos, sin, S, n_heads, hd, inverse=inverse)
+
+        def abwd(*a, **kw):
+            self.bwd_rope += kw.get("rope") is not None
+            return self._abwd(*a, **kw)
+
+        self.fused = self.inverse_rope = self.bwd_rope = 0
         ops.moe_route, ops.grouped_gemm, ops.grouped_gemm_swiglu, ops.moe_router_fused = route, gg, ggs, router_fused
         ops.grouped_gemm_swiglu_gather = ggsg
+        ops.rope_, ops.attention_bwd = rope_, abwd
         return self
 
     def __exit__(self, *exc):
         self.ops.moe_route, self.ops.grouped_gemm, self.ops.grouped_gemm_swiglu, self.ops.moe_router_fused = self._route, self._gg, self._ggs, self._rf
         self.ops.grouped_gemm_swiglu_gather = self._ggsg
+        self.ops.rope_, self.ops.attention_bwd = self._rope, self._abwd
         return False
 
 
@@ -309,6 +321,8 @@ def case_lm(dev, case, *, hidden, heads, experts, topk, inter, vocab, layers, B,
     assert len(rec.idx) == layers, len(rec.idx)
     if expect_big_gemm:
         assert rec.variants and min(rec.variants) >= 2, rec.variants
+    if os.environ.get("ARIA_FUSE_QKV_ROPE", "1") != "0" and ocfg.head_dim == 128:   # no stand-alone inverse-RoPE pass in the backward
+        assert rec.bwd_rope == layers and rec.inverse_rope == 0, (rec.bwd_rope, rec.inverse_rope)
     with _OracleLogits() as ol, O.forced_routing(rec.idx), oracle_ctx():
         lgo = O.lm_forward(wf["model.embed_tokens.weight"][ids_o], wf, ocfg, training=True)
     if not eval_pass:

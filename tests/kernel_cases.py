@@ -6,6 +6,7 @@
     <= 1 bf16 ulp on hardware (device expf / rsqrt may differ from the host's libm by one fp32 ulp);
   * GEMM / attention / reductions: tolerance stated per case (bf16 inputs, fp32 accumulation).
 """
+import pytest
 import torch
 
 from oracle import aria_oracle as O
@@ -853,6 +854,37 @@ def case_attention_forward_variants(dev, B, Sq, Skv, H, hd, causal, masked, use_
     kk, vv = (kv[:, i * D:(i + 1) * D].float().view(B, Skv, H, hd).transpose(1, 2) for i in range(2))
     want = O.attention_eager(qq, kk, vv, hd ** -0.5, causal, key_padding=pad)
     close(got["3"][0], want.transpose(1, 2).reshape(B * Sq, D), 2e-2, 2e-2)
+
+
+def case_attention_bwd_rope(dev, B, S, H, causal, use_len, s_rope=None):
+    """r05: ``aria_attn_bwd_rope`` -- the inverse half-split RoPE of dq / dk (the chain rule through apply_rotary_pos_emb,
+    modeling_llama.py:130-160) in the attention backward's register epilogues -- gives the bits of ``aria_attn_bwd`` followed by the in-place
+    inverse pass (``rope_(.., inverse=True)``), dv untouched; and rotating back forward returns the un-fused gradients' neighbourhood."""
+    from aria_amd import functional as Fn
+    from aria_amd import ops
+
+    hd = 128
+    D = H * hd
+    g = torch.Generator().manual_seed(B * 100 + S + H)
+    qkv = torch.randn(B * S, 3 * D, generator=g).to(bf16).to(dev)
+    do = torch.randn(B * S, D, generator=g).to(bf16).to(dev)
+    kl = torch.randint(1, S + 1, (B,), generator=g).to(torch.int32).to(dev) if use_len else None
+    cos, sin = Fn.rope_tables(s_rope or S, hd, 1e4, dev)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    o, lse = ops.attention_fwd(q, k, v, B, S, H, hd, hd ** -0.5, causal, kv_len=kl)
+    ref = torch.empty(B * S, 3 * D, dtype=bf16, device=dev)
+    ops.attention_bwd(q, k, v, o, do, lse, B, S, H, hd, hd ** -0.5, causal, kv_len=kl, dq=ref[:, :D], dk=ref[:, D:2 * D], dv=ref[:, 2 * D:])
+    plain = ref.clone()
+    ops.rope_(ref[:, :2 * D], cos, sin, S, 2 * H, hd, inverse=True)
+    got = torch.full((B * S, 3 * D), float("nan"), dtype=bf16, device=dev)
+    ops.attention_bwd(q, k, v, o, do, lse, B, S, H, hd, hd ** -0.5, causal, kv_len=kl, dq=got[:, :D], dk=got[:, D:2 * D], dv=got[:, 2 * D:],
+                      rope=(cos, sin))
+    assert torch.equal(got.cpu(), ref.cpu()), float((got.float() - ref.float()).abs().max())
+    assert not torch.equal(got[:, :2 * D].cpu(), plain[:, :2 * D].cpu())       # (the rotation did happen)
+    assert ops.attention_bwd_rope_fusable(hd, S, cos) and not ops.attention_bwd_rope_fusable(64, S, cos)
+    with pytest.raises(Exception):
+        ops.attention_bwd(q[:, :H * 64], k[:, :H * 64], v[:, :H * 64], o[:, :H * 64], do[:, :H * 64], lse, B, S, H, 64, 0.125, causal,
+                          rope=(cos[:, :64].contiguous(), sin[:, :64].contiguous()))
 
 
 # ------------------------------------------------------------------------------------------ single-query decode attention

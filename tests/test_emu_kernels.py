@@ -293,3 +293,8 @@ def test_qkv_projection_with_rope_and_cache_write_epilogue(B, S, D, hd, K, S_cac
 @pytest.mark.parametrize("T,E,k,D", [(70, 8, 2, 512), (37, 64, 6, 2560)])
 def test_dispatch_kernels_with_a_compile_time_row_width(T, E, k, D):
     C.case_dispatch_fixed_width(DEV, T, E, k, D)
+
+
+@pytest.mark.parametrize("B,S,H,causal,use_len,s_rope", [(2, 70, 2, True, False, None), (1, 300, 1, False, True, 512), (1, 130, 2, True, True, None)])
+def test_attention_backward_with_the_inverse_rope_in_its_epilogue(B, S, H, causal, use_len, s_rope):
+    C.case_attention_bwd_rope(DEV, B, S, H, causal, use_len, s_rope)
