@@ -251,3 +251,31 @@ def test_full_reference_model_with_both_seams():
         a, b = pe[n].grad.float().flatten(), po[n].grad.float().flatten()
         cos = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp(min=1e-30))
         assert cos >= 0.97, (n, cos)
+
+
+def test_image_rows_scatter_equals_masked_scatter_forward_and_backward():
+    """modeling_aria.py:272-283 merges the projector's rows into the token embeddings with ``masked_scatter`` over a mask expanded along D;
+    ``scatter_image_rows`` does it on the rows (no 42 M-element prefix sum / partition in the step): same values, same gradients."""
+    import torch
+
+    from aria_amd.modeling_aria import scatter_image_rows
+
+    torch.manual_seed(0)
+    B, S, D = 3, 17, 8
+    is_img = torch.zeros(B, S, dtype=torch.bool)
+    is_img[0, 2:6] = True
+    is_img[1, 0] = True
+    is_img[1, 13:16] = True          # sample 2: no image tokens at all
+    n = int(is_img.sum())
+    for feats_shape in ((2, n // 2, D), (n, D)):
+        emb = torch.randn(B, S, D, requires_grad=True)
+        emb2 = emb.detach().clone().requires_grad_(True)
+        feats = torch.randn(*feats_shape, requires_grad=True)
+        feats2 = feats.detach().clone().requires_grad_(True)
+        got = scatter_image_rows(emb, is_img, feats)
+        want = emb2.masked_scatter(is_img.unsqueeze(-1).expand_as(emb2), feats2)
+        assert torch.equal(got, want)
+        g = torch.randn_like(got)
+        got.backward(g)
+        want.backward(g)
+        assert torch.equal(emb.grad, emb2.grad) and torch.equal(feats.grad, feats2.grad)
