@@ -22,28 +22,29 @@ constexpr int kMaxPerLane = 4;  // E <= 256
 //   * routing per token by route_one_token (aria_device.h: the decode engine's; lane = expert) on the LDS row; histogram per wave in LDS,
 //     one global atomic per (wave, expert with a count).
 template <int NB>
-__global__ __launch_bounds__(64) void router_fused_kernel(const bf16_t* x, const bf16_t* w, bf16_t* logits, bf16_t* scores, int32_t* indices,
-                                                          int32_t* counts, int T, int D, int k, long long ldx) {
+__global__ __launch_bounds__(64 * NB) void router_fused_kernel(const bf16_t* x, const bf16_t* w, bf16_t* logits, bf16_t* scores, int32_t* indices,
+                                                               int32_t* counts, int T, int D, int k, long long ldx) {
+    // r05b: ONE WAVE PER 32-EXPERT BLOCK (NB waves per workgroup; was one wave with NB accumulators): 16 384 tokens are only 512 token blocks
+    // on 1024 SIMDs, and a lone wave per SIMD is latency-bound on its operand loads (102 us per launch against ~20 us of traffic) -- twice the
+    // waves, half the weight loads and MFMAs per wave, the routing of the block's 32 tokens dealt to the waves.  Every logit is still ONE
+    // accumulator run over the whole reduction in gemm's order: bit-identical to gemm + route as before.
     constexpr int E = 32 * NB, CH = 4, DEPTH = 4;
     ARIA_SMEM_STATIC bf16_t tile[32 * E];
     ARIA_SMEM_STATIC int hist[64];
-    const int l = threadIdx.x & 63, lr = l & 31, kh = l >> 5;
+    const int l = threadIdx.x & 63, lr = l & 31, kh = l >> 5, b = first_lane(int(threadIdx.x) >> 6);
     const int t0 = blockIdx.x * 32;
-    hist[l] = 0;
+    if (b == 0) hist[l] = 0;
     const bf16_t* xp = x + (long long)min(t0 + lr, T - 1) * ldx + 8 * kh;   // (rows past T: clamped, computed, never stored)
-    const bf16_t* wp = w + (long long)lr * D + 8 * kh;
-    f32x16 acc[NB];
+    const bf16_t* wp = w + (long long)(32 * b + lr) * D + 8 * kh;
+    f32x16 acc;
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[b][j] = 0.f;
-    s16x8 xa[DEPTH][CH], wb[2][NB][CH];
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    s16x8 xa[DEPTH][CH], wb[2][CH];
     const int nch = D / 64;   // (a multiple of DEPTH: the launcher checks D % 256 == 0)
 #define RF_LOADX(slot, c)                                                                       \
     _Pragma("unroll") for (int i = 0; i < CH; ++i) xa[slot][i] = *reinterpret_cast<const s16x8*>(xp + (c) * 64 + 16 * i)
 #define RF_LOADW(slot, c)                                                                       \
-    _Pragma("unroll") for (int b = 0; b < NB; ++b) _Pragma("unroll") for (int i = 0; i < CH; ++i)  \
-        wb[slot][b][i] = *reinterpret_cast<const s16x8*>(wp + (long long)(32 * b) * D + (c) * 64 + 16 * i)
+    _Pragma("unroll") for (int i = 0; i < CH; ++i) wb[slot][i] = *reinterpret_cast<const s16x8*>(wp + (c) * 64 + 16 * i)
     RF_LOADX(0, 0);
     RF_LOADX(1, 1);
     RF_LOADX(2, 2);
@@ -55,26 +56,22 @@ __global__ __launch_bounds__(64) void router_fused_kernel(const bf16_t* x, const
             if (c + DEPTH - 1 < nch) RF_LOADX((s + DEPTH - 1) % DEPTH, c + DEPTH - 1);
             if (c + 1 < nch) RF_LOADW((s + 1) & 1, c + 1);
 #pragma unroll
-            for (int i = 0; i < CH; ++i)
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = mfma32(xa[s][i], wb[s & 1][b][i], acc[b]);
+            for (int i = 0; i < CH; ++i) acc = mfma32(xa[s][i], wb[s & 1][i], acc);
         }
     }
 #undef RF_LOADX
 #undef RF_LOADW
     // C layout of the 32 x 32 tile: register j of lane l = (token (j & 3) + 8 (j >> 2) + 4 (l >> 5), expert l & 31)
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) tile[((j & 3) + 8 * (j >> 2) + 4 * kh) * E + 32 * b + lr] = f2bf(acc[b][j]);
+    for (int j = 0; j < 16; ++j) tile[((j & 3) + 8 * (j >> 2) + 4 * kh) * E + 32 * b + lr] = f2bf(acc[j]);
     sync();
 #pragma unroll
-    for (int it = 0; it < (32 * E) / (64 * 8); ++it) {   // the tile = rows t0 .. t0 + 31 of logits [T, E]: contiguous, 16 bytes per lane
-        const int ci = it * 64 + l, tr = ci / (E / 8);
+    for (int it = 0; it < (32 * E) / (64 * NB * 8); ++it) {   // the tile = rows t0 .. t0 + 31 of logits [T, E]: contiguous, 16 bytes per lane
+        const int ci = it * 64 * NB + int(threadIdx.x), tr = ci / (E / 8);
         if (t0 + tr < T) st16(logits + (long long)t0 * E + ci * 8, ld16(tile + ci * 8));
     }
     const int nt = min(32, T - t0);
-    for (int t = 0; t < nt; ++t) {
+    for (int t = b; t < nt; t += NB) {
         float sc;
         int id;
         route_one_token(tile + t * E, E, k, l, 0, sc, id);
@@ -85,7 +82,7 @@ __global__ __launch_bounds__(64) void router_fused_kernel(const bf16_t* x, const
         }
     }
     sync();
-    if (l < E && hist[l]) atomic_add(&counts[l], hist[l]);
+    if (b == 0 && l < E && hist[l]) atomic_add(&counts[l], hist[l]);
 }
 
 // ------------------------------------------------------------------------------------------- route
@@ -638,7 +635,7 @@ int aria_moe_router_fused(const void* x, const void* w, void* logits, void* scor
     if (hipMemsetAsync(counts, 0, sizeof(int32_t) * E, static_cast<hipStream_t>(stream)) != hipSuccess) return ARIA_ERR_LAUNCH;
 #endif
     if (T == 0) return ARIA_OK;
-    const dim3 grid(unsigned((T + 31) / 32)), block(64);
+    const dim3 grid(unsigned((T + 31) / 32)), block(unsigned(2 * E));   // (one wave per 32-expert block)
     if (E == 64)
         ARIA_LAUNCH((router_fused_kernel<2>), grid, block, 0, stream, static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w),
                     static_cast<bf16_t*>(logits), static_cast<bf16_t*>(scores), indices, counts, int(T), int(D), int(k), (long long)ldx);

@@ -1,0 +1,40 @@
+"""router_fused_kernel (gating GEMM + top-k + softmax + histogram, one launch) at the config #3 shape: 16 384 tokens x 2560 -> 64 experts, top-6;
+beside it the two-launch chain it replaces (gemm + route).  us per call, medians of 5 x 50."""
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from aria_amd import ops  # noqa: E402
+
+dev, bf16 = "cuda", torch.bfloat16
+T, D, E, k = 16384, 2560, 64, 6
+x = (torch.randn(T, D, device=dev) * 0.5).to(bf16)
+w = (torch.randn(E, D, device=dev) * 0.02).to(bf16)
+
+
+def timed(fn, n=50):
+    fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+
+def chain():
+    lg = ops.gemm(x, w)
+    return ops.moe_route(lg, k)
+
+
+fused = [timed(lambda: ops.moe_router_fused(x, w, k)) for _ in range(5)]
+two = [timed(chain) for _ in range(5)]
+a, b = ops.moe_router_fused(x, w, k), chain()
+print(json.dumps({"fused_us": round(statistics.median(fused), 1), "gemm_plus_route_us": round(statistics.median(two), 1),
+                  "indices_equal": bool(torch.equal(a[2], b[1])), "counts_equal": bool(torch.equal(a[3], b[2])),
+                  "fused_runs": [round(v, 1) for v in fused]}))
