@@ -21,7 +21,7 @@ constexpr int kMaxPerLane = 4;  // E <= 256
 //   * the rounded logits go to the wave's LDS tile [32 tokens][E] and from there to HBM (the backward wants them) in 16-byte pieces;
 //   * routing per token by route_one_token (aria_device.h: the decode engine's; lane = expert) on the LDS row; histogram per wave in LDS,
 //     one global atomic per (wave, expert with a count).
-template <int NB>
+template <int NB, int NCH = 0>
 __global__ __launch_bounds__(64 * NB) void router_fused_kernel(const bf16_t* x, const bf16_t* w, bf16_t* logits, bf16_t* scores, int32_t* indices,
                                                                int32_t* counts, int T, int D, int k, long long ldx) {
     // r05b: ONE WAVE PER 32-EXPERT BLOCK (NB waves per workgroup; was one wave with NB accumulators): 16 384 tokens are only 512 token blocks
@@ -39,24 +39,35 @@ __global__ __launch_bounds__(64 * NB) void router_fused_kernel(const bf16_t* x, 
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    s16x8 xa[DEPTH][CH], wb[2][CH];
-    const int nch = D / 64;   // (a multiple of DEPTH: the launcher checks D % 256 == 0)
+    s16x8 xa[DEPTH][CH], wb[DEPTH][CH];   // (both operands three chunks ahead: the weights are L2-resident, but one chunk ahead was a dependent
+                                          //  L2 round trip per step -- 40 of them in a row)
+    // NCH > 0 (the launcher: Aria's D = 2560 -> 40): the reduction loop fully unrolled -- across a loop's back-edge the compiler's wait
+    // counters start from "everything older must have landed", which drained the two chunks in flight behind the one being consumed once
+    // per iteration; straight-line code gets exact counted waits (three chunks ahead all the way)
+    const int nch = NCH > 0 ? NCH : D / 64;   // (a multiple of DEPTH: the launcher checks D % 256 == 0)
 #define RF_LOADX(slot, c)                                                                       \
     _Pragma("unroll") for (int i = 0; i < CH; ++i) xa[slot][i] = *reinterpret_cast<const s16x8*>(xp + (c) * 64 + 16 * i)
 #define RF_LOADW(slot, c)                                                                       \
     _Pragma("unroll") for (int i = 0; i < CH; ++i) wb[slot][i] = *reinterpret_cast<const s16x8*>(wp + (c) * 64 + 16 * i)
     RF_LOADX(0, 0);
-    RF_LOADX(1, 1);
-    RF_LOADX(2, 2);
     RF_LOADW(0, 0);
+    RF_LOADX(1, 1);
+    RF_LOADW(1, 1);
+    RF_LOADX(2, 2);
+    RF_LOADW(2, 2);
+#pragma unroll NCH > 0 ? NCH / DEPTH : 1
     for (int c0 = 0; c0 < nch; c0 += DEPTH) {
 #pragma unroll
         for (int s = 0; s < DEPTH; ++s) {
-            const int c = c0 + s;
-            if (c + DEPTH - 1 < nch) RF_LOADX((s + DEPTH - 1) % DEPTH, c + DEPTH - 1);
-            if (c + 1 < nch) RF_LOADW((s + 1) & 1, c + 1);
+            // (unconditional, the chunk index clamped: a branch around the loads made the compiler drain every load in flight -- vmcnt(0) -- at
+            // the join in front of the next MFMA group, once per four chunks; the last three steps re-read the last chunk into dead slots)
+            const int cn = min(c0 + s + DEPTH - 1, nch - 1);
+            RF_LOADX((s + DEPTH - 1) % DEPTH, cn);
+            RF_LOADW((s + DEPTH - 1) % DEPTH, cn);
+            sched_fence();   // (the scheduler otherwise sinks the requests to just in front of their use three steps later)
 #pragma unroll
-            for (int i = 0; i < CH; ++i) acc = mfma32(xa[s][i], wb[s & 1][i], acc);
+            for (int i = 0; i < CH; ++i) acc = mfma32(xa[s][i], wb[s][i], acc);
+            sched_fence();
         }
     }
 #undef RF_LOADX
@@ -636,7 +647,10 @@ int aria_moe_router_fused(const void* x, const void* w, void* logits, void* scor
 #endif
     if (T == 0) return ARIA_OK;
     const dim3 grid(unsigned((T + 31) / 32)), block(unsigned(2 * E));   // (one wave per 32-expert block)
-    if (E == 64)
+    if (E == 64 && D == 2560)
+        ARIA_LAUNCH((router_fused_kernel<2, 40>), grid, block, 0, stream, static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w),
+                    static_cast<bf16_t*>(logits), static_cast<bf16_t*>(scores), indices, counts, int(T), int(D), int(k), (long long)ldx);
+    else if (E == 64)
         ARIA_LAUNCH((router_fused_kernel<2>), grid, block, 0, stream, static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w),
                     static_cast<bf16_t*>(logits), static_cast<bf16_t*>(scores), indices, counts, int(T), int(D), int(k), (long long)ldx);
     else

@@ -240,7 +240,7 @@ def test_gemm_qkv_rope_hf_is_gemm_plus_rope(force_gemm_v3, B, S, D, hd, K):
     assert C.case_gemm_qkv_rope_hf(DEV, B, S, D, hd, K)
 
 
-@pytest.mark.parametrize("T,D,E,k", [(70, 256, 64, 6), (33, 512, 32, 2), (1, 256, 64, 1), (64, 256, 64, 8)])
+@pytest.mark.parametrize("T,D,E,k", [(70, 256, 64, 6), (33, 512, 32, 2), (1, 256, 64, 1), (64, 256, 64, 8), (45, 2560, 64, 6)])
 def test_router_fused_is_gemm_plus_route(T, D, E, k):
     C.case_router_fused(DEV, T, D, E, k)
 
