@@ -28,6 +28,10 @@ __global__ __launch_bounds__(64 * NB) void router_fused_kernel(const bf16_t* x, 
     // on 1024 SIMDs, and a lone wave per SIMD is latency-bound on its operand loads (102 us per launch against ~20 us of traffic) -- twice the
     // waves, half the weight loads and MFMAs per wave, the routing of the block's 32 tokens dealt to the waves.  Every logit is still ONE
     // accumulator run over the whole reduction in gemm's order: bit-identical to gemm + route as before.
+    // What bounds the launch now (74 us for 16 384 x 2560 -> 64; 84 MB of tokens would stream in ~20): an MFMA operand fragment is 16 bytes
+    // of 32 DIFFERENT rows per wave-instruction, i.e. 32 cache lines per request through the vector L1 (1280 such requests per CU at ~120
+    // cycles each).  Coalesced staging through the LDS (8 whole lines per request, fragments read back with a row swizzle -- gemm3's loader)
+    // is the next step; not built: ~1 ms per step.
     constexpr int E = 32 * NB, CH = 4, DEPTH = 4;
     ARIA_SMEM_STATIC bf16_t tile[32 * E];
     ARIA_SMEM_STATIC int hist[64];
