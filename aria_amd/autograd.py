@@ -349,9 +349,9 @@ class LMHeadLossFn(torch.autograd.Function):
         ctx.d_hn = ctx.g_w = None
         # dloss is a device scalar (ones for a plain loss.backward()): scale in place, no host sync
         if d_hn is not None:
-            d_hn.mul_(dloss)
+            ops.scale_(d_hn, dloss)
         if g_w is not None:
-            g_w.mul_(dloss)
+            ops.scale_(g_w, dloss)
         return d_hn, g_w, None
 
 
@@ -374,7 +374,7 @@ class LoraLMHeadLossFn(torch.autograd.Function):
         ctx.g = None
         for t in (d_hn, dA, dB):
             if t is not None:
-                t.mul_(dloss)
+                ops.scale_(t, dloss)
         return d_hn, None, None, dA, dB, None, None, None, None
 
 
@@ -461,4 +461,4 @@ class CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         d, ctx.dlogits = ctx.dlogits, None
-        return (d.mul_(dloss) if d is not None else None), None
+        return (ops.scale_(d, dloss) if d is not None else None), None

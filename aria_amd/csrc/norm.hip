@@ -195,6 +195,23 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* a, const bf16_t*
     }
 }
 
+// x *= *scale (a device-side fp32 scalar), in place: autograd hands a fused loss node its upstream gradient as a 0-dim device tensor (ones for a
+// plain loss.backward(), 1 / accumulation_steps under gradient accumulation), and the node's ready-made gradients ([V, D] for lm_head, [T, D]
+// for the hidden state) have to be scaled by it without a host read.  torch's mixed-dtype tensor x 0-dim-tensor multiply runs on its
+// strided element-wise path: 778 + 111 us per config #3 step.  Here: the identity (scale == 1.0f, the common case) touches no memory at all,
+// anything else streams at the copy rate; arithmetic = torch's (bf16 -> fp32, multiply, round to bf16).
+__global__ __launch_bounds__(256) void scale_kernel(bf16_t* x, const float* scale, long long nchunks) {
+    const float s = *scale;
+    if (s == 1.0f) return;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (long long)gridDim.x * blockDim.x) {
+        const u32x4 v = ld16(x + c * 8);
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = pack2bf(bflo(v[q]) * s, bfhi(v[q]) * s);
+        st16(x + c * 8, o);
+    }
+}
+
 // LoRA's input dropout (nn.Dropout(lora_dropout) in front of lora_A: aria/lora/layers.py:83-85, 131; recipes/config_lora.yaml:46): inverted
 // dropout on 8-element chunks -- out = keep ? bf16(x / (1 - p)) : 0 and ONE mask byte per chunk (bit e = element e kept), so the backward
 // re-applies the same mask from 1/16 of the bytes instead of keeping a second activation-sized tensor.  Counter-based randomness: the 8
@@ -393,6 +410,14 @@ int aria_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stre
     if (n == 0) return ARIA_OK;
     ARIA_LAUNCH(add_kernel, dim3(grid1d(n / 8, 256)), dim3(256), 0, stream, static_cast<const bf16_t*>(a),
                 static_cast<const bf16_t*>(b), static_cast<bf16_t*>(out), (long long)(n / 8));
+    return aria_check_launch();
+}
+
+int aria_scale_bf16(void* x, const float* scale, int64_t n, void* stream) {
+    if (!x || !scale || n < 0) return ARIA_ERR_INVALID;
+    if ((n & 7) || (reinterpret_cast<uintptr_t>(x) & 15)) return ARIA_ERR_ALIGN;
+    if (n == 0) return ARIA_OK;
+    ARIA_LAUNCH(scale_kernel, dim3(grid1d(n / 8, 256)), dim3(256), 0, stream, static_cast<bf16_t*>(x), scale, (long long)(n / 8));
     return aria_check_launch();
 }
 

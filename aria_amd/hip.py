@@ -85,6 +85,7 @@ SIGNATURES = {
     "aria_adamw_step": [P, P, P, P, P, I64, F32, F32, F32, F32, F32, I64, F32, P],
     "aria_sumsq_bf16": [P, I64, P, I32, P, P],
     "aria_add_bf16": [P, P, P, I64, P],
+    "aria_scale_bf16": [P, P, I64, P],
     "aria_attn_fwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
     "aria_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P],
     "aria_attn_bwd_rope": [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, I32, P, P, I64, P],

@@ -721,6 +721,16 @@ def rmsnorm_bwd(dy, h, w, rstd, dres: Optional[torch.Tensor] = None, dw_out: Opt
     return dx, dw_out
 
 
+def scale_(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """x *= s in place, s a one-element fp32 tensor ON THE DEVICE (an autograd upstream gradient): no host read, and no memory traffic when
+    s == 1 (aria_scale_bf16).  Falls back to torch for shapes the kernel does not take (n % 8, other dtypes)."""
+    if (x.dtype == bf16 and x.is_contiguous() and x.numel() % 8 == 0 and s.numel() == 1 and s.dtype == torch.float32 and s.device == x.device
+            and x.data_ptr() % 16 == 0):
+        hip.get_lib().call("aria_scale_bf16", _p(x), _p(s), x.numel(), _stream(x))
+        return x
+    return x.mul_(s)
+
+
 def rope_(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, S: int, n_heads: int, hd: int, inverse: bool = False):
     """In-place half-split RoPE on the first n_heads*hd columns of the 2-D view x [T, >= n_heads*hd]."""
     _chk(x, name="x"), _chk(cos, name="cos"), _chk(sin, name="sin")

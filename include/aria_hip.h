@@ -297,6 +297,10 @@ int aria_sumsq_bf16(const void* x, int64_t n, float* out, int accumulate, float*
 
 /* out = bf16(a + b), n elements (n % 8 == 0) */
 int aria_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* x[0..n) *= *scale in place; scale: ONE fp32 on the device (autograd's upstream gradient of a loss node: torch's `grad.mul_(dloss)` in the
+ * fused loss nodes behind modeling_aria.py:301-323).  Reads the scalar on the device (no host sync); the identity (1.0f) touches no memory.
+ * n % 8 == 0, x 16-byte aligned. */
+int aria_scale_bf16(void* x, const float* scale, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention (attn.hip)

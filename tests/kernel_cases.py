@@ -887,6 +887,25 @@ def case_attention_bwd_rope(dev, B, S, H, causal, use_len, s_rope=None):
                           rope=(cos[:, :64].contiguous(), sin[:, :64].contiguous()))
 
 
+def case_scale_by_device_scalar(dev, n):
+    """``ops.scale_`` (aria_scale_bf16): x *= s with s ONE fp32 on the device -- what the fused loss nodes do with autograd's upstream gradient
+    (modeling_aria.py:301-323's loss under ``loss.backward()`` / ``(loss / k).backward()``); torch's own ``x.mul_(s)`` is the reference, bit
+    for bit (bf16 -> fp32, multiply, round), and s == 1 leaves every bit alone."""
+    from aria_amd import ops
+
+    x = rnd(n, seed=n)
+    x[0], x[-1] = float("inf"), -0.0
+    for sv in (1.0, 0.25, 1.0 / 3.0, -2.5, 0.0):
+        s = torch.tensor(sv, dtype=torch.float32)
+        want = x.clone().mul_(s)
+        got = ops.scale_(x.clone().to(dev), s.to(dev))
+        got = got.cpu()
+        assert torch.equal(got.isnan(), want.isnan()), sv          # (inf x 0: a NaN either way; its payload is the platform's)
+        assert torch.equal(got.nan_to_num(0.0).view(torch.int16), want.nan_to_num(0.0).view(torch.int16)), sv
+    odd = rnd(12, seed=1)                      # n % 8 != 0: torch's path
+    assert torch.equal(ops.scale_(odd.clone().to(dev), torch.tensor(0.5).to(dev)).cpu(), odd * 0.5)
+
+
 # ------------------------------------------------------------------------------------------ single-query decode attention
 def case_decode_attention(dev, H, hd, pos, splits, S_max=None):
     """aria_decode_attn (RoPE of q / k with freqs_cis[pos], cache write at row pos, softmax over rows 0..pos) against fp32 torch on the same

@@ -271,3 +271,8 @@ def test_dispatch_kernels_with_a_compile_time_row_width(T, E, k, D):
 @pytest.mark.parametrize("B,S,H,causal,use_len,s_rope", [(2, 70, 2, True, False, None), (8, 2048, 20, True, False, None), (1, 16384, 4, True, True, None), (2, 1000, 3, False, True, 1024)])
 def test_attention_backward_with_the_inverse_rope_in_its_epilogue(B, S, H, causal, use_len, s_rope):
     C.case_attention_bwd_rope(DEV, B, S, H, causal, use_len, s_rope)
+
+
+@pytest.mark.parametrize("n", [8, 4096, 100352 * 256])
+def test_scale_by_a_device_scalar(n):
+    C.case_scale_by_device_scalar(DEV, n)
