@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--gen-image", type=int, default=1, help="debug only (config #2: one 980px image)")
     ap.add_argument("--prefill-seq", type=int, default=53248, help="debug only (config #4: 32 x 128 frame tokens + 49 152 text tokens)")
     ap.add_argument("--prefill-frames", type=int, default=32, help="debug only (config #4: 32 frames at 490px)")
+    ap.add_argument("--no-fusions-ab", action="store_true", help="skip the `step_fusions_ab` sub-record (N = 1 only: 4 + 4 extra steps, the round-5 "
+                    "launch fusions switched off / on alternately inside this process -- box variance cancels)")
     ap.add_argument("--no-lora-record", action="store_true", help="skip the `lora_config` sub-record (N = 1 only: recipes/config_lora.yaml's adapter set "
                     "on the same model and micro-batch, three timed steps + the frozen-base forward + input-gradient reference)")
     ap.add_argument("--ep", action="store_true", help="BASELINE config #5 instead of #3: routed experts sharded over the N ranks (all-to-all "
@@ -332,6 +334,46 @@ def prefill_config4_record(twin, tcfg, S=53248, frames=32, runs=2, img_px=490, q
             "kv_cache_GB": round(L * 2 * S * D * 2 / 1e9, 1), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
             "roofline": {"kernel": "whole prefill (GEMMs + causal attention + ViT)", "bound": "mfma", "achieved": round(flops / t / 1e12, 1),
                          "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / t / 2.5e15, 4), "algorithmic_flops": flops, "traffic": None}}
+
+
+FUSION_SWITCHES = ("ARIA_FUSE_WGRAD_GATHER", "ARIA_FUSE_ROUTER", "ARIA_FUSE_QKV_ROPE")
+
+
+def step_fusions_ab(step, pairs=4):
+    """The config #3 step with round 5's launch fusions OFF and ON, alternating inside this process (same box, same clocks, same allocator
+    state): OFF = the tokens permuted into a [6T, D] copy for fc1 and its weight gradient, gating GEMM + routing as two launches, RoPE and
+    its inverse as passes of their own (round 4's step); ON = the default.  The switches are read per call.  Medians of `pairs` steps."""
+    import statistics
+
+    t = {"off": [], "on": []}
+    prev = {k: os.environ.get(k) for k in FUSION_SWITCHES}
+    try:
+        for i in range(pairs + 1):                     # (first pair = warm-up of both paths)
+            for arm in ("off", "on"):
+                for k in FUSION_SWITCHES:
+                    if arm == "off":
+                        os.environ[k] = "0"
+                    else:
+                        os.environ.pop(k, None)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                if i:
+                    t[arm].append((time.perf_counter() - t0) * 1e3)
+    finally:
+        for k, v in prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    off, on = statistics.median(t["off"]), statistics.median(t["on"])
+    return {"off_ms_per_step": round(off, 1), "on_ms_per_step": round(on, 1), "gain_ms": round(off - on, 1), "pairs": pairs,
+            "off_runs_ms": [round(v, 1) for v in t["off"]], "on_runs_ms": [round(v, 1) for v in t["on"]],
+            "switches_off_arm": {k: "0" for k in FUSION_SWITCHES},
+            "note": "interleaved in ONE process: off = K2 in the training step, K1 and both RoPE fusions switched off (round 4's launches), on = "
+                    "the default path; not switchable and therefore in BOTH arms: packed q|k|v / gate|up weights, the row-level image merge, "
+                    "the device-scalar loss scaling"}
 
 
 def lora_config_record(model, cfg, step, ops, B, S, steps=3):
@@ -694,6 +736,11 @@ def main():
         except Exception as ex:  # noqa: BLE001
             res["sub_records_error"] = f"{type(ex).__name__}: {ex}"[:400]
             cfg.gradient_checkpointing = bool(args.recompute)
+        try:
+            if world == 1 and not args.long and not args.ep and not args.recompute and not args.no_fusions_ab:
+                res["step_fusions_ab"] = step_fusions_ab(step)
+        except Exception as ex:  # noqa: BLE001
+            res["step_fusions_ab"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
         try:
             if world == 1 and not args.long and not args.ep and not args.recompute and not args.no_lora_record:
                 res["lora_config"] = lora_config_record(model, cfg, step, ops, B, S)

@@ -41,6 +41,9 @@ def test_bench_line_carries_the_contract(world):
         assert pre["value"] > 0 and pre["finite_logits"] is True and pre["roofline"]["bound"] == "mfma" and "INVALID" in pre
         assert res["long64k"]["recompute_level"] == "moe" and res["recipe_grad_checkpointing"]["recompute_level"] == "moe"
         assert "recipe gradient checkpointing: OFF" in res["config"]["workload"]
+        # the round-5 launch fusions off / on, alternating in this process (an A/B printed by bench.py itself)
+        ab = res["step_fusions_ab"]
+        assert "error" not in ab and ab["pairs"] == 4 and len(ab["off_runs_ms"]) == 4 == len(ab["on_runs_ms"]) and ab["on_ms_per_step"] > 0
         # recipes/config_lora.yaml on the same model: the adapters' step, the frozen-base floor, the recipe's checkpointing
         assert "lora_record_error" not in res, res.get("lora_record_error")
         lora = res["lora_config"]
