@@ -562,6 +562,70 @@ __device__ __forceinline__ void store_tile3_rows(const P& p, const f32x16 (&acc)
     }
 }
 
+// The row form for what used to fall back to the 4-byte-per-lane path (r05b): `accumulate` (C += tile: the frozen ViT's residual adds live in
+// its out_proj / fc2 epilogues, vision.py forward_frozen -- 58 launches per step whose narrow read-modify-write epilogue was a third of an
+// out_proj tile's time) and column tiles that hang over N (N = 1152 / 3456 / 4304 are 4.5 / 13.5 / 16.8 tiles wide).  The OLD tile comes in
+// first, by the same complete-row mapping the write-out uses (16 coalesced 16-byte loads per lane instead of 64 strided dword loads), and
+// waits in the LDS where the new values will be parked; each lane then adds its accumulators to the old pair IN FP32 and rounds once --
+// the narrow path's arithmetic, bit for bit -- and the rows leave as in store_tile3_rows.  N % 8 == 0 (the caller checks).
+template <int ACT, class P>
+__device__ __forceinline__ void store_tile3_rows_gen(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
+                                                     int wm, int wn, char* smem) {
+    const int c = l & 31, h = l >> 5, odd = l & 1;
+    const int rr = l >> 5, cc = (l & 31) * 8;  // two rows per instruction, 32 lanes x 16 bytes each
+    const bool col_in = n0 + cc < p.N;         // this lane's 8 columns exist (N % 8 == 0)
+    const bool old = p.accumulate != 0;
+    if (old) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32x4 o[8];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                const int row = w * 32 + (half * 8 + s2) * 2 + rr, m = m0 + row;
+                o[s2] = (m < m_end && col_in) ? ld16(reinterpret_cast<const bf16_t*>(C) + (long long)m * p.ldc + n0 + cc) : zero16();
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                const int row = w * 32 + (half * 8 + s2) * 2 + rr;
+                *reinterpret_cast<u32x4*>(smem + row * ROWP3 + cc * 2) = o[s2];
+            }
+        }
+        sync();
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + b * 128 + wn * 32 + c;
+        const float bv = (p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    const float v0 = aria_epilogue_act_c<ACT>(acc[a][i][b][2 * rp] + bv), v1 = aria_epilogue_act_c<ACT>(acc[a][i][b][2 * rp + 1] + bv);
+                    const int r = 2 * rp;
+                    const int row = a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;  // inside the tile
+                    const float got = xor1(odd ? v0 : v1);
+                    float lo = odd ? got : v0, hi = odd ? v1 : got;
+                    uint32_t* slot = reinterpret_cast<uint32_t*>(smem + row * ROWP3 + (b * 128 + wn * 32 + (c & ~1)) * 2);
+                    if (old) {
+                        const uint32_t ov = *slot;
+                        lo += bflo(ov);
+                        hi += bfhi(ov);
+                    }
+                    *slot = pack2bf(lo, hi);
+                }
+    }
+    sync();
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+        const int row = w * 32 + s2 * 2 + rr;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * ROWP3 + cc * 2);
+        const int m = m0 + row;
+        if (m < m_end && col_in) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + n0 + cc) = v;
+    }
+}
+
 // Row form of the epilogue for the fused wqkv projection (K7): the parked 256 x 256 tile leaves as complete 512-byte rows like
 // store_tile3_rows; a lane's 16 bytes are four interleaved (x[2i], x[2i+1]) pairs of ONE head, so the rotation is lane-local:
 // one 16-byte load of (cos, sin) x 4 from the bf16 freqs_cis row of the token's position per row piece.
@@ -673,6 +737,8 @@ __device__ __forceinline__ void store_any3(const P& p, const f32x16 (&acc)[2][2]
                                            int wn, char* smem) {
     if (!p.c_f32 && !p.accumulate && n0 + BN <= p.N && p.wide_store == 2)
         store_tile3_rows<ACT>(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
+    else if (!p.c_f32 && p.wide_store == 2 && !(p.N & 7) && !(ARIA_ABL & 4096))   // accumulate and / or a column tile that hangs over N
+        store_tile3_rows_gen<ACT>(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
     else if (!p.c_f32 && !p.accumulate && n0 + BN <= p.N && p.wide_store)
         store_tile3_wide<ACT>(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
     else

@@ -65,6 +65,32 @@ def case_gemm_layouts(dev, M, N, K, a_oc, b_oc):
     close(accb, (want + 1.0).to(bf16), 1e-2, 1e-2 * K ** 0.5)
 
 
+def case_gemm_accumulate_exact(dev, M, N, K, b_oc=False):
+    """C += A B + bias on a bf16 C: whichever epilogue carries it (r05b: the complete-row form with the old tile staged through the LDS, also for
+    column tiles that hang over N -- the frozen ViT's residual adds, vision.py forward_frozen; the 4-byte-per-lane form elsewhere), the result
+    is bf16(fp32(A B + bias) + C_old) with ONE rounding: exactly what the fp32-output launch of the same GEMM plus an fp32 add gives."""
+    from aria_amd import ops
+
+    a = rnd(M, K, seed=M + 1).to(dev)
+    w = rnd(N, K, seed=N + 2, scale=0.3)
+    w_arg = (w.t().contiguous() if b_oc else w).to(dev)
+    bias = rnd(N, seed=3).to(dev)
+    old = rnd(M, N, seed=4).to(dev)
+    for bv in (None, bias):
+        c32 = ops.gemm(a, w_arg, b_oc=b_oc, bias=bv, out_dtype=torch.float32)
+        want = (c32 + old.float()).to(bf16)
+        got = old.clone()
+        ops.gemm(a, w_arg, b_oc=b_oc, bias=bv, out=got, accumulate=True)
+        assert torch.equal(got.cpu(), want.cpu()), float((got.float() - want.float()).abs().max())
+        plain = ops.gemm(a, w_arg, b_oc=b_oc, bias=bv)                 # (and the plain store of the same tiles, partial column tile included)
+        assert torch.equal(plain.cpu(), c32.to(bf16).cpu())
+    big = torch.zeros(M + 2, N + 16, dtype=bf16, device=dev)           # a strided C (row pitch > N): neighbours untouched
+    view = big[1:M + 1, 8:N + 8]
+    view.copy_(old)
+    ops.gemm(a, w_arg, b_oc=b_oc, bias=bias, out=view, accumulate=True)
+    assert torch.equal(view.cpu(), want.cpu()) and float(big[0].abs().max()) == 0 and float(big[:, :8].abs().max()) == 0 and float(big[:, N + 8:].abs().max()) == 0
+
+
 def case_gemm_fused_gelu(dev, M, N, K):
     """fc1 + gelu_pytorch_tanh in the GEMM epilogue == the GEMM followed by the stand-alone GELU kernel, bit for bit (the activation
     sees bf16(acc + bias) in both), also through accumulate (x += gelu(...) is never used, but the order act -> accumulate is ABI)."""

@@ -303,3 +303,9 @@ def test_attention_backward_with_the_inverse_rope_in_its_epilogue(B, S, H, causa
 @pytest.mark.parametrize("n", [8, 4096])
 def test_scale_by_a_device_scalar(n):
     C.case_scale_by_device_scalar(DEV, n)
+
+
+@pytest.mark.parametrize("M,N,K,b_oc", [(300, 1152 // 4, 128, False), (513, 264, 192, False), (256, 512, 64, True), (40, 72, 64, False)])
+def test_gemm_accumulate_into_bf16_is_one_rounding(M, N, K, b_oc, monkeypatch):
+    monkeypatch.setenv("ARIA_GEMM_FORCE", "3")     # the 256 x 256 kernels also at the toy sizes (their epilogues are what is under test)
+    C.case_gemm_accumulate_exact(DEV, M, N, K, b_oc)
