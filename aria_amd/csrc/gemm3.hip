@@ -1059,8 +1059,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     ts_mark(2);
 
     const int c = l & 31, h = l >> 5, odd = l & 1;
-    if (slab >= 0) {  // raw fp32 partial sums, tile-shaped [256][256]; gemm3_reduce_kernel finishes the job
-        float* dst = p.ws + (long long)slab * (BM * BN);
+    if (slab >= 0) {  // raw fp32 partial sums for gemm3_reduce_kernel, which is their only reader -- so they leave in the ACCUMULATORS' order,
+        // r05b: 16 bytes per lane and 1 KiB contiguous per store instruction (32 dwordx4 stores per lane; the tile-shaped [256][256] form was
+        // 128 dword stores per lane, ~16 us of epilogue on a split tile).  Float offset of register 4 q + e of accumulator tile (b, a, i) of wave
+        // w, lane l:  ((((w * 8 + (b * 2 + a) * 2 + i) * 4 + q) * 64 + l) * 4 + e
+        float* dst = p.ws + (long long)slab * (BM * BN) + (long long)w * 8 * 4 * 64 * 4 + l * 4;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -1068,8 +1071,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        dst[(a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + b * 128 + wn * 32 + c] = acc[a][i][b][r];
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x4*>(dst + (((b * 2 + a) * 2 + i) * 4 + q) * 256) =
+                            f32x4{acc[a][i][b][4 * q], acc[a][i][b][4 * q + 1], acc[a][i][b][4 * q + 2], acc[a][i][b][4 * q + 3]};
         return;
     }
     if ((ARIA_ABL & 64) && p.M > 0) return;  // (timing experiment: no C write-out)
@@ -1094,33 +1098,39 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
 }
 
 // Sums the `split` slabs of every split tile in slab order (deterministic), then bias / accumulate / round exactly like the
-// main epilogue.  grid (split tiles, 16): block (r, part) finishes rows [16 part, 16 part + 16) of split tile r.
+// main epilogue.  grid (split tiles, 16): block (r, part) finishes the part-th sixteenth of split tile r IN THE SLABS' ORDER (the accumulators'
+// order, see the slab store in gemm3_kernel): a thread's four consecutive floats are registers 4 q .. 4 q + 3 of one lane = one column, four
+// consecutive rows.
 __global__ __launch_bounds__(256) void gemm3_reduce_kernel(GemmParams p) {
     int tn, tmi;
     if (!aria_tile_from_pos(p, p.split_first + blockIdx.x, tmi, tn)) return;
-    const int t = threadIdx.x, col = (t & 63) * 4;
+    const int t = threadIdx.x;
     const float* ws = p.ws + (long long)blockIdx.x * p.split * (BM * BN);
-    const int n = tn * BN + col;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        const int row = blockIdx.y * 16 + (t >> 6) + 4 * it;
-        const int m = tmi * BM + row;
-        f32x4 sum = *reinterpret_cast<const f32x4*>(ws + row * BN + col);
+        const int j = (blockIdx.y * 4 + it) * 256 + t;   // 16-byte piece of the slab
+        const int l = j & 63, q = (j >> 6) & 3, t8 = (j >> 8) & 7, w = j >> 11;
+        const int b = t8 >> 2, a = (t8 >> 1) & 1, i = t8 & 1, wm = w >> 2, wn = w & 3;
+        const int row0 = a * 128 + wm * 64 + i * 32 + 8 * q + 4 * (l >> 5), col = b * 128 + wn * 32 + (l & 31);
+        f32x4 sum = *reinterpret_cast<const f32x4*>(ws + 4 * j);
         for (int s = 1; s < p.split; ++s) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (long long)s * (BM * BN) + row * BN + col);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (long long)s * (BM * BN) + 4 * j);
 #pragma unroll
             for (int e = 0; e < 4; ++e) sum[e] += v[e];
         }
-        if (m >= p.M) continue;
+        const int n = tn * BN + col;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? bf2f(p.bias[n]) : 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (n + e >= p.N) continue;
-            float v = aria_epilogue_act(p, sum[e] + (p.bias ? bf2f(p.bias[n + e]) : 0.f));
+            const int m = tmi * BM + row0 + e;
+            if (m >= p.M) continue;
+            float v = aria_epilogue_act(p, sum[e] + bv);
             if (p.c_f32) {
-                float* d = static_cast<float*>(p.C) + (long long)m * p.ldc + n + e;
+                float* d = static_cast<float*>(p.C) + (long long)m * p.ldc + n;
                 *d = p.accumulate ? *d + v : v;
             } else {
-                bf16_t* d = static_cast<bf16_t*>(p.C) + (long long)m * p.ldc + n + e;
+                bf16_t* d = static_cast<bf16_t*>(p.C) + (long long)m * p.ldc + n;
                 if (p.accumulate) v += bf2f(*d);
                 *d = f2bf(v);
             }

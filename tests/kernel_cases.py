@@ -91,6 +91,29 @@ def case_gemm_accumulate_exact(dev, M, N, K, b_oc=False):
     assert torch.equal(view.cpu(), want.cpu()) and float(big[0].abs().max()) == 0 and float(big[:, :8].abs().max()) == 0 and float(big[:, N + 8:].abs().max()) == 0
 
 
+def case_gemm_split_k_slabs(dev, M, N, K, a_oc, b_oc):
+    """The remainder split-K of the 256 x 256 kernels (aria_gemm_bf16_ws): partial sums leave as fp32 slabs in the ACCUMULATORS' order (r05b: 16
+    bytes per lane, 1 KiB per store instruction) and gemm3_reduce_kernel, their only reader, maps them back -- every element of C (ragged
+    row / column tiles, bias, accumulate, fp32 output) against fp32 torch."""
+    from aria_amd import hip, ops
+
+    assert hip.get_lib().cdll.aria_gemm_workspace_bytes(M, N, K, int(a_oc), int(b_oc)) > 0, "the shape is expected to split"
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(bf16)
+    B = (torch.randn(N, K, generator=g) * 0.5).to(bf16)
+    a = (A.t().contiguous() if a_oc else A).to(dev)
+    b = (B.t().contiguous() if b_oc else B).to(dev)
+    bias, old = torch.randn(N, generator=g).to(bf16), torch.randn(M, N, generator=g).to(bf16)
+    want = A.float() @ B.float().t()
+    g32 = ops.gemm(a, b, a_oc=a_oc, b_oc=b_oc, out_dtype=torch.float32)
+    close(g32, want, 1e-4, 1e-3)
+    gb = ops.gemm(a, b, a_oc=a_oc, b_oc=b_oc, bias=bias.to(dev))
+    close(gb, (want + bias.float()).to(bf16), 1e-2, 1e-2 * K ** 0.5)
+    acc = old.clone().to(dev)
+    ops.gemm(a, b, a_oc=a_oc, b_oc=b_oc, bias=bias.to(dev), out=acc, accumulate=True)
+    assert torch.equal(acc.cpu(), (ops.gemm(a, b, a_oc=a_oc, b_oc=b_oc, bias=bias.to(dev), out_dtype=torch.float32).cpu() + old.float()).to(bf16))
+
+
 def case_gemm_fused_gelu(dev, M, N, K):
     """fc1 + gelu_pytorch_tanh in the GEMM epilogue == the GEMM followed by the stand-alone GELU kernel, bit for bit (the activation
     sees bf16(acc + bias) in both), also through accumulate (x += gelu(...) is never used, but the order act -> accumulate is ABI)."""

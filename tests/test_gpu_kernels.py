@@ -282,3 +282,8 @@ def test_scale_by_a_device_scalar(n):
 def test_gemm_accumulate_into_bf16_is_one_rounding(M, N, K, b_oc, monkeypatch):
     monkeypatch.setenv("ARIA_GEMM_FORCE", "3")     # the 256 x 256 kernels also at the toy sizes (their epilogues are what is under test)
     C.case_gemm_accumulate_exact(DEV, M, N, K, b_oc)
+
+
+@pytest.mark.parametrize("M,N,K,a_oc,b_oc", [(512, 512, 2048, False, False), (300, 520, 1536, False, True), (7680, 2560, 16384, True, True), (2560, 3328, 16384, True, True), (16384, 2560, 7680, False, True)])
+def test_gemm_split_k_slabs_in_accumulator_order(M, N, K, a_oc, b_oc):
+    C.case_gemm_split_k_slabs(DEV, M, N, K, a_oc, b_oc)
