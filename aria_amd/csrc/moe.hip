@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void permute_rows_kernel(const bf16_t* x, cons
 // same arithmetic in the same order as unpermute_kernel -- bit-identical)
 template <int NC, int K>
 __global__ __launch_bounds__(256) void unpermute_rows_kernel(const bf16_t* eo, const int32_t* inv, const bf16_t* scores, const bf16_t* add,
-                                                             bf16_t* out, int T) {
+                                                             const bf16_t* res, bf16_t* out, int T) {
     const int l = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -342,6 +342,11 @@ __global__ __launch_bounds__(256) void unpermute_rows_kernel(const bf16_t* eo, c
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = pack2bf(acc[2 * q], acc[2 * q + 1]);
+            }
+            if (res) {   // r05b: the decoder layer's residual add `h + moe(h)` (moe_lm.py:617-627 through LlamaDecoderLayer) as a second rounding step
+                const u32x4 rv = ld16(res + (long long)t * D + c * 8);   // here instead of a launch of its own: bf16(h + bf16(moe)), as add_kernel gives
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = pack2bf(bflo(rv[q]) + bflo(o[q]), bfhi(rv[q]) + bfhi(o[q]));
             }
             st16(out + (long long)t * D + c * 8, o);
         }
@@ -702,15 +707,23 @@ int aria_moe_permute(const void* x, const int32_t* sorted_src, void* permuted, i
 
 int aria_moe_unpermute(const void* expert_out, const int32_t* inv, const void* scores, const void* add, void* out, int64_t T,
                        int64_t D, int64_t k, void* stream) {
+    return aria_moe_unpermute_res(expert_out, inv, scores, add, nullptr, out, T, D, k, stream);
+}
+
+int aria_moe_unpermute_res(const void* expert_out, const int32_t* inv, const void* scores, const void* add, const void* residual, void* out,
+                           int64_t T, int64_t D, int64_t k, void* stream) {
     if (!expert_out || !inv || !out || T < 0 || D <= 0 || k <= 0) return ARIA_ERR_INVALID;
     if (D & 7) return ARIA_ERR_ALIGN;
     if (k > 8) return ARIA_ERR_UNSUPPORTED;
+    const bool rows_form = ((D == 2560 && k == 6) || (D == 512 && k == 2)) && !generic_dispatch_kernels();
+    if (residual && !rows_form) return ARIA_ERR_UNSUPPORTED;   // (the generic kernel has no residual step: aria_moe_unpermute + aria_add_bf16)
     if (T == 0) return ARIA_OK;
     const bf16_t *eo = static_cast<const bf16_t*>(expert_out), *sc = static_cast<const bf16_t*>(scores), *ad = static_cast<const bf16_t*>(add);
+    const bf16_t* rs = static_cast<const bf16_t*>(residual);
     if (D == 2560 && k == 6 && !generic_dispatch_kernels())   // Aria's width and top-k: compile-time row width, everything in flight together
-        ARIA_LAUNCH((unpermute_rows_kernel<5, 6>), dim3(grid_for_waves(T)), dim3(256), 0, stream, eo, inv, sc, ad, static_cast<bf16_t*>(out), int(T));
+        ARIA_LAUNCH((unpermute_rows_kernel<5, 6>), dim3(grid_for_waves(T)), dim3(256), 0, stream, eo, inv, sc, ad, rs, static_cast<bf16_t*>(out), int(T));
     else if (D == 512 && k == 2 && !generic_dispatch_kernels())   // (the same template at a width the CPU suite runs)
-        ARIA_LAUNCH((unpermute_rows_kernel<1, 2>), dim3(grid_for_waves(T)), dim3(256), 0, stream, eo, inv, sc, ad, static_cast<bf16_t*>(out), int(T));
+        ARIA_LAUNCH((unpermute_rows_kernel<1, 2>), dim3(grid_for_waves(T)), dim3(256), 0, stream, eo, inv, sc, ad, rs, static_cast<bf16_t*>(out), int(T));
     else
         ARIA_LAUNCH((unpermute_kernel<8>), dim3(grid_for_waves(T)), dim3(256), 0, stream, eo, inv, sc, ad, static_cast<bf16_t*>(out), int(T), int(D),
                     int(k));

@@ -95,7 +95,7 @@ def fused_weight(*ws: torch.Tensor) -> torch.Tensor:
     return v if v is not None else torch.cat([w.detach() for w in ws], dim=0)
 
 
-def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save=True):
+def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save=True, residual=None):
     """MoELayer.forward on x [T,D] -> (out [T,D], ctx).  ``save``: True = everything the backward needs; False = nothing; "lean" = everything
     EXCEPT the four expert-row tensors (perm, h1, act, eo: 24 of the layer's 36 KB per token) -- ``moe_rematerialize`` rebuilds those in
     the backward from what is kept (selective recompute: the routed experts only, 60 % of the layer's forward GEMM flops)."""
@@ -134,7 +134,8 @@ def moe_fwd(x, router_w, fc1, fc2, gate_w, up_w, down_w, cfg: MoEConfig, save=Tr
         ops.gemm(x, wgu, out=gu)
         sact = ops.swiglu(gu)
     sh = ops.gemm(sact, down_w)
-    out = ops.moe_unpermute(eo, inv, scores, k, add=sh)              # token_unpermutation :336-365 + `output += shared` :576
+    # token_unpermutation :336-365 + `output += shared` :576 (+ the decoder layer's residual add when the caller hands its stream in: r05b)
+    out = ops.moe_unpermute(eo, inv, scores, k, add=sh, residual=residual)
     ctx = None
     if save:
         ctx = dict(x=x, logits=logits, scores=scores, idx=idx, counts=counts, offsets=offsets, inv=inv, sorted_src=sorted_src, rows=rows,
@@ -326,8 +327,7 @@ def decoder_layer_fwd(x, p: dict, cos, sin, B: int, S: int, acfg: AttnConfig, mc
     xn, _, rstd1 = ops.rmsnorm(x, p["ln1"], eps, want_rstd=full)
     a, actx = attn_block_fwd(xn, p["wq"], p["wk"], p["wv"], p["wo"], cos, sin, B, S, acfg, kv_len, full, attn_cache, keep_attn)
     hn, h, rstd2 = ops.rmsnorm(a, p["ln2"], eps, residual=x, want_rstd=full)   # fused residual add
-    mo, mctx = moe_fwd(hn, p["router"], p["fc1"], p["fc2"], p["gate"], p["up"], p["down"], mcfg, save)
-    out = ops.add(h, mo)
+    out, mctx = moe_fwd(hn, p["router"], p["fc1"], p["fc2"], p["gate"], p["up"], p["down"], mcfg, save, residual=h)   # h + MoE(hn), one launch less
     ctx = dict(x=x, h=h, rstd1=rstd1, rstd2=rstd2, actx=actx, mctx=mctx, eps=eps) if full else actx
     return out, ctx
 

@@ -72,6 +72,7 @@ SIGNATURES = {
     "aria_moe_sort": [P, P, P, P, P, P, I64, I64, I64, P],
     "aria_moe_permute": [P, P, P, I64, I64, I64, I64, P],
     "aria_moe_unpermute": [P, P, P, P, P, I64, I64, I64, P],
+    "aria_moe_unpermute_res": [P, P, P, P, P, P, I64, I64, I64, P],
     "aria_moe_unpermute_bwd": [P, P, P, P, P, P, I64, I64, I64, P],
     "aria_moe_route_bwd": [P, P, P, P, P, P, I64, I64, I64, F32, F32, F32, P],
     "aria_embedding_bwd": [P, P, P, I64, I64, P],

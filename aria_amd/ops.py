@@ -622,7 +622,7 @@ def moe_permute(x: torch.Tensor, sorted_src: torch.Tensor, k: int) -> torch.Tens
 
 
 def moe_unpermute(expert_out: torch.Tensor, inv: torch.Tensor, scores: Optional[torch.Tensor], k: int,
-                  add: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  add: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(expert_out, name="expert_out"), _chk(inv, torch.int32, "inv")
     if not expert_out.is_contiguous():
         raise ValueError("moe_unpermute: expert_out must be contiguous")
@@ -635,6 +635,17 @@ def moe_unpermute(expert_out: torch.Tensor, inv: torch.Tensor, scores: Optional[
         _chk(add, name="add")
         assert add.is_contiguous() and add.shape == (T, D)
     out = torch.empty((T, D), dtype=bf16, device=expert_out.device)
+    if residual is not None:   # the decoder layer's `h + moe(h)` as the kernel's last step (same two roundings as unpermute + add)
+        _chk(residual, name="residual")
+        assert residual.is_contiguous() and residual.shape == (T, D)
+        lib = hip.get_lib()
+        rc = lib.cdll.aria_moe_unpermute_res(_p(expert_out), _p(inv), _p(scores), _p(add), _p(residual), _p(out), T, D, k, _stream(expert_out))
+        if rc == 3:   # ARIA_ERR_UNSUPPORTED: the generic-width kernel has no residual step
+            lib.call("aria_moe_unpermute", _p(expert_out), _p(inv), _p(scores), _p(add), _p(out), T, D, k, _stream(expert_out))
+            return globals()["add"](residual, out)
+        if rc != 0:
+            raise hip.AriaHipError(f"aria_moe_unpermute_res failed: {hip.ERRORS.get(rc, rc)}")
+        return out
     hip.get_lib().call("aria_moe_unpermute", _p(expert_out), _p(inv), _p(scores), _p(add), _p(out), T, D, k, _stream(expert_out))
     return out
 

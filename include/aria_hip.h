@@ -231,6 +231,12 @@ int aria_moe_permute(const void* x, const int32_t* sorted_src, void* permuted, i
  * scores == NULL -> plain sum (used as the backward of the permute gather). */
 int aria_moe_unpermute(const void* expert_out, const int32_t* inv, const void* scores, const void* add, void* out,
                        int64_t T, int64_t D, int64_t k, void* stream);
+/* The same followed by the decoder layer's residual add (`hidden = residual + moe(hidden)`, LlamaDecoderLayer.forward via moe_lm.py:617-627):
+ * out = bf16(residual + bf16(unpermute (+ add))) -- the rounding sequence of aria_moe_unpermute + aria_add_bf16, one launch less.
+ * residual [T, D] bf16 or NULL (= aria_moe_unpermute).  Compile-time row widths only (D = 2560 / k = 6, D = 512 / k = 2): ARIA_ERR_UNSUPPORTED
+ * otherwise. */
+int aria_moe_unpermute_res(const void* expert_out, const int32_t* inv, const void* scores, const void* add, const void* residual,
+                           void* out, int64_t T, int64_t D, int64_t k, void* stream);
 
 /* backward of token_unpermutation: d_expert_out[inv[t,j]] = bf16(dout[t] * scores[t,j]);
  * dscores[t,j] = <expert_out[inv[t,j]], dout[t]> (fp32 reduce, stored bf16). */

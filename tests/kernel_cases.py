@@ -114,6 +114,25 @@ def case_gemm_split_k_slabs(dev, M, N, K, a_oc, b_oc):
     assert torch.equal(acc.cpu(), (ops.gemm(a, b, a_oc=a_oc, b_oc=b_oc, bias=bias.to(dev), out_dtype=torch.float32).cpu() + old.float()).to(bf16))
 
 
+def case_unpermute_with_residual(dev, T, D, k, E=8):
+    """r05b: the decoder layer's residual add as the last step of the un-permute launch (aria_moe_unpermute_res) == aria_moe_unpermute +
+    aria_add_bf16, bit for bit (bf16(h + bf16(combine + shared))), with and without scores / shared rows; widths without a compile-time kernel
+    take the two launches inside ``ops.moe_unpermute``."""
+    from aria_amd import ops
+
+    g = torch.Generator().manual_seed(T + D)
+    idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(T)]).to(torch.int32).to(dev)
+    counts = torch.bincount(idx.flatten().cpu().long(), minlength=E).to(torch.int32).to(dev)
+    _, _, inv = ops.moe_sort(idx, counts)
+    eo = rnd(T * k, D, seed=1).to(dev)
+    scores = torch.rand(T, k, generator=g).to(bf16).to(dev)
+    sh, h = rnd(T, D, seed=2).to(dev), rnd(T, D, seed=3).to(dev)
+    for sc, ad in ((scores, sh), (scores, None), (None, None)):
+        want = ops.add(h, ops.moe_unpermute(eo, inv, sc, k, add=ad))
+        got = ops.moe_unpermute(eo, inv, sc, k, add=ad, residual=h)
+        assert torch.equal(got.cpu(), want.cpu()), float((got.float() - want.float()).abs().max())
+
+
 def case_gemm_fused_gelu(dev, M, N, K):
     """fc1 + gelu_pytorch_tanh in the GEMM epilogue == the GEMM followed by the stand-alone GELU kernel, bit for bit (the activation
     sees bf16(acc + bias) in both), also through accumulate (x += gelu(...) is never used, but the order act -> accumulate is ABI)."""

@@ -314,3 +314,8 @@ def test_gemm_accumulate_into_bf16_is_one_rounding(M, N, K, b_oc, monkeypatch):
 @pytest.mark.parametrize("M,N,K,a_oc,b_oc", [(512, 512, 2048, False, False), (300, 520, 1536, False, True), (256, 264, 1024, True, True)])
 def test_gemm_split_k_slabs_in_accumulator_order(M, N, K, a_oc, b_oc):
     C.case_gemm_split_k_slabs(DEV, M, N, K, a_oc, b_oc)
+
+
+@pytest.mark.parametrize("T,D,k", [(70, 512, 2), (33, 128, 3)])
+def test_unpermute_with_the_residual_add_as_its_last_step(T, D, k):
+    C.case_unpermute_with_residual(DEV, T, D, k, E=8 if k < 6 else 64)
