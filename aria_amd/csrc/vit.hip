@@ -4,6 +4,7 @@
 // inherited by aria/model/vision_encoder.py:58-152; aria/model/projector.py:26-189.
 #include "aria_device.h"
 #include "aria_hip.h"
+#include <cstdlib>
 
 namespace {
 using namespace ad;
@@ -62,6 +63,80 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* x, con
                     o[q] = pack2bf((v[i][2 * q] - mu) * r * bflo(wv[q]) + bflo(bv[q]),
                                    (v[i][2 * q + 1] - mu) * r * bfhi(wv[q]) + bfhi(bv[q]));
                 st16(y + (long long)t * D + c * 8, o);
+            }
+        }
+    }
+}
+
+// The same with a compile-time row width (NCPL 16-byte chunks per lane) and TWO rows in flight per wave (r05b: the ViT's 54 LayerNorms per step
+// ran at 3.9 TB/s -- a wave fetched a row, reduced it twice and stored it before it asked for the next one; here the second row's loads
+// are requested before the first row's reductions start, and only the chunks the width has are held in registers).  Same arithmetic per row,
+// same order: bit-identical to layernorm_fwd_kernel.
+template <int NCPL>
+__global__ __launch_bounds__(256) void layernorm_fwd2_kernel(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, float* mean,
+                                                             float* rstd, int T, int D, float eps) {
+    const int l = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nch = D >> 3;
+    for (int t0 = wave; t0 < T; t0 += 2 * nwaves) {
+        u32x4 raw[2][NCPL];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int t = min(t0 + r * nwaves, T - 1);   // (a second row past the end: the last row again, computed, not stored)
+#pragma unroll
+            for (int i = 0; i < NCPL; ++i) {
+                const int c = l + 64 * i;
+                raw[r][i] = c < nch ? ld16(x + (long long)t * D + c * 8) : zero16();
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int t = t0 + r * nwaves;
+            float v[NCPL][8];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCPL; ++i) {
+                const int c = l + 64 * i;
+                if (c < nch) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[i][2 * q] = bflo(raw[r][i][q]);
+                        v[i][2 * q + 1] = bfhi(raw[r][i][q]);
+                        s += v[i][2 * q] + v[i][2 * q + 1];
+                    }
+                }
+            }
+            const float mu = wave_sum_bcast(s) / float(D);
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCPL; ++i) {
+                const int c = l + 64 * i;
+                if (c < nch)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float d = v[i][q] - mu;
+                        ss += d * d;
+                    }
+            }
+            const float rs = rsqrtf(wave_sum_bcast(ss) / float(D) + eps);
+            if (t >= T) continue;   // wave-uniform
+            if (l == 0) {
+                if (mean) mean[t] = mu;
+                if (rstd) rstd[t] = rs;
+            }
+#pragma unroll
+            for (int i = 0; i < NCPL; ++i) {
+                const int c = l + 64 * i;
+                if (c < nch) {
+                    const u32x4 wv = ld16(w + c * 8), bv = ld16(b + c * 8);
+                    u32x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        o[q] = pack2bf((v[i][2 * q] - mu) * rs * bflo(wv[q]) + bflo(bv[q]),
+                                       (v[i][2 * q + 1] - mu) * rs * bfhi(wv[q]) + bfhi(bv[q]));
+                    st16(y + (long long)t * D + c * 8, o);
+                }
             }
         }
     }
@@ -289,8 +364,13 @@ int aria_layernorm_fwd(const void* x, const void* w, const void* b, void* y, flo
     if (D & 7) return ARIA_ERR_ALIGN;
     if (D > 64 * 8 * MAX_CPL) return ARIA_ERR_UNSUPPORTED;
     if (T == 0) return ARIA_OK;
-    ARIA_LAUNCH(layernorm_fwd_kernel, dim3(grid1d(T, 4, 2048)), dim3(256), 0, stream, static_cast<const bf16_t*>(x),
-                static_cast<const bf16_t*>(w), static_cast<const bf16_t*>(b), static_cast<bf16_t*>(y), mean, rstd, int(T), int(D), eps);
+    const char* v1 = std::getenv("ARIA_LAYERNORM_V1");   // "1": the one-row-at-a-time kernel (A/B, bit-identity test)
+    if (D <= 64 * 8 * 3 && !(v1 && v1[0] == '1'))          // the ViT's 1152 (and the CPU suite's toy widths): two rows in flight per wave
+        ARIA_LAUNCH((layernorm_fwd2_kernel<3>), dim3(grid1d((T + 1) / 2, 4, 2048)), dim3(256), 0, stream, static_cast<const bf16_t*>(x),
+                    static_cast<const bf16_t*>(w), static_cast<const bf16_t*>(b), static_cast<bf16_t*>(y), mean, rstd, int(T), int(D), eps);
+    else
+        ARIA_LAUNCH(layernorm_fwd_kernel, dim3(grid1d(T, 4, 2048)), dim3(256), 0, stream, static_cast<const bf16_t*>(x),
+                    static_cast<const bf16_t*>(w), static_cast<const bf16_t*>(b), static_cast<bf16_t*>(y), mean, rstd, int(T), int(D), eps);
     return aria_check_launch();
 }
 

@@ -133,6 +133,30 @@ def case_unpermute_with_residual(dev, T, D, k, E=8):
         assert torch.equal(got.cpu(), want.cpu()), float((got.float() - want.float()).abs().max())
 
 
+def case_layernorm_two_rows_in_flight(dev, T, D):
+    """r05b: ``layernorm_fwd2_kernel`` (two rows in flight per wave, compile-time row width; the frozen ViT's LayerNorms) gives the bits of the
+    one-row-at-a-time kernel (ARIA_LAYERNORM_V1=1): y, mean, rstd -- odd row counts and rows past the grid's last pair included."""
+    import os
+
+    from aria_amd import ops
+
+    x = rnd(T, D, seed=T).to(dev)
+    w, b = rnd(D, seed=1).to(dev), rnd(D, seed=2).to(dev)
+    prev = os.environ.get("ARIA_LAYERNORM_V1")
+    try:
+        os.environ["ARIA_LAYERNORM_V1"] = "1"
+        want = ops.layernorm(x, w, b, 1e-6)
+        os.environ.pop("ARIA_LAYERNORM_V1")
+        got = ops.layernorm(x, w, b, 1e-6)
+    finally:
+        if prev is None:
+            os.environ.pop("ARIA_LAYERNORM_V1", None)
+        else:
+            os.environ["ARIA_LAYERNORM_V1"] = prev
+    for g, wnt in zip(got, want):
+        assert torch.equal(g.cpu(), wnt.cpu())
+
+
 def case_gemm_fused_gelu(dev, M, N, K):
     """fc1 + gelu_pytorch_tanh in the GEMM epilogue == the GEMM followed by the stand-alone GELU kernel, bit for bit (the activation
     sees bf16(acc + bias) in both), also through accumulate (x += gelu(...) is never used, but the order act -> accumulate is ABI)."""

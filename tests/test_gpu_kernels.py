@@ -292,3 +292,8 @@ def test_gemm_split_k_slabs_in_accumulator_order(M, N, K, a_oc, b_oc):
 @pytest.mark.parametrize("T,D,k", [(16384, 2560, 6), (70, 512, 2), (33, 128, 3)])
 def test_unpermute_with_the_residual_add_as_its_last_step(T, D, k):
     C.case_unpermute_with_residual(DEV, T, D, k, E=8 if k < 6 else 64)
+
+
+@pytest.mark.parametrize("T,D", [(78400, 1152), (37, 1152), (4901, 1152), (300, 64)])
+def test_layernorm_with_two_rows_in_flight_gives_the_same_bits(T, D):
+    C.case_layernorm_two_rows_in_flight(DEV, T, D)
