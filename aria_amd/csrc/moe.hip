@@ -14,74 +14,75 @@ constexpr int kMaxPerLane = 4;  // E <= 256
 // TopKRouter.forward (moe_lm.py:190-201, 243-293): logits = x W^T ([T, D] x [E, D]^T, E = 32 NB), then per token top-k with ties to the
 // lowest expert id, softmax over the selected logits in fp32, scores cast to bf16, and the tokens-per-expert histogram -- the logits GEMM
 // (a 75 %-empty 256-wide tile of the general kernel), a memset and route_kernel as ONE launch.  One wave = 32 tokens:
-//   * logits on the matrix pipe straight from global memory: per 16 reduction indices ONE 16-byte load per lane is the A fragment (32 token
-//     rows x 32 bytes) and one per 32 experts the B fragment (the 320 KB of W stay in the L2s); four 64-index chunks of x in flight per wave
-//     (the launch is a single pass over x: HBM-bound), W one chunk ahead.  Accumulation order = the general kernels' (k ascending in blocks
-//     of 16 on v_mfma_f32_32x32x16_bf16): the bf16 logits are bit-identical to aria_gemm_bf16's, so is everything derived from them.
+//   * logits on the matrix pipe, 32 tokens x 32 experts per wave; accumulation order = the general kernels' (k ascending in blocks of 16 on
+//     v_mfma_f32_32x32x16_bf16): the bf16 logits are bit-identical to aria_gemm_bf16's, so is everything derived from them;
 //   * the rounded logits go to the wave's LDS tile [32 tokens][E] and from there to HBM (the backward wants them) in 16-byte pieces;
 //   * routing per token by route_one_token (aria_device.h: the decode engine's; lane = expert) on the LDS row; histogram per wave in LDS,
 //     one global atomic per (wave, expert with a count).
-template <int NB, int NCH = 0>
+// One wave per 32-expert block (NB waves per workgroup, the block's 32 tokens' routing dealt to them), operands STAGED THROUGH THE LDS.  An MFMA
+// fragment is 16 bytes of 32 different rows: read straight from global memory (round 5's first form) that is 32 cache lines per wave-instruction
+// through the vector L1 -- 102 us per launch with one wave per token block, 74 us with two and three chunks of prefetch, against ~20 us of
+// traffic.  Here a wave-instruction is an
+// LDS-DMA piece of 8 whole 128-byte row chunks (global_load_lds_dwordx4: lane -> row 8 j + (l >> 3), 16-byte piece (l & 7) ^ (row & 7) -- the XOR
+// spreads a fragment read's 8 rows over the banks), four stages deep with counted waits, and the fragments come back by ds_read_b128.  Per chunk of
+// 64 reduction indices: the block's x tile (32 rows, shared by its waves: each wave brings half of it) + one 32-row weight tile per wave.
+// 54.9 us at 16 384 x 2560 -> 64 (same box: the direct form 73.9, gemm + route 84.2).  Every logit is ONE accumulator run over the whole reduction
+// in gemm's order: bit-identical to gemm + route.
+template <int NB>
 __global__ __launch_bounds__(64 * NB) void router_fused_kernel(const bf16_t* x, const bf16_t* w, bf16_t* logits, bf16_t* scores, int32_t* indices,
-                                                               int32_t* counts, int T, int D, int k, long long ldx) {
-    // r05b: ONE WAVE PER 32-EXPERT BLOCK (NB waves per workgroup; was one wave with NB accumulators): 16 384 tokens are only 512 token blocks
-    // on 1024 SIMDs, and a lone wave per SIMD is latency-bound on its operand loads (102 us per launch against ~20 us of traffic) -- twice the
-    // waves, half the weight loads and MFMAs per wave, the routing of the block's 32 tokens dealt to the waves.  Every logit is still ONE
-    // accumulator run over the whole reduction in gemm's order: bit-identical to gemm + route as before.
-    // What bounds the launch now (74 us for 16 384 x 2560 -> 64; 84 MB of tokens would stream in ~20): an MFMA operand fragment is 16 bytes
-    // of 32 DIFFERENT rows per wave-instruction, i.e. 32 cache lines per request through the vector L1 (1280 such requests per CU at ~120
-    // cycles each).  Coalesced staging through the LDS (8 whole lines per request, fragments read back with a row swizzle -- gemm3's loader)
-    // is the next step; not built: ~1 ms per step.
-    constexpr int E = 32 * NB, CH = 4, DEPTH = 4;
+                                                                   int32_t* counts, int T, int D, int k, long long ldx) {
+    constexpr int E = 32 * NB, CH = 4, ST = 4, XT = 4096, WT = 4096, STAGE = XT + NB * WT;
+    constexpr int XP = 4 / NB;              // x pieces per wave and chunk (the tile's four 8-row pieces dealt to the waves)
+    constexpr int PER = XP + 4;             // DMA pieces per wave and chunk
+    ARIA_SMEM_STATIC char stage[ST * STAGE];
     ARIA_SMEM_STATIC bf16_t tile[32 * E];
     ARIA_SMEM_STATIC int hist[64];
     const int l = threadIdx.x & 63, lr = l & 31, kh = l >> 5, b = first_lane(int(threadIdx.x) >> 6);
     const int t0 = blockIdx.x * 32;
     if (b == 0) hist[l] = 0;
-    const bf16_t* xp = x + (long long)min(t0 + lr, T - 1) * ldx + 8 * kh;   // (rows past T: clamped, computed, never stored)
-    const bf16_t* wp = w + (long long)(32 * b + lr) * D + 8 * kh;
+    const int nch = D / 64;
+    // this lane's part of a piece: row (l >> 3) of the piece's 8, source piece (l & 7) ^ (row & 7) (row & 7 == l >> 3)
+    const int prow = l >> 3, psrc = ((l & 7) ^ prow) * 8;
+    const bf16_t* xsrc[XP];
+#pragma unroll
+    for (int j = 0; j < XP; ++j) xsrc[j] = x + (long long)min(t0 + 8 * (b * XP + j) + prow, T - 1) * ldx + psrc;   // (rows past T: clamped, never stored)
+    const bf16_t* wsrc = w + (long long)(32 * b + prow) * D + psrc;
+    auto issue = [&](int c) __attribute__((always_inline)) {   // chunk c -> stage c % ST (past the end: the last chunk again, into a free stage)
+        const int cc = min(c, nch - 1);
+        char* st = stage + (c % ST) * STAGE;
+#pragma unroll
+        for (int j = 0; j < XP; ++j) glds16_raw(xsrc[j] + cc * 64, st + (b * XP + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16_raw(wsrc + (long long)(8 * j) * D + cc * 64, st + XT + b * WT + j * 1024);
+    };
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    s16x8 xa[DEPTH][CH], wb[DEPTH][CH];   // (both operands three chunks ahead: the weights are L2-resident, but one chunk ahead was a dependent
-                                          //  L2 round trip per step -- 40 of them in a row)
-    // NCH > 0 (the launcher: Aria's D = 2560 -> 40): the reduction loop fully unrolled -- across a loop's back-edge the compiler's wait
-    // counters start from "everything older must have landed", which drained the two chunks in flight behind the one being consumed once
-    // per iteration; straight-line code gets exact counted waits (three chunks ahead all the way)
-    const int nch = NCH > 0 ? NCH : D / 64;   // (a multiple of DEPTH: the launcher checks D % 256 == 0)
-#define RF_LOADX(slot, c)                                                                       \
-    _Pragma("unroll") for (int i = 0; i < CH; ++i) xa[slot][i] = *reinterpret_cast<const s16x8*>(xp + (c) * 64 + 16 * i)
-#define RF_LOADW(slot, c)                                                                       \
-    _Pragma("unroll") for (int i = 0; i < CH; ++i) wb[slot][i] = *reinterpret_cast<const s16x8*>(wp + (c) * 64 + 16 * i)
-    RF_LOADX(0, 0);
-    RF_LOADW(0, 0);
-    RF_LOADX(1, 1);
-    RF_LOADW(1, 1);
-    RF_LOADX(2, 2);
-    RF_LOADW(2, 2);
-#pragma unroll NCH > 0 ? NCH / DEPTH : 1
-    for (int c0 = 0; c0 < nch; c0 += DEPTH) {
 #pragma unroll
-        for (int s = 0; s < DEPTH; ++s) {
-            // (unconditional, the chunk index clamped: a branch around the loads made the compiler drain every load in flight -- vmcnt(0) -- at
-            // the join in front of the next MFMA group, once per four chunks; the last three steps re-read the last chunk into dead slots)
-            const int cn = min(c0 + s + DEPTH - 1, nch - 1);
-            RF_LOADX((s + DEPTH - 1) % DEPTH, cn);
-            RF_LOADW((s + DEPTH - 1) % DEPTH, cn);
-            sched_fence();   // (the scheduler otherwise sinks the requests to just in front of their use three steps later)
+    for (int c = 0; c < ST - 1; ++c) issue(c);
+    const int fo = lr * 128;   // fragment row offset; piece q of row lr sits in slot q ^ (lr & 7)
+    for (int c = 0; c < nch; ++c) {
+        wait_vm<(ST - 2) * PER>();   // this wave's pieces of chunk c have landed (the two newer chunks stay in flight)
+        sync();                      // ... and every other wave's; the readers of chunk c - 1 are done with its stage
+        issue(c + ST - 1);           // -> stage (c - 1) % ST
+        const char* st = stage + (c % ST) * STAGE;
+        s16x8 xa[CH], wb[CH];
 #pragma unroll
-            for (int i = 0; i < CH; ++i) acc = mfma32(xa[s][i], wb[s][i], acc);
-            sched_fence();
+        for (int i = 0; i < CH; ++i) {
+            const int slot = ((2 * i + kh) ^ (lr & 7)) * 16;
+            xa[i] = *reinterpret_cast<const s16x8*>(st + fo + slot);
+            wb[i] = *reinterpret_cast<const s16x8*>(st + XT + b * WT + fo + slot);
         }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) acc = mfma32(xa[i], wb[i], acc);
     }
-#undef RF_LOADX
-#undef RF_LOADW
+    wait_vm<0>();   // (the duplicate pieces of the last steps: nothing may still be writing the LDS when the block ends)
     // C layout of the 32 x 32 tile: register j of lane l = (token (j & 3) + 8 (j >> 2) + 4 (l >> 5), expert l & 31)
 #pragma unroll
     for (int j = 0; j < 16; ++j) tile[((j & 3) + 8 * (j >> 2) + 4 * kh) * E + 32 * b + lr] = f2bf(acc[j]);
     sync();
 #pragma unroll
-    for (int it = 0; it < (32 * E) / (64 * NB * 8); ++it) {   // the tile = rows t0 .. t0 + 31 of logits [T, E]: contiguous, 16 bytes per lane
+    for (int it = 0; it < (32 * E) / (64 * NB * 8); ++it) {
         const int ci = it * 64 * NB + int(threadIdx.x), tr = ci / (E / 8);
         if (t0 + tr < T) st16(logits + (long long)t0 * E + ci * 8, ld16(tile + ci * 8));
     }
@@ -656,10 +657,7 @@ int aria_moe_router_fused(const void* x, const void* w, void* logits, void* scor
 #endif
     if (T == 0) return ARIA_OK;
     const dim3 grid(unsigned((T + 31) / 32)), block(unsigned(2 * E));   // (one wave per 32-expert block)
-    if (E == 64 && D == 2560)
-        ARIA_LAUNCH((router_fused_kernel<2, 40>), grid, block, 0, stream, static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w),
-                    static_cast<bf16_t*>(logits), static_cast<bf16_t*>(scores), indices, counts, int(T), int(D), int(k), (long long)ldx);
-    else if (E == 64)
+    if (E == 64)
         ARIA_LAUNCH((router_fused_kernel<2>), grid, block, 0, stream, static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w),
                     static_cast<bf16_t*>(logits), static_cast<bf16_t*>(scores), indices, counts, int(T), int(D), int(k), (long long)ldx);
     else
