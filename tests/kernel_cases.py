@@ -972,7 +972,7 @@ def case_attention_bwd_rope(dev, B, S, H, causal, use_len, s_rope=None):
     ops.attention_bwd(q, k, v, o, do, lse, B, S, H, hd, hd ** -0.5, causal, kv_len=kl, dq=got[:, :D], dk=got[:, D:2 * D], dv=got[:, 2 * D:],
                       rope=(cos, sin))
     assert torch.equal(got.cpu(), ref.cpu()), float((got.float() - ref.float()).abs().max())
-    assert not torch.equal(got[:, :2 * D].cpu(), plain[:, :2 * D].cpu())       # (the rotation did happen)
+    assert S == 1 or not torch.equal(got[:, :2 * D].cpu(), plain[:, :2 * D].cpu())       # (the rotation did happen; position 0 alone is the identity)
     assert ops.attention_bwd_rope_fusable(hd, S, cos) and not ops.attention_bwd_rope_fusable(64, S, cos)
     with pytest.raises(Exception):
         ops.attention_bwd(q[:, :H * 64], k[:, :H * 64], v[:, :H * 64], o[:, :H * 64], do[:, :H * 64], lse, B, S, H, 64, 0.125, causal,

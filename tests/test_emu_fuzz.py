@@ -56,3 +56,29 @@ def test_fused_glu_launches_any_counts(counts, K64, I128, T, monkeypatch):
 @given(V=st.integers(1, 3000), kfrac=st.floats(0.0, 1.2), temp=st.sampled_from([1e-6, 0.5, 0.8, 1.0, 2.0]), seed=st.integers(0, 5))
 def test_sample_topk_any_vocabulary(V, kfrac, temp, seed):
     C.case_sample_topk(DEV, V, max(1, int(kfrac * V)) if kfrac <= 1.0 else None, temp, seed)
+
+
+@settings(max_examples=14, **COMMON)
+@given(M=st.integers(1, 600), N8=st.integers(1, 70), K64=st.integers(1, 3), b_oc=st.booleans())
+def test_gemm_accumulate_any_shape(M, N8, K64, b_oc, monkeypatch):
+    """round 5: `C += A B + bias` on a bf16 C through the complete-row epilogue (old tile staged through the LDS; ragged row AND column tiles,
+    single rows, a strided C): one rounding, == the fp32-output launch + an fp32 add."""
+    monkeypatch.setenv("ARIA_GEMM_FORCE", "3")
+    C.case_gemm_accumulate_exact(DEV, M, 8 * N8, 64 * K64, b_oc)
+
+
+@settings(max_examples=10, **COMMON)
+@given(B=st.integers(1, 2), S=st.integers(1, 330), H=st.integers(1, 2), causal=st.booleans(), use_len=st.booleans(), extra=st.integers(0, 40))
+def test_attention_backward_rope_any_shape(B, S, H, causal, use_len, extra):
+    """round 5: the inverse RoPE inside the attention backward == the backward + the in-place inverse pass, any length (ragged last blocks,
+    single tokens), tables longer than the sequence."""
+    C.case_attention_bwd_rope(DEV, B, S, H, causal, use_len, s_rope=S + extra)
+
+
+@settings(max_examples=10, **COMMON)
+@given(T=st.integers(1, 200), kD=st.sampled_from([(2, 512), (3, 128), (1, 64), (6, 2560)]))
+def test_unpermute_with_residual_any_rows(T, kD):
+    k, D = kD
+    if D == 2560 and T > 40:
+        T = 40   # (the emulator's patience)
+    C.case_unpermute_with_residual(DEV, T, D, k, E=8 if k < 6 else 64)
