@@ -82,3 +82,17 @@ def test_unpermute_with_residual_any_rows(T, kD):
     if D == 2560 and T > 40:
         T = 40   # (the emulator's patience)
     C.case_unpermute_with_residual(DEV, T, D, k, E=8 if k < 6 else 64)
+
+
+@settings(max_examples=14, **COMMON)
+@given(T=st.integers(1, 150), D=st.sampled_from([256, 512, 1024, 2560]), E=st.sampled_from([32, 64]), k=st.integers(1, 8))
+def test_router_fused_any_shape(T, D, E, k):
+    """round 5: the one-launch router with its operands staged through the LDS == gemm + route, bit for bit, on ragged token blocks and every
+    supported width / top-k."""
+    C.case_router_fused(DEV, T if D < 2560 else min(T, 40), D, E, k)
+
+
+@settings(max_examples=12, **COMMON)
+@given(T=st.integers(1, 700), D8=st.integers(1, 320))
+def test_layernorm_any_shape(T, D8):
+    C.case_layernorm_two_rows_in_flight(DEV, T, 8 * D8)
