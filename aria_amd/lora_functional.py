@@ -181,8 +181,7 @@ def decoder_layer_lora_fwd(x, p: dict, L: Dict[str, LoraSite], cos, sin, B: int,
         gu, c_gu = dense_lora_fwd(hn, wgu, [L.get("gate"), L.get("up")], [I2, I2], training, seeds)
         sact = ops.swiglu(gu)
     sh, c_down = dense_lora_fwd(sact, p["down"], [L.get("down")], [p["down"].shape[0]], training, seeds)
-    mo = ops.moe_unpermute(eo, inv, scores, k, add=sh)
-    out = ops.add(h, mo)
+    out = ops.moe_unpermute(eo, inv, scores, k, add=sh, residual=h)   # h + MoE(hn): the residual add is the un-permute launch's last step
     ctx = dict(x=x, h=h, hn=hn, rstd1=rstd1, rstd2=rstd2, xn=xn, o=o, actx=actx, wqkv=wqkv, wgu=wgu, B=B, S=S, acfg=acfg, mcfg=mcfg, kv_len=kv_len,
                logits=logits, scores=scores, idx=idx, counts=counts, offsets=offsets, inv=inv, perm=perm, h1=h1, act=act, eo=eo, gu=gu, sact=sact,
                c_qkv=c_qkv, c_o=c_o, c_fc1=c_fc1, c_fc2=c_fc2, c_gu=c_gu, c_down=c_down)
