@@ -154,3 +154,18 @@ def test_attention_backward_tiles_arrive_by_lds_dma_without_compiler_drains(kern
     last_mfma = max(i for i, (s, _) in enumerate(c) if s.startswith("v_mfma"))
     own = [s for s, a in c[dma[0][0]:last_mfma] if s.startswith("s_waitcnt") and "vmcnt(0)" in s and not a]
     assert own == [], f"compiler-inserted drains between the DMA issue and the last MFMA of the tile: {own}"
+
+
+def test_router_reduction_loop_keeps_its_dma_pieces_in_flight():
+    """Round 5: router_fused_kernel stages its operands by LDS-DMA, four stages deep: per 64-index chunk a wave issues 6 pieces (2 of the x tile + 4 of
+    its weight tile) as its own instructions, waits with a COUNTED vmcnt (two newer chunks stay in flight), reads 8 fragments by ds_read_b128 and
+    issues 4 MFMAs -- and the compiler must not put a drain (vmcnt(0)) into the loop."""
+    body = kernel_body(isa("moe.hip"), "19router_fused_kernelILi2E")
+    main = max((ls for _, ls in loops(body)), key=lambda ls: sum(1 for s, _ in code(ls) if s.startswith("v_mfma")))
+    c = [s for s, _ in code(main)]
+    assert sum(1 for s in c if s.startswith("v_mfma")) == 4
+    assert sum(1 for s in c if s.startswith("global_load_lds_dwordx4")) == 6
+    assert sum(1 for s in c if s.startswith("ds_read_b128")) == 8
+    waits = [s for s in c if s.startswith("s_waitcnt") and "vmcnt" in s]
+    assert waits and all("vmcnt(12)" in s for s in waits), waits
+    assert not [s for s in c if s.startswith("global_load_dwordx4")], "an operand fragment is read straight from global memory again"
