@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--gen-image", type=int, default=1, help="debug only (config #2: one 980px image)")
     ap.add_argument("--prefill-seq", type=int, default=53248, help="debug only (config #4: 32 x 128 frame tokens + 49 152 text tokens)")
     ap.add_argument("--prefill-frames", type=int, default=32, help="debug only (config #4: 32 frames at 490px)")
+    ap.add_argument("--sub-record-repeats", type=int, default=0, help="debug only (the CPU dry run): > 0 = that many timed repetitions in the "
+                    "generate / LoRA / fusions-A/B sub-records instead of their protocol's 5 / 3 / 4")
     ap.add_argument("--no-fusions-ab", action="store_true", help="skip the `step_fusions_ab` sub-record (N = 1 only: 4 + 4 extra steps, the round-5 "
                     "launch fusions switched off / on alternately inside this process -- box variance cancels)")
     ap.add_argument("--no-lora-record", action="store_true", help="skip the `lora_config` sub-record (N = 1 only: recipes/config_lora.yaml's adapter set "
@@ -738,13 +740,15 @@ def main():
             cfg.gradient_checkpointing = bool(args.recompute)
         try:
             if world == 1 and not args.long and not args.ep and not args.recompute and not args.no_fusions_ab:
-                res["step_fusions_ab"] = step_fusions_ab(step)
+                res["step_fusions_ab"] = step_fusions_ab(step, pairs=args.sub_record_repeats or 4)
+                if not full_depth or args.sub_record_repeats:
+                    res["step_fusions_ab"]["INVALID"] = "debug run (reduced depth / repetitions)"
         except Exception as ex:  # noqa: BLE001
             res["step_fusions_ab"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
         try:
             if world == 1 and not args.long and not args.ep and not args.recompute and not args.no_lora_record:
-                res["lora_config"] = lora_config_record(model, cfg, step, ops, B, S)
-                if not full_depth:
+                res["lora_config"] = lora_config_record(model, cfg, step, ops, B, S, steps=args.sub_record_repeats or 3)
+                if not full_depth or args.sub_record_repeats:
                     res["lora_config"]["INVALID"] = "debug run (reduced depth)"
         except Exception as ex:  # noqa: BLE001
             res["lora_record_error"] = f"{type(ex).__name__}: {ex}"[:400]
@@ -760,10 +764,12 @@ def main():
                 twin = model.to_gptfast()
                 torch.cuda.synchronize()
                 t_conv = time.perf_counter() - t0
-                debug = not full_depth or args.gen_new != 200 or args.gen_image != 1 or args.prefill_seq != 53248 or args.prefill_frames != 32
+                debug = not full_depth or args.gen_new != 200 or args.gen_image != 1 or args.prefill_seq != 53248 or args.prefill_frames != 32 or args.sub_record_repeats
                 img_px = model.config.vision_config.image_size
+                rep = dict(runs=args.sub_record_repeats, warmup=1) if args.sub_record_repeats else {}
                 res["generate_config2"] = generate_config2_record(twin, cfg, new_tokens=args.gen_new, n_img=args.gen_image, img_px=img_px,
-                                                                  qtok=acfg.projector_patch_to_query_dict.get((img_px // 14) ** 2, QTOK), img_token=IMG_TOKEN)
+                                                                  qtok=acfg.projector_patch_to_query_dict.get((img_px // 14) ** 2, QTOK), img_token=IMG_TOKEN,
+                                                                  **rep)
                 res["generate_config2"]["hf_to_gptfast_s"] = round(t_conv, 2)
                 res["prefill_config4"] = prefill_config4_record(twin, cfg, S=args.prefill_seq, frames=args.prefill_frames, img_token=IMG_TOKEN)
                 if debug:

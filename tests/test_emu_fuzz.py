@@ -58,8 +58,8 @@ def test_sample_topk_any_vocabulary(V, kfrac, temp, seed):
     C.case_sample_topk(DEV, V, max(1, int(kfrac * V)) if kfrac <= 1.0 else None, temp, seed)
 
 
-@settings(max_examples=14, **COMMON)
-@given(M=st.integers(1, 600), N8=st.integers(1, 70), K64=st.integers(1, 3), b_oc=st.booleans())
+@settings(max_examples=8, **COMMON)
+@given(M=st.integers(1, 600), N8=st.integers(1, 70), K64=st.integers(1, 2), b_oc=st.booleans())
 def test_gemm_accumulate_any_shape(M, N8, K64, b_oc, monkeypatch):
     """round 5: `C += A B + bias` on a bf16 C through the complete-row epilogue (old tile staged through the LDS; ragged row AND column tiles,
     single rows, a strided C): one rounding, == the fp32-output launch + an fp32 add."""
@@ -67,8 +67,8 @@ def test_gemm_accumulate_any_shape(M, N8, K64, b_oc, monkeypatch):
     C.case_gemm_accumulate_exact(DEV, M, 8 * N8, 64 * K64, b_oc)
 
 
-@settings(max_examples=10, **COMMON)
-@given(B=st.integers(1, 2), S=st.integers(1, 330), H=st.integers(1, 2), causal=st.booleans(), use_len=st.booleans(), extra=st.integers(0, 40))
+@settings(max_examples=6, **COMMON)
+@given(B=st.integers(1, 2), S=st.integers(1, 200), H=st.integers(1, 2), causal=st.booleans(), use_len=st.booleans(), extra=st.integers(0, 40))
 def test_attention_backward_rope_any_shape(B, S, H, causal, use_len, extra):
     """round 5: the inverse RoPE inside the attention backward == the backward + the in-place inverse pass, any length (ragged last blocks,
     single tokens), tables longer than the sequence."""

@@ -74,7 +74,7 @@ def run(world: int, rank: int, ep: bool):
 
     moe_lm.AriaMoELMConfig, vision.AriaVisionConfig = tiny_lm, tiny_vis
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--layers", "2", "--vit-layers", "1", "--images", "0",
-                "--batch", "2", "--seq", "64", "--no-cpu-baseline", "--long64k-seq", "96", "--long64k-images", "0", "--gen-new", "6", "--gen-image", "0", "--prefill-seq", "96", "--prefill-frames", "0"] + (["--ep"] if ep else []) + (["--time-grouped"] if world == 1 else [])
+                "--batch", "2", "--seq", "64", "--no-cpu-baseline", "--long64k-seq", "96", "--long64k-images", "0", "--gen-new", "6", "--gen-image", "0", "--prefill-seq", "96", "--prefill-frames", "0", "--sub-record-repeats", "1"] + (["--ep"] if ep else []) + (["--time-grouped"] if world == 1 else []) + os.environ.get("ARIA_DRY_EXTRA", "").split()
     try:
         bench.main()
     finally:
