@@ -215,12 +215,12 @@ def test_lora_fused_sites_with_dropout(force_v3, monkeypatch):
 def test_lora_fused_node_matches_modular(force_v3, monkeypatch):
     if force_v3:
         monkeypatch.setenv("ARIA_GEMM_FORCE", "3")
-    M.case_lora_fused_vs_modular(DEV)
+    M.case_lora_fused_vs_modular(DEV, layers=1 if force_v3 else 2)   # (one layer under the emulated 256 x 256 kernels: the CPU suite's time)
 
 
 def test_training_step_without_permuted_copy(monkeypatch):
     monkeypatch.setenv("ARIA_GEMM_FORCE", "3")   # (toy shapes: the 256 x 256 kernels -- the gathered weight gradient is one of them)
-    M.case_training_step_without_permuted_copy(DEV)
+    M.case_training_step_without_permuted_copy(DEV, layers=1)
 
 
 def test_adapted_decoder_layer_with_gradient_checkpointing():
