@@ -301,35 +301,51 @@ class LoraDecoderLayerFn(torch.autograd.Function):
     """One MoEDecoderLayer whose GEMMs carry LoRA adapters (recipes/config_lora.yaml:44-59) as a single node: the adapters' second projections
     ride inside the base launches (K-extension), everything else is the un-adapted layer's kernel sequence (aria_amd.lora_functional).
     ``keys``: the adapted parameter keys (subset of lora_functional.SITES), ``hyper``: (scaling, dropout p) per key; tensors: the 12 layer
-    parameters, then (lora_A.weight, lora_B.weight) per key.  The dropout masks are a function of ``seed``: re-running the forward (the
-    recipe's gradient checkpointing) reproduces them."""
+    parameters, then (lora_A.weight, lora_B.weight) per key.  The dropout masks are a function of ``seed``.
+    ``recompute`` (the recipe's gradient_checkpointing, recipes/config_lora.yaml:17) is done INSIDE the node (torch's non-reentrant
+    checkpoint only intercepts save_for_backward tensors, so wrapping this node kept every activation alive in ``ctx.c`` AND ran the forward
+    twice): the forward keeps the layer input and the seed, nothing else; the backward runs decoder_layer_lora_fwd again -- same seed, same
+    masks, same bits -- and hands its context to decoder_layer_lora_bwd."""
+
+    forward_calls = 0   # (test hook: how many times the layer forward ran)
 
     @staticmethod
-    def forward(ctx, x, cos, sin, B, S, acfg, mcfg, eps, kv_len, training, seed, keys, hyper, *tensors):
+    def forward(ctx, x, cos, sin, B, S, acfg, mcfg, eps, kv_len, training, seed, keys, hyper, recompute, *tensors):
         from . import lora_functional as LF
 
         params, ab = tensors[:len(_LAYER_KEYS)], tensors[len(_LAYER_KEYS):]
         p = dict(zip(_LAYER_KEYS, params))
         L = {k: LF.LoraSite(ab[2 * i], ab[2 * i + 1], hyper[i][0], hyper[i][1]) for i, k in enumerate(keys)}
         out, c = LF.decoder_layer_lora_fwd(x, p, L, cos, sin, B, S, acfg, mcfg, eps, kv_len, training, seed)
-        ctx.c, ctx.keys = c, keys
-        ctx.save_for_backward(cos, sin, *params)
+        LoraDecoderLayerFn.forward_calls += 1
+        ctx.keys, ctx.hyper = keys, hyper
+        ctx.meta = (B, S, acfg, mcfg, eps, kv_len, training, seed, bool(recompute))
+        ctx.c = None if recompute else c
+        ctx.save_for_backward(x, cos, sin, *tensors)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         from . import lora_functional as LF
 
-        cos, sin, *params = ctx.saved_tensors
+        x, cos, sin, *tensors = ctx.saved_tensors
+        params, ab_in = tensors[:len(_LAYER_KEYS)], tensors[len(_LAYER_KEYS):]
         p = dict(zip(_LAYER_KEYS, params))
-        n0 = 13
+        B, S, acfg, mcfg, eps, kv_len, training, seed, recompute = ctx.meta
+        c = ctx.c
+        if recompute:
+            L = {k: LF.LoraSite(ab_in[2 * i], ab_in[2 * i + 1], ctx.hyper[i][0], ctx.hyper[i][1]) for i, k in enumerate(ctx.keys)}
+            with torch.no_grad():
+                _, c = LF.decoder_layer_lora_fwd(x, p, L, cos, sin, B, S, acfg, mcfg, eps, kv_len, training, seed)
+            LoraDecoderLayerFn.forward_calls += 1
+        n0 = 14
         need = {k for k, w in zip(_LAYER_KEYS, ctx.needs_input_grad[n0:n0 + len(_LAYER_KEYS)]) if w}
-        dx, gb, g = LF.decoder_layer_lora_bwd(_c(dout), ctx.c, p, cos, sin, need)
+        dx, gb, g = LF.decoder_layer_lora_bwd(_c(dout), c, p, cos, sin, need)
         ctx.c = None
         ab = []
         for k in ctx.keys:
             ab += list(g.get(k, (None, None)))
-        return (dx,) + (None,) * 12 + tuple(gb[k] if k in need else None for k in _LAYER_KEYS) + tuple(ab)
+        return (dx,) + (None,) * 13 + tuple(gb[k] if k in need else None for k in _LAYER_KEYS) + tuple(ab)
 
 
 class LMHeadLossFn(torch.autograd.Function):

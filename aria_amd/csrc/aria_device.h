@@ -26,6 +26,10 @@ typedef void* hipStream_t;
     hipLaunchKernelGGL(kernel, grid, block, shmem, static_cast<hipStream_t>(stream), __VA_ARGS__)
 #endif
 
+// internal helper shared by the translation units (common.hip): ARIA_OK, or ARIA_ERR_LAUNCH when the launch just enqueued failed.  NOT part
+// of the C ABI: hidden, so libaria_hip.so exports the extern "C" entry points of include/aria_hip.h and nothing else of ours.
+__attribute__((visibility("hidden"))) int aria_check_launch();
+
 #ifdef ARIA_EMU
 #include <algorithm>
 #include <cmath>

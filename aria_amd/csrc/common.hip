@@ -10,4 +10,4 @@ int aria_check_launch() {
 #endif
 }
 
-extern "C" int aria_abi_version(void) { return 2; }
+extern "C" int aria_abi_version(void) { return ARIA_ABI_VERSION; }

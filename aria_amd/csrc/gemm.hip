@@ -29,6 +29,7 @@
 #include "aria_hip.h"
 #include "gemm_params.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 using namespace ad;
@@ -708,8 +709,20 @@ int aria_gemm_dswiglu_bf16(const void* dY, const void* B, const void* H, void* D
 // permuted row; the 64 entries of padding are read, never used).  v3 only.
 int aria_grouped_gemm_wgrad_gather_bf16(const void* X, const int32_t* rows, const void* dY, void* dW, const int32_t* offsets, int64_t E, int64_t T,
                                         int64_t K, int64_t N, int64_t ldx, int64_t ldy, int c_f32, int accumulate, void* stream) {
-    if (!X || !rows || !dY || !dW || !offsets || E <= 0 || T <= 0) return ARIA_ERR_INVALID;
+    // T == 0 (no tokens: every expert's reduction is empty) is a valid call like its sibling aria_grouped_gemm_wgrad_bf16's: dW is
+    // zero-filled (or left alone with `accumulate`) -- ADVICE r5
+    if (!dW || !offsets || E <= 0 || T < 0 || K < 0 || N < 0) return ARIA_ERR_INVALID;
     if (K == 0 || N == 0) return ARIA_OK;
+    if (T == 0) {
+        const size_t nbytes = size_t(E) * size_t(K) * size_t(N) * (c_f32 ? 4 : 2);
+#ifdef ARIA_EMU
+        if (!accumulate) std::memset(dW, 0, nbytes);
+#else
+        if (!accumulate && hipMemsetAsync(dW, 0, nbytes, static_cast<hipStream_t>(stream)) != hipSuccess) return ARIA_ERR_LAUNCH;
+#endif
+        return ARIA_OK;
+    }
+    if (!X || !rows || !dY) return ARIA_ERR_INVALID;
     if (!aligned16(X) || !aligned16(dY) || (ldx & 7) || (ldy & 7) || (K & 7) || (N & 7) || (reinterpret_cast<uintptr_t>(rows) & 3)) return ARIA_ERR_ALIGN;
     if (T >= (1ll << 24) || 2 * ldx >= (1ll << 24) || 2 * T * ldx >= (1ll << 32) || !use_v3(((K + 255) / 256) * ((N + 255) / 256) * E, 64, 0, 0, K, N))
         return ARIA_ERR_UNSUPPORTED;

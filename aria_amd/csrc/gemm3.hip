@@ -261,7 +261,8 @@ __device__ __forceinline__ void stage_half(const Stage& st, int gtile) {
         s0 = st.gA0 + st.gk[WH][0] + col2;
         s1 = st.gA0 + st.gk[WH][1] + col2;
     }
-    if (TAIL && st.tail_k < BK && tile == st.nk - 1) {  // wave-uniform: the ragged end of the reduction -> granules past it read zeros
+    // (the K-extension tile ALWAYS goes through here, also when it is a full 64 deep: its sources are the adapter's operands -- ADVICE r5)
+    if (TAIL && (st.tail_k < BK || (EXT && st.ext > 0)) && tile == st.nk - 1) {  // wave-uniform: the ragged end of the reduction -> granules past it read zeros
         if (EXT && !(GATHER && OPERAND == 0)) {  // K-extension tile: the adapter's operands, same lane <-> (row, reduction index) map
             const char* e = OPERAND == 0 ? st.eA : st.eB;
             const uint32_t le2 = OPERAND == 0 ? st.ldeA2 : st.ldeB2;
@@ -412,7 +413,7 @@ __device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4
     int kt = 0;
     if (!EDGE) {
         // steady part: K-tile t stages tiles t + 1 and t + 2, both of which must exist and be full -- t + 2 <= last full tile
-        const int last_full = st.tail_k < BK ? nk - 2 : nk - 1;
+        const int last_full = (st.tail_k < BK || ((XM & 2) && st.ext > 0)) ? nk - 2 : nk - 1;  // (an extension tile is never a steady one)
         for (; kt + 1 <= last_full - 2; kt += 2) {
             k_tile<A_OC, B_OC, 0, false, true, XM>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
             k_tile<A_OC, B_OC, 1, false, true, XM>(acc, fa, fb, aa, ab, smem, st, kt + 1, nk, rl, cl);

@@ -191,10 +191,11 @@ __device__ __forceinline__ float aria_epilogue_act_c(float v) {
     return ACT == 1 ? ad::gelu_tanh(ad::rbf(v)) : v;
 }
 
+// (internal to the library: hidden, not part of the C ABI)
 // v2 launcher (gemm2.hip); returns ARIA_* status
-int aria_launch_gemm2(const GemmParams& p, int a_oc, int b_oc, int ntm_or_max_tm, int grid_y, void* stream);
+__attribute__((visibility("hidden"))) int aria_launch_gemm2(const GemmParams& p, int a_oc, int b_oc, int ntm_or_max_tm, int grid_y, void* stream);
 // v3 launcher (gemm3.hip): modes 0/1, K % 64 == 0
-int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm_or_max_tm, void* stream, void* workspace = nullptr,
+__attribute__((visibility("hidden"))) int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm_or_max_tm, void* stream, void* workspace = nullptr,
                       long long workspace_bytes = 0);
 // fp32 workspace bytes the v3 remainder split-K wants for a dense problem (0: it would not split)
-long long aria_gemm3_workspace_bytes(long long M, long long N, long long K);
+__attribute__((visibility("hidden"))) long long aria_gemm3_workspace_bytes(long long M, long long N, long long K);

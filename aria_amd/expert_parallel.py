@@ -181,6 +181,41 @@ class _Streams:
                 t.record_stream(self.main)
 
 
+
+def _local_experts(rows: torch.Tensor, recv_counts: torch.Tensor, fc1_local, fc2_local, W: int, El: int) -> torch.Tensor:
+    """fc1 + glu + fc2 of this rank's experts over the rows one exchange delivered, ordered (source rank, local expert); recv_counts
+    [W, El] on the device.  -> expert outputs in the SAME row order.  A rank-local choice between two forms (no collective inside, so ranks
+    may differ): the SEGMENT launches take the rows as they arrived (r04) -- v3-only, 32-bit per-lane DMA offsets, i.e.
+    2 * rows * leading dimension < 2^32 for fc1's input and fc2's -- and the REORDER form (local-expert-major copy, grouped launches that
+    fall back to the v2 kernels) takes anything.  The row count is data dependent (a routing skew towards this rank's experts grows it):
+    the test is made here, on the count the host knows (ADVICE r4 for the whole exchange, ADVICE r5 for every chunk of the chunked one)."""
+    K, K2 = fc1_local.shape[1], fc2_local.shape[1]
+    R = rows.shape[0]
+    seg_rows_ok = 2 * R * K < (1 << 32) and 2 * R * K2 < (1 << 32)
+    if seg_rows_ok and ops.segments_supported(K) and ops.segments_supported(K2) and ops.glu_fusable(K, fc1_local.shape[2]):
+        seg_off = torch.zeros(W * El + 1, dtype=torch.int32, device=rows.device)
+        seg_off[1:] = torch.cumsum(recv_counts.reshape(-1), 0).to(torch.int32)
+        act = AG.ExpertsGluSegFn.apply(rows, fc1_local, seg_off)
+        return AG.ExpertsGemmSegFn.apply(act, fc2_local, seg_off)
+    # reorder to local-expert-major -- destination segment (e, s) takes source segment (s, e)
+    rcd = recv_counts.long()                                                       # [source rank, local expert] on the device
+    src_start = (torch.cumsum(rcd.reshape(-1), 0) - rcd.reshape(-1)).view(W, El)   # where segment (s, e) starts in `rows`
+    lens_em, src_em = rcd.t().reshape(-1), src_start.t().reshape(-1)               # expert-major order of the segments
+    dst_start = torch.cumsum(lens_em, 0) - lens_em
+    order = (torch.repeat_interleave(src_em - dst_start, lens_em, output_size=R) + torch.arange(R, device=rows.device)).to(torch.int32)
+    inverse = torch.empty_like(order)
+    inverse[order.long()] = torch.arange(R, dtype=torch.int32, device=rows.device)
+    local_in = GatherRowsFn.apply(rows, order, inverse)
+    local_off = torch.zeros(El + 1, dtype=torch.int32, device=rows.device)
+    local_off[1:] = torch.cumsum(rcd.sum(0), 0).to(torch.int32)
+    if ops.glu_fusable(K, fc1_local.shape[2]):                                     # fc1 + glu in one launch, as on the local path
+        act = AG.ExpertsGluFn.apply(local_in, fc1_local, local_off)
+    else:
+        act = AG.SwiGLUFn.apply(AG.ExpertsGemmFn.apply(local_in, fc1_local, local_off))
+    eo_local = AG.ExpertsGemmFn.apply(act, fc2_local, local_off)
+    return GatherRowsFn.apply(eo_local, inverse, order)                            # (source rank, local expert) order again
+
+
 def _ep_moe_forward_chunked(x, router_w, fc1_local, fc2_local, gate_w, up_w, down_w, cfg: Fn.MoEConfig, group, C: int) -> torch.Tensor:
     """The segment form of ``ep_moe_forward`` with the exchange cut into C token chunks (the Megatron dispatcher the
     reference's is derived from, moe_lm.py:296-365, exchanges the whole micro-batch at once and waits for it):
@@ -245,10 +280,9 @@ def _ep_moe_forward_chunked(x, router_w, fc1_local, fc2_local, gate_w, up_w, dow
         if st.on:
             st.main.wait_event(ev_d[c])
             p["rows"].record_stream(st.main)
-        seg_off = torch.zeros(W * El + 1, dtype=torch.int32, device=x.device)
-        seg_off[1:] = torch.cumsum(recv_counts[:, c].reshape(-1), 0).to(torch.int32)
-        act = AG.ExpertsGluSegFn.apply(p["rows"], fc1_local, seg_off)
-        p["eo_local"] = AG.ExpertsGemmSegFn.apply(act, fc2_local, seg_off)
+        # (per chunk, on the row count this rank actually received: segment launches, or the reorder form when a skew pushed the chunk
+        # past their 32-bit row offsets -- ADVICE r5: the fixed "4 x its share" estimate in ep_moe_forward is not a bound)
+        p["eo_local"] = _local_experts(p["rows"], recv_counts[:, c], fc1_local, fc2_local, W, El)
         if st.on:
             e = torch.cuda.Event()
             e.record(st.main)
@@ -280,9 +314,7 @@ def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w
     assert fc1_local.shape[0] == El
     C = ep_chunks(x.shape[0])
     if (C > 1 and ops.segments_supported(fc1_local.shape[1]) and ops.segments_supported(fc2_local.shape[1])
-            and ops.glu_fusable(fc1_local.shape[1], fc1_local.shape[2]) and 2 * 4 * x.shape[0] * k * fc1_local.shape[1] < (1 << 32)):
-        # (a chunk may receive up to 4 x its share of rows before the segment launches' 32-bit row offsets overflow: beyond that the
-        # unchunked form below decides per call, on the row count it knows)
+            and ops.glu_fusable(fc1_local.shape[1], fc1_local.shape[2])):
         return _ep_moe_forward_chunked(x, router_w, fc1_local, fc2_local, gate_w, up_w, down_w, cfg, group, C)
     logits = AG.linear(x, router_w)
     scores, idx, counts = RouteFn.apply(logits, cfg)
@@ -319,46 +351,10 @@ def ep_moe_forward(x: torch.Tensor, router_w, fc1_local, fc2_local, gate_w, up_w
         both = both_dev.cpu()
     send_splits, recv_splits = both[0].sum(1).tolist(), both[1].sum(1).tolist()
     rows = AllToAllRowsFn.apply(perm, send_splits, recv_splits, group)             # ordered (source rank, local expert)
-    K = fc1_local.shape[1]
-    R_recv = rows.shape[0]   # data-dependent: a routing skew towards this rank's experts grows it (known on the host: sum of recv_splits)
-    # the segment launches are v3-only: per-lane DMA offsets are 32-bit, i.e. 2 * rows * leading dimension < 2^32 for fc1's input and fc2's
-    # (at 64K tokens per rank a ~2.1x skew crossed that line and the step aborted with ARIA_ERR_UNSUPPORTED instead of taking
-    # the reorder path below, whose grouped launches fall back to the v2 kernels)
-    seg_rows_ok = 2 * R_recv * K < (1 << 32) and 2 * R_recv * fc2_local.shape[1] < (1 << 32)
-    if (seg_rows_ok and ops.segments_supported(K) and ops.segments_supported(fc2_local.shape[1])
-            and ops.glu_fusable(K, fc1_local.shape[2])):
-        # r04: the grouped launches take the exchange's output AS IT ARRIVED -- W * El segments ordered (source rank, local expert), segment
-        # g multiplying with local expert g % El -- so no row passes over [6T, D] in front of fc1 or behind fc2, forward or backward
-        seg_off = torch.zeros(W * El + 1, dtype=torch.int32, device=x.device)
-        seg_off[1:] = torch.cumsum(recv_counts.reshape(-1), 0).to(torch.int32)
-        act = AG.ExpertsGluSegFn.apply(rows, fc1_local, seg_off)
-        eo_local = AG.ExpertsGemmSegFn.apply(act, fc2_local, seg_off)
-        eo = AllToAllRowsFn.apply(eo_local, recv_splits, send_splits, group)       # my rows, original expert-major order
-        if sh is None:
-            sh = _shared_expert(x, gate_w, up_w, down_w)
-        else:
-            torch.cuda.current_stream(x.device).wait_stream(side)
-            sh.record_stream(torch.cuda.current_stream(x.device))
-            x.record_stream(side)
-        return UnpermuteFn.apply(eo, inv, scores, sh, k)
-    # (widths the segment launches do not take: reorder to local-expert-major -- destination segment (e, s) takes source segment (s, e))
-    R = rows.shape[0]
-    rcd = recv_counts.long()                                                       # [source rank, local expert] on the device
-    src_start = (torch.cumsum(rcd.reshape(-1), 0) - rcd.reshape(-1)).view(W, El)   # where segment (s, e) starts in `rows`
-    lens_em, src_em = rcd.t().reshape(-1), src_start.t().reshape(-1)               # expert-major order of the segments
-    dst_start = torch.cumsum(lens_em, 0) - lens_em
-    order = (torch.repeat_interleave(src_em - dst_start, lens_em, output_size=R) + torch.arange(R, device=x.device)).to(torch.int32)
-    inverse = torch.empty_like(order)
-    inverse[order.long()] = torch.arange(R, dtype=torch.int32, device=x.device)
-    local_in = GatherRowsFn.apply(rows, order, inverse)
-    local_off = torch.zeros(El + 1, dtype=torch.int32, device=x.device)
-    local_off[1:] = torch.cumsum(rcd.sum(0), 0).to(torch.int32)
-    if ops.glu_fusable(fc1_local.shape[1], fc1_local.shape[2]):                    # fc1 + glu in one launch, as on the local path
-        act = AG.ExpertsGluFn.apply(local_in, fc1_local, local_off)
-    else:
-        act = AG.SwiGLUFn.apply(AG.ExpertsGemmFn.apply(local_in, fc1_local, local_off))
-    eo_local = AG.ExpertsGemmFn.apply(act, fc2_local, local_off)
-    back = GatherRowsFn.apply(eo_local, inverse, order)                            # (source rank, local expert) order again
+    # r04: where the widths and the received row count allow it the grouped launches take the exchange's output AS IT ARRIVED -- W * El
+    # segments ordered (source rank, local expert), segment g multiplying with local expert g % El -- so no row passes over [6T, D] in front
+    # of fc1 or behind fc2, forward or backward; else the rows are reordered to local-expert-major and back (_local_experts)
+    back = _local_experts(rows, recv_counts, fc1_local, fc2_local, W, El)
     eo = AllToAllRowsFn.apply(back, recv_splits, send_splits, group)               # my rows, original expert-major order
     # shared expert (replicated) and weighted combine
     if sh is None:

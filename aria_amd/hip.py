@@ -103,6 +103,9 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 3   # include/aria_hip.h ARIA_ABI_VERSION this host code was written against
+
+
 class AriaHipError(RuntimeError):
     pass
 
@@ -127,6 +130,8 @@ class HipLibrary:
                 continue
             fn.argtypes = argtypes
             fn.restype = RESTYPES.get(name, c_int)
+        if "aria_abi_version" not in self.missing and self.cdll.aria_abi_version() != ABI_VERSION:
+            raise AriaHipError(f"{path} has ABI version {self.cdll.aria_abi_version()}, aria_amd expects {ABI_VERSION}: rebuild it (`make`)")
 
     def call(self, name: str, *args) -> None:
         rc = getattr(self.cdll, name)(*args)

@@ -92,7 +92,11 @@ class _PackedWeights(nn.Module):
     so the fused blocks' [3D, D] / [2I, D] operand is a view of the parameters, not a per-forward copy (functional.py ``fused_weight`` /
     ``pack_adjacent_``).  Packed at construction and again after every ``_apply`` (``.to()``, ``.bfloat16()``, ``.cuda()`` re-allocate each
     parameter on its own); anything that breaks the adjacency later (``load_state_dict(assign=True)``, an adapter wrapping one projection)
-    only brings the copy back -- ``fused_weight`` checks the tensors at every call."""
+    only brings the copy back -- ``fused_weight`` checks the tensors at every call.
+    Copies: ``copy.deepcopy`` / pickling re-create every parameter in a storage of its own, so ``__setstate__`` packs the copy
+    again (EMA / cloned models keep the view instead of silently going back to the per-forward ``torch.cat``).  A packed parameter is a
+    SLICE of the shared buffer: ``torch.save`` of a whole ``state_dict()`` stores that buffer once, but saving ONE such tensor on its own
+    serialises the whole buffer behind it -- ``.clone()`` a slice before saving a partial state dict."""
 
     def _packed(self):
         return ()
@@ -106,6 +110,10 @@ class _PackedWeights(nn.Module):
         out = super()._apply(fn, *args, **kwargs)
         self.pack_weights_()
         return out
+
+    def __setstate__(self, state):   # deepcopy / unpickling: the copies' parameters have lost the adjacency
+        super().__setstate__(state)
+        self.pack_weights_()
 
 
 def _plain_linears(*mods) -> bool:
@@ -402,15 +410,11 @@ class MoEDecoderLayer(nn.Module):
             seed = int(torch.empty((), dtype=torch.int64).random_()) if self.training else 0   # (host generator: torch.manual_seed governs it)
             mcfg, acfg, eps = self.mlp.moe_config(), self.self_attn.attn_config(), self.config.rms_norm_eps
 
-            def node(xx):
-                return AG.LoraDecoderLayerFn.apply(xx, cos, sin, B, S, acfg, mcfg, eps, kv_len, self.training, seed, keys, hyper,
-                                                   *self.layer_params(), *ab)
-
-            if self.config.gradient_checkpointing and self.training and torch.is_grad_enabled():
-                from torch.utils.checkpoint import checkpoint   # (the masks are a function of `seed`: the re-run forward repeats them)
-
-                return checkpoint(node, x, use_reentrant=False).view(B, S, D)
-            return node(x).view(B, S, D)
+            # the recipe's gradient_checkpointing (recipes/config_lora.yaml:17) is the node's own recompute flag: the forward keeps the layer
+            # input and the seed, the backward re-runs the layer (same masks) -- no torch.utils.checkpoint wrapper
+            recompute = bool(self.config.gradient_checkpointing and self.training and torch.is_grad_enabled())
+            return AG.LoraDecoderLayerFn.apply(x, cos, sin, B, S, acfg, mcfg, eps, kv_len, self.training, seed, keys, hyper, recompute,
+                                               *self.layer_params(), *ab).view(B, S, D)
         if self.mlp.ep_enabled or self.mlp.has_adapter() or not _plain_linears(a.q_proj, a.k_proj, a.v_proj, a.o_proj):
             # an adapter (aria_amd/lora.py) wraps a GEMM of this layer, or the experts are sharded over ranks (an all-to-all sits inside
             # the MoE block): LlamaDecoderLayer.forward module by module (modeling_llama.py:295-325)

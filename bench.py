@@ -64,6 +64,8 @@ def parse():
                     "generate / LoRA / fusions-A/B sub-records instead of their protocol's 5 / 3 / 4")
     ap.add_argument("--no-fusions-ab", action="store_true", help="skip the `step_fusions_ab` sub-record (N = 1 only: 4 + 4 extra steps, the round-5 "
                     "launch fusions switched off / on alternately inside this process -- box variance cancels)")
+    ap.add_argument("--no-launch-classes", action="store_true", help="skip the `launch_classes` pass (N = 1 only: ONE extra step after the timed "
+                    "region with HIP events around every large launch class -> `roofline.worst_large_launch`)")
     ap.add_argument("--no-lora-record", action="store_true", help="skip the `lora_config` sub-record (N = 1 only: recipes/config_lora.yaml's adapter set "
                     "on the same model and micro-batch, three timed steps + the frozen-base forward + input-gradient reference)")
     ap.add_argument("--ep", action="store_true", help="BASELINE config #5 instead of #3: routed experts sharded over the N ranks (all-to-all "
@@ -168,7 +170,21 @@ def cpu_baseline(cfg_kwargs, seconds_budget=40.0):
         t_heads.append(time.perf_counter() - t0)
     t_head = sorted(t_heads)[1]
     value = S / (28 * t_layer + t_head)
-    return {"value": round(value, 3), "unit": "tokens/s", "cores": nthreads, "kind": "port",
+    ref = {}
+    try:   # the LIVE reference timed in the build container (it cannot travel): committed figures, carried beside the port's
+        with open(os.path.join(ROOT, "profiles", "r05_cpu_reference_config1.json")) as f:
+            d = json.load(f)
+        ref = {"reference_tokens_per_s": d["port_shape"]["reference_tokens_per_s_28_layers"],
+               "reference_cores": d["host"]["torch.get_num_threads"],
+               "reference_sample": "LIVE reference (aria/model, sequential_gemm fallback, eager attention) at THIS sample's shape -- one full-width decoder "
+                                   "layer fwd+bwd B=1 S=2048, best of 5, x 28 layers -- timed in the build container "
+                                   "(profiles/r05_cpu_reference_config1.json); the same file's config #1 forward: reference "
+                                   f"{d['config1']['extrapolated_28_layers']['reference_tokens_per_s']} tok/s vs port "
+                                   f"{d['config1']['extrapolated_28_layers']['port_tokens_per_s']}",
+               "port_tokens_per_s_same_host_as_reference": d["port_shape"]["port_tokens_per_s_28_layers"]}
+    except Exception:  # noqa: BLE001
+        pass
+    return {"value": round(value, 3), "unit": "tokens/s", "cores": nthreads, "kind": "port", **ref,
             "sample": f"oracle fp32, 1 of 28 full-width decoder layers fwd+bwd (1 warm-up + 3 timed at B=1,S={S}: "
                       f"{', '.join(f'{t:.2f}' for t in t_layers)} s, median {t_layer:.2f}) + lm_head/CE fwd+bwd (median of 3: {t_head:.2f} s); "
                       f"value = S/(28*t_layer+t_head); os.cpu_count()={os.cpu_count()}; the LIVE reference (cannot travel to this box) timed in the build "
@@ -339,6 +355,99 @@ def prefill_config4_record(twin, tcfg, S=53248, frames=32, runs=2, img_px=490, q
 
 
 FUSION_SWITCHES = ("ARIA_FUSE_WGRAD_GATHER", "ARIA_FUSE_ROUTER", "ARIA_FUSE_QKV_ROPE")
+
+
+def executed_flops_per_step(cfg, B, S, labelled_rows, n_images, vit_layers=27, P=4900, Dv=1152, Iv=4304, Hv=16, hdv=72, qtok=256):
+    """The flops the config #3 step EXECUTES (not the algorithmic 3 x forward of SURVEY 8d: the ViT is frozen = forward only, lm_head + CE run
+    on the labelled rows only, the attention backward is counted at the algorithm's 2.5 x forward).  Decoder GEMMs per token and layer =
+    SURVEY 8d's 2 * (4 D^2 + D E + k 3 D I + 3 D Is); x 3 for forward + input gradient + weight gradient.  ViT per image and layer =
+    2 P (4 Dv^2 + 2 Dv Iv) + 4 P^2 hd H.  Projector (trainable) per image ~ 0.1 TF forward, x 3."""
+    D, E, k, I = cfg.hidden_size, cfg.moe_num_experts, cfg.moe_topk, cfg.moe_intermediate_size
+    Is = I * cfg.moe_num_shared_experts
+    T = B * S
+    H, hd = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
+    layer_gemm = 2.0 * (4 * D * D + D * E + k * 3 * D * I + 3 * D * Is)
+    llm = 3.0 * cfg.num_hidden_layers * layer_gemm * T
+    attn = 3.5 * cfg.num_hidden_layers * 4.0 * B * H * (S * S / 2.0) * hd
+    head = 3.0 * 2.0 * D * cfg.vocab_size * labelled_rows
+    vit = n_images * vit_layers * (2.0 * P * (4 * Dv * Dv + 2 * Dv * Iv) + 4.0 * P * P * hdv * Hv) + n_images * 2.0 * P * 588 * Dv
+    proj = 3.0 * n_images * (2.0 * P * 2 * Dv * Dv * 2 + 4.0 * qtok * P * Dv + 2.0 * qtok * (Dv * D + D * D))
+    return {"decoder_gemms": llm, "decoder_attention": attn, "lm_head": head, "vit_forward": vit, "projector": proj,
+            "total": llm + attn + head + vit + proj}
+
+
+def launch_classes_record(step, ops, peak_tf=2500.0, min_ms=4.0):
+    """ONE extra step after the timed region with a HIP-event pair around every large launch class (GEMM families by operand form and
+    shape, attention by head dim and direction): per class launches, ms per step, TF/s on the launch's own algorithmic flops, fraction of
+    the dense bf16 MFMA peak.  `worst_large_launch` in the driver line = the lowest fraction among the classes that take >= min_ms of the
+    step (VERDICT r5 weak #8: the headline `roofline` is the BEST grouped launch; a reader also needs the worst and the whole step)."""
+    ev = {}
+
+    def wrap(name, key_flops):
+        orig = getattr(ops, name)
+
+        def timed(*a, **kw):
+            key, fl = key_flops(*a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(*a, **kw)
+            e.record()
+            rec = ev.setdefault(key, [0.0, []])
+            rec[0] += fl
+            rec[1].append((s, e))
+            return r
+
+        setattr(ops, name, timed)
+        return orig
+
+    def kf_gemm(a, b, **kw):
+        a_oc, b_oc = bool(kw.get("a_oc")), bool(kw.get("b_oc"))
+        M, K = (a.shape[1], a.shape[0]) if a_oc else (a.shape[0], a.shape[1])
+        N = b.shape[1] if b_oc else b.shape[0]
+        return f"gemm {'oc' if a_oc else 'rc'},{'oc' if b_oc else 'rc'} M{M} N{N} K{K}", 2.0 * M * N * K
+
+    table = {
+        "gemm": kf_gemm,
+        "gemm_swiglu": lambda x, w, **kw: (f"gemm+swiglu M{x.shape[0]} N{w.shape[0]} K{x.shape[1]}", 2.0 * x.shape[0] * w.shape[0] * x.shape[1]),
+        "gemm_dswiglu": lambda dy, w, h, **kw: (f"gemm+dswiglu M{dy.shape[0]} I{h.shape[1] // 2} K{dy.shape[1]}", 2.0 * dy.shape[0] * (h.shape[1] // 2) * dy.shape[1]),
+        "gemm_qkv_rope": lambda x, wqkv, *a, **kw: (f"gemm+rope (q|k|v) M{x.shape[0]} N{wqkv.shape[0]} K{x.shape[1]}", 2.0 * x.shape[0] * wqkv.shape[0] * x.shape[1]),
+        "grouped_gemm": lambda a, w, off, **kw: (f"grouped {'fwd' if kw.get('w_is_kn', True) else 'dgrad'} rows{a.shape[0]} w{tuple(w.shape[1:])}",
+                                                 2.0 * a.shape[0] * w.shape[1] * w.shape[2]),
+        "grouped_gemm_swiglu": lambda a, w, off, **kw: (f"grouped fc1+swiglu rows{a.shape[0]} w{tuple(w.shape[1:])}", 2.0 * a.shape[0] * w.shape[1] * w.shape[2]),
+        "grouped_gemm_swiglu_gather": lambda x, rows, w, off, **kw: (f"grouped fc1+swiglu (gathered rows) rows{rows.numel()} w{tuple(w.shape[1:])}",
+                                                                    2.0 * rows.numel() * w.shape[1] * w.shape[2]),
+        "grouped_gemm_dswiglu": lambda dy, w, off, h, **kw: (f"grouped fc2 dgrad+dswiglu rows{dy.shape[0]} w{tuple(w.shape[1:])}",
+                                                            2.0 * dy.shape[0] * w.shape[1] * w.shape[2]),
+        "grouped_gemm_wgrad": lambda a, dy, off, E, **kw: (f"grouped wgrad rows{a.shape[0]} [{a.shape[1]} x {dy.shape[1]}]", 2.0 * a.shape[0] * a.shape[1] * dy.shape[1]),
+        "grouped_gemm_wgrad_gather": lambda x, rows, dy, off, E, **kw: (f"grouped wgrad (gathered rows) rows{dy.shape[0]} [{x.shape[1]} x {dy.shape[1]}]",
+                                                                       2.0 * dy.shape[0] * x.shape[1] * dy.shape[1]),
+        "attention_fwd": lambda q, k, v, B, S, H, hd, scale, causal, *a, **kw: (f"attention fwd hd{hd} S{S}{' causal' if causal else ''}",
+                                                                                4.0 * B * H * S * S * hd * (0.5 if causal else 1.0)),
+        "attention_bwd": lambda q, k, v, o, do, lse, B, S, H, hd, scale, causal, *a, **kw: (f"attention bwd hd{hd} S{S}{' causal' if causal else ''}",
+                                                                                           2.5 * 4.0 * B * H * S * S * hd * (0.5 if causal else 1.0)),
+    }
+    saved = {name: wrap(name, kf) for name, kf in table.items() if hasattr(ops, name)}
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        for name, orig in saved.items():
+            setattr(ops, name, orig)
+    rows = []
+    for key, (fl, pairs) in ev.items():
+        ms = sum(s.elapsed_time(e) for s, e in pairs)
+        if ms <= 0:
+            continue
+        tf = fl / (ms * 1e-3) / 1e12
+        rows.append({"class": key, "launches": len(pairs), "ms_per_step": round(ms, 2), "tflops": round(tf, 1), "frac": round(tf / peak_tf, 4)})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    large = [r for r in rows if r["ms_per_step"] >= min_ms]
+    worst = min(large, key=lambda r: r["frac"]) if large else None
+    return {"step_ms_with_events": round(dt * 1e3, 1), "classes_ge_%gms" % min_ms: large, "timed_ms_total": round(sum(r["ms_per_step"] for r in rows), 1),
+            "worst": worst}
 
 
 def step_fusions_ab(step, pairs=4):
@@ -709,6 +818,23 @@ def main():
                          "launches_timed": len(durs), "avg_launch_ms": round(avg * 1e3, 4),
                          "algorithmic_flops_per_launch": flops_launch},
         }
+        # whole-step fraction: EXECUTED flops (frozen ViT forward only, lm_head + CE on the labelled rows only) / ms_per_step / peak
+        try:
+            labelled = int((batch["labels"][:, 1:] != -100).sum())
+            fl = executed_flops_per_step(cfg, B, S, labelled, B * n_img, vit_layers=args.vit_layers)
+            res["roofline"]["step_executed_tflop"] = round(fl["total"] / 1e12, 1)
+            res["roofline"]["step_frac"] = round(fl["total"] / (dt / args.steps) / (peak * 1e12), 4)
+            res["roofline"]["step_flops_breakdown_tflop"] = {k: round(v / 1e12, 1) for k, v in fl.items() if k != "total"}
+        except Exception as ex:  # noqa: BLE001
+            res["roofline"]["step_frac_error"] = f"{type(ex).__name__}: {ex}"[:200]
+        try:
+            if world == 1 and not args.no_launch_classes:
+                ops.gemm, ops.grouped_gemm, ops.grouped_gemm_swiglu, ops.grouped_gemm_swiglu_gather = orig_gemm, orig_gg, orig_ggs, orig_ggsg
+                lc = launch_classes_record(step, ops, peak)
+                res["roofline"]["worst_large_launch"] = lc.pop("worst")
+                res["launch_classes"] = lc
+        except Exception as ex:  # noqa: BLE001
+            res["launch_classes"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
         if args.layers != 28 or args.vit_layers != 27 or (n_img != 2 and not args.long):
             res["config"]["INVALID"] = "reduced depth / no images (debug run)"
         full_depth = args.layers == 28 and args.vit_layers == 27

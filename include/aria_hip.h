@@ -26,7 +26,10 @@ extern "C" {
 #define ARIA_ERR_UNSUPPORTED 3 /* shape outside what the kernels implement (e.g. > 256 experts) */
 #define ARIA_ERR_LAUNCH 4      /* hipGetLastError() != hipSuccess after the launch */
 
-/* Library / ABI version (bumped when a signature changes). */
+/* Library / ABI version: bumped whenever an entry point is added or a signature changes (3 = round 5's additions: aria_moe_router_fused,
+ * aria_attn_bwd_rope, aria_moe_unpermute_res, aria_scale_bf16, aria_gemm_qkv_rope_hf_bf16, the *_lora_* family).  The Python host
+ * (aria_amd/hip.py) refuses a library whose version is not the one it was written against. */
+#define ARIA_ABI_VERSION 3
 int aria_abi_version(void);
 /* Test/diagnostic aid: which GEMM kernel family the calling thread's last aria_*gemm* call dispatched to
  * (1 = 128x128 tile, 2 = 256x256 register-staged, 3 = 256x256 LDS-DMA phase-scheduled; 0 = none yet). */
@@ -433,7 +436,5 @@ void aria_decode_graph_destroy(void* graph);
 
 #ifdef __cplusplus
 }
-/* internal helper shared by the translation units */
-int aria_check_launch();
 #endif
 #endif /* ARIA_HIP_H */

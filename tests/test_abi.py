@@ -30,7 +30,14 @@ def test_library_exports_every_declared_symbol():
         g.build()
     lib = hip.HipLibrary(hip.LIB_PATH)
     assert lib.missing == []
-    assert lib.cdll.aria_abi_version() == 2
+    assert lib.cdll.aria_abi_version() == hip.ABI_VERSION == 3
+    assert "#define ARIA_ABI_VERSION 3" in open(os.path.join(ROOT, "include", "aria_hip.h")).read()
+    # the library's own `aria_*` exports are exactly the header's entry points (internal helpers such as aria_check_launch are hidden)
+    import subprocess
+
+    nm = subprocess.run(["nm", "-D", "--defined-only", hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1] for line in nm.splitlines() if re.search(r" [TW] _?(Z\d+)?aria_", line)})
+    assert exported == header_symbols(), set(exported) ^ set(header_symbols())
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -203,7 +203,8 @@ def test_gemm_swiglu_split(force_gemm_v3, counts, K, I, T):
     C.case_gemm_swiglu_split(DEV, counts, K, I, T)
 
 
-@pytest.mark.parametrize("counts,K,I,T,r", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300, 8), ([130, 520], 192, 128, 72, 24), ([0, 0, 257], 64, 256, 9, 16)])
+@pytest.mark.parametrize("counts,K,I,T,r", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300, 8), ([130, 520], 192, 128, 72, 24), ([0, 0, 257], 64, 256, 9, 16),
+                                              ([40, 0, 300], 128, 128, 40, 64), ([70, 9], 128, 128, 40, 56)])   # r = 64: a FULL extension tile
 def test_gemm_lora_k_extension(force_gemm_v3, counts, K, I, T, r):
     C.case_gemm_lora_ext(DEV, counts, K, I, T, r)
 

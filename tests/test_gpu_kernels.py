@@ -220,7 +220,8 @@ def test_router_fused_is_gemm_plus_route(T, D, E, k):   # K1: gating GEMM + top-
 
 
 @pytest.mark.parametrize("counts,K,I,T,r", [([300, 0, 70, 5, 0, 0, 260, 1], 128, 128, 300, 8), ([1536] * 8 + [1500, 1580], 2560, 1664, 4096, 8),
-                                              ([1536] * 8 + [1500, 1580], 2560, 1664, 4096, 24)])
+                                              ([1536] * 8 + [1500, 1580], 2560, 1664, 4096, 24),
+                                              ([1536] * 8 + [1500, 1580], 2560, 1664, 4096, 64)])   # r = 64 (lora_r 32 on gate + up): a full extension tile
 def test_gemm_lora_k_extension(counts, K, I, T, r):  # LoRA's second projection inside the base launch, every base form
     C.case_gemm_lora_ext(DEV, counts, K, I, T, r, expect_fused=K >= 2560)
 
