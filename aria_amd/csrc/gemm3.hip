@@ -949,7 +949,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         if (!aria_grouped_tile(p, blockIdx.x, l, expert, m0, m_end, tn)) return;
         n0 = tn * bn_step;
         const int ew = p.expert_mod > 0 ? expert % p.expert_mod : expert;
-        b_off = (long long)ew * p.strideB;
+        b_off = (ARIA_ABL & 16384) ? 0 : (long long)ew * p.strideB;
         e_off = (long long)ew * p.stride_extB;
     }
     char* C = static_cast<char*>(p.C) + c_off * (p.c_f32 ? 4 : 2);
@@ -976,7 +976,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
-                const int row = min(m0 + hh * 128 + st.la_a + 8 * ss, p.M - 1);
+                const int row = min(((ARIA_ABL & 8192) ? 0 : m0) + hh * 128 + st.la_a + 8 * ss, p.M - 1);
                 st.ga[hh][ss] = mul24(uint32_t(p.gather_rows[row]), st.ldA2) + uint32_t(st.la_b ^ (64 * ss));
             }
     }
@@ -993,8 +993,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         st.ldeA2 = uint32_t(2 * p.ld_extA);
         st.ldeB2 = uint32_t(2 * p.ld_extB);
     }
-    st.m0 = (ARIA_ABL & 2048) ? 0 : m0;  // (timing experiment: every workgroup loads tile (0, 0)'s operands -- all L2 hits)
-    st.n0 = (ARIA_ABL & 2048) ? 0 : n0;
+    st.m0 = (ARIA_ABL & (2048 | 8192)) ? 0 : m0;  // (timing experiment: every workgroup loads tile (0, 0)'s operands -- all L2 hits)
+    st.n0 = (ARIA_ABL & (2048 | 16384)) ? 0 : n0;
+    // (r06 traffic attribution, profiles/r06_pmc_fc1_operands.json: bit 8192 = every workgroup stages the A rows of tile row 0 -- the launch's
+    // fabric-side fetches are then the B operand's alone; bit 16384 = every workgroup stages expert 0's column tile 0 -- the A operand's alone)
     FragAddr<A_OC> aa;
     FragAddr<B_OC> ab;
     aa.init(wm * 64, l);

@@ -8,6 +8,10 @@
 #   prof[=<args>]         rocprofv3 --kernel-trace --stats of the bench command -> kernel_stats_<tag>.txt (tools/gpu_prof_bench.sh)
 #   pmc=<t1,t2>           PMC passes of tools/pmc_targets.py targets, separate runs -> <tag>_pmc_<target>_<counter>.csv (tools/gpu_pmc.sh)
 #   py=<script.py args>   any probe under tools/ -> <tag>_<script>.json / .err  (commas separate the arguments)
+#   lib=<path|restore>    copy an ablation / variant build over aria_amd/libaria_hip.so for the steps that follow (the box's tree is a scratch
+#                         copy); `lib=restore` puts the product library back
+#   tag=<newtag>          change the output tag for the steps that follow
+#   counters=<regex>      rocprofv3 -L filtered -> <tag>_counters.txt
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out
 tag=$1; shift
 for step in "$@"; do
@@ -31,6 +35,13 @@ for step in "$@"; do
       set -- ${arg//,/ }; script=$1; base=$(basename ${script%.py})
       timeout 600 python tools/${arg//,/ } > gpurun_out/${tag}_$base.json 2> gpurun_out/${tag}_$base.err
       tail -c 1500 gpurun_out/${tag}_$base.json; grep -v amdgpu.ids gpurun_out/${tag}_$base.err | tail -3 ;;
+    lib)
+      [ -f /tmp/product.so ] || cp aria_amd/libaria_hip.so /tmp/product.so
+      if [ "$arg" = restore ]; then cp /tmp/product.so aria_amd/libaria_hip.so; else cp "$arg" aria_amd/libaria_hip.so; fi
+      echo "library: $arg ($(stat -c %s aria_amd/libaria_hip.so) bytes)" ;;
+    tag) tag=$arg ;;
+    counters)
+      ( cd /tmp && rocprofv3 -L 2>&1 | grep -i -E "$arg" | cut -c1-300 | sort -u | head -200 ) > gpurun_out/${tag}_counters.txt; wc -l gpurun_out/${tag}_counters.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done
