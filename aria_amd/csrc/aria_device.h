@@ -336,6 +336,18 @@ __device__ __forceinline__ void glds16_raw(const void* g, void* lds_wave_base) {
 #pragma clang diagnostic pop
 #endif
 }
+// 4 bytes per lane (global_load_lds_dword): the wave's 256 bytes land lane-linearly at lds_wave_base + 4 * lane.  Same counter, same order.
+__device__ __forceinline__ void glds4_raw(const void* g, void* lds_wave_base) {
+#ifdef ARIA_EMU
+    emu::glds(g, static_cast<char*>(lds_wave_base) + 4 * emu::lane(), 4);
+#else
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    const uint32_t lds = __builtin_amdgcn_readfirstlane(uint32_t(reinterpret_cast<uintptr_t>(lds_wave_base)));
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds) : "memory", "m0");
+#pragma clang diagnostic pop
+#endif
+}
 // wait until at most N of this wave's VMEM operations (LDS-DMA pieces included) are still outstanding
 template <int N>
 __device__ __forceinline__ void wait_vm() {

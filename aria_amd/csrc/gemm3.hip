@@ -55,12 +55,14 @@ using namespace ad;
 #if ARIA_ABL & 512
 // (timing experiment) per-workgroup wall-clock marks, 10 ns units: 0 entry, 1 first operands landed, 2 K loop done, 3 tile parked,
 // 4 stores issued, 5 stores acknowledged -- read back with aria_abl_ts()
-__device__ unsigned long long aria_ts[4096 * 8];
+// (r06: 16384 workgroups by FLATTENED id, so that the per-expert grids of the weight gradients -- blockIdx.y = expert -- are sampled too)
+__device__ unsigned long long aria_ts[16384 * 8];
 __device__ __forceinline__ void ts_mark(int i) {
-    if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
-        aria_ts[blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+    const unsigned id = blockIdx.x + blockIdx.y * gridDim.x;
+    if (threadIdx.x == 0 && id < 16384) {
+        aria_ts[id * 8 + i] = __builtin_amdgcn_s_memrealtime();
         // slots 6 / 7: the SHADER-clock counter at marks 1 / 2 (K loop start / end) -> average core clock inside the K loop
-        if (i == 1 || i == 2) aria_ts[blockIdx.x * 8 + 5 + i] = __builtin_readcyclecounter();
+        if (i == 1 || i == 2) aria_ts[id * 8 + 5 + i] = __builtin_readcyclecounter();
     }
 }
 #else
@@ -209,6 +211,7 @@ struct Stage {  // everything a wave needs to issue its two DMA pieces of any ha
     uint32_t gk[2][2];
     const int* grows;   // gather_rows at the expert's first reduction row (+ this workgroup's first K-tile)
     const char* gA0;    // the operand base (token row 0)
+    char* idx_lds;      // r06: this wave's two 256-byte index slots (LDS_IDX + 512 w): the indices of K-tile j wait in slot j & 1
     // K-extension (GemmParams::ext_k): the LAST K-tile's sources.  ext = 0: off
     int ext;
     const char* eA;
@@ -238,6 +241,37 @@ __device__ __forceinline__ void gather_k_rows(Stage& st, int which, const i32x8&
     const int b = q == 0 ? r[4] : q == 1 ? r[5] : q == 2 ? r[6] : r[7];
     st.gk[which][0] = mul24(uint32_t(a), st.ldA2);
     st.gk[which][1] = mul24(uint32_t(b), st.ldA2);
+}
+
+// r06: the gathered weight gradient's indices travel by LDS-DMA, not by scalar loads.  A scalar load counts on lgkmcnt, the counter of the
+// fragment reads, and returns out of order -- the `s_waitcnt lgkmcnt(0)` in front of the NEXT phase's MFMAs therefore waited for it in full: ~0.5 us
+// of index latency exposed in every K-tile (r06 timeline: 1.78 us per K-tile at 1.84 GHz against 1.64 at 1.68 GHz for the un-gathered oc,oc
+// loop).  Now every wave copies the 64 indices of K-tile t + 3 into one of its two 256-byte slots as ONE more DMA piece in front of phase 1's
+// two (vmcnt, in issue order: whatever wait later confirms those two has confirmed the indices), and reads its two entries of tile t + 2's
+// slot between phases 1 and 2 -- an ordinary LDS read that the next fragment wait covers.  Slots: bytes [131072, 135168) of the allocation, which
+// only the parked output tile uses (after the K loop).
+constexpr int LDS_IDX = 2 * LDS_OPERAND;
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+template <int SLOT>
+__device__ __forceinline__ void idx_dma(const Stage& st, int tile) {   // (tile clamped: the index array is padded by one K-tile, not more)
+    glds4_raw(st.grows + min(tile, st.nk - 1) * BK + lane_id(), st.idx_lds + SLOT * 256);
+}
+template <int SLOT>
+__device__ __forceinline__ void idx_read_issue(const Stage& st, i32x2& v, int l) {   // entries 8 w + (l >> 4) and + 4: this lane's two reduction rows
+#ifdef ARIA_EMU
+    const int* sl = reinterpret_cast<const int*>(st.idx_lds + SLOT * 256) + 8 * st.w + (l >> 4);
+    v[0] = sl[0], v[1] = sl[4];
+#else
+    const uint32_t a = uint32_t(reinterpret_cast<uintptr_t>(st.idx_lds)) + uint32_t(SLOT * 256 + 32 * st.w + 4 * (l >> 4));
+    asm volatile("ds_read2_b32 %0, %1 offset1:4" : "=v"(v) : "v"(a));
+#endif
+}
+__device__ __forceinline__ void idx_consume(Stage& st, int which, i32x2& v) {   // behind a wait_lds(): the registers pass through, no use moves in front
+#ifndef ARIA_EMU
+    asm volatile("" : "+v"(v));
+#endif
+    st.gk[which][0] = mul24(uint32_t(v[0]), st.ldA2);
+    st.gk[which][1] = mul24(uint32_t(v[1]), st.ldA2);
 }
 
 template <bool A_OC, bool B_OC, int OPERAND, int HALF, int BUF, bool TAIL = true, int XM = 0, int GKW = -1>
@@ -314,6 +348,7 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
                                       const FragAddr<B_OC>& ab, const char* smem, const Stage& st, int stage_tile, bool do_stage,
                                       bool more_in_flight, int rows_left, int cols_left) {
     static_assert(!(STEADY && EDGE), "the steady form is for interior tiles");
+    constexpr bool GK = (XM & 1) && A_OC;   // gathered reduction rows: phase 1 also copies tile t + 3's indices (stage_tile = t + 1) into slot SB
     const bool col_ok = !EDGE || QB * 128 < cols_left;
     const bool row_ok[2] = {!EDGE || QA * 128 < rows_left, !EDGE || QA * 128 + 32 < rows_left};
     if (!(ARIA_ABL & 2) && LOAD_B && (!EDGE || (col_ok && rows_left > 0))) {
@@ -335,6 +370,7 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
     // LATE measures +4 % with two k-contiguous operands and +1..2 % with transposing reads (round 1 had -5 % there: that was the
     // compiler's vmcnt(0) in front of every transposing read, see FragAddr::read_raw)
     constexpr bool LATE = true;
+    static_assert(LATE || !GK, "the index piece is counted for the LATE placement only");
     if (!LATE) {
         if (STEADY)
             stage_half<A_OC, B_OC, SO, SH, SB, false, XM>(st, stage_tile);
@@ -349,7 +385,7 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
     }
     if (!(ARIA_ABL & 32) && WAIT == 4) {  // phase 4: A0 and B0 of the NEXT tile must have landed; newer = its A1, B1 and A0 (, B0) of the tile after
         if (STEADY || more_in_flight)
-            wait_vm<LATE ? 6 : 8>();
+            wait_vm<(LATE ? 6 : 8) + (GK ? 1 : 0)>();   // (GK: this tile's phase 1 issued an index piece in front of its two)
         else
             wait_vm<0>();
     }
@@ -367,15 +403,21 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
                 sched_fence();
                 if (ARIA_ABL & 4) {
                     // (timing experiment: no DMA)
-                } else if (STEADY)
+                } else if (STEADY) {
+                    if (GK && WAIT == 1) idx_dma<SB>(st, stage_tile + 2);
                     stage_half<A_OC, B_OC, SO, SH, SB, false, XM>(st, stage_tile);
-                else if (do_stage)
+                } else if (do_stage) {
+                    if (GK && WAIT == 1) idx_dma<SB>(st, stage_tile + 2);
                     stage_half<A_OC, B_OC, SO, SH, SB, true, XM>(st, stage_tile);
+                }
                 sched_fence();
             }
         }
     } else {
-        if (LATE && do_stage) stage_half<A_OC, B_OC, SO, SH, SB, true, XM>(st, stage_tile);
+        if (LATE && do_stage) {
+            if (GK && WAIT == 1) idx_dma<SB>(st, stage_tile + 2);
+            stage_half<A_OC, B_OC, SO, SH, SB, true, XM>(st, stage_tile);
+        }
         if (col_ok) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -392,16 +434,13 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
 template <bool A_OC, bool B_OC, int BUF, bool EDGE, bool STEADY = false, int XM = 0>
 __device__ __forceinline__ void k_tile(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4], s16x8 (&fb)[2][4], const FragAddr<A_OC>& aa,
                                        const FragAddr<B_OC>& ab, const char* smem, Stage& st, int t, int nk, int rl, int cl) {
-    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-    constexpr bool GK = (XM & 1) && A_OC;   // gathered reduction rows: tile t + 2's indices requested behind phase 1, consumed in front of phase 3
-    i32x8 gr;
+    const bool n1 = STEADY || t + 1 < nk, n2 = STEADY || t + 2 < nk;   // (steady K-tiles stage t + 1 and t + 2 by construction: no tests left)
+    constexpr bool GK = (XM & 1) && A_OC;   // gathered reduction rows: tile t + 2's indices wait in slot BUF (copied there by tile t - 1's phase 1)
+    i32x2 gi;
     phase<A_OC, B_OC, 0, 0, true, true, BUF, 0, 1, BUF ^ 1, 1, EDGE, STEADY, XM>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, n1, rl, cl);
-    if (GK && n2) sload8_issue(gr, st.grows + (t + 2) * BK + 8 * st.w);
+    if (GK && n2) idx_read_issue<BUF>(st, gi, lane_id());
     phase<A_OC, B_OC, 0, 1, false, true, BUF, 1, 1, BUF ^ 1, 0, EDGE, STEADY, XM>(acc, fa, fb, aa, ab, smem, st, t + 1, n1, false, rl, cl);
-    if (GK && n2) {
-        sload8_wait(gr);
-        gather_k_rows(st, 1, gr, lane_id());
-    }
+    if (GK && n2) idx_consume(st, 1, gi);   // (phase 2's fragment wait covered the read)
     phase<A_OC, B_OC, 1, 1, true, false, BUF, 0, 0, BUF, 0, EDGE, STEADY, XM>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, false, rl, cl);
     phase<A_OC, B_OC, 1, 0, false, false, BUF, 1, 0, BUF, 4, EDGE, STEADY, XM>(acc, fa, fb, aa, ab, smem, st, t + 2, n2, n2, rl, cl);
     if (GK) st.gk[0][0] = st.gk[1][0], st.gk[0][1] = st.gk[1][1];
@@ -862,6 +901,7 @@ __device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)
                     *reinterpret_cast<uint32_t*>(mine + (a * 2 + b) * 4096 + row * 64 + (c & ~1) * 2) = pack2bf(lo, hi);
                 }
     wave_barrier();
+    ts_mark(3);
     sched_fence();  // (half 1's loads must not be hoisted above the parking: the accumulators are still live there)
     load_q(0, 0, 0, 4);
     load_q(0, 1, 0, 4);
@@ -905,6 +945,11 @@ __device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)
                 sched_fence();
             }
         }
+    }
+    if (ARIA_ABL & 512) {
+        ts_mark(4);
+        wait_vm<0>();
+        ts_mark(5);
     }
 }
 
@@ -1021,27 +1066,31 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     } else {
         // ---- prologue: tile 0 completely, A0 and B0 of tile 1 (phases 1 and 2 of tile 0 issue its A1 and B1) -- the steady-state
         // queue shape
-        if (GATHER && A_OC) {   // reduction rows of tiles 0 and 1 (rows past the expert's end are read -- the index array is padded -- and zero-paged)
+        if (GATHER && A_OC) {   // reduction rows of tiles 0 and 1 by scalar loads, both requested before the one wait (rows past the expert's end are
+            // read -- the index array is padded -- and zero-paged); from tile 2 on the indices come through the LDS slots (idx_dma)
             st.gA0 = reinterpret_cast<const char*>(p.A);
             st.grows = p.gather_rows + k_begin + kt_first * BK;
-            i32x8 gr;
+            st.idx_lds = smem + LDS_IDX + 512 * w;
+            i32x8 gr, gr1;
             sload8_issue(gr, st.grows + 8 * w);
+            if (nk > 1) sload8_issue(gr1, st.grows + BK + 8 * w);
             sload8_wait(gr);
             gather_k_rows(st, 0, gr, l);
             st.gk[1][0] = st.gk[0][0], st.gk[1][1] = st.gk[0][1];
+            if (nk > 1) {
+                sload8_wait(gr1);
+                gather_k_rows(st, 1, gr1, l);   // A0 of tile 1 below takes NXT; phase 1 of K-tile 0 (A1 of tile 1) takes CUR, set behind tile 0's pieces
+            }
         }
         if (nk > 0) {
-            stage_half<A_OC, B_OC, 0, 0, 0, true, XM>(st, 0);
+            stage_half<A_OC, B_OC, 0, 0, 0, true, XM, 0>(st, 0);   // (GKW = 0: tile 0's rows are in gk[0] whatever the half)
             stage_half<A_OC, B_OC, 1, 0, 0, true, XM & 2>(st, 0);
             stage_half<A_OC, B_OC, 1, 1, 0, true, XM & 2>(st, 0);
-            stage_half<A_OC, B_OC, 0, 1, 0, true, XM>(st, 0);
+            stage_half<A_OC, B_OC, 0, 1, 0, true, XM, 0>(st, 0);
         }
         if (GATHER && A_OC && nk > 1) {
-            i32x8 gr;
-            sload8_issue(gr, st.grows + BK + 8 * w);
-            sload8_wait(gr);
-            gather_k_rows(st, 1, gr, l);                        // A0 of tile 1 below takes NXT ...
-            st.gk[0][0] = st.gk[1][0], st.gk[0][1] = st.gk[1][1];   // ... and phase 1 of K-tile 0 (A1 of tile 1) CUR
+            st.gk[0][0] = st.gk[1][0], st.gk[0][1] = st.gk[1][1];
+            idx_dma<0>(st, 2);   // tile 2's indices: in front of tile 1's pieces, so the wait below confirms them
         }
         if (nk > 1) {
             stage_half<A_OC, B_OC, 0, 0, 1, true, XM>(st, 1);

@@ -24,23 +24,24 @@ void yield(int state) {
 struct PendingDma {
     const void* src;
     void* dst;
+    int bytes;
 };
 static std::vector<std::vector<PendingDma>> g_dma;  // per thread, oldest first
 static int g_glds_defer = 0;  // re-read from the environment at every launch (run_grid)
 static int glds_defer() { return g_glds_defer; }
-void glds(const void* src, void* dst) {
+void glds(const void* src, void* dst, int bytes) {
     if (!glds_defer()) {
-        std::memcpy(dst, src, 16);
+        std::memcpy(dst, src, size_t(bytes));
         return;
     }
     if (g_dma.size() <= size_t(cur->linear)) g_dma.resize(cur->linear + 1);
-    g_dma[cur->linear].push_back({src, dst});
+    g_dma[cur->linear].push_back({src, dst, bytes});
 }
 void wait_vm(int keep) {
     if (g_dma.size() <= size_t(cur->linear)) return;
     auto& q = g_dma[cur->linear];
     while (q.size() > size_t(keep)) {
-        std::memcpy(q.front().dst, q.front().src, 16);
+        std::memcpy(q.front().dst, q.front().src, size_t(q.front().bytes));
         q.erase(q.begin());
     }
 }

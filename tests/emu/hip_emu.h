@@ -77,7 +77,7 @@ bool lane_alive(int linear);
 // LDS-DMA model.  Default: the 16 bytes land at once (adversarial for WAR: a slot restaged too early is clobbered before its
 // last reader runs).  ARIA_EMU_GLDS_DEFER=1: they land only when a vmcnt wait (or the end of the thread) forces them to
 // (adversarial for RAW: a read that is not covered by a counted wait + barrier sees the 0xFF poison).
-void glds(const void* src, void* dst);
+void glds(const void* src, void* dst, int bytes = 16);
 void wait_vm(int keep);
 
 inline unsigned long long ballot(bool p) {

@@ -231,7 +231,9 @@ def test_causal_forward_grouped_block_order_gives_the_same_bits(B, S, H, monkeyp
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("T,E,k,K,N", [(150, 8, 2, 264, 136), (40, 4, 3, 64, 72), (700, 8, 1, 128, 256)])
+# (r06: the last two cases give an expert 5 to 12 K-tiles -- from K-tile 2 on the indices reach the loader through the LDS slots, through the
+# straight-line steady pairs and the general tail)
+@pytest.mark.parametrize("T,E,k,K,N", [(150, 8, 2, 264, 136), (40, 4, 3, 64, 72), (700, 8, 1, 128, 256), (1100, 3, 1, 256, 256), (900, 4, 2, 64, 136)])
 def test_grouped_gemm_wgrad_with_gathered_rows(force_gemm_v3, T, E, k, K, N):
     C.case_grouped_gemm_wgrad_gather(DEV, T, E, k, K, N)
 

@@ -73,9 +73,12 @@ def code(lines):
 
 GEMM3 = ["12gemm3_kernelILb0ELb0ELi3", "12gemm3_kernelILb0ELb1ELi3", "12gemm3_kernelILb1ELb1ELi3"]
 GEMM3_DGLU = ["12gemm3_kernelILb0ELb0ELi5", "12gemm3_kernelILb0ELb1ELi5"]  # same K loop, SwiGLU-backward epilogue (round 3)
+# r06: the gathered launches too -- the weight gradient with gathered reduction rows had NO straight-line steady loop (its per-K-tile index
+# requests sat behind run-time tests) and its scalar index loads were waited for in full by the next phase's `s_waitcnt lgkmcnt(0)`
+GEMM3_GATHER = ["12gemm3_kernelILb0ELb1ELi8", "12gemm3_kernelILb1ELb1ELi11"]
 
 
-@pytest.mark.parametrize("kernel", GEMM3 + GEMM3_DGLU)
+@pytest.mark.parametrize("kernel", GEMM3 + GEMM3_DGLU + GEMM3_GATHER)
 def test_gemm3_steady_loop_has_no_compiler_waits_and_no_branches(kernel):
     body = kernel_body(isa("gemm3.hip"), kernel)
     steady = None
@@ -91,6 +94,11 @@ def test_gemm3_steady_loop_has_no_compiler_waits_and_no_branches(kernel):
     assert sum(1 for s, _ in steady if s.startswith("global_load_lds_dwordx4")) == 16  # 4 half-tiles x 2 pieces per wave and K-tile
     assert sum(1 for s, _ in steady if s.startswith("s_barrier")) == 16
     assert not any(s.startswith("scratch_") for s, _ in steady), "register spills inside the steady K loop"
+    # no scalar loads inside the loop (lgkmcnt is the fragment reads' counter: the next `lgkmcnt(0)` would wait for the load in full); the gathered
+    # weight gradient's indices arrive as one 4-byte-per-lane LDS-DMA piece per K-tile and leave their slot through one ds_read2_b32
+    assert not any(s.startswith("s_load") for s, _ in steady), "scalar loads inside the steady K loop"
+    n_idx = sum(1 for s, _ in steady if s.startswith("global_load_lds_dword "))
+    assert n_idx == (2 if kernel.endswith("Li11") else 0), n_idx
 
 
 @pytest.mark.parametrize("kernel", GEMM3)
