@@ -398,7 +398,7 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                if (!(ARIA_ABL & 1)) acc[QA][i][QB] = mfma32(fa[i][kk], fb[QB][kk], acc[QA][i][QB]);
+                if (!(ARIA_ABL & 1)) acc[QA][i][QB] = mfma32(fb[QB][kk], fa[i][kk], acc[QA][i][QB]);
             if (LATE && kk == 0) {
                 sched_fence();
                 if (ARIA_ABL & 4) {
@@ -423,7 +423,7 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4],
             for (int i = 0; i < 2; ++i)
                 if (row_ok[i]) {
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) acc[QA][i][QB] = mfma32(fa[i][kk], fb[QB][kk], acc[QA][i][QB]);
+                    for (int kk = 0; kk < 4; ++kk) acc[QA][i][QB] = mfma32(fb[QB][kk], fa[i][kk], acc[QA][i][QB]);
                 }
         }
     }
@@ -465,126 +465,99 @@ __device__ __forceinline__ void k_loop3(f32x16 (&acc)[2][2][2], s16x8 (&fa)[2][4
     if (kt < nk) k_tile<A_OC, B_OC, 0, EDGE, false, XM>(acc, fa, fb, aa, ab, smem, st, kt, nk, rl, cl);
 }
 
+// ---- epilogues.  r06: the accumulators are held TRANSPOSED -- the K loop issues mfma(B fragment, A fragment), so register 4 q + j of lane
+// (c = l & 31, h = l >> 5) of accumulator tile (a, i, b) is the output element
+//     row  a * 128 + wm * 64 + i * 32 + c,      column  b * 128 + wn * 32 + 8 q + 4 h + j      (q, j = 0..3)
+// i.e. a lane owns FOUR CONSECUTIVE COLUMNS of one row per q: two v_cvt_pk_bf16_f32 and one 8-byte LDS store park them.  With the natural
+// operand order a lane owned 16 rows of ONE column and every pair of values cost an exchange with the neighbour lane (one DPP move + three
+// selects) in front of its conversion: 320 vector instructions and 64 four-byte LDS stores per wave and tile against 64 + 32 now -- the
+// packing was ~2 us of every tile's ~4.5 us epilogue (r06 tile timeline: "K loop end -> parked" 2.4-3.2 us at 1.6 GHz, vector-ALU bound).
+// The products and their summation order per output element are the same (the emulator and the bit-identity cases against the 128 x 128
+// and the register-staged kernels hold on hardware).
 template <int ACT, class P>
 __device__ __forceinline__ void store_tile3(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l,
                                             int wm, int wn) {
-    const int c = l & 31, h = l >> 5, odd = l & 1;
+    const int c = l & 31, h = l >> 5;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + b * 128 + wn * 32 + c;
-        const float bv = (p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f;
-        const int npair = n & ~1;
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + b * 128 + wn * 32 + 8 * q + 4 * h;
+            float bv[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int j = 0; j < 4; ++j) bv[j] = (p.bias && n + j < p.N) ? bf2f(p.bias[n + j]) : 0.f;
 #pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {  // register pair (2rp, 2rp+1) = two consecutive rows
-                    const float v0 = aria_epilogue_act_c<ACT>(acc[a][i][b][2 * rp] + bv), v1 = aria_epilogue_act_c<ACT>(acc[a][i][b][2 * rp + 1] + bv);
-                    const int r = 2 * rp;
-                    const int mrow = m0 + a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (p.c_f32) {
-                        if (n < p.N) {
-                            float* d0 = reinterpret_cast<float*>(C) + (long long)mrow * p.ldc + n;
-                            if (mrow < m_end) *d0 = p.accumulate ? *d0 + v0 : v0;
-                            if (mrow + 1 < m_end) d0[p.ldc] = p.accumulate ? d0[p.ldc] + v1 : v1;
-                        }
-                    } else {
-                        const float got = xor1(odd ? v0 : v1);   // wave-uniform control flow: every lane exchanges
-                        const int m = mrow + odd;
-                        float lo = odd ? got : v0, hi = odd ? v1 : got;  // columns npair, npair+1 of row m
-                        if (m < m_end && npair < p.N) {
-                            uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + npair);
-                            if (p.accumulate) {
-                                const uint32_t old = *dst;
-                                lo += bflo(old);
-                                hi += bfhi(old);
-                            }
-                            *dst = pack2bf(lo, hi);
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int m = m0 + a * 128 + wm * 64 + i * 32 + c;
+                    if (m >= m_end) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (n + j >= p.N) continue;
+                        const float v = aria_epilogue_act_c<ACT>(acc[a][i][b][4 * q + j] + bv[j]);
+                        if (p.c_f32) {
+                            float* d = reinterpret_cast<float*>(C) + (long long)m * p.ldc + n + j;
+                            *d = p.accumulate ? *d + v : v;
+                        } else {
+                            bf16_t* d = reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + n + j;
+                            *d = f2bf(p.accumulate ? v + bf2f(*d) : v);
                         }
                     }
                 }
-            }
+        }
+}
+
+// this lane's four bias values of column group (b, q), or zeros
+template <class P>
+__device__ __forceinline__ void bias4(const P& p, int n, float (&bv)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = 0.f;
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n + j < p.N) bv[j] = bf2f(p.bias[n + j]);
     }
 }
 
-// Wide form of the epilogue for bf16 outputs (no accumulate): the 4-byte-per-lane stores above are 512 store instructions per tile and
-// CU, and the texture-address unit retires one wave-instruction per ~31 cycles whatever its width (measured: an LDS-DMA-only loop runs at
-// 1 KiB per 31 cycles per CU) -- 8 us per tile, 10 % of a K = 2560 tile, with no MFMA running.  Here every wave parks its 128 x 64 block
-// of the tile in its own 16 KiB of the (now idle) operand images as bf16 rows of 64 bytes and writes it out in 16-byte pieces: 16
-// global_store_dwordx4 per wave instead of 64 dword stores, each covering 16 rows x 64 contiguous bytes.
-// Only for column tiles that lie wholly inside N with 16-byte aligned rows (the caller checks); rows past m_end are predicated off.
-template <int ACT, class P>
-__device__ __forceinline__ void store_tile3_wide(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
-                                                 int wm, int wn, char* smem) {
-    const int c = l & 31, h = l >> 5, odd = l & 1;
-    char* mine = smem + 16384 * w;  // [a][b][64 rows][64 bytes]
-    wave_barrier();
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + b * 128 + wn * 32 + c;
-        const float bv = p.bias ? bf2f(p.bias[n]) : 0.f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {  // register pair (2rp, 2rp+1) = two consecutive rows
-                    const float v0 = aria_epilogue_act_c<ACT>(acc[a][i][b][2 * rp] + bv), v1 = aria_epilogue_act_c<ACT>(acc[a][i][b][2 * rp + 1] + bv);
-                    const int r = 2 * rp;
-                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;  // inside the 64-row block
-                    const float got = xor1(odd ? v0 : v1);
-                    const float lo = odd ? got : v0, hi = odd ? v1 : got;  // columns (c & ~1), (c | 1) of that row
-                    *reinterpret_cast<uint32_t*>(mine + (a * 2 + b) * 4096 + row * 64 + (c & ~1) * 2) = pack2bf(lo, hi);
-                }
-    }
-    wave_barrier();
-    const int rr = l >> 2, cc = (l & 3) * 8;  // this lane's row inside a 16-row slab / first of its 8 columns
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int s16 = 0; s16 < 4; ++s16) {
-                const int row = s16 * 16 + rr;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(mine + (a * 2 + b) * 4096 + row * 64 + cc * 2);
-                const int m = m0 + a * 128 + wm * 64 + row;
-                if (m < m_end) {
-                    bf16_t* dst = reinterpret_cast<bf16_t*>(C) + (long long)m * p.ldc + n0 + b * 128 + wn * 32 + cc;
-                    if (ARIA_ABL & 256)
-                        st16_stream(dst, v);
-                    else
-                        *reinterpret_cast<u32x4*>(dst) = v;
-                }
-            }
-}
-
-// Row form of the wide epilogue (p.wide_store == 2): the WHOLE workgroup parks the 256 x 256 tile in LDS ([256 rows][512 + 16 bytes]) and,
-// after one barrier, wave w writes rows 32 w .. 32 w + 31 -- every store instruction covers two complete 512-byte tile rows (four full
-// cache lines each) instead of sixteen 64-byte row pieces that meet their neighbours from other waves in the L2 at some other time.
+// Row form of the wide epilogue: the WHOLE workgroup parks the 256 x 256 tile in LDS ([256 rows][512 + 16 bytes]) and, after one barrier, wave w
+// writes rows 32 w .. 32 w + 31 -- every store instruction covers two complete 512-byte tile rows (four full cache lines each).  (The per-wave
+// form of round 2 -- sixteen 64-byte row pieces per instruction -- left the library in r06; ARIA_GEMM_WIDE_STORE=1 selects this form too.)
 constexpr int ROWP3 = 528;  // LDS row pitch of the parked tile (bytes)
+// parks the tile (bias, activation, rounding); OLD: the slots already hold the previous C tile -- each lane adds its values to the old four IN
+// FP32 and rounds once
+template <int ACT, bool OLD, class P>
+__device__ __forceinline__ void park_tile3(const P& p, const f32x16 (&acc)[2][2][2], int n0, int l, int wm, int wn, char* smem) {
+    const int c = l & 31, h = l >> 5;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = b * 128 + wn * 32 + 8 * q + 4 * h;
+            float bv[4];
+            bias4(p, n0 + col, bv);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = a * 128 + wm * 64 + i * 32 + c;  // inside the tile
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = aria_epilogue_act_c<ACT>(acc[a][i][b][4 * q + j] + bv[j]);
+                    u32x2* slot = reinterpret_cast<u32x2*>(smem + row * ROWP3 + col * 2);
+                    if (OLD) {
+                        const u32x2 ov = *slot;
+                        v[0] += bflo(ov[0]), v[1] += bfhi(ov[0]), v[2] += bflo(ov[1]), v[3] += bfhi(ov[1]);
+                    }
+                    *slot = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                }
+        }
+}
+
 template <int ACT, class P>
 __device__ __forceinline__ void store_tile3_rows(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
                                                  int wm, int wn, char* smem) {
-    const int c = l & 31, h = l >> 5, odd = l & 1;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + b * 128 + wn * 32 + c;
-        const float bv = p.bias ? bf2f(p.bias[n]) : 0.f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {
-                    const float v0 = aria_epilogue_act_c<ACT>(acc[a][i][b][2 * rp] + bv), v1 = aria_epilogue_act_c<ACT>(acc[a][i][b][2 * rp + 1] + bv);
-                    const int r = 2 * rp;
-                    const int row = a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;  // inside the tile
-                    const float got = xor1(odd ? v0 : v1);
-                    const float lo = odd ? got : v0, hi = odd ? v1 : got;
-                    *reinterpret_cast<uint32_t*>(smem + row * ROWP3 + (b * 128 + wn * 32 + (c & ~1)) * 2) = pack2bf(lo, hi);
-                }
-    }
+    park_tile3<ACT, false>(p, acc, n0, l, wm, wn, smem);
     sync();
     ts_mark(3);
     const int rr = l >> 5, cc = (l & 31) * 8;  // two rows per instruction, 32 lanes x 16 bytes each
@@ -606,12 +579,11 @@ __device__ __forceinline__ void store_tile3_rows(const P& p, const f32x16 (&acc)
 // its out_proj / fc2 epilogues, vision.py forward_frozen -- 58 launches per step whose narrow read-modify-write epilogue was a third of an
 // out_proj tile's time) and column tiles that hang over N (N = 1152 / 3456 / 4304 are 4.5 / 13.5 / 16.8 tiles wide).  The OLD tile comes in
 // first, by the same complete-row mapping the write-out uses (16 coalesced 16-byte loads per lane instead of 64 strided dword loads), and
-// waits in the LDS where the new values will be parked; each lane then adds its accumulators to the old pair IN FP32 and rounds once --
+// waits in the LDS where the new values will be parked; each lane then adds its accumulators to the old values IN FP32 and rounds once --
 // the narrow path's arithmetic, bit for bit -- and the rows leave as in store_tile3_rows.  N % 8 == 0 (the caller checks).
 template <int ACT, class P>
 __device__ __forceinline__ void store_tile3_rows_gen(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
                                                      int wm, int wn, char* smem) {
-    const int c = l & 31, h = l >> 5, odd = l & 1;
     const int rr = l >> 5, cc = (l & 31) * 8;  // two rows per instruction, 32 lanes x 16 bytes each
     const bool col_in = n0 + cc < p.N;         // this lane's 8 columns exist (N % 8 == 0)
     const bool old = p.accumulate != 0;
@@ -631,30 +603,9 @@ __device__ __forceinline__ void store_tile3_rows_gen(const P& p, const f32x16 (&
             }
         }
         sync();
-    }
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + b * 128 + wn * 32 + c;
-        const float bv = (p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {
-                    const float v0 = aria_epilogue_act_c<ACT>(acc[a][i][b][2 * rp] + bv), v1 = aria_epilogue_act_c<ACT>(acc[a][i][b][2 * rp + 1] + bv);
-                    const int r = 2 * rp;
-                    const int row = a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;  // inside the tile
-                    const float got = xor1(odd ? v0 : v1);
-                    float lo = odd ? got : v0, hi = odd ? v1 : got;
-                    uint32_t* slot = reinterpret_cast<uint32_t*>(smem + row * ROWP3 + (b * 128 + wn * 32 + (c & ~1)) * 2);
-                    if (old) {
-                        const uint32_t ov = *slot;
-                        lo += bflo(ov);
-                        hi += bfhi(ov);
-                    }
-                    *slot = pack2bf(lo, hi);
-                }
+        park_tile3<ACT, true>(p, acc, n0, l, wm, wn, smem);
+    } else {
+        park_tile3<ACT, false>(p, acc, n0, l, wm, wn, smem);
     }
     sync();
 #pragma unroll
@@ -672,22 +623,7 @@ __device__ __forceinline__ void store_tile3_rows_gen(const P& p, const f32x16 (&
 template <class P>
 __device__ __forceinline__ void store_tile3_rows_rope(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
                                                       int wm, int wn, char* smem) {
-    const int c = l & 31, h = l >> 5, odd = l & 1;
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {
-                    const float v0 = acc[a][i][b][2 * rp], v1 = acc[a][i][b][2 * rp + 1];
-                    const int r = 2 * rp;
-                    const int row = a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;  // inside the tile
-                    const float got = xor1(odd ? v0 : v1);
-                    const float lo = odd ? got : v0, hi = odd ? v1 : got;
-                    *reinterpret_cast<uint32_t*>(smem + row * ROWP3 + (b * 128 + wn * 32 + (c & ~1)) * 2) = pack2bf(lo, hi);
-                }
+    park_tile3<0, false>(p, acc, n0, l, wm, wn, smem);   // (no bias in this launch: the entry point rejects it)
     sync();
     const int region = n0 / p.rope_D;                 // 0 q, 1 k, 2 v (tile-uniform)
     const int col0 = n0 - region * p.rope_D;          // first column of the tile inside its block
@@ -728,22 +664,7 @@ __device__ __forceinline__ void store_tile3_rows_rope(const P& p, const f32x16 (
 template <class P>
 __device__ __forceinline__ void store_tile3_rows_rope_hf(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
                                                          int wm, int wn, char* smem) {
-    const int c = l & 31, h = l >> 5, odd = l & 1;
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {
-                    const float v0 = acc[a][i][b][2 * rp], v1 = acc[a][i][b][2 * rp + 1];
-                    const int r = 2 * rp;
-                    const int row = a * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;  // inside the tile
-                    const float got = xor1(odd ? v0 : v1);
-                    const float lo = odd ? got : v0, hi = odd ? v1 : got;
-                    *reinterpret_cast<uint32_t*>(smem + row * ROWP3 + (b * 128 + wn * 32 + (c & ~1)) * 2) = pack2bf(lo, hi);
-                }
+    park_tile3<0, false>(p, acc, n0, l, wm, wn, smem);
     sync();
     const bool rotate = n0 < 2 * p.rope_D;            // q and k column tiles (tile-uniform); v leaves as it is
     const int rr = l >> 5, cc = (l & 31) * 8;
@@ -775,17 +696,20 @@ __device__ __forceinline__ void store_tile3_rows_rope_hf(const P& p, const f32x1
 template <int ACT, class P>
 __device__ __forceinline__ void store_any3(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w, int wm,
                                            int wn, char* smem) {
-    if (!p.c_f32 && !p.accumulate && n0 + BN <= p.N && p.wide_store == 2)
+    if (!p.c_f32 && !p.accumulate && n0 + BN <= p.N && p.wide_store)
         store_tile3_rows<ACT>(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
-    else if (!p.c_f32 && p.wide_store == 2 && !(p.N & 7) && !(ARIA_ABL & 4096))   // accumulate and / or a column tile that hangs over N
+    else if (!p.c_f32 && p.wide_store && !(p.N & 7) && !(ARIA_ABL & 4096))   // accumulate and / or a column tile that hangs over N
         store_tile3_rows_gen<ACT>(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
-    else if (!p.c_f32 && !p.accumulate && n0 + BN <= p.N && p.wide_store)
-        store_tile3_wide<ACT>(p, acc, C, m0, m_end, n0, l, w, wm, wn, smem);
     else
         store_tile3<ACT>(p, acc, C, m0, m_end, n0, l, wm, wn);
 }
 
-// Fused SwiGLU epilogue (p.glu): accumulator block b = 0 holds gate columns n0 + wn*32 + c, block b = 1 the up columns I + the same, so a
+// Per-wave parking blocks of the two SwiGLU epilogues: [64 rows][64 bytes], a lane's 8 bytes (row, columns 8 q + 4 h .. + 3) at 16-byte pair
+// q ^ ((row >> 1) & 3), half h -- the 16 lanes of an 8-byte LDS store (16 consecutive rows) then meet two to a bank instead of eight, and a
+// 16-byte read of pair P of a row finds it at pair P ^ ((row >> 1) & 3) (the four lanes of a row still cover its 64 bytes: conflict-free)
+__device__ __forceinline__ int wave_blk_off(int row, int pair) { return row * 64 + ((pair ^ ((row >> 1) & 3)) << 4); }
+
+// Fused SwiGLU epilogue (p.glu): accumulator block b = 0 holds gate columns n0 + wn*32 + .., block b = 1 the up columns I + the same, so a
 // lane owns gate and up of the same output elements.  Rounding points as the unfused chain materialises them (moe_lm.py:505-507 on bf16
 // tensors: h = fc1(x) rounded to bf16, silu(h_gate) rounded, the product rounded): act = bf16(bf16(silu(bf16(gate))) * bf16(up)).
 // Everything leaves through the wide path (three 4 KiB blocks per 64-row group in the wave's 16 KiB of idle LDS): act -> C2, and, if C
@@ -795,7 +719,7 @@ __device__ __forceinline__ float silu3(float a) { return silu_fast(a); }
 template <class P>
 __device__ __forceinline__ void store_tile3_glu(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
                                                 int wm, int wn, char* smem) {
-    const int c = l & 31, h = l >> 5, odd = l & 1;
+    const int c = l & 31, h = l >> 5;
     char* mine = smem + 16384 * w;  // [gate | up | act][64 rows][64 bytes]
     const int rr = l >> 2, cc = (l & 3) * 8;
     const int I = p.N / 2;
@@ -807,22 +731,18 @@ __device__ __forceinline__ void store_tile3_glu(const P& p, const f32x16 (&acc)[
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int rp = 0; rp < 8; ++rp) {
-                const int r = 2 * rp;
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;
-                float g[2], u[2], y[2];
+            for (int q = 0; q < 4; ++q) {
+                float g[4], u[4], y[4];
 #pragma unroll
-                for (int z = 0; z < 2; ++z) {
-                    g[z] = rbf(acc[a][i][0][r + z]);
-                    u[z] = rbf(acc[a][i][1][r + z]);
-                    y[z] = rbf(silu3(g[z])) * u[z];
+                for (int j = 0; j < 4; ++j) {
+                    g[j] = rbf(acc[a][i][0][4 * q + j]);
+                    u[j] = rbf(acc[a][i][1][4 * q + j]);
+                    y[j] = rbf(silu3(g[j])) * u[j];
                 }
-                // pair exchange: every lane ends up with two adjacent columns of one row (as in the plain epilogue)
-                const float gg = xor1(odd ? g[0] : g[1]), uu = xor1(odd ? u[0] : u[1]), yy = xor1(odd ? y[0] : y[1]);
-                const int off = row * 64 + (c & ~1) * 2;
-                *reinterpret_cast<uint32_t*>(mine + off) = odd ? pack2bf(gg, g[1]) : pack2bf(g[0], gg);
-                *reinterpret_cast<uint32_t*>(mine + 4096 + off) = odd ? pack2bf(uu, u[1]) : pack2bf(u[0], uu);
-                *reinterpret_cast<uint32_t*>(mine + 8192 + off) = odd ? pack2bf(yy, y[1]) : pack2bf(y[0], yy);
+                const int off = wave_blk_off(i * 32 + c, q) + 8 * h;
+                *reinterpret_cast<u32x2*>(mine + off) = u32x2{pack2bf(g[0], g[1]), pack2bf(g[2], g[3])};
+                *reinterpret_cast<u32x2*>(mine + 4096 + off) = u32x2{pack2bf(u[0], u[1]), pack2bf(u[2], u[3])};
+                *reinterpret_cast<u32x2*>(mine + 8192 + off) = u32x2{pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
             }
         wave_barrier();
 #pragma unroll
@@ -830,9 +750,10 @@ __device__ __forceinline__ void store_tile3_glu(const P& p, const f32x16 (&acc)[
             const int row = s16 * 16 + rr;
             const int m = m0 + a * 128 + wm * 64 + row;
             const int n = n0 + wn * 32 + cc;
-            const u32x4 vg = *reinterpret_cast<const u32x4*>(mine + row * 64 + cc * 2);
-            const u32x4 vu = *reinterpret_cast<const u32x4*>(mine + 4096 + row * 64 + cc * 2);
-            const u32x4 vy = *reinterpret_cast<const u32x4*>(mine + 8192 + row * 64 + cc * 2);
+            const int off = wave_blk_off(row, l & 3);
+            const u32x4 vg = *reinterpret_cast<const u32x4*>(mine + off);
+            const u32x4 vu = *reinterpret_cast<const u32x4*>(mine + 4096 + off);
+            const u32x4 vy = *reinterpret_cast<const u32x4*>(mine + 8192 + off);
             if (m < m_end) {
                 if (H) {
                     *reinterpret_cast<u32x4*>(H + (long long)m * p.ldc + n) = vg;
@@ -857,10 +778,12 @@ __device__ __forceinline__ void store_tile3_glu(const P& p, const f32x16 (&acc)[
 // first use -- the accumulators are dead by then), swiglu_bwd_elem gives d_gate / d_up, two 16-byte stores.  Saves the d_act round trip
 // (write + read of M x I bf16) and a launch per GEMM; bit-identical to aria_swiglu_bwd on the unfused product.
 // Column blocks of 128 are all-or-nothing (I % 128 == 0, checked by the entry point); rows past m_end are predicated off.
+// (r06 timeline + ISA count: this epilogue is VECTOR-ALU bound, not memory bound -- ~2400 vector instructions per wave, 256 of them quarter-rate
+// exponentials / reciprocals, two waves per SIMD = ~15 us per tile at 1.6 GHz; the request schedule of the H loads does not show.)
 template <class P>
 __device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)[2][2][2], char* C, int m0, int m_end, int n0, int l, int w,
                                                  int wm, int wn, char* smem) {
-    const int c = l & 31, h = l >> 5, odd = l & 1;
+    const int c = l & 31, h = l >> 5;
     char* mine = smem + 16384 * w;  // [a][b][64 rows][64 bytes]
     const int I = p.N;
     const int rr = l >> 2, cc = (l & 3) * 8;  // this lane's row inside a 16-row slab / first of its 8 columns
@@ -870,8 +793,6 @@ __device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)
     // of half 1) are requested right behind the parking, when the 128 accumulator registers are dead, and every finished quarter (32 registers
     // freed) requests the next 8: one exposed HBM round trip for the whole tile, half 1's rows land under half 0's arithmetic and stores.
     // (Requesting a part BEFORE the parking, beside the live accumulators, spilled 24 registers; 24 loads behind it spilled 16; 20 is spill-free.)
-    // (Was: park, load half 0, wait, compute, store, load half 1, wait, compute, store -- two exposed round trips of ~2 us on a CU with
-    // nothing else to do: 270 us of the launch's 1094.)
     u32x4 vg[2][2][4], vu[2][2][4];
     auto load_q = [&](int a, int b, int s0, int s1) {  // pieces s0 .. s1-1 of quarter (a, b) = this wave's 64 rows x 32 columns of a 128 x 128 block
         if (n0 + b * 128 < I) {  // block-uniform
@@ -892,14 +813,9 @@ __device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {  // register pair (2rp, 2rp+1) = two consecutive rows
-                    const float v0 = acc[a][i][b][2 * rp], v1 = acc[a][i][b][2 * rp + 1];
-                    const int r = 2 * rp;
-                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h + odd;  // inside the 64-row block
-                    const float got = xor1(odd ? v0 : v1);
-                    const float lo = odd ? got : v0, hi = odd ? v1 : got;  // columns (c & ~1), (c | 1) of that row
-                    *reinterpret_cast<uint32_t*>(mine + (a * 2 + b) * 4096 + row * 64 + (c & ~1) * 2) = pack2bf(lo, hi);
-                }
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<u32x2*>(mine + (a * 2 + b) * 4096 + wave_blk_off(i * 32 + c, q) + 8 * h) =
+                        u32x2{pack2bf(acc[a][i][b][4 * q], acc[a][i][b][4 * q + 1]), pack2bf(acc[a][i][b][4 * q + 2], acc[a][i][b][4 * q + 3])};
     wave_barrier();
     ts_mark(3);
     sched_fence();  // (half 1's loads must not be hoisted above the parking: the accumulators are still live there)
@@ -915,7 +831,7 @@ __device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)
 #pragma unroll
                 for (int s16 = 0; s16 < 4; ++s16) {
                     const int row = s16 * 16 + rr;
-                    const u32x4 d = *reinterpret_cast<const u32x4*>(mine + (a * 2 + b) * 4096 + row * 64 + cc * 2);
+                    const u32x4 d = *reinterpret_cast<const u32x4*>(mine + (a * 2 + b) * 4096 + wave_blk_off(row, l & 3));
                     u32x4 og, ou;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -1110,7 +1026,6 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     if (wm == 0 && stagger_groups) raw_barrier();  // balance the barrier count of the two groups
     ts_mark(2);
 
-    const int c = l & 31, h = l >> 5, odd = l & 1;
     if (slab >= 0) {  // raw fp32 partial sums for gemm3_reduce_kernel, which is their only reader -- so they leave in the ACCUMULATORS' order,
         // r05b: 16 bytes per lane and 1 KiB contiguous per store instruction (32 dwordx4 stores per lane; the tile-shaped [256][256] form was
         // 128 dword stores per lane, ~16 us of epilogue on a split tile).  Float offset of register 4 q + e of accumulator tile (b, a, i) of wave
@@ -1151,8 +1066,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
 
 // Sums the `split` slabs of every split tile in slab order (deterministic), then bias / accumulate / round exactly like the
 // main epilogue.  grid (split tiles, 16): block (r, part) finishes the part-th sixteenth of split tile r IN THE SLABS' ORDER (the accumulators'
-// order, see the slab store in gemm3_kernel): a thread's four consecutive floats are registers 4 q .. 4 q + 3 of one lane = one column, four
-// consecutive rows.
+// order, see the slab store in gemm3_kernel): a thread's four consecutive floats are registers 4 q .. 4 q + 3 of one lane = one row, four
+// consecutive columns (r06: transposed accumulators).
 __global__ __launch_bounds__(256) void gemm3_reduce_kernel(GemmParams p) {
     int tn, tmi;
     if (!aria_tile_from_pos(p, p.split_first + blockIdx.x, tmi, tn)) return;
@@ -1163,20 +1078,21 @@ __global__ __launch_bounds__(256) void gemm3_reduce_kernel(GemmParams p) {
         const int j = (blockIdx.y * 4 + it) * 256 + t;   // 16-byte piece of the slab
         const int l = j & 63, q = (j >> 6) & 3, t8 = (j >> 8) & 7, w = j >> 11;
         const int b = t8 >> 2, a = (t8 >> 1) & 1, i = t8 & 1, wm = w >> 2, wn = w & 3;
-        const int row0 = a * 128 + wm * 64 + i * 32 + 8 * q + 4 * (l >> 5), col = b * 128 + wn * 32 + (l & 31);
+        // (r06, transposed accumulators: registers 4 q .. 4 q + 3 of a lane = one ROW, four consecutive columns)
+        const int row = a * 128 + wm * 64 + i * 32 + (l & 31), col0 = b * 128 + wn * 32 + 8 * q + 4 * (l >> 5);
         f32x4 sum = *reinterpret_cast<const f32x4*>(ws + 4 * j);
         for (int s = 1; s < p.split; ++s) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (long long)s * (BM * BN) + 4 * j);
 #pragma unroll
             for (int e = 0; e < 4; ++e) sum[e] += v[e];
         }
-        const int n = tn * BN + col;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? bf2f(p.bias[n]) : 0.f;
+        const int m = tmi * BM + row;
+        if (m >= p.M) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int m = tmi * BM + row0 + e;
-            if (m >= p.M) continue;
+            const int n = tn * BN + col0 + e;
+            if (n >= p.N) continue;
+            const float bv = p.bias ? bf2f(p.bias[n]) : 0.f;
             float v = aria_epilogue_act(p, sum[e] + bv);
             if (p.c_f32) {
                 float* d = static_cast<float*>(p.C) + (long long)m * p.ldc + n;
@@ -1254,7 +1170,7 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     // wide epilogue: every 8-column piece of a C row must be 16-byte aligned.  ARIA_GEMM_WIDE_STORE=0 switches it off (A/B measurements).
     const char* wsd = std::getenv("ARIA_GEMM_WIDE_STORE");
     q.wide_store = !(wsd && wsd[0] == '0') && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.ldc & 7) == 0 && (p.strideC & 7) == 0;
-    if (q.wide_store && !(wsd && wsd[0] == '1')) q.wide_store = 2;  // row form (whole tile parked, complete 512-byte rows per store): +0.6..2.9 % over the per-wave form (=1)
+    if (q.wide_store) q.wide_store = 2;  // row form (whole tile parked, complete 512-byte rows per store); the per-wave form (=1) left the library in r06
     if (ntn * ntm <= 0) return ARIA_OK;
     if (a_oc && !b_oc) return ARIA_ERR_INVALID;
     if (p.ext_k) {  // K-extension: whole K-tiles in front of it, 16-byte granules, neither split-K nor the forms whose loaders it does not cover
