@@ -57,10 +57,12 @@ using namespace ad;
 // 4 stores issued, 5 stores acknowledged -- read back with aria_abl_ts()
 // (r06: 16384 workgroups by FLATTENED id, so that the per-expert grids of the weight gradients -- blockIdx.y = expert -- are sampled too)
 __device__ unsigned long long aria_ts[16384 * 8];
+__device__ unsigned aria_ts_hw[16384];   // where the workgroup ran: HW_ID[15:0] (wave, SIMD, pipe, CU, SH, SE) | XCC_ID << 16
 __device__ __forceinline__ void ts_mark(int i) {
     const unsigned id = blockIdx.x + blockIdx.y * gridDim.x;
     if (threadIdx.x == 0 && id < 16384) {
         aria_ts[id * 8 + i] = __builtin_amdgcn_s_memrealtime();
+        if (i == 0) aria_ts_hw[id] = (__builtin_amdgcn_s_getreg(4 | (15 << 11)) & 0xffffu) | ((__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu) << 16);
         // slots 6 / 7: the SHADER-clock counter at marks 1 / 2 (K loop start / end) -> average core clock inside the K loop
         if (i == 1 || i == 2) aria_ts[id * 8 + 5 + i] = __builtin_readcyclecounter();
     }
@@ -1240,5 +1242,8 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
 #if ARIA_ABL & 512
 extern "C" int aria_abl_ts(unsigned long long* host, int n_words) {
     return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(aria_ts), size_t(n_words) * 8));
+}
+extern "C" int aria_abl_hw(unsigned* host, int n_words) {
+    return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(aria_ts_hw), size_t(n_words) * 4));
 }
 #endif

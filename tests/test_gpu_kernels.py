@@ -298,3 +298,7 @@ def test_unpermute_with_the_residual_add_as_its_last_step(T, D, k):
 @pytest.mark.parametrize("T,D", [(78400, 1152), (37, 1152), (4901, 1152), (300, 64)])
 def test_layernorm_with_two_rows_in_flight_gives_the_same_bits(T, D):
     C.case_layernorm_two_rows_in_flight(DEV, T, D)
+
+
+def test_adamw_step_values_vs_fp32_adamw():   # the optimizer kernel's gfx950 build value-checked (decay groups, odd numel)
+    C.case_adamw_values(DEV)

@@ -18,6 +18,7 @@ from aria_amd import hip, ops  # noqa: E402
 
 lib = hip.get_lib()
 lib.cdll.aria_abl_ts.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.cdll.aria_abl_hw.argtypes = [ctypes.c_void_p, ctypes.c_int]
 NWG = 16384
 dev, bf16 = "cuda", torch.bfloat16
 T, D, I, E, k = 16384, 2560, 1664, 64, 6
@@ -66,9 +67,12 @@ for name, (launch, flops) in launches.items():
     torch.cuda.synchronize()
     ts = np.zeros(NWG * 8, dtype=np.uint64)
     lib.cdll.aria_abl_ts(ts.ctypes.data, NWG * 8)
+    hw = np.zeros(NWG, dtype=np.uint32)
+    lib.cdll.aria_abl_hw(hw.ctypes.data, NWG)
     full = ts.reshape(NWG, 8).astype(np.int64)
     t_last = full[:, 0].max()
-    full = full[(full[:, 0] > t_last - 1_000_000) & (full[:, 5] > full[:, 0]) & (full[:, 2] > full[:, 1])]   # entered within the last 10 ms, ran a tile
+    keep = (full[:, 0] > t_last - 1_000_000) & (full[:, 5] > full[:, 0]) & (full[:, 2] > full[:, 1])   # entered within the last 10 ms, ran a tile
+    full, hw = full[keep], hw[keep]
     rel = (full[:, :6] - full[:, 0].min()) * 0.01
     seg = {"entry -> first operands": rel[:, 1] - rel[:, 0], "K loop": rel[:, 2] - rel[:, 1], "K loop end -> parked": rel[:, 3] - rel[:, 2],
            "parked -> stores issued": rel[:, 4] - rel[:, 3], "store ack": rel[:, 5] - rel[:, 4], "tile total": rel[:, 5] - rel[:, 0]}
@@ -85,5 +89,25 @@ for name, (launch, flops) in launches.items():
     busy = seg["tile total"].sum() / 256.0
     r["sampled span us / sum of tile totals per CU us"] = [round(float(span), 1), round(float(busy), 1)]
     r["share of tile time (sum over workgroups)"] = {k2: round(float(v.sum() / seg["tile total"].sum()), 3) for k2, v in seg.items() if k2 != "tile total"}
+    # where the CU time outside any tile goes: per CU (XCC, SE, SH, CU of HW_ID) the tiles in entry order -> idle before the first tile, gaps
+    # between a tile's store acknowledgement and the next tile's entry, idle behind the last tile until the launch's last acknowledgement
+    cu_key = ((hw >> 16) & 0xf) * 4096 + ((hw >> 8) & 0xff)   # XCC | SE, SH, CU
+    t0, t1 = rel[:, 0].min(), rel[:, 5].max()
+    lead, gaps, tail, ntile = [], [], [], []
+    for key in np.unique(cu_key):
+        sel = np.where(cu_key == key)[0]
+        o = sel[np.argsort(rel[sel, 0])]
+        lead.append(rel[o[0], 0] - t0)
+        tail.append(t1 - rel[o[-1], 5])
+        gaps.extend((rel[o[1:], 0] - rel[o[:-1], 5]).tolist())
+        ntile.append(len(o))
+    xcc = (hw >> 16) & 0xf
+    r["CUs seen"] = int(len(lead))
+    r["tiles per CU min/median/max"] = [int(np.min(ntile)), int(np.median(ntile)), int(np.max(ntile))]
+    r["idle before a CU's first tile us p10/50/90"] = pct(np.array(lead))
+    r["gap between tiles on a CU (ack -> next entry) us p10/50/90"] = pct(np.array(gaps))
+    r["idle behind a CU's last tile us p10/50/90"] = pct(np.array(tail))
+    r["CU time outside tiles: lead / gaps / tail, us per CU"] = [round(float(np.mean(lead)), 1), round(float(np.sum(gaps) / len(lead)), 1), round(float(np.mean(tail)), 1)]
+    r["last acknowledgement per XCC, us after the launch's first entry"] = [round(float(rel[xcc == xc, 5].max() - t0), 1) for xc in np.unique(xcc)]
     res[name] = r
 print(json.dumps(res))
