@@ -1010,12 +1010,15 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
             st.gk[0][0] = st.gk[1][0], st.gk[0][1] = st.gk[1][1];
             idx_dma<0>(st, 2);   // tile 2's indices: in front of tile 1's pieces, so the wait below confirms them
         }
+        // r06: the barrier in front of K-tile 0 only needs A0 and B0 of tile 0 (phase 1 reads nothing else and carries its own counted wait for
+        // B1 / A1): the pieces issued behind them stay in flight -- B1, A1 of tile 0 (4), the gathered weight gradient's index piece (1), A0, B0 of
+        // tile 1 (4).  (Was: everything of tile 0.)
         if (nk > 1) {
             stage_half<A_OC, B_OC, 0, 0, 1, true, XM>(st, 1);
             stage_half<A_OC, B_OC, 1, 0, 1, true, XM & 2>(st, 1);
-            wait_vm<4>();
+            wait_vm<8 + ((GATHER && A_OC) ? 1 : 0)>();
         } else {
-            wait_vm<0>();
+            wait_vm<4>();
         }
         raw_barrier();
         ts_mark(1);

@@ -113,8 +113,71 @@ __device__ __forceinline__ bool aria_tile_coords(const P& p, int bid, int nwg, i
 // of step with the CUs that share its panels -- measured, fc1 forward: L2 hit rate 47 % with routed counts against 75 % with every expert at
 // a multiple of 256 rows (tools/gpu_pmc_grouped.sh).  With the bit set every XCD first runs its share of the FULL row tiles (same list
 // order) and then its share of the ragged ones (one per expert and column), which are alike among themselves.
+// p.order bit 12 (r06, per-expert interleave): instead of one contiguous eighth of the whole list, XCD x takes an eighth of EVERY expert's tiles
+// (share y = (x + e) & 7 of expert e: positions [c_e y / 8, c_e (y + 1) / 8) of its column-major list -- the rotation by e spreads the
+// rounding remainders), in expert order.  Every XCD then sees the same mix of experts at the same time, as the per-expert grids of the weight
+// gradients do by construction (their XCDs finish within 0.3 % of each other; the contiguous eighths of the grouped-row launches 5-8 % apart,
+// profiles/r06_grouped6_timeline_*.json) -- at the price of an XCD's patch of one expert being 8 tiles instead of ~32.
+template <class P>
+__device__ __forceinline__ bool aria_grouped_tile_interleaved(const P& p, int bid, int l, int& expert, int& m0, int& m_end, int& tn) {
+    const bool split = (p.order >> 9) & 1, rfirst = (p.order >> 11) & 1;
+    const int xcd = bid & 7, idx = bid >> 3;
+    // pass 0: this XCD's tile counts in the two lists; pass 1: locate
+    int nF = 0, nR = 0;
+    for (int e0 = 0; e0 < p.E; e0 += 64) {
+        const int e = e0 + l;
+        int sf = 0, sr = 0;
+        if (e < p.E) {
+            const int n = p.offsets[e + 1] - p.offsets[e], y = (xcd + e) & 7;
+            const int cf = (split ? n / 256 : (n + 255) / 256) * p.ntn, cr = (split && (n & 255)) ? p.ntn : 0;
+            sf = cf * (y + 1) / 8 - cf * y / 8;
+            sr = cr * (y + 1) / 8 - cr * y / 8;
+        }
+        nF += ad::wave_bcast(ad::wave_incl_scan(sf), 63);
+        if (split) nR += ad::wave_bcast(ad::wave_incl_scan(sr), 63);
+    }
+    if (idx >= nF + nR) return false;
+    const bool ragged = rfirst ? idx < nR : idx >= nF;
+    const int v = ragged ? idx - (rfirst ? 0 : nF) : idx - (rfirst ? nR : 0);   // position in this XCD's share of the list
+    int base = 0;
+    for (int e0 = 0; e0 < p.E; e0 += 64) {
+        const int e = e0 + l;
+        int o0 = 0, o1 = 0;
+        if (e < p.E) {
+            o0 = p.offsets[e];
+            o1 = p.offsets[e + 1];
+        }
+        const int n = o1 - o0, y = (xcd + e) & 7;
+        const int nt = split ? n / 256 : (n + 255) / 256;
+        const int c = ragged ? ((n & 255) ? p.ntn : 0) : nt * p.ntn;
+        const int first = c * y / 8, share = (e < p.E) ? c * (y + 1) / 8 - first : 0;
+        const int incl = ad::wave_incl_scan(share);
+        const int excl = base + incl - share;
+        const unsigned long long mask = ad::ballot(share > 0 && v >= excl && v < excl + share);
+        if (mask) {
+            const int src = __builtin_ctzll(mask);
+            const int local = ad::wave_bcast(first, src) + v - ad::wave_bcast(excl, src), nts = ad::wave_bcast(nt, src);
+            expert = e0 + src;
+            int row;
+            if (ragged) {
+                tn = local;
+                row = nts;
+            } else {
+                tn = local / nts;
+                row = local % nts;
+            }
+            m0 = ad::wave_bcast(o0, src) + row * 256;
+            m_end = ad::wave_bcast(o1, src);
+            return true;
+        }
+        base += ad::wave_bcast(incl, 63);
+    }
+    return false;
+}
+
 template <class P>
 __device__ __forceinline__ bool aria_grouped_tile(const P& p, int bid, int l, int& expert, int& m0, int& m_end, int& tn) {
+    if ((p.order >> 12) & 1) return aria_grouped_tile_interleaved(p, bid, l, expert, m0, m_end, tn);
     const bool split = (p.order >> 9) & 1;
     int TF = 0, TR = 0;  // tiles in the list of full (or, without the bit, all) row tiles / of ragged row tiles
     for (int e0 = 0; e0 < p.E; e0 += 64) {
@@ -175,7 +238,8 @@ __device__ __forceinline__ bool aria_grouped_tile(const P& p, int bid, int l, in
 inline int aria_tile_grid(const GemmParams& p) {
     // aria_grouped_tile: 8 XCD chunks of ceil(T / 8) <= bound / 8 + 1 tiles; the ragged-last order (order bit 9) cuts TWO lists (full
     // row tiles, ragged last row tiles) 8 ways each, so one XCD can need ceil(TF / 8) + ceil(TR / 8) slots: 16 spare workgroups
-    if (p.mode == 1) return p.ntn * p.ntm + 16;
+    // (bit 12, per-expert interleave: an XCD's share is sum_e of a rounded eighth -- at most one tile per expert and list above the mean)
+    if (p.mode == 1) return p.ntn * p.ntm + 16 + (((p.order >> 12) & 1) ? 16 * p.E : 0);
     if (p.split > 1) return p.split_first + (p.ntn * p.ntm - p.split_first) * p.split;
     return p.ntn * p.ntm;
 }

@@ -90,13 +90,13 @@ def init_params(model, seed):
                     flat[o:o + chunk].normal_(0.0, 0.02, generator=g)
 
 
-PMC_FILE = "r05_pmc_fc1.json"
-KERNEL_REV = "r05"    # bumped with every change of the v3 K loop / epilogues: a PMC pass of an older build does not describe this one
-PMC_KERNEL_TAG = "gemm3_kernel<rc,oc,8>+gather+wide_store+ragged_last+swiglu@r05"   # the fc1 launch the committed PMC pass profiled
+PMC_FILE = "r06_pmc_fc1.json"
+KERNEL_REV = "r06"    # bumped with every change of the v3 K loop / epilogues: a PMC pass of an older build does not describe this one
+PMC_KERNEL_TAG = "gemm3_kernel<rc,oc,8>+gather+wide_store+ragged_last+swiglu@r06"   # the fc1 launch the committed PMC pass profiled
 
 
 def fc1_kernel_tag(variant, gather=None):
-    """What the default path launched for experts.fc1 in THIS run, spelled like profiles/r05_pmc_fc1.json's kernel_tag."""
+    """What the default path launched for experts.fc1 in THIS run, spelled like profiles/r06_pmc_fc1.json's kernel_tag."""
     if variant != 3:
         return f"gemm{variant}_kernel<rc,oc>"
     if gather is None:

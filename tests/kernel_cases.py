@@ -1174,3 +1174,47 @@ def case_adamw_values(dev):
     for i, (k, p) in enumerate(params.items()):
         torch.testing.assert_close(opt.state[i]["master"].cpu(), ref[k].reshape(-1), rtol=2e-5, atol=1e-6)
         assert torch.equal(p.detach().cpu().reshape(-1), opt.state[i]["master"].to(bf16).cpu())
+
+
+def case_grouped_tile_orders(dev, T=900, E=5, k=2, K=128, I=128, seed=77):
+    """The grouped-row launches' tile ORDER (ARIA_GEMM_ORDER: expert-major eighths per XCD, ragged-last = bit 9, ragged-first = bit 11, the
+    r06 per-expert interleave = bit 12, and their combinations) only re-assigns tiles to workgroup ids: every order must cover every tile
+    exactly once -- same bits as the default order for the plain grouped GEMM, the fused fc1 + SwiGLU launch and its gathered form, on a
+    routing with an empty expert, experts of less than one tile and of several tiles with a ragged last one."""
+    import os
+
+    from aria_amd import ops
+
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(T, K, generator=g) * 0.5).to(bf16).to(dev)
+    logits = torch.randn(T, E, generator=g)
+    logits[:, 1] = -1e9                     # expert 1 gets nothing
+    logits[: T // 2, 0] += 3.0              # expert 0 gets many rows (several row tiles), the others few
+    idx = torch.topk(logits, k, dim=1).indices.to(torch.int32).to(dev)
+    counts = torch.bincount(idx.flatten().long(), minlength=E).to(torch.int32)
+    offsets, sorted_src, inv = ops.moe_sort(idx, counts)
+    perm = ops.moe_permute(x, sorted_src, k)
+    rows = ops.permuted_token_rows(sorted_src, k)
+    w1 = (torch.randn(E, K, 2 * I, generator=g) * 0.05).to(bf16).to(dev)
+    prev = os.environ.get("ARIA_GEMM_ORDER")
+    outs = {}
+    try:
+        for order in (None, 4 | 512, 4 | 512 | 2048, 4 | 4096, 4 | 512 | 4096, 4 | 512 | 2048 | 4096):
+            if order is None:
+                os.environ.pop("ARIA_GEMM_ORDER", None)
+            else:
+                os.environ["ARIA_GEMM_ORDER"] = str(order)
+            plain = ops.grouped_gemm(perm, w1, offsets)
+            h, act = ops.grouped_gemm_swiglu(perm, w1, offsets, want_h=True)
+            hg, actg = ops.grouped_gemm_swiglu_gather(x, rows, w1, offsets, want_h=True)
+            outs[order] = [t.cpu().clone() for t in (plain, h, act, hg, actg)]
+    finally:
+        if prev is None:
+            os.environ.pop("ARIA_GEMM_ORDER", None)
+        else:
+            os.environ["ARIA_GEMM_ORDER"] = prev
+    ref = outs[None]
+    assert float(ref[0].float().abs().max()) > 0
+    for order, o in outs.items():
+        for a, b in zip(o, ref):
+            assert torch.equal(a, b), order

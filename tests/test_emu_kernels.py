@@ -331,3 +331,7 @@ def test_layernorm_with_two_rows_in_flight_gives_the_same_bits(T, D):
 
 def test_adamw_step_values_vs_fp32_adamw():
     C.case_adamw_values(DEV)
+
+
+def test_grouped_tile_orders_cover_every_tile_once(force_gemm_v3):
+    C.case_grouped_tile_orders(DEV)

@@ -302,3 +302,9 @@ def test_layernorm_with_two_rows_in_flight_gives_the_same_bits(T, D):
 
 def test_adamw_step_values_vs_fp32_adamw():   # the optimizer kernel's gfx950 build value-checked (decay groups, odd numel)
     C.case_adamw_values(DEV)
+
+
+def test_grouped_tile_orders_cover_every_tile_once(monkeypatch):
+    monkeypatch.setenv("ARIA_GEMM_FORCE", "3")
+    C.case_grouped_tile_orders(DEV)
+    C.case_grouped_tile_orders(DEV, T=6000, E=9, k=2, K=256, I=256, seed=78)
