@@ -859,49 +859,6 @@ Scratch carve(char* base, int64_t L, int64_t D, int64_t H, int64_t hd, int64_t E
     return s;
 }
 
-// ---- r06: keep HBM busy across the token's dependency chain.  A token is 28 x 6 dependent launches of 5-22 us each, none
-// long enough to reach the steady streaming rate (3.3-4.9 TB/s per launch against 7.2 for the same read pattern in one long launch,
-// profiles/r04_gemv_stream_rate.json).  In the CAPTURED graph a second branch reads layer i + 1's routing-independent weights (q|k|v, o, router,
-// shared gate / up / down: 103 MB of the layer's 256) while layer i's launches run -- the lines wait in the 256 MB infinity cache (memory side,
-// shared by all XCDs) when layer i + 1 asks for them.  The branch touches nothing the token reads or writes: results are bit-identical by
-// construction.  ARIA_DECODE_PREFETCH=<workgroups> (0 / unset: off) -- see profiles/r06_decode_prefetch_ab.json for the measured effect.
-struct PrefetchSegs {
-    const char* p[6];
-    long long n16[6];  // 16-byte chunks per segment
-};
-__global__ __launch_bounds__(256) void prefetch_kernel(PrefetchSegs s) {
-    const long long stride = (long long)gridDim.x * 256, t0 = (long long)blockIdx.x * 256 + threadIdx.x;
-    u32x4 acc = zero16();
-#pragma unroll 1
-    for (int g = 0; g < 6; ++g) {
-        const char* base = s.p[g];
-        const long long n = s.n16[g];
-        long long i = t0;
-#pragma unroll 1
-        for (; i + 7 * stride < n; i += 8 * stride) {  // eight 16-byte loads in flight per lane
-            u32x4 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = ld16(base + 16 * (i + j * stride));
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc ^= v[j];
-        }
-        for (; i < n; i += stride) acc ^= ld16(base + 16 * i);
-    }
-#ifndef ARIA_EMU
-    asm volatile("" ::"v"(acc));  // (the loads are the point; their value is not)
-#endif
-}
-
-#ifndef ARIA_EMU
-struct PrefetchCtx {  // set by aria_decode_graph_create around its capture of aria_decode_token
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    int workgroups = 0;
-    bool used = false;
-};
-thread_local PrefetchCtx* g_prefetch = nullptr;
-#endif
-
 }  // namespace
 
 extern "C" {
@@ -956,20 +913,6 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
                      *sw2 = static_cast<const bf16_t*>(lp[10]);
         bf16_t *kc = static_cast<bf16_t*>(const_cast<void*>(lp[11])), *vc = static_cast<bf16_t*>(const_cast<void*>(lp[12]));
         bf16_t* h = s.xa;  // hidden state after the attention block
-#ifndef ARIA_EMU
-        if (g_prefetch && g_prefetch->workgroups > 0 && li + 1 < L) {  // (capture only) the side branch reads layer li + 1's dense weights under this layer
-            const void* const* np = lp + ARIA_DECODE_LAYER_PTRS;
-            PrefetchSegs ps;
-            const void* segp[6] = {np[1], np[2], np[4], np[8], np[9], np[10]};   // wqkv, wo, router, shared w1 / w3 / w2
-            const long long segb[6] = {3 * D * D * 2, D * D * 2, E * D * 2, Is * D * 2, Is * D * 2, D * Is * 2};
-            for (int g = 0; g < 6; ++g) ps.p[g] = static_cast<const char*>(segp[g]), ps.n16[g] = segb[g] / 16;
-            if (hipEventRecord(g_prefetch->fork, static_cast<hipStream_t>(stream)) != hipSuccess ||
-                hipStreamWaitEvent(g_prefetch->side, g_prefetch->fork, 0) != hipSuccess)
-                return ARIA_ERR_LAUNCH;
-            ARIA_LAUNCH(prefetch_kernel, dim3(unsigned(g_prefetch->workgroups)), dim3(256), 0, g_prefetch->side, ps);
-            g_prefetch->used = true;
-        }
-#endif
         bf16_t *const rl = s.rl + li * s.rl_stride, *const scores = s.scores + li * s.sc_stride;  // this layer's routing record
         int32_t* const idx = s.idx + li * s.idx_stride;
         // attention block: h = x + wo( attn( rope(wqkv(norm(x))) ) )
@@ -1046,13 +989,6 @@ int aria_decode_token(const void* const* ptrs, const int64_t* dims, float eps, v
         x = s.xb;  // the next layer reads x = xb and writes its h into xa again (h is dead once this add has run)
     }
     ARIA_TRY(launch_gemv(int(V), stream, out_w, (long long)D, x, final_norm, eps, int(D), nullptr, logits));
-#ifndef ARIA_EMU
-    if (g_prefetch && g_prefetch->used) {  // the side branch joins the token's stream again (a capture must end on one stream)
-        if (hipEventRecord(g_prefetch->join, g_prefetch->side) != hipSuccess ||
-            hipStreamWaitEvent(static_cast<hipStream_t>(stream), g_prefetch->join, 0) != hipSuccess)
-            return ARIA_ERR_LAUNCH;
-    }
-#endif
 #undef ARIA_TRY
     return ARIA_OK;
 }
@@ -1113,25 +1049,12 @@ void* aria_decode_graph_create(const void* const* ptrs, const int64_t* dims, flo
         delete g;
         return nullptr;
     }
-    PrefetchCtx pf;
-    const char* pfe = std::getenv("ARIA_DECODE_PREFETCH");
-    pf.workgroups = pfe ? atoi(pfe) : 0;
-    if (pf.workgroups > 0) {
-        if (hipStreamCreateWithFlags(&pf.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&pf.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&pf.join, hipEventDisableTiming) != hipSuccess)
-            pf.workgroups = 0;
-    }
     bool ok = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
     if (ok) {
-        g_prefetch = pf.workgroups > 0 ? &pf : nullptr;
         const int rc = aria_decode_token(ptrs, dims, eps, cap);
-        g_prefetch = nullptr;
         const hipError_t e = hipStreamEndCapture(cap, &g->graph);
         ok = rc == ARIA_OK && e == hipSuccess && g->graph;
     }
-    if (pf.fork) (void)hipEventDestroy(pf.fork);
-    if (pf.join) (void)hipEventDestroy(pf.join);
-    if (pf.side) (void)hipStreamDestroy(pf.side);
     if (ok) ok = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) == hipSuccess;
     (void)hipStreamDestroy(cap);
     if (!ok) {
