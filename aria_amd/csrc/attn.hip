@@ -1023,7 +1023,8 @@ __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, co
                         continue;
                     }
 #pragma unroll
-                    for (int dt = 0; dt < C::DT; ++dt) acc[dt] = mfma32(pf, frag_tr3<HD>(second, i * 32 + 16 * u, 32 * dt, l), acc[dt]);
+                    // (r06: operands swapped -- the accumulators are dV^T / dK^T, see the epilogue)
+                    for (int dt = 0; dt < C::DT; ++dt) acc[dt] = mfma32(frag_tr3<HD>(second, i * 32 + 16 * u, 32 * dt, l), pf, acc[dt]);
                 }
         }
         if (more && t < 64) {
@@ -1034,39 +1035,51 @@ __global__ __launch_bounds__(512) void attn_bwd3_dkdv_kernel(const bf16_t* Q, co
             sDel[(cur ^ 1) * 64 + t] = ok ? del_n : 0.f;
         }
     }
+    // r06: the accumulators are held TRANSPOSED (the product above is (Q | dO)^T x (dS | P), features x keys): lane (l & 31, h2) owns ONE key
+    // and, per feature tile dt and q = 0..3, the four consecutive features 32 dt + 8 q + 4 h2 + 0..3 (registers 4 q .. 4 q + 3) -- 16 eight-byte
+    // stores per lane instead of 64 two-byte ones, and the inverse RoPE's tables come in as 8-byte vectors (32 loads instead of 128 two-byte
+    // ones).  At the training shape (S = 2048: 2 .. 32 query tiles per workgroup) this epilogue was a fifth of the kernel.  Same sums, same
+    // roundings: bit-identical.
     bf16_t* out = role ? dK : dV;
     const long long ldout = role ? lddk : lddv;
+    const int kv = kv_wmin + (l & 31);
+    if (kv >= S) return;
+    bf16_t* orow = out + (tok0 + kv) * ldout + head * HD + 4 * h2;
     if (role == 1 && rope_cs) {
         // r05: the inverse half-split RoPE of dK (the chain rule through apply_rotary_pos_emb, modeling_llama.py:130-160; was an in-place pass
-        // over [T, 2 D] after this kernel: rope_kernel, 55 us per layer).  Feature f = 32 dt + (l & 31) pairs with f + HD / 2 = tile dt + DT / 2,
-        // same lane, same register; the key's position is its index in the sequence.  Rounding for rounding what the two launches did: the
-        // gradient rounded to bf16 (the store), then bf16(bf16(a cos) + bf16(b sin)) / bf16(bf16(b cos) - bf16(a sin)).
+        // over [T, 2 D] after this kernel: rope_kernel, 55 us per layer).  Feature f pairs with f + HD / 2 = tile dt + DT / 2, same lane, same
+        // register; the key's position is its index in the sequence.  Rounding for rounding what the two launches did: the gradient rounded to
+        // bf16 (the store), then bf16(bf16(a cos) + bf16(b sin)) / bf16(bf16(b cos) - bf16(a sin)).
         static_assert(C::DT % 2 == 0, "half-split pairs are whole feature tiles");
+        const bf16_t* cs = rope_cs + (long long)(kv % rope_S) * HD + 4 * h2;
+        const bf16_t* sn = rope_sn + (long long)(kv % rope_S) * HD + 4 * h2;
 #pragma unroll
         for (int dt = 0; dt < C::DT / 2; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kv = kv_wmin + acc_row(r, l);
-                if (kv >= S) continue;
-                const int f = 32 * dt + (l & 31);
-                const long long tb = (long long)(kv % rope_S) * HD;
-                const float c1 = bf2f(rope_cs[tb + f]), c2 = bf2f(rope_cs[tb + f + HD / 2]);
-                const float s1 = bf2f(rope_sn[tb + f]), s2 = bf2f(rope_sn[tb + f + HD / 2]);
-                const float a = rbf(acc[dt][r]), b = rbf(acc[dt + C::DT / 2][r]);
-                bf16_t* orow = out + (tok0 + kv) * ldout + head * HD + f;
-                orow[0] = f2bf(rbf(a * c1) + rbf(b * s1));
-                orow[HD / 2] = f2bf(rbf(b * c2) + rbf(-a * s2));
+            for (int q = 0; q < 4; ++q) {
+                const int f = 32 * dt + 8 * q;
+                const u32x2 c1 = *reinterpret_cast<const u32x2*>(cs + f), c2 = *reinterpret_cast<const u32x2*>(cs + f + HD / 2);
+                const u32x2 s1 = *reinterpret_cast<const u32x2*>(sn + f), s2 = *reinterpret_cast<const u32x2*>(sn + f + HD / 2);
+                float lo[4], hi[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = rbf(acc[dt][4 * q + j]), b = rbf(acc[dt + C::DT / 2][4 * q + j]);
+                    const float vc1 = (j & 1) ? bfhi(c1[j >> 1]) : bflo(c1[j >> 1]), vc2 = (j & 1) ? bfhi(c2[j >> 1]) : bflo(c2[j >> 1]);
+                    const float vs1 = (j & 1) ? bfhi(s1[j >> 1]) : bflo(s1[j >> 1]), vs2 = (j & 1) ? bfhi(s2[j >> 1]) : bflo(s2[j >> 1]);
+                    lo[j] = rbf(a * vc1) + rbf(b * vs1);
+                    hi[j] = rbf(b * vc2) + rbf(-a * vs2);
+                }
+                *reinterpret_cast<u32x2*>(orow + f) = u32x2{pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3])};
+                *reinterpret_cast<u32x2*>(orow + f + HD / 2) = u32x2{pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3])};
             }
         return;
     }
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kv = kv_wmin + acc_row(r, l);
-            if (kv >= S) continue;
-            out[(tok0 + kv) * ldout + head * HD + 32 * dt + (l & 31)] = f2bf(acc[dt][r]);
-        }
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<u32x2*>(orow + 32 * dt + 8 * q) =
+                u32x2{pack2bf(acc[dt][4 * q], acc[dt][4 * q + 1]), pack2bf(acc[dt][4 * q + 2], acc[dt][4 * q + 3])};
 }
 
 
@@ -1603,6 +1616,8 @@ int aria_attn_bwd_rope(const void* q, const void* k, const void* v, const void* 
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(d_o) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) ||
         (lddq & 3) || (lddk & 1) || (lddv & 1) || (reinterpret_cast<uintptr_t>(dq) & 7))
         return ARIA_ERR_ALIGN;
+    // (r06: the hd 128 dK / dV kernel stores 8 bytes per lane: rows 8-byte aligned like dq's)
+    if (hd == 128 && ((lddk & 3) || (lddv & 3) || ((reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) & 7))) return ARIA_ERR_ALIGN;
     if (B == 0 || Sq == 0 || Skv == 0) return ARIA_OK;
     const bf16_t *Q = static_cast<const bf16_t*>(q), *K = static_cast<const bf16_t*>(k), *V = static_cast<const bf16_t*>(v);
     const bf16_t *Op = static_cast<const bf16_t*>(o), *dO = static_cast<const bf16_t*>(d_o);
