@@ -437,18 +437,48 @@ __device__ __forceinline__ float rcp_fast(float x) {
 // x * sigmoid(x) (SiLU): x / (1 + e^-x) on v_exp_f32 + v_rcp_f32.  ONE definition for the fused GEMM epilogue, the stand-alone SwiGLU
 // kernels and the decode path, so that all of them round identically.
 __device__ __forceinline__ float silu_fast(float a) { return a * rcp_fast(1.f + exp2_fast(-1.4426950408889634f * a)); }
-// Backward of y = bf16(silu(a)) * b for one element (GroupedMLP's glu, moe_lm.py:505-507): d_a = g b silu'(a), d_b = g bf16(silu(a)), with
-// silu(a) evaluated exactly as silu_fast does (so bf16(silu(a)) here IS the value the forward multiplied by).  ONE definition for the
-// stand-alone kernel (moe.hip) and the GEMM epilogue that absorbs it (gemm3.hip, VER 5): both round identically.
+// ---- r06: the two activation formulas whose evaluation sits in GEMM epilogues are written ON PAIRS of values, as explicit operation sequences
+// (every fused multiply-add spelled out, no sum of products left to the compiler's contraction): the compiler then emits v_pk_mul / v_pk_fma /
+// v_pk_add for everything but the two quarter-rate transcendentals, and every caller -- fused epilogue, stand-alone kernel, the scalar wrappers
+// below -- executes the same IEEE operations in the same order, i.e. rounds identically.  (The scalar forms left to the auto-vectorizer packed
+// only part of the work: 36 full-rate instructions per four GELU values against 22 now; the ViT fc1 launch spends ~10 us of a ~42 us tile in
+// this epilogue, the SwiGLU backward ~15 of ~83.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
+#ifdef ARIA_EMU
+    return f32x2{std::fma(a.x, b.x, c.x), std::fma(a.y, b.y, c.y)};
+#else
+    return __builtin_elementwise_fma(a, b, c);
+#endif
+}
+__device__ __forceinline__ f32x2 exp2_fast2(f32x2 x) { return f32x2{exp2_fast(x.x), exp2_fast(x.y)}; }
+__device__ __forceinline__ f32x2 rcp_fast2(f32x2 x) { return f32x2{rcp_fast(x.x), rcp_fast(x.y)}; }
+__device__ __forceinline__ f32x2 rbf2(f32x2 v) {   // both values rounded to bf16 (one v_cvt_pk_bf16_f32, two unpacks)
+    const uint32_t w = pack2bf(v.x, v.y);
+    return f32x2{bflo(w), bfhi(w)};
+}
+// Backward of y = bf16(silu(a)) * b (GroupedMLP's glu, moe_lm.py:505-507): d_a = g b silu'(a), d_b = g bf16(silu(a)), with silu(a) = a sig
+// evaluated as silu_fast does (so bf16(silu(a)) here IS the value the forward multiplied by); silu'(a) = sig (1 + a (1 - sig)).  ONE definition
+// for the stand-alone kernel (moe.hip) and the GEMM epilogue that absorbs it (gemm3.hip, VER 5).
+__device__ __forceinline__ void swiglu_bwd_pair(f32x2 a, f32x2 b, f32x2 g, f32x2& da, f32x2& db) {
+    const f32x2 one = {1.f, 1.f};
+    const f32x2 sig = rcp_fast2(exp2_fast2(a * -1.4426950408889634f) + one);
+    db = g * rbf2(a * sig);
+    da = (g * b) * (sig * fma2(a, one - sig, one));
+}
 __device__ __forceinline__ void swiglu_bwd_elem(float a, float b, float g, float& da, float& db) {
-    const float sig = rcp_fast(1.f + exp2_fast(-1.4426950408889634f * a));
-    db = g * rbf(a * sig);
-    da = g * b * (sig * (1.f + a * (1.f - sig)));
+    f32x2 va, vb;
+    swiglu_bwd_pair(f32x2{a, a}, f32x2{b, b}, f32x2{g, g}, va, vb);
+    da = va.x, db = vb.x;
 }
-__device__ __forceinline__ float gelu_tanh(float x) {
+// gelu_pytorch_tanh: x / (1 + 2^(-k2 (x + 0.044715 x^3))), the cubic as fma(0.044715 x, x x, x)
+__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
     const float k2 = 2.f * 0.7978845608028654f * 1.4426950408889634f;  // 2 sqrt(2/pi) log2(e)
-    return x * rcp_fast(1.f + exp2_fast(-k2 * (x + 0.044715f * x * x * x)));
+    const f32x2 one = {1.f, 1.f};
+    const f32x2 u = fma2(x * 0.044715f, x * x, x);
+    return x * rcp_fast2(exp2_fast2(u * -k2) + one);
 }
+__device__ __forceinline__ float gelu_tanh(float x) { return gelu_tanh2(f32x2{x, x}).x; }
 
 // ds_read_b64_tr_b16: every lane passes the LDS address of 4 consecutive bf16 (8-byte aligned); within each 16-lane group
 // lane q receives element (q & 3) of the four lanes 4j + (q >> 2), j = 0..3 (semantics verified on hardware by

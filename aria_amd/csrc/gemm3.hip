@@ -545,7 +545,10 @@ __device__ __forceinline__ void park_tile3(const P& p, const f32x16 (&acc)[2][2]
                     const int row = a * 128 + wm * 64 + i * 32 + c;  // inside the tile
                     float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = aria_epilogue_act_c<ACT>(acc[a][i][b][4 * q + j] + bv[j]);
+                    for (int j = 0; j < 4; j += 2) {
+                        const f32x2 pr = aria_epilogue_act2<ACT>(f32x2{acc[a][i][b][4 * q + j] + bv[j], acc[a][i][b][4 * q + j + 1] + bv[j + 1]});
+                        v[j] = pr.x, v[j + 1] = pr.y;
+                    }
                     u32x2* slot = reinterpret_cast<u32x2*>(smem + row * ROWP3 + col * 2);
                     if (OLD) {
                         const u32x2 ov = *slot;
@@ -837,11 +840,11 @@ __device__ __forceinline__ void store_tile3_dglu(const P& p, const f32x16 (&acc)
                     u32x4 og, ou;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float da[2], db[2];
-                        swiglu_bwd_elem(bflo(vg[a][b][s16][q]), bflo(vu[a][b][s16][q]), bflo(d[q]), da[0], db[0]);
-                        swiglu_bwd_elem(bfhi(vg[a][b][s16][q]), bfhi(vu[a][b][s16][q]), bfhi(d[q]), da[1], db[1]);
-                        og[q] = pack2bf(da[0], da[1]);
-                        ou[q] = pack2bf(db[0], db[1]);
+                        f32x2 da, db;
+                        swiglu_bwd_pair(f32x2{bflo(vg[a][b][s16][q]), bfhi(vg[a][b][s16][q])}, f32x2{bflo(vu[a][b][s16][q]), bfhi(vu[a][b][s16][q])},
+                                        f32x2{bflo(d[q]), bfhi(d[q])}, da, db);
+                        og[q] = pack2bf(da.x, da.y);
+                        ou[q] = pack2bf(db.x, db.y);
                     }
                     const int m = m0 + a * 128 + wm * 64 + row;
                     if (m < m_end) {

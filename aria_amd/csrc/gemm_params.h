@@ -255,6 +255,12 @@ __device__ __forceinline__ float aria_epilogue_act_c(float v) {
     return ACT == 1 ? ad::gelu_tanh(ad::rbf(v)) : v;
 }
 
+// the same on a pair (r06: packed arithmetic in the GELU epilogue of the ViT's fc1)
+template <int ACT>
+__device__ __forceinline__ ad::f32x2 aria_epilogue_act2(ad::f32x2 v) {
+    return ACT == 1 ? ad::gelu_tanh2(ad::rbf2(v)) : v;
+}
+
 // (internal to the library: hidden, not part of the C ABI)
 // v2 launcher (gemm2.hip); returns ARIA_* status
 __attribute__((visibility("hidden"))) int aria_launch_gemm2(const GemmParams& p, int a_oc, int b_oc, int ntm_or_max_tm, int grid_y, void* stream);

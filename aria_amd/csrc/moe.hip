@@ -566,16 +566,10 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* h, const 
         u32x4 oa, ob;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float da[2], db[2];
-#pragma unroll
-            for (int z = 0; z < 2; ++z) {
-                const float av = z ? bfhi(a[q]) : bflo(a[q]);
-                const float bv = z ? bfhi(b[q]) : bflo(b[q]);
-                const float gv = z ? bfhi(g[q]) : bflo(g[q]);
-                swiglu_bwd_elem(av, bv, gv, da[z], db[z]);
-            }
-            oa[q] = pack2bf(da[0], da[1]);
-            ob[q] = pack2bf(db[0], db[1]);
+            f32x2 da, db;
+            swiglu_bwd_pair(f32x2{bflo(a[q]), bfhi(a[q])}, f32x2{bflo(b[q]), bfhi(b[q])}, f32x2{bflo(g[q]), bfhi(g[q])}, da, db);
+            oa[q] = pack2bf(da.x, da.y);
+            ob[q] = pack2bf(db.x, db.y);
         }
         st16(dh + row * lda + col, oa);
         st16(dh2 + row * ldb + col, ob);

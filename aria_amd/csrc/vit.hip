@@ -235,7 +235,10 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* x, bf16_t* 
         const u32x4 a = ld16(x + c * 8);
         u32x4 o;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = pack2bf(gelu_tanh_f(bflo(a[q])), gelu_tanh_f(bfhi(a[q])));
+        for (int q = 0; q < 4; ++q) {
+            const f32x2 y = gelu_tanh2(f32x2{bflo(a[q]), bfhi(a[q])});
+            o[q] = pack2bf(y.x, y.y);
+        }
         st16(y + c * 8, o);
     }
 }
