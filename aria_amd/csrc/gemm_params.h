@@ -191,7 +191,9 @@ __device__ __forceinline__ bool aria_grouped_tile(const P& p, int bid, int l, in
         TF += ad::wave_bcast(ad::wave_incl_scan(cf), 63);
         if (split) TR += ad::wave_bcast(ad::wave_incl_scan(cr), 63);
     }
-    const int xcd = bid & 7, idx = bid >> 3;
+    // (order bits 16-18, diagnostic: the eighth of the list a hardware XCD takes is rotated by that many places -- do the late XCDs of a launch
+    // follow the hardware id or the share?  profiles/r06_xcd_rotation.json)
+    const int xcd = ((bid & 7) + ((p.order >> 16) & 7)) & 7, idx = bid >> 3;
     const int loF = int((long long)TF * xcd / 8), nF = int((long long)TF * (xcd + 1) / 8) - loF;
     const int loR = int((long long)TR * xcd / 8), nR = int((long long)TR * (xcd + 1) / 8) - loR;
     if (idx >= nF + nR) return false;
