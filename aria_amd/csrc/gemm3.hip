@@ -981,7 +981,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
 
     // rows / columns of this wave's part of half 0 that are in range (half 1 lies 128 further)
     const int rows_left = m_end - m0 - wm * 64, cols_left = p.glu ? BN : p.N - n0 - wn * 32;  // (glu: I % 128 == 0, no column edge)
-    const bool interior = m0 + BM <= m_end && (p.glu || n0 + BN <= p.N);
+    // order bit 13 (r06, opt-in): row tiles that hang over their expert's rows run the straight-line steady K loop too -- the rows past the end are
+    // clamped loads whose products land in accumulators that are never stored.  The general form skips those MFMAs but is the slower loop: in the
+    // r06 timeline the K loop's p90 (= the ragged tiles, 15 % of a grouped-row launch) sits 7-11 % ABOVE the median.  Measured
+    // (profiles/r06_edge_steady_ab.json): launch by launch fc1 dgrad +3.1 %, fc2 forward +0.6-1.9 %, the rest level -- and the config #3 step
+    // 1.2 ms SLOWER with it as the default of the plain grouped-row launches: the chip is power-limited there, and 7 % more MFMAs on clamped rows
+    // cost the step more clock than the straight-line loop saves in time.  Column-edge tiles always keep the general form.
+    const bool full_cols = p.glu || n0 + BN <= p.N;
+    const bool interior = full_cols && (m0 + BM <= m_end || ((p.order >> 13) & 1));
     if (ARIA_ABL & 128) {
         // (timing experiment: no prologue, no K loop -- launch + tile lookup + epilogue only)
     } else {
@@ -1175,6 +1182,8 @@ int aria_launch_gemm3(const GemmParams& p, int a_oc, int b_oc, int ntm, void* st
     // (profiles/r04_grouped_order_ab.json, r04_pmc_grouped_orders_and_clocks.json): fabric-side fetches 7.0 -> 3.9 GB per launch, L2 hit rate
     // 49 -> 69 %, TF/s level (975 / 1023 vs 1012 / 993); the plain grouped launches lose 1-2 % under it and keep the expert-major order
     if (!ord && p.glu && p.mode == 1) q.order |= 512;
+    // (order bit 13 -- ragged row tiles on the steady K loop -- wins 2-3 % on the plain grouped-row launches alone and LOSES 1.2 ms per step inside the
+    // power-limited training step, profiles/r06_edge_steady_ab.json: opt-in)
     // wide epilogue: every 8-column piece of a C row must be 16-byte aligned.  ARIA_GEMM_WIDE_STORE=0 switches it off (A/B measurements).
     const char* wsd = std::getenv("ARIA_GEMM_WIDE_STORE");
     q.wide_store = !(wsd && wsd[0] == '0') && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.ldc & 7) == 0 && (p.strideC & 7) == 0;

@@ -1178,7 +1178,7 @@ def case_adamw_values(dev):
 
 def case_grouped_tile_orders(dev, T=900, E=5, k=2, K=128, I=128, seed=77):
     """The grouped-row launches' tile ORDER (ARIA_GEMM_ORDER: expert-major eighths per XCD, ragged-last = bit 9, ragged-first = bit 11, the
-    r06 per-expert interleave = bit 12, and their combinations) only re-assigns tiles to workgroup ids: every order must cover every tile
+    r06 per-expert interleave = bit 12, ragged row tiles on the steady K loop = bit 13, the diagnostic rotation = bits 16-18, and combinations) only re-assigns tiles to workgroup ids: every order must cover every tile
     exactly once -- same bits as the default order for the plain grouped GEMM, the fused fc1 + SwiGLU launch and its gathered form, on a
     routing with an empty expert, experts of less than one tile and of several tiles with a ragged last one."""
     import os
@@ -1199,7 +1199,7 @@ def case_grouped_tile_orders(dev, T=900, E=5, k=2, K=128, I=128, seed=77):
     prev = os.environ.get("ARIA_GEMM_ORDER")
     outs = {}
     try:
-        for order in (None, 4 | 512, 4 | 512 | 2048, 4 | 4096, 4 | 512 | 4096, 4 | 512 | 2048 | 4096):
+        for order in (None, 4, 4 | 512, 4 | 512 | 2048, 4 | 4096, 4 | 512 | 4096, 4 | 512 | 2048 | 4096, 4 | 8192, 4 | 512 | 8192, 4 | (3 << 16)):
             if order is None:
                 os.environ.pop("ARIA_GEMM_ORDER", None)
             else:
