@@ -209,7 +209,7 @@ struct Stage {  // everything a wave needs to issue its two DMA pieces of any ha
     // reduction runs over the expert's permuted rows r, whose A rows are TOKEN rows reached through the dispatcher's index -- the [6T, D]
     // permuted copy is never built).  A piece of an A half-tile = 4 reduction rows x 256 bytes of features: the lane's two rows of the tile
     // being staged, as byte offsets from the operand base (gk[CUR]: the tile phase 1 stages, gk[NXT]: the one phase 3 stages).  The indices
-    // arrive by SCALAR loads (lgkmcnt: the counted vmcnt pipeline of the DMA pieces never sees them), eight per wave and tile.
+    // of K-tiles 0 and 1 arrive by scalar loads in the prologue, those of every later K-tile as one LDS-DMA piece (r06: idx_dma below).
     uint32_t gk[2][2];
     const int* grows;   // gather_rows at the expert's first reduction row (+ this workgroup's first K-tile)
     const char* gA0;    // the operand base (token row 0)

@@ -141,8 +141,8 @@ int aria_dropout_bwd_bf16(const void* term, const void* mask, void* dx, int64_t 
 
 /* K2 for the TRAINING step (round 5): the weight gradient of experts.fc1 through the dispatcher's index -- dW[e] = sum over the expert's permuted rows r
  * of X[rows[r]]^T dY[r] (autograd of experts_gemm(index_select(x, sorted // topk), fc1), moe_lm.py:326-334, 467-484) -- so that the [6T, D] permuted copy
- * of the tokens is never written: forward = aria_grouped_gemm_swiglu_gather_bf16, weight gradient = this.  The indices of a K-tile reach the loader by
- * scalar loads (eight per wave), outside the counted-vmcnt pipeline of its DMA pieces.  rows: int32 [M_total + 64] (64 entries of padding are read,
+ * of the tokens is never written: forward = aria_grouped_gemm_swiglu_gather_bf16, weight gradient = this.  The indices of a K-tile reach the loader as one
+ * more LDS-DMA piece of the counted-vmcnt pipeline (r06; K-tiles 0 and 1 by scalar loads in the prologue).  rows: int32 [M_total + 64] (64 entries of padding are read,
  * never used); T < 2^24, 2 T ldx < 2^32.  Bit-identical to aria_moe_permute + aria_grouped_gemm_wgrad_bf16.  Shapes the 256 x 256 kernels do not take:
  * ARIA_ERR_UNSUPPORTED. */
 int aria_grouped_gemm_wgrad_gather_bf16(const void* X, const int32_t* rows, const void* dY, void* dW, const int32_t* offsets, int64_t E, int64_t T,

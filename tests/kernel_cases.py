@@ -1102,7 +1102,7 @@ def case_gemm_qkv_rope_hf(dev, B, S, D, hd, K):
 
 def case_grouped_gemm_wgrad_gather(dev, T, E, k, K, N, seed=321):
     """The weight gradient of experts.fc1 through the dispatcher's index (aria_grouped_gemm_wgrad_gather_bf16: the reduction rows of a K-tile
-    are token rows reached by scalar index loads) == aria_moe_permute + aria_grouped_gemm_wgrad_bf16, bit for bit (same tiles, same reduction
+    are token rows reached through indices that travel by LDS-DMA beside the operand pieces) == aria_moe_permute + aria_grouped_gemm_wgrad_bf16, bit for bit (same tiles, same reduction
     order), bf16 and fp32 outputs, on a real routing (ragged and empty experts: expert 1 gets no token, the last one ends mid-tile)."""
     from aria_amd import hip, ops
 
